@@ -1,0 +1,329 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/*.npz from the REAL reference.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+The reference is imported through tests/golden/_ref_shim.py; its randomness is either
+injected (Dropout2d masks) or recorded at the call site (Exp(1) noise of gumbel_softmax and
+of multinomial-without-replacement, the float64 uniform stream of multinomial-with-
+replacement, randperm) so that the oracle / the HIP path can be replayed on the same draws.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from _ref_shim import load_reference  # noqa: E402
+import weights as W  # noqa: E402
+
+torch.set_num_threads(8)
+R = load_reference()
+
+
+# ----------------------------------------------------------------------------- recorders
+class Recorder:
+    """Wraps the RNG entry points the reference uses and records what they drew."""
+
+    def __init__(self):
+        self.exp = []         # every Tensor.exponential_ result (gumbel noise)
+        self.multi_rep = []   # (weights, uniforms f64, indices)
+        self.multi_norep = [] # (weights, k, exp noise, sorted indices)
+        self.perms = []
+        self._orig = {}
+
+    def __enter__(self):
+        rec = self
+        self._orig = dict(exp=torch.Tensor.exponential_, multi=torch.multinomial,
+                          perm=torch.randperm)
+        o_exp, o_multi, o_perm = self._orig["exp"], self._orig["multi"], self._orig["perm"]
+
+        def exponential_(t, *a, **k):
+            out = o_exp(t, *a, **k)
+            rec.exp.append(out.detach().clone())
+            return out
+
+        def multinomial(w, n, replacement=False, **k):
+            gen_state = torch.random.get_rng_state()
+            torch.Tensor.exponential_ = o_exp          # do not double-record
+            idx = o_multi(w, n, replacement=replacement, **k)
+            after = torch.random.get_rng_state()
+            torch.random.set_rng_state(gen_state)
+            if replacement:
+                u = torch.rand(n, dtype=torch.float64)
+                assert torch.equal(torch.random.get_rng_state(), after), "stream mismatch"
+                rec.multi_rep.append((w.detach().clone(), u, idx.clone()))
+            else:
+                q = o_exp(torch.empty_like(w), 1)
+                assert torch.equal(torch.random.get_rng_state(), after), "stream mismatch"
+                rec.multi_norep.append((w.detach().clone(), n, q, torch.sort(idx)[0].clone()))
+            torch.random.set_rng_state(after)
+            torch.Tensor.exponential_ = exponential_
+            return idx
+
+        def randperm(n, *a, **k):
+            p = o_perm(n, *a, **k)
+            rec.perms.append(p.clone())
+            return p
+
+        torch.Tensor.exponential_ = exponential_
+        torch.multinomial = multinomial
+        torch.randperm = randperm
+        return self
+
+    def __exit__(self, *a):
+        torch.Tensor.exponential_ = self._orig["exp"]
+        torch.multinomial = self._orig["multi"]
+        torch.randperm = self._orig["perm"]
+
+
+def install_dropout_masks(model, masks):
+    """Replace every Dropout2d.forward by an injected [B,C] multiplier."""
+    for name, mod in model.named_modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            if name in masks:
+                m = masks[name]
+                mod.forward = (lambda x, m=m: x * m[:, :, None, None])
+            else:
+                mod.forward = (lambda x: x)
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path)/1e6:.2f} MB, keys={len(out)}")
+
+
+# ----------------------------------------------------------------------------- blocks
+def gold_blocks():
+    out = {}
+    g = np.random.Generator(np.random.PCG64(11))
+    b, h, w = 2, 16, 64
+    # ResContextBlock 5 -> 8
+    x = torch.from_numpy(g.standard_normal((b, 5, h, w)).astype(np.float32))
+    st = W.block_state("ctx", 5, 8)
+    blk = R.ResContextBlock(5, 8)
+    blk.load_state_dict({k[4:]: v for k, v in st.items()})
+    blk.train()
+    out["ctx_x"], out["ctx_y"] = x, blk(x)
+    # ResBlock 8 -> 16, pooling + dropout
+    x = torch.from_numpy(g.standard_normal((b, 8, h, w)).astype(np.float32))
+    st = W.block_state("res", 8, 16)
+    mask = torch.from_numpy((g.random((b, 16)) >= 0.2).astype(np.float32) * 1.25)
+    blk = R.ResBlock(8, 16, 0.2, pooling=True, drop_out=True)
+    blk.load_state_dict({k[4:]: v for k, v in st.items()})
+    blk.train()
+    blk.dropout.forward = lambda t: t * mask[:, :, None, None]
+    yb, ya = blk(x)
+    out.update(res_x=x, res_mask=mask, res_pooled=yb, res_skip=ya)
+    # ResBlock 8 -> 16, no pooling
+    blk = R.ResBlock(8, 16, 0.2, pooling=False, drop_out=True)
+    blk.load_state_dict({k[4:]: v for k, v in st.items()})
+    blk.train()
+    blk.dropout.forward = lambda t: t * mask[:, :, None, None]
+    out["res_nopool"] = blk(x)
+    # UpBlock 32 -> 8 (in: 32 ch at h/2, skip: 16 ch at h)
+    xin = torch.from_numpy(g.standard_normal((b, 32, h // 2, w // 2)).astype(np.float32))
+    skip = torch.from_numpy(g.standard_normal((b, 16, h, w)).astype(np.float32))
+    st = W.block_state("up", 32, 8)
+    m1 = torch.from_numpy((g.random((b, 8)) >= 0.2).astype(np.float32) * 1.25)
+    m2 = torch.from_numpy((g.random((b, 24)) >= 0.2).astype(np.float32) * 1.25)
+    m3 = torch.from_numpy((g.random((b, 8)) >= 0.2).astype(np.float32) * 1.25)
+    blk = R.UpBlock(32, 8, 0.2, drop_out=True)
+    blk.load_state_dict({k[4:]: v for k, v in st.items()})
+    blk.train()
+    blk.dropout1.forward = lambda t: t * m1[:, :, None, None]
+    blk.dropout2.forward = lambda t: t * m2[:, :, None, None]
+    blk.dropout3.forward = lambda t: t * m3[:, :, None, None]
+    out.update(up_x=xin, up_skip=skip, up_m1=m1, up_m2=m2, up_m3=m3, up_y=blk(xin, skip))
+    npz("blocks.npz", **out)
+
+
+# ----------------------------------------------------------------------------- full model
+def build_ref_model(state, dataset="SemanticKitti", ncls=20):
+    m = R.SalsaNextProto(5, ncls, 20, 0, use_prototype=True, dataset=dataset)
+    sd = {k: v.clone() for k, v in state.items()}
+    m.load_state_dict(sd)
+    return m
+
+
+def gold_model(tag, b, h, w, ncls, dataset, seed, label_rate):
+    st = W.closed_form_state(nclasses=ncls)
+    x, tr, ev = W.synthetic_batch(b, h, w, ncls, seed, label_rate, gh=8, gw=16)
+    masks = W.dropout_masks_for(None, b, seed + 1)
+    m = build_ref_model(st, dataset, ncls)
+    m.train()
+    install_dropout_masks(m, masks)
+    stats = {}
+
+    def hook(name):
+        def f(mod, inp, out):
+            t = inp[0]
+            stats[name] = (t.mean(dim=(0, 2, 3)).detach(), t.var(dim=(0, 2, 3), unbiased=False).detach())
+        return f
+    for name, mod in m.named_modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.register_forward_hook(hook(name))
+    torch.manual_seed(seed + 2)
+    with Recorder() as rec:
+        out = m(x, label=tr, eval_mask=tr > 0, return_feat=True, proto_loss=True)
+    sd = m.state_dict()
+    arrs = dict(pred_2d=out["pred_2d"], feat_2d_sub=out["feat_2d"][:, :, ::2, ::4],
+                contrast_logits_sub=out["contrast_logits"][::16],
+                contrast_target=out["contrast_target"], new_prototypes=sd["prototypes"])
+    # gumbel noise per class in execution order (classes present among labelled pixels)
+    present = [c for c in range(1, ncls) if int((tr == c).sum()) > 0]
+    assert len(present) == len(rec.exp), (len(present), len(rec.exp))
+    for c, e in zip(present, rec.exp):
+        arrs[f"gumbel_{c}"] = e
+    for name, (mu, var) in stats.items():
+        arrs[f"bnmean/{name}"] = mu
+        arrs[f"bnvar/{name}"] = var
+    for k, v in sd.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            arrs[f"run/{k}"] = v
+    npz(f"model_{tag}.npz", **arrs)
+    return st, x, tr, ev, masks, m, rec
+
+
+# ----------------------------------------------------------------------------- losses
+def gold_contrast():
+    g = np.random.Generator(np.random.PCG64(21))
+    b, ncls, h, w, d, m_ = 2, 6, 16, 32, 256, 20
+    feats = torch.from_numpy(g.standard_normal((b, d, h, w)).astype(np.float32)).requires_grad_(True)
+    logits = torch.from_numpy(g.standard_normal((b, ncls, h, w)).astype(np.float32) * 2)
+    prob = torch.softmax(logits, 1)
+    labels = torch.from_numpy(g.integers(0, ncls, (b, h, w)))
+    labels[1][labels[1] == 3] = 0          # class 3 absent in image 1 (ragged case)
+    keep = torch.from_numpy(g.random((b, h, w)) < 0.7)
+    queue = torch.from_numpy(g.standard_normal((ncls, m_, d)).astype(np.float32))
+    crit = R.ContrastMEMLoss(ignore_label=0, temperature=0.07, num_anchor=64)
+    torch.manual_seed(5)
+    with Recorder() as rec:
+        loss = crit(feats=feats, output=prob, labels=labels, keep_mask=keep,
+                    proto_queue=queue.unsqueeze(0))
+    loss.backward()
+    arrs = dict(feats=feats.detach(), prob=prob, labels=labels, keep=keep, queue=queue,
+                loss=loss.detach(), grad_feats=feats.grad,
+                uniforms=torch.stack([u for _, u, _ in rec.multi_rep]),
+                indices=torch.stack([i for _, _, i in rec.multi_rep]),
+                perms=torch.stack(rec.perms))
+    npz("contrast.npz", **arrs)
+
+
+def gold_pl_select():
+    g = np.random.Generator(np.random.PCG64(31))
+    b, ncls, h, w = 2, 6, 16, 64
+    logits = torch.from_numpy(g.standard_normal((b, ncls, h, w)).astype(np.float32) * 1.5)
+    prob = torch.softmax(logits, 1)
+    ev = torch.from_numpy(g.integers(0, ncls, (b, h, w)))
+    tr = ev * torch.from_numpy(g.random((b, h, w)) < 0.02)
+    tr[1][tr[1] == 2] = 0
+    fake_self = types.SimpleNamespace(settings=types.SimpleNamespace(ignore_cls=0, n_classes=ncls))
+    ratio = float(np.log(1 + (1 + 10) / 100) / np.log(2) * 0.5)
+    torch.manual_seed(9)
+    with Recorder() as rec:
+        lab, mask = R.entropy_based_selection(fake_self, output=prob, wss_mask=tr > 0,
+                                              eval_mask=ev > 0, train_label=tr,
+                                              select_ratio=ratio)
+    arrs = dict(prob=prob, eval_label=ev, train_label=tr, ratio=np.float64(ratio),
+                labels=lab, mask=mask,
+                noise=torch.stack([q for _, _, q, _ in rec.multi_norep]),
+                ks=np.array([k for _, k, _, _ in rec.multi_norep]))
+    npz("pl_select.npz", **arrs)
+
+
+def gold_losses():
+    g = np.random.Generator(np.random.PCG64(41))
+    b, ncls, h, w = 2, 6, 8, 32
+    prob = torch.softmax(torch.from_numpy(g.standard_normal((b, ncls, h, w)).astype(np.float32)), 1)
+    prob.requires_grad_(True)
+    tr = torch.from_numpy(g.integers(0, ncls, (b, h, w))) * torch.from_numpy(g.random((b, h, w)) < 0.1)
+    alpha = torch.from_numpy(g.uniform(0.2, 1, ncls).astype(np.float32))
+    alpha[0] = 0
+    focal = R.FocalSoftmaxLoss(ncls, gamma=2, alpha=alpha.numpy(), softmax=False)
+    lov = R.Lovasz_softmax(ignore=0, per_image=False, softmax=False)
+    lf = focal(prob, tr, mask=tr > 0)
+    ll = lov(prob, tr)
+    gf, = torch.autograd.grad(lf, prob, retain_graph=True)
+    gl, = torch.autograd.grad(ll, prob)
+    npz("losses.npz", prob=prob.detach(), train_label=tr, alpha=alpha, focal=lf.detach(),
+        lovasz=ll.detach(), grad_focal=gf, grad_lovasz=gl)
+
+
+# ----------------------------------------------------------------------------- full step
+def gold_step():
+    """One optimisation step of the reference modules, trainer.py:621-704 order, with
+    use_prototype / proto_loss switched on (latent in the shipped trainer)."""
+    b, h, w, ncls = 2, 64, 128, 20
+    st = W.closed_form_state(nclasses=ncls)
+    x, tr, ev = W.synthetic_batch(b, h, w, ncls, 77, 0.02, gh=8, gw=16)
+    masks = W.dropout_masks_for(None, b, 78)
+    m = build_ref_model(st)
+    m.train()
+    install_dropout_masks(m, masks)
+    alpha = torch.ones(ncls)
+    alpha[0] = 0
+    focal = R.FocalSoftmaxLoss(ncls, gamma=2, alpha=alpha.numpy(), softmax=False)
+    lov = R.Lovasz_softmax(ignore=0, per_image=False, softmax=False)
+    con = R.ContrastMEMLoss(ignore_label=0, temperature=0.07, num_anchor=64)
+    fake_self = types.SimpleNamespace(settings=types.SimpleNamespace(ignore_cls=0, n_classes=ncls))
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    torch.manual_seed(79)
+    with Recorder() as rec:
+        out = m(x, label=tr, eval_mask=tr > 0, return_feat=True, proto_loss=True)
+        n_gumbel = len(rec.exp)
+        pred, feat = out["pred_2d"], out["feat_2d"]
+        l_ce = focal(pred, tr, mask=tr > 0)
+        l_lov = lov(pred, tr)
+        ratio = float(np.log(1 + (1 + 10) / 100) / np.log(2) * 0.5)
+        with torch.no_grad():
+            lab_c, mask_c = R.entropy_based_selection(
+                fake_self, output=pred, wss_mask=tr > 0, eval_mask=ev > 0, train_label=tr,
+                select_ratio=ratio)
+        l_con = con(feats=feat, output=pred, labels=lab_c, keep_mask=mask_c,
+                    proto_queue=m.prototypes.detach().unsqueeze(0))
+        total = 1.0 * l_ce + 1.0 * l_lov + 0.1 * l_con
+    opt.zero_grad()
+    total.backward()
+    arrs = dict(loss=total.detach(), ce=l_ce.detach(), lov=l_lov.detach(), contrast=l_con.detach(),
+                labels_contra=lab_c, mask_contra=mask_c, pred_2d=pred.detach(),
+                new_prototypes=m.prototypes.detach(),
+                pl_noise=torch.stack([q for _, _, q, _ in rec.multi_norep]),
+                uniforms=torch.stack([u for _, u, _ in rec.multi_rep]),
+                anchor_idx=torch.stack([i for _, _, i in rec.multi_rep]),
+                perms=torch.stack(rec.perms))
+    present = [c for c in range(1, ncls) if int((tr == c).sum()) > 0]
+    assert len(present) == n_gumbel
+    for c, e in zip(present, rec.exp[:n_gumbel]):
+        arrs[f"gumbel_{c}"] = e
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        gr = p.grad.detach()
+        arrs[f"gnorm/{k}"] = gr.norm()
+        arrs[f"grad/{k}"] = gr if gr.numel() <= 4096 else gr.reshape(-1)[:: max(gr.numel() // 2048, 1)]
+    opt.step()
+    for k in ("downCntx.conv1.weight", "resBlock3.bn2.bias", "cls_head.weight",
+              "projector.proj.3.bias", "upBlock2.conv4.bias"):
+        arrs[f"after/{k}"] = dict(m.named_parameters())[k].detach()
+    npz("step.npz", **arrs)
+
+
+if __name__ == "__main__":
+    gold_blocks()
+    gold_model("kitti_small", 2, 32, 64, 20, "SemanticKitti", 101, 0.02)
+    gold_model("poss_small", 1, 24, 56, 14, "SemanticPOSS", 201, 0.02)
+    gold_contrast()
+    gold_pl_select()
+    gold_losses()
+    gold_step()

@@ -1,0 +1,175 @@
+"""The CPU oracle (oracle/coarse3d_oracle.py) against golden vectors captured from the REAL
+reference by tests/golden/make_golden.py.  CPU only; this is what pins the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import weights as W
+from oracle import coarse3d_oracle as oc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return {k: torch.from_numpy(v) if isinstance(v, np.ndarray) and v.dtype != np.float64 or
+            (isinstance(v, np.ndarray) and v.ndim > 0) else v
+            for k, v in np.load(os.path.join(GOLD, name)).items()}
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+def test_blocks():
+    g = load("blocks.npz")
+    st = W.block_state("ctx", 5, 8)
+    c = oc._Ctx(st, True, None)
+    close(oc.res_context_block(c, "blk", g["ctx_x"]), g["ctx_y"])
+    st = W.block_state("res", 8, 16)
+    c = oc._Ctx(st, True, {"blk.dropout": g["res_mask"]})
+    pooled, skip = oc.res_block(c, "blk", g["res_x"], True, True)
+    close(pooled, g["res_pooled"])
+    close(skip, g["res_skip"])
+    c = oc._Ctx(W.block_state("res", 8, 16), True, {"blk.dropout": g["res_mask"]})
+    close(oc.res_block(c, "blk", g["res_x"], False, True), g["res_nopool"])
+    st = W.block_state("up", 32, 8)
+    c = oc._Ctx(st, True, {"blk.dropout1": g["up_m1"], "blk.dropout2": g["up_m2"],
+                           "blk.dropout3": g["up_m3"]})
+    close(oc.up_block(c, "blk", g["up_x"], g["up_skip"], True), g["up_y"])
+
+
+@pytest.mark.parametrize("tag,b,h,w,ncls,dataset,seed", [
+    ("kitti_small", 2, 32, 64, 20, "SemanticKitti", 101),
+    ("poss_small", 1, 24, 56, 14, "SemanticPOSS", 201),
+])
+def test_model_forward_and_bank(tag, b, h, w, ncls, dataset, seed):
+    g = load(f"model_{tag}.npz")
+    st = W.closed_form_state(nclasses=ncls)
+    x, tr, ev = W.synthetic_batch(b, h, w, ncls, seed, 0.02, gh=8, gw=16)
+    masks = W.dropout_masks_for(None, b, seed + 1)
+    with torch.no_grad():
+        out = oc.backbone_forward(st, x, True, masks, True, dataset)
+        close(out["pred_2d"], g["pred_2d"])
+        close(out["feat_2d"][:, :, ::2, ::4], g["feat_2d_sub"])
+        for name, (mu, var) in out["bn_stats"].items():
+            close(mu, g[f"bnmean/{name}"])
+            close(var, g[f"bnvar/{name}"], rtol=2e-4)
+        for k in st:
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                close(st[k], g[f"run/{k}"], rtol=2e-4)
+        rows, sim, nearest, pl2 = oc.prototype_similarity(st, out["feat_2d"])
+        noise = {c: g[f"gumbel_{c}"] for c in range(1, ncls) if f"gumbel_{c}" in g}
+        bank, logits, target = oc.prototype_learning(pl2, rows, nearest, tr.reshape(-1), sim, noise)
+        close(logits[::16], g["contrast_logits_sub"])
+        assert torch.equal(target, g["contrast_target"])
+        close(bank, g["new_prototypes"])
+
+
+def test_multinomial_contracts_against_torch():
+    """The two sampler restatements ARE torch.multinomial on CPU."""
+    gen = np.random.Generator(np.random.PCG64(3))
+    for trial in range(6):
+        n = [50, 1000, 4096, 20000, 131072, 777][trial]
+        w = torch.from_numpy(gen.random(n).astype(np.float32))
+        w[torch.from_numpy(gen.random(n) < 0.6)] = 0
+        torch.manual_seed(100 + trial)
+        ref = torch.multinomial(w, 512, replacement=True)
+        torch.manual_seed(100 + trial)
+        u = torch.rand(512, dtype=torch.float64)
+        got = oc.multinomial_replace(w.numpy(), u.numpy())
+        assert np.array_equal(got, ref.numpy())
+        k = max(int((w > 0).sum()) // 7, 1)
+        torch.manual_seed(200 + trial)
+        ref = torch.sort(torch.multinomial(w, k, replacement=False))[0]
+        torch.manual_seed(200 + trial)
+        q = torch.empty_like(w).exponential_(1)
+        got = oc.multinomial_noreplace_set(w.numpy(), k, q.numpy())
+        assert np.array_equal(got, ref.numpy())
+
+
+def test_contrast_loss():
+    g = load("contrast.npz")
+    feats = g["feats"].clone().requires_grad_(True)
+    loss, (img, cls, idx) = oc.contrast_mem_loss(
+        feats, g["prob"], g["labels"], g["keep"], g["queue"], g["uniforms"], g["perms"],
+        temperature=0.07, num_anchor=64, return_idx=True)
+    assert torch.equal(idx, g["indices"])          # bit-exact anchor selection
+    close(loss, g["loss"], rtol=1e-5, atol=1e-6)
+    loss.backward()
+    close(feats.grad, g["grad_feats"], rtol=1e-4, atol=1e-8)
+
+
+def test_entropy_selection():
+    g = load("pl_select.npz")
+    tr, ev = g["train_label"], g["eval_label"]
+    lab, mask = oc.entropy_selection(g["prob"], tr > 0, ev > 0, tr, float(g["ratio"]),
+                                     list(g["noise"]))
+    assert torch.equal(lab, g["labels"])
+    assert torch.equal(mask, g["mask"])
+
+
+def test_supervised_losses():
+    g = load("losses.npz")
+    prob = g["prob"].clone().requires_grad_(True)
+    tr = g["train_label"]
+    lf = oc.focal_loss(prob, tr, tr > 0, g["alpha"])
+    ll = oc.lovasz_loss(prob, tr)
+    close(lf, g["focal"], rtol=1e-5)
+    close(ll, g["lovasz"], rtol=1e-5)
+    gf, = torch.autograd.grad(lf, prob, retain_graph=True)
+    gl, = torch.autograd.grad(ll, prob)
+    close(gf, g["grad_focal"], rtol=1e-4, atol=1e-7)
+    close(gl, g["grad_lovasz"], rtol=1e-4, atol=1e-7)
+
+
+def test_full_step_gradients():
+    g = load("step.npz")
+    b, h, w, ncls = 2, 64, 128, 20
+    st = W.closed_form_state(nclasses=ncls)
+    for k in oc.trainable_names(st):
+        st[k].requires_grad_(True)
+    x, tr, ev = W.synthetic_batch(b, h, w, ncls, 77, 0.02, gh=8, gw=16)
+    masks = W.dropout_masks_for(None, b, 78)
+    rng = dict(gumbel={c: g[f"gumbel_{c}"] for c in range(1, ncls) if f"gumbel_{c}" in g},
+               pl_noise=list(g["pl_noise"]), uniforms=g["uniforms"], perms=g["perms"])
+    info, grads = oc.train_step(st, x, tr, ev, rng, temperature=0.07, num_anchor=64,
+                                dropout_masks=masks)
+    assert torch.equal(info["labels_contra"], g["labels_contra"])
+    assert torch.equal(info["mask_contra"], g["mask_contra"])
+    close(info["pred_2d"], g["pred_2d"])
+    close(info["ce"], g["ce"], rtol=1e-5)
+    close(info["lov"], g["lov"], rtol=1e-5)
+    close(info["contrast"], g["contrast"], rtol=1e-5)
+    close(st["prototypes"], g["new_prototypes"])
+    # fp32 conditioning: the reference's OWN fp32 gradients move by ~0.5-1 % of max|grad|
+    # (median over tensors, up to ~7 % for single tensors) when the input is perturbed by one
+    # ulp or when the evaluation order changes -- measured with this oracle in fp32 vs float64
+    # and vs x*(1+1e-7), at 64x128 and 64x512 alike; in float64 this oracle and the reference
+    # agree to <1e-8 on every tensor.  So whole-network gradients can only be compared at that
+    # noise level; the tight (1e-4) gradient checks are done per kernel / per block.
+    checked, errs = 0, []
+    for k, gr in grads.items():
+        if gr is None:
+            assert f"gnorm/{k}" not in g
+            continue
+        ref_norm = float(g[f"gnorm/{k}"])
+        ref = g[f"grad/{k}"]
+        sub = gr if gr.numel() <= 4096 else gr.reshape(-1)[:: max(gr.numel() // 2048, 1)]
+        if k == "projector.proj.0.bias":      # exactly cancelled by the BatchNorm that follows
+            assert float(gr.abs().max()) < 1e-6
+            continue
+        assert abs(float(gr.norm()) - ref_norm) <= 2e-2 * ref_norm + 1e-9, k
+        errs.append(float((sub - ref).abs().max()) / (float(ref.abs().max()) + 1e-12))
+        checked += 1
+    assert np.median(errs) < 2e-2 and max(errs) < 0.25, (np.median(errs), max(errs))
+    assert checked > 150
+    # AdamW (trainer.py:146-151: defaults, lr from config) on a few tensors
+    for k in ("downCntx.conv1.weight", "resBlock3.bn2.bias", "cls_head.weight",
+              "projector.proj.3.bias", "upBlock2.conv4.bias"):
+        p = st[k].detach().clone()
+        oc.adamw_update(p, g[f"grad/{k}"].reshape(p.shape), torch.zeros_like(p), torch.zeros_like(p), 1, 1e-3)
+        close(p, g[f"after/{k}"], rtol=1e-5, atol=1e-7)
