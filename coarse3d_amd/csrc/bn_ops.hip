@@ -1,0 +1,265 @@
+// Train-mode BatchNorm2d pieces around the conv engine (gfx950, HBM-bound reductions).
+//
+// Forward: the conv epilogue leaves per-tile (sum, sumsq) partials; stat_reduce folds them in
+// fp64, bn_finalize turns them into the per-channel affine (scale, shift) that CONSUMERS apply
+// on load, and updates running statistics (momentum 0.1, unbiased variance) exactly like
+// nn.BatchNorm2d in pc_processor/models/salsanext_proto.py:46,50,89-105,168-180 and
+// projector.py:20.  Between stat_reduce and bn_finalize the fp64 sums can be all-reduced across
+// ranks (SyncBatchNorm, tasks/weak_segmentation/trainer.py:54).
+//
+// Backward (autograd of LeakyReLU -> BatchNorm, or BatchNorm -> LeakyReLU for the projector):
+//   bn_bwd_reduce : per-channel sum(dy), sum(dy * a)            (partials, then stat_reduce)
+//   bn_bwd_coeffs : k1,k2,k3 with  da = k1*dy + k2*a + k3, plus dgamma, dbeta
+//   bn_bwd_apply  : dz = LeakyReLU'(.) * da   and per-channel sum(dz) partials (bias gradient)
+#include "common.h"
+#include "../../include/coarse3d_hip.h"
+
+namespace {
+
+// partial [n][C][2] fp32  ->  sums [C][2] fp64.  block = 8 row-lanes x 32 channels
+__global__ __launch_bounds__(256) void stat_reduce_kernel(const float* __restrict__ partial, int n, int C,
+                                                         double* __restrict__ sums) {
+  __shared__ double red[8][32][2];
+  const int ch = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + ch;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int t = rl; t < n; t += 8) {
+      const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)t * C + c) * 2);
+      s1 += (double)v.x;
+      s2 += (double)v.y;
+    }
+  }
+  red[rl][ch][0] = s1;
+  red[rl][ch][1] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      s1 += red[k][ch][0];
+      s2 += red[k][ch][1];
+    }
+    sums[c * 2 + 0] = s1;
+    sums[c * 2 + 1] = s2;
+  }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean, float* running_var,
+                                   float momentum, float eps, int C, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = sums[c * 2] / count;
+  double var = sums[c * 2 + 1] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = invstd;
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                      int C, float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(rv[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+struct BwdArgs {
+  const float* dy; int dy_cs;
+  const float* a; int a_cs;
+  int npix, C, mode;
+  const float* pre_scale; const float* pre_shift;   // mode 1: y = a*pre_scale + pre_shift
+  const float* k1; const float* k2; const float* k3;
+  float* dz; int dz_cs;
+  float* partial;            // [gridDim.x][C][2]
+  int pix_per_block;
+};
+
+// thread = (pixel lane, channel quad); block walks a contiguous pixel chunk
+template <bool APPLY>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
+  extern __shared__ float red[];  // [PL][C][2]
+  const int Q = p.C >> 2;
+  const int PL = max(256 / Q, 1);
+  const int tid = threadIdx.x;
+  const int pl = tid / Q, c = (tid % Q) * 4;
+  const bool active = tid < PL * Q;
+  const int p0 = blockIdx.x * p.pix_per_block;
+  const int p1 = min(p0 + p.pix_per_block, p.npix);
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    f32x4 ps = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+    f32x4 k1 = {1.f, 1.f, 1.f, 1.f}, k2 = {0.f, 0.f, 0.f, 0.f}, k3 = {0.f, 0.f, 0.f, 0.f};
+    if (p.mode == 1) {
+      ps = *reinterpret_cast<const f32x4*>(p.pre_scale + c);
+      psh = *reinterpret_cast<const f32x4*>(p.pre_shift + c);
+    }
+    if (APPLY && p.mode != 2) {
+      k1 = *reinterpret_cast<const f32x4*>(p.k1 + c);
+      k2 = *reinterpret_cast<const f32x4*>(p.k2 + c);
+      k3 = *reinterpret_cast<const f32x4*>(p.k3 + c);
+    }
+    for (int i = p0 + pl; i < p1; i += PL) {
+      f32x4 dy = *reinterpret_cast<const f32x4*>(p.dy + (size_t)i * p.dy_cs + c);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p.a + (size_t)i * p.a_cs + c);
+      if (p.mode == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dy[q] *= (a[q] * ps[q] + psh[q] > 0.f) ? 1.f : C3D_LRELU_SLOPE;
+      }
+      if (!APPLY) {
+        s1 += dy;
+        s2 += dy * a;
+      } else {
+        f32x4 dz;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float da = k1[q] * dy[q] + k2[q] * a[q] + k3[q];
+          if (p.mode != 1) da *= (a[q] > 0.f) ? 1.f : C3D_LRELU_SLOPE;
+          dz[q] = da;
+        }
+        *reinterpret_cast<f32x4*>(p.dz + (size_t)i * p.dz_cs + c) = dz;
+        s1 += dz;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      red[(pl * p.C + c + q) * 2 + 0] = s1[q];
+      red[(pl * p.C + c + q) * 2 + 1] = s2[q];
+    }
+  }
+  __syncthreads();
+  for (int ch = tid; ch < p.C; ch += 256) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int k = 0; k < PL; ++k) {
+      t1 += red[(k * p.C + ch) * 2 + 0];
+      t2 += red[(k * p.C + ch) * 2 + 1];
+    }
+    float* o = p.partial + ((size_t)blockIdx.x * p.C + ch) * 2;
+    o[0] = t1;
+    o[1] = t2;
+  }
+}
+
+__global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums, double count, const float* __restrict__ mean,
+                                     const float* __restrict__ invstd, const float* __restrict__ gamma, int C,
+                                     float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ k3,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double sdy = sums[c * 2], sdya = sums[c * 2 + 1];
+  const double mu = mean[c], is = invstd[c], g = gamma[c];
+  const double sdyx = is * (sdya - mu * sdy);   // sum(dy * xhat)
+  const double kk1 = g * is;
+  const double kk2 = -g * is * is * sdyx / count;
+  const double kk3 = -g * is * sdy / count - kk2 * mu;
+  k1[c] = (float)kk1;
+  k2[c] = (float)kk2;
+  k3[c] = (float)kk3;
+  dgamma[c] = (float)sdyx;
+  dbeta[c] = (float)sdy;
+}
+
+// column `col` of fp64 sums [C][2] -> fp32 vector (bias gradients)
+__global__ void sums_to_f32_kernel(const double* __restrict__ sums, int C, int col, float* __restrict__ out,
+                                   int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float v = (float)sums[c * 2 + col];
+  out[c] = accumulate ? out[c] + v : v;
+}
+
+}  // namespace
+
+extern "C" int c3d_stat_reduce(const float* partial, int n, int C, double* sums, c3d_stream stream) {
+  hipLaunchKernelGGL(stat_reduce_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, n, C, sums);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps, int C,
+                               float* scale, float* shift, float* save_mean, float* save_invstd,
+                               c3d_stream stream) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count,
+                     gamma, beta, running_mean, running_var, momentum, eps, C, scale, shift, save_mean,
+                     save_invstd);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, int C, float* scale, float* shift,
+                                  c3d_stream stream) {
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, C, scale, shift);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_bn_bwd_num_blocks(int npix) {
+  int nb = (npix + 255) / 256;
+  return nb > 1024 ? 1024 : (nb < 1 ? 1 : nb);
+}
+
+static int bn_bwd_launch(bool apply, const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C, int mode,
+                         const float* pre_scale, const float* pre_shift, const float* k1, const float* k2,
+                         const float* k3, float* dz, int dz_cs, float* partial, hipStream_t st) {
+  C3D_REQUIRE(C % 4 == 0 && C <= 1024, "bn_bwd: C must be a multiple of 4 and <= 1024");
+  C3D_REQUIRE(dy_cs % 4 == 0 && a_cs % 4 == 0 && (!apply || dz_cs % 4 == 0), "bn_bwd: strides must be multiples of 4");
+  BwdArgs p;
+  p.dy = dy; p.dy_cs = dy_cs; p.a = a; p.a_cs = a_cs; p.npix = npix; p.C = C; p.mode = mode;
+  p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.k1 = k1; p.k2 = k2; p.k3 = k3;
+  p.dz = dz; p.dz_cs = dz_cs; p.partial = partial;
+  const int nb = c3d_bn_bwd_num_blocks(npix);
+  p.pix_per_block = (npix + nb - 1) / nb;
+  const int Q = C / 4;
+  const int PL = 256 / Q > 0 ? 256 / Q : 1;
+  const size_t lds = (size_t)PL * C * 2 * sizeof(float);
+  if (apply) hipLaunchKernelGGL(bn_bwd_kernel<true>, dim3(nb), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(bn_bwd_kernel<false>, dim3(nb), dim3(256), lds, st, p);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_bn_bwd_reduce(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C, int mode,
+                                 const float* pre_scale, const float* pre_shift, float* partial,
+                                 c3d_stream stream) {
+  return bn_bwd_launch(false, dy, dy_cs, a, a_cs, npix, C, mode, pre_scale, pre_shift, nullptr, nullptr, nullptr,
+                       nullptr, 0, partial, (hipStream_t)stream);
+}
+
+extern "C" int c3d_bn_bwd_coeffs(const double* sums, double count, const float* mean, const float* invstd,
+                                 const float* gamma, int C, float* k1, float* k2, float* k3, float* dgamma,
+                                 float* dbeta, c3d_stream stream) {
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count,
+                     mean, invstd, gamma, C, k1, k2, k3, dgamma, dbeta);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_bn_bwd_apply(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C, int mode,
+                                const float* pre_scale, const float* pre_shift, const float* k1, const float* k2,
+                                const float* k3, float* dz, int dz_cs, float* partial, c3d_stream stream) {
+  return bn_bwd_launch(true, dy, dy_cs, a, a_cs, npix, C, mode, pre_scale, pre_shift, k1, k2, k3, dz, dz_cs, partial,
+                       (hipStream_t)stream);
+}
+
+extern "C" int c3d_sums_to_f32(const double* sums, int C, int col, float* out, int accumulate, c3d_stream stream) {
+  hipLaunchKernelGGL(sums_to_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, col, out,
+                     accumulate);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,53 @@
+// Shared device/host helpers for the COARSE3D gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define C3D_LRELU_SLOPE 0.01f
+#define C3D_MAX_SRC 3
+#define C3D_MAX_TAPS 9
+
+__device__ __forceinline__ float c3d_lrelu(float v) { return v > 0.f ? v : C3D_LRELU_SLOPE * v; }
+
+// Bijective XCD-aware remap: consecutive logical tiles land on the same XCD (block b runs on
+// XCD b % 8 on MI355X), so neighbouring tiles that share halos / weights hit one L2.
+__device__ __forceinline__ int c3d_xcd_remap(int bid, int n) {
+  const int nx = 8;
+  int q = n / nx, r = n % nx;
+  int xcd = bid % nx, idx = bid / nx;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// wave-level sum over 64 lanes
+__device__ __forceinline__ float c3d_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double c3d_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// host-side error plumbing (c_api.cpp owns the storage)
+extern "C" void c3d_set_error(const char* msg);
+#define C3D_CHECK_LAUNCH()                                        \
+  do {                                                            \
+    hipError_t e_ = hipGetLastError();                            \
+    if (e_ != hipSuccess) {                                       \
+      c3d_set_error(hipGetErrorString(e_));                       \
+      return 1;                                                   \
+    }                                                             \
+  } while (0)
+#define C3D_REQUIRE(cond, msg)    \
+  do {                            \
+    if (!(cond)) {                \
+      c3d_set_error(msg);         \
+      return 2;                   \
+    }                             \
+  } while (0)

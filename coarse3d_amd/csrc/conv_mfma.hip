@@ -1,0 +1,307 @@
+// Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+// Replaces nn.Conv2d + LeakyReLU (+ the batch statistics of the BatchNorm2d that follows) of
+// the SalsaNext blocks (reference pc_processor/models/salsanext_proto.py:41-62, 82-132,
+// 164-208, 318 and projector.py:18-23).  The same kernel computes input gradients when given
+// transposed weights and negated tap offsets.
+//
+// GEMM view: M = pixels (a TR x 32 spatial tile per workgroup), N = Cout (32*NT per
+// workgroup), K = taps x Cin.  Per Cin chunk of CK channels the input tile (+halo) and the
+// weight slab of every tap are staged in LDS; the BatchNorm affine of the PRODUCER layer is
+// applied while staging (zero padding afterwards), so normalised tensors never exist in HBM.
+// LDS rows are padded to CK+4 floats: ds_read_b128 / ds_write_b128 conflict-free.
+//   A fragment: lane l reads 4 consecutive k of pixel (l&31), k-half (l>>5)
+//   B fragment: lane l reads 4 consecutive k of cout  (l&31), same k-half
+// so one b128 read per operand feeds 4 MFMAs.  Accumulator (32x32): lane holds cout l&31 for
+// 16 pixels -> stores are 128 B contiguous per pixel.
+#include "common.h"
+#include "../../include/coarse3d_hip.h"
+
+namespace {
+
+struct ConvArgs {
+  c3d_src src[C3D_MAX_SRC];
+  int nsrc;
+  int B, H, W, Cout;
+  int T;
+  int dy[C3D_MAX_TAPS];
+  int dx[C3D_MAX_TAPS];
+  const float* wpack;
+  const float* bias;
+  int epi_lrelu;
+  float* out;
+  int out_cstride, out_coff, accumulate;
+  float* stat_partial;
+  int tiles_x, tiles_y, Kq;  // Kq = padded K / 4 (rows of the packed weight per tap)
+};
+
+template <int TR, int NT, int CK, int HALO>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
+  constexpr int CS = CK + 4;
+  constexpr int TWh = 32 + 2 * HALO;
+  constexpr int THh = TR + 2 * HALO;
+  constexpr int TN = 32 * NT;
+  constexpr int WM = (TR >= 4) ? 4 : TR;  // waves along tile rows
+  constexpr int WN = 4 / WM;              // waves along cout tiles
+  constexpr int RPW = TR / WM;
+  constexpr int NPW = NT / WN;
+  static_assert(NT % WN == 0, "NT must split across waves");
+  constexpr int CQ = CK / 4;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_in = smem;                    // [THh][TWh][CS]
+  float* s_w = smem + THh * TWh * CS;    // [T][TN][CS]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave % WM, wn = wave / WM;
+
+  const int ntile = a.B * a.tiles_y * a.tiles_x;
+  int mt = c3d_xcd_remap(blockIdx.x, ntile);
+  const int tx = mt % a.tiles_x;
+  const int ty = (mt / a.tiles_x) % a.tiles_y;
+  const int b = mt / (a.tiles_x * a.tiles_y);
+  const int x0 = tx * 32, y0 = ty * TR;
+  const int n0 = blockIdx.y * TN;
+
+  f32x16 acc[RPW][NPW];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i)
+#pragma unroll
+    for (int j = 0; j < NPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int kbase = 0;  // first k (input channel) of the current source inside the packed weights
+  for (int s = 0; s < a.nsrc; ++s) {
+    const c3d_src sr = a.src[s];
+    for (int c0 = 0; c0 < sr.C; c0 += CK) {
+      __syncthreads();
+      // ---- stage input tile: (THh x TWh) pixels x CK channels, transform on load
+      for (int u = tid; u < THh * TWh * CQ; u += 256) {
+        const int c4 = u % CQ;
+        const int p = u / CQ;
+        const int px = p % TWh, py = p / TWh;
+        const int gx = x0 + px - HALO, gy = y0 + py - HALO;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H) {
+          const size_t off = ((size_t)(b * a.H + gy) * a.W + gx) * sr.cstride + sr.coff + c0 + c4 * 4;
+          v = *reinterpret_cast<const f32x4*>(sr.ptr + off);
+          if (sr.scale) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(sr.scale + c0 + c4 * 4);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(sr.shift + c0 + c4 * 4);
+            v = v * sc + sh;
+          }
+          if (sr.lrelu) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q]);
+          }
+        }
+        *reinterpret_cast<f32x4*>(s_in + p * CS + c4 * 4) = v;
+      }
+      // ---- stage weights of all taps for this K chunk: [t][n][k]
+      const int kq0 = (kbase + c0) >> 2;
+      for (int u = tid; u < a.T * TN * CQ; u += 256) {
+        const int n = u % TN;
+        const int r = u / TN;
+        const int kq = r % CQ, t = r / CQ;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n0 + n < a.Cout)
+          v = *reinterpret_cast<const f32x4*>(a.wpack + (((size_t)t * a.Kq + kq0 + kq) * a.Cout + n0 + n) * 4);
+        *reinterpret_cast<f32x4*>(s_w + (t * TN + n) * CS + kq * 4) = v;
+      }
+      __syncthreads();
+      // ---- MFMA over taps x k
+      for (int t = 0; t < a.T; ++t) {
+        const int tap_off = ((HALO + a.dy[t]) * TWh + (HALO + a.dx[t]) + l31) * CS + half * 4;
+        const float* wb = s_w + (t * TN + wn * NPW * 32 + l31) * CS + half * 4;
+#pragma unroll
+        for (int kk = 0; kk < CK / 8; ++kk) {
+          f32x4 av[RPW], bv[NPW];
+#pragma unroll
+          for (int i = 0; i < RPW; ++i)
+            av[i] = *reinterpret_cast<const f32x4*>(s_in + (wm + i * WM) * TWh * CS + tap_off + kk * 8);
+#pragma unroll
+          for (int j = 0; j < NPW; ++j)
+            bv[j] = *reinterpret_cast<const f32x4*>(wb + j * 32 * CS + kk * 8);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < RPW; ++i)
+#pragma unroll
+              for (int j = 0; j < NPW; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    kbase += sr.C;
+  }
+
+  // ---- epilogue: bias, LeakyReLU, store, per-tile channel statistics
+  float s1[NPW], s2[NPW];
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) {
+    const int co = n0 + (wn * NPW + j) * 32 + l31;
+    const bool cok = co < a.Cout;
+    const float bias = (a.bias && cok) ? a.bias[co] : 0.f;
+    s1[j] = 0.f;
+    s2[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int gy = y0 + wm + i * WM;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[i][j][r] + bias;
+        if (a.epi_lrelu) v = c3d_lrelu(v);
+        if (cok && gy < a.H && gx < a.W) {
+          float* o = a.out + ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co;
+          if (a.accumulate) v += *o;
+          *o = v;
+          s1[j] += v;
+          s2[j] += v * v;
+        }
+      }
+    }
+  }
+  if (a.stat_partial) {
+    __syncthreads();
+    float* red = smem;  // [WM][TN][2]
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+      float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+      float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+      if (half == 0) {
+        const int n = (wn * NPW + j) * 32 + l31;
+        red[(wm * TN + n) * 2 + 0] = t1;
+        red[(wm * TN + n) * 2 + 1] = t2;
+      }
+    }
+    __syncthreads();
+    for (int n = tid; n < TN; n += 256) {
+      if (n0 + n < a.Cout) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          t1 += red[(w * TN + n) * 2 + 0];
+          t2 += red[(w * TN + n) * 2 + 1];
+        }
+        float* sp = a.stat_partial + ((size_t)mt * a.Cout + n0 + n) * 2;
+        sp[0] = t1;
+        sp[1] = t2;
+      }
+    }
+  }
+}
+
+template <int TR, int NT, int CK, int HALO>
+int launch_cfg(const ConvArgs& a, hipStream_t st) {
+  constexpr int CS = CK + 4;
+  const size_t lds = ((size_t)(TR + 2 * HALO) * (32 + 2 * HALO) + (size_t)a.T * 32 * NT) * CS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TR, NT, CK, HALO>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(a.B * a.tiles_x * a.tiles_y, (a.Cout + 32 * NT - 1) / (32 * NT));
+  hipLaunchKernelGGL((conv_mfma_kernel<TR, NT, CK, HALO>), grid, dim3(256), lds, st, a);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int TR, int NT>
+int launch_halo(const ConvArgs& a, int halo, hipStream_t st) {
+  switch (halo) {
+    case 0: return launch_cfg<TR, NT, 16, 0>(a, st);
+    case 1: return launch_cfg<TR, NT, 16, 1>(a, st);
+    default: return launch_cfg<TR, NT, 16, 2>(a, st);
+  }
+}
+
+}  // namespace
+
+// tile rows chosen from the image height only, so that every conv over the same [B,H,W]
+// produces the same number of statistic partials
+static int c3d_tile_rows(int H) { return H >= 8 ? 8 : (H >= 4 ? 4 : 2); }
+
+extern "C" int c3d_conv_num_mtiles(int B, int H, int W) {
+  const int tr = c3d_tile_rows(H);
+  return B * ((H + tr - 1) / tr) * ((W + 31) / 32);
+}
+
+extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
+  C3D_REQUIRE(d->nsrc >= 1 && d->nsrc <= C3D_MAX_SRC, "conv: nsrc must be 1..3");
+  C3D_REQUIRE(d->ntaps >= 1 && d->ntaps <= C3D_MAX_TAPS, "conv: ntaps must be 1..9");
+  ConvArgs a;
+  int K = 0, halo = 0;
+  for (int s = 0; s < d->nsrc; ++s) {
+    C3D_REQUIRE(d->src[s].C % 16 == 0 && d->src[s].C > 0, "conv: source channels must be a multiple of 16");
+    C3D_REQUIRE(d->src[s].cstride % 4 == 0 && d->src[s].coff % 4 == 0, "conv: source stride/offset must be multiples of 4");
+    a.src[s] = d->src[s];
+    K += d->src[s].C;
+  }
+  for (int t = 0; t < d->ntaps; ++t) {
+    a.dy[t] = d->tap_dy[t];
+    a.dx[t] = d->tap_dx[t];
+    int m = abs(d->tap_dy[t]) > abs(d->tap_dx[t]) ? abs(d->tap_dy[t]) : abs(d->tap_dx[t]);
+    if (m > halo) halo = m;
+  }
+  C3D_REQUIRE(halo <= 2, "conv: tap offsets beyond +-2 are not supported");
+  a.nsrc = d->nsrc;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.T = d->ntaps;
+  a.wpack = d->wpack; a.bias = d->bias; a.epi_lrelu = d->epi_lrelu;
+  a.out = d->out; a.out_cstride = d->out_cstride; a.out_coff = d->out_coff;
+  a.accumulate = d->accumulate;
+  a.stat_partial = d->stat_partial;
+  const int tr = c3d_tile_rows(d->H);
+  a.tiles_x = (d->W + 31) / 32;
+  a.tiles_y = (d->H + tr - 1) / tr;
+  a.Kq = K / 4;
+  hipStream_t st = (hipStream_t)stream;
+  const bool wide = d->Cout > 32;
+  if (tr == 8) return wide ? launch_halo<8, 2>(a, halo, st) : launch_halo<8, 1>(a, halo, st);
+  if (tr == 4) return wide ? launch_halo<4, 2>(a, halo, st) : launch_halo<4, 1>(a, halo, st);
+  return launch_halo<2, 2>(a, halo, st);
+}
+
+// ------------------------------------------------------------------ weight repack
+namespace {
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin,
+                                    int T, int mode, int c_off, int c_cnt, int Kpad) {
+  // dst[t][kq][n][j]
+  const int N = mode == 0 ? Cout : c_cnt;
+  const int K = mode == 0 ? c_cnt : Cout;
+  const size_t total = (size_t)T * (Kpad / 4) * N * 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 3;
+    size_t r = i >> 2;
+    const int n = r % N;
+    r /= N;
+    const int kq = r % (Kpad / 4);
+    const int t = r / (Kpad / 4);
+    const int k = kq * 4 + j;
+    float v = 0.f;
+    if (k < K) {
+      if (mode == 0) v = w[((size_t)n * Cin + c_off + k) * T + t];
+      else v = w[((size_t)k * Cin + c_off + n) * T + t];
+    }
+    dst[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int c3d_pack_weights(const float* w_oihw, float* dst, int Cout, int Cin, int T, int mode,
+                                int c_off, int c_cnt, int Kpad, c3d_stream stream) {
+  C3D_REQUIRE(Kpad % 16 == 0, "pack: Kpad must be a multiple of 16");
+  const int N = mode == 0 ? Cout : c_cnt;
+  const size_t total = (size_t)T * (Kpad / 4) * N * 4;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, dst, Cout,
+                     Cin, T, mode, c_off, c_cnt, Kpad);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,82 @@
+"""conv / wgrad MFMA engines vs plain PyTorch fp32 (F.conv2d on CPU).  Tolerance 1e-4 of
+max|ref| (fp32 MFMA == fmaf chain; only the summation order differs)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+CASES = [
+    # B, H, W, srcC (list), Cout, kh, dil, pad
+    (2, 16, 64, [32], 32, 3, 1, 1),
+    (2, 16, 64, [32], 64, 3, 2, 2),
+    (1, 8, 96, [64], 64, 2, 2, 1),
+    (2, 4, 40, [64, 64, 64], 64, 1, 1, 0),
+    (1, 3, 113, [48, 32], 32, 3, 1, 1),
+    (2, 2, 64, [256], 256, 3, 2, 2),
+    (1, 32, 32, [32], 20, 1, 1, 0),
+    (1, 8, 64, [128], 400, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("B,H,W,srcC,Cout,k,dil,pad", CASES)
+def test_conv_forward_and_grads(B, H, W, srcC, Cout, k, dil, pad):
+    from coarse3d_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + H + W + Cout)
+    Cin = sum(srcC)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in srcC]
+    scs = [torch.rand(c, generator=g) + 0.5 for c in srcC]
+    shs = [torch.randn(c, generator=g) * 0.3 for c in srcC]
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    xin = torch.cat([x * s[None, :, None, None] + t[None, :, None, None] for x, s, t in zip(xs, scs, shs)], 1)
+    xin.requires_grad_(True)
+    w_ref = w.clone().requires_grad_(True)
+    z = F.conv2d(xin, w_ref, bias, padding=pad, dilation=dil)
+    y_ref = F.leaky_relu(z, 0.01)
+    dz = torch.randn(z.shape, generator=g)
+    z.backward(dz)
+
+    dev = "cuda"
+    taps = ops.conv_taps(k, k, dil, pad)
+    srcs = [ops.Source(ops.to_nhwc(x).to(dev), s.to(dev), t.to(dev)) for x, s, t in zip(xs, scs, shs)]
+    wp = ops.pack_weights(w.to(dev), mode=0)
+    y, partial = ops.conv_forward(srcs, wp, bias.to(dev), Cout, taps, lrelu=True, stats=True)
+    torch.cuda.synchronize()
+    y_cpu = ops.from_nhwc(y.cpu())
+    assert rel_err(y_cpu, y_ref.detach()) < 1e-4
+    # per-tile statistics sum up to the channel sums
+    sums = partial.double().sum(0).cpu()
+    ref1 = y_ref.detach().double().sum(dim=(0, 2, 3))
+    ref2 = (y_ref.detach().double() ** 2).sum(dim=(0, 2, 3))
+    assert float((sums[:, 0] - ref1).abs().max()) < 1e-4 * float(ref2.max()) ** 0.5 * (B * H * W) ** 0.5
+    assert rel_err(sums[:, 1], ref2) < 1e-4
+
+    # input gradient = conv with transposed weights and negated taps
+    dzd = ops.to_nhwc(dz).to(dev)
+    if Cout % 16:       # K of the dgrad GEMM must be a multiple of 16: zero-pad dz channels
+        dzp = torch.zeros(B, H, W, (Cout + 15) // 16 * 16, device=dev)
+        dzp[..., :Cout] = dzd
+        dzd = dzp
+    off = 0
+    for x, s, c in zip(xs, scs, srcC):
+        wd = ops.pack_weights(w.to(dev), mode=1, c_off=off, c_cnt=c)
+        dx, _ = ops.conv_forward([ops.Source(dzd)], wd, None, c, ops.negate_taps(taps))
+        torch.cuda.synchronize()
+        ref = xin.grad[:, off:off + c]
+        assert rel_err(ops.from_nhwc(dx.cpu()), ref) < 1e-4
+        off += c
+    # weight gradient
+    dw = torch.zeros_like(w, device=dev)
+    off = 0
+    for src, c in zip(srcs, srcC):
+        ops.conv_wgrad(src, dzd, dw, taps, cin_off=off)
+        off += c
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), w_ref.grad) < 1e-4
