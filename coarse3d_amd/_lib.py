@@ -46,9 +46,36 @@ def lib():
                 "(run `python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`make -C coarse3d_amd/csrc`). There is no CPU fallback.")
         _lib = C.CDLL(LIB_PATH)
-        _lib.c3d_last_error.restype = C.c_char_p
-        _lib.c3d_wgrad_partial_floats.restype = C.c_int64
+        for name, (res, args) in prototypes().items():
+            fn = getattr(_lib, name)          # AttributeError = header/library mismatch
+            fn.restype, fn.argtypes = res, args
     return _lib
+
+
+_CTYPES = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "float": C.c_float,
+           "double": C.c_double, "c3d_stream": C.c_void_p, "void": None}
+
+
+def prototypes():
+    """{symbol: (restype, argtypes)} parsed from include/coarse3d_hip.h -- the header is the
+    single source of truth for the ABI."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "coarse3d_hip.h")
+    txt = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
+    out = {}
+    for m in re.finditer(r"([A-Za-z_0-9 ]+?[ \*]+)(c3d_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", txt):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        res = C.c_char_p if "char" in ret else _CTYPES[ret.replace("const", "").strip()]
+        at = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    at.append(C.c_void_p)
+                else:
+                    at.append(_CTYPES[a.replace("const", "").split()[0]])
+        out[name] = (res, at)
+    return out
 
 
 def check(rc, what):
@@ -57,8 +84,5 @@ def check(rc, what):
 
 
 def exported_symbols():
-    """Every entry point declared in include/coarse3d_hip.h (parsed from the header)."""
-    import re
-    hdr = os.path.join(os.path.dirname(_HERE), "include", "coarse3d_hip.h")
-    txt = open(hdr).read()
-    return sorted(set(re.findall(r"\b(c3d_[a-z0-9_]+)\s*\(", txt)))
+    """Every entry point declared in include/coarse3d_hip.h."""
+    return sorted(prototypes())

@@ -1,0 +1,353 @@
+"""SalsaNext-style range-image backbone: hand-orchestrated forward / backward over the HIP ops.
+
+Mirrors the arithmetic of the reference ``SalsaNextProto.forward`` encoder / decoder / head /
+embedding branch (pc_processor/models/salsanext_proto.py:423-492, blocks :38-212,
+projector.py:11-27) with an MI355X-first dataflow:
+
+* activations are NHWC fp32 and every conv stores its *pre-BatchNorm* output ``a``; the
+  BatchNorm affine (scale, shift) is applied by the consumers while they stage their input
+  tiles in LDS, so the 43 normalised tensors never exist in HBM;
+* batch statistics come out of the conv epilogue as per-tile partials (deterministic two-stage
+  reduction, fp64 fold) -- the hook ``reduce_fn`` lets data-parallel ranks all-reduce the
+  fp64 sums (SyncBatchNorm semantics, tasks/weak_segmentation/trainer.py:54);
+* backward is explicit (no autograd tape): per layer BN-backward reduce -> coefficients ->
+  dz, then MFMA wgrad and MFMA dgrad (the forward conv kernel with transposed weights).
+
+Parameter tensors are taken by *reference-compatible names* (``downCntx.conv1.weight`` ...)
+in OIHW layout, gradients are produced in the same layout.
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class Act:
+    """An activation tensor as consumers see it: raw NHWC tensor + optional affine of its BN."""
+    __slots__ = ("t", "scale", "shift", "grad", "mask")
+
+    def __init__(self, t, scale=None, shift=None, mask=None):
+        self.t, self.scale, self.shift = t, scale, shift
+        self.grad = None      # gradient w.r.t. the affine-transformed value (NHWC, same shape)
+        self.mask = mask      # Dropout2d multiplier [B,C] applied by the consumer (UpBlock out)
+
+    def src(self, lrelu=False):
+        return ops.Source(self.t, self.scale, self.shift, lrelu=lrelu)
+
+
+class _ConvRec:
+    __slots__ = ("name", "srcs", "src_lrelu", "taps", "cout", "mode", "bn", "out", "stats")
+
+
+class _BNRec:
+    __slots__ = ("name", "mean", "invstd", "scale", "shift", "count")
+
+
+class Backbone:
+    def __init__(self, params, nclasses=20, dataset="SemanticKitti", reduce_fn=None, world_size=1):
+        """params: mapping name -> CUDA tensor (the module's parameters and buffers)."""
+        self.P = params
+        self.ncls = nclasses
+        self.dataset = dataset
+        self.reduce_fn = reduce_fn
+        self.world = world_size
+        self.tape = None
+
+    # ------------------------------------------------------------------ forward helpers
+    def _bn_forward(self, name, partial, c, count):
+        P = self.P
+        rec = _BNRec()
+        rec.name = name
+        if self.train:
+            sums = ops.stat_reduce(partial, c)
+            if self.reduce_fn is not None:
+                self.reduce_fn(sums)
+                count = count * self.world
+            rec.scale, rec.shift, rec.mean, rec.invstd = ops.bn_finalize(
+                sums, count, P[f"{name}.weight"], P[f"{name}.bias"],
+                P[f"{name}.running_mean"] if self.update_running else None,
+                P[f"{name}.running_var"] if self.update_running else None, BN_MOMENTUM, BN_EPS)
+            rec.count = count
+            self.bn_seen.append(name)
+        else:
+            rec.scale, rec.shift = ops.bn_eval_affine(P[f"{name}.weight"], P[f"{name}.bias"],
+                                                      P[f"{name}.running_mean"], P[f"{name}.running_var"], BN_EPS)
+            rec.mean = rec.invstd = None
+            rec.count = count
+        return rec
+
+    def _conv(self, name, srcs, k, dil, pad, lrelu=True, bn=None, src_lrelu=False, cout_pad=None):
+        """srcs: list[Act].  Returns Act of the conv output (pre-BN tensor + BN affine)."""
+        w = self.P[f"{name}.weight"]
+        cout = w.shape[0]
+        taps = ops.conv_taps(k, k, dil, pad)
+        wp = ops.pack_weights(w, 0)
+        b, h, wd = srcs[0].t.shape[:3]
+        out = None
+        if cout_pad is not None and cout_pad != cout:
+            out = torch.zeros(b, h, wd, cout_pad, device=w.device, dtype=torch.float32)
+        need_stats = bn is not None and self.train
+        y, partial = ops.conv_forward([s.src(src_lrelu) for s in srcs], wp, self.P[f"{name}.bias"], cout, taps,
+                                      lrelu=lrelu, stats=need_stats, out=out)
+        rec = _ConvRec()
+        rec.name, rec.srcs, rec.src_lrelu, rec.taps, rec.cout = name, srcs, src_lrelu, taps, cout
+        rec.mode = 0 if (lrelu and bn) else (2 if lrelu else (1 if bn else 3))
+        rec.bn = self._bn_forward(bn, partial, cout, b * h * wd) if bn is not None else None
+        rec.out = Act(y, rec.bn.scale if rec.bn else None, rec.bn.shift if rec.bn else None)
+        self.tape[name] = rec
+        return rec.out
+
+    def _mask(self, name):
+        if not self.train or self.masks is None:
+            return None
+        return self.masks.get(name)
+
+    # ------------------------------------------------------------------ blocks (forward)
+    def _ctx_block(self, name, xin, first=False):
+        if first:
+            w = self.P[f"{name}.conv1.weight"]
+            s_t = ops.conv_in5(xin, w.reshape(w.shape[0], -1).contiguous(), self.P[f"{name}.conv1.bias"])
+            s = Act(s_t)
+            self.tape[f"{name}.conv1"] = ("in5", xin, s)
+        else:
+            s = self._conv(f"{name}.conv1", [xin], 1, 1, 0, lrelu=True)
+        a1 = self._conv(f"{name}.conv2", [s], 3, 1, 1, bn=f"{name}.bn1")
+        a2 = self._conv(f"{name}.conv3", [a1], 3, 2, 2, bn=f"{name}.bn2")
+        out = Act(ops.affine_add(s.t, a2.t, a2.scale, a2.shift))
+        self.tape[f"{name}.out"] = (s, a2, out)
+        return out
+
+    def _res_block(self, name, xin, pooling=True, drop_out=True):
+        short = self._conv(f"{name}.conv1", [xin], 1, 1, 0, lrelu=True)
+        r1 = self._conv(f"{name}.conv2", [xin], 3, 1, 1, bn=f"{name}.bn1")
+        r2 = self._conv(f"{name}.conv3", [r1], 3, 2, 2, bn=f"{name}.bn2")
+        r3 = self._conv(f"{name}.conv4", [r2], 2, 2, 1, bn=f"{name}.bn3")
+        a5 = self._conv(f"{name}.conv5", [r1, r2, r3], 1, 1, 0, bn=f"{name}.bn4")
+        res_a = Act(ops.affine_add(short.t, a5.t, a5.scale, a5.shift))
+        mask = self._mask(f"{name}.dropout") if drop_out else None
+        if pooling or mask is not None:
+            res_b = Act(ops.maskpool(res_a.t, mask, pooling))
+        else:
+            res_b = res_a
+        self.tape[f"{name}.tail"] = (short, a5, res_a, res_b, mask, pooling)
+        return res_b, res_a
+
+    def _up_block(self, name, xin, skip, drop_out=True):
+        m1 = self._mask(f"{name}.dropout1") if drop_out else None
+        m2 = self._mask(f"{name}.dropout2") if drop_out else None
+        up_b = Act(ops.pixshuf_cat(xin.t, xin.scale, xin.shift, xin.mask, m1, m2, skip.t))
+        e1 = self._conv(f"{name}.conv1", [up_b], 3, 1, 1, bn=f"{name}.bn1")
+        e2 = self._conv(f"{name}.conv2", [e1], 3, 2, 2, bn=f"{name}.bn2")
+        e3 = self._conv(f"{name}.conv3", [e2], 2, 2, 1, bn=f"{name}.bn3")
+        a4 = self._conv(f"{name}.conv4", [e1, e2, e3], 1, 1, 0, bn=f"{name}.bn4")
+        a4.mask = self._mask(f"{name}.dropout3") if drop_out else None
+        self.tape[f"{name}.head"] = (xin, skip, up_b, m1, m2)
+        return a4
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, train=True, dropout_masks=None, return_feat=True, update_running=True):
+        """x [B,Cin,H,W] fp32 (NCHW, as the reference feeds it).  Returns dict with NHWC tensors:
+        prob [B,Ho,Wo,C], logits [B,H,W,32], feat [B,Ho,Wo,256] (if return_feat)."""
+        self.train, self.masks, self.update_running = train, dropout_masks, update_running
+        self.tape = OrderedDict()
+        self.bn_seen = []
+        ho, wo = x.shape[2], x.shape[3]
+        if self.dataset == "SemanticPOSS":
+            x = torch.nn.functional.pad(x, (0, 8, 0, 8))
+        x = x.contiguous()
+        assert x.shape[2] % 16 == 0 and x.shape[3] % 16 == 0, "H and W must be multiples of 16"
+        self.x = x
+        d = self._ctx_block("downCntx", x, first=True)
+        d = self._ctx_block("downCntx2", d)
+        d = self._ctx_block("downCntx3", d)
+        d0c, d0b = self._res_block("resBlock1", d, True, False)
+        d1c, d1b = self._res_block("resBlock2", d0c)
+        d2c, d2b = self._res_block("resBlock3", d1c)
+        d3c, d3b = self._res_block("resBlock4", d2c)
+        d5c, _ = self._res_block("resBlock5", d3c, pooling=False)
+        u4 = self._up_block("upBlock1", d5c, d3b)
+        u3 = self._up_block("upBlock2", u4, d2b)
+        u2 = self._up_block("upBlock3", u3, d1b)
+        u1 = self._up_block("upBlock4", u2, d0b, drop_out=False)
+        logits = self._conv("cls_head", [u1], 1, 1, 0, lrelu=False, cout_pad=32)
+        prob = ops.softmax(logits.t, self.ncls, ho, wo)
+        self._prob = prob
+        out = {"prob": prob, "logits": logits.t}
+        self.skips = (d0b, d1b, d2b, d3b)
+        self.out_hw = (ho, wo)
+        self.return_feat = return_feat
+        if return_feat:
+            b = x.shape[0]
+            hh, wh = ho // 2, wo // 2
+            feat = torch.empty(b, hh, wh, sum(s.t.shape[3] for s in self.skips), device=x.device,
+                               dtype=torch.float32)
+            off = 0
+            for s in self.skips:
+                ops.bilinear(s.t, hh, wh, dst=feat, dcoff=off, c=s.t.shape[3])
+                off += s.t.shape[3]
+            feat_a = Act(feat)
+            z0 = self._conv("projector.proj.0", [feat_a], 1, 1, 0, lrelu=False, bn="projector.proj.1")
+            emb = self._conv("projector.proj.3", [z0], 1, 1, 0, lrelu=False, src_lrelu=True)
+            embn, norm = ops.l2norm(emb.t, 1e-12)
+            feat2d = ops.bilinear(embn, ho, wo)
+            self.tape["embed"] = (feat_a, z0, emb, embn, norm)
+            out["feat"] = feat2d
+        if train and update_running:
+            torch._foreach_add_([self.P[f"{n}.num_batches_tracked"] for n in self.bn_seen], 1)
+        return out
+
+    # ------------------------------------------------------------------ backward helpers
+    def _accum(self, act, g):
+        """act.grad += g  (g is a full tensor we own)."""
+        if act.grad is None:
+            act.grad = g
+        else:
+            ops.axpy(g, act.grad)
+
+    def _conv_backward(self, name, dy):
+        """dy: gradient w.r.t. the layer's consumer-visible output (BN output if it has BN)."""
+        rec = self.tape[name]
+        a = rec.out.t
+        c = rec.cout
+        cpad = a.shape[3]
+        G = self.grads
+        if rec.mode == 0 or rec.mode == 1:
+            bn = rec.bn
+            pre_s, pre_h = (bn.scale, bn.shift) if rec.mode == 1 else (None, None)
+            part = ops.bn_bwd_reduce(dy, a, c, rec.mode, pre_s, pre_h)
+            sums = ops.stat_reduce(part, c)
+            if self.reduce_fn is not None:
+                self.reduce_fn(sums)
+            k = ops.bn_bwd_coeffs(sums, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
+                                  G[f"{bn.name}.weight"], G[f"{bn.name}.bias"])
+            dz, pz = ops.bn_bwd_apply(dy, a, c, rec.mode, k, pre_s, pre_h)
+        elif rec.mode == 2:
+            dz, pz = ops.bn_bwd_apply(dy, a, c, 2)
+        else:
+            dz, pz = ops.bn_bwd_apply(dy, dy, cpad, 3, dz=dy)
+        ops.sums_to_f32(ops.stat_reduce(pz, pz.shape[1]), 0, G[f"{name}.bias"])
+        w = self.P[f"{name}.weight"]
+        dw = G[f"{name}.weight"]
+        ntaps = ops.negate_taps(rec.taps)
+        off = 0
+        for s in rec.srcs:
+            cs = s.t.shape[3]
+            ops.conv_wgrad(s.src(rec.src_lrelu), dz, dw, rec.taps, cin_off=off)
+            if not getattr(s, "no_grad", False):
+                wd = ops.pack_weights(w, 1, c_off=off, c_cnt=cs, kpad=(dz.shape[3] + 15) // 16 * 16)
+                if s.grad is None:
+                    s.grad = torch.empty_like(s.t)
+                    acc = False
+                else:
+                    acc = True
+                ops.conv_forward([ops.Source(dz)], wd, None, cs, ntaps, out=s.grad, accumulate=acc)
+            off += cs
+        rec.out.grad = None
+
+    def _ctx_backward(self, name, first=False):
+        s, a2, out = self.tape[f"{name}.out"]
+        g = out.grad
+        out.grad = None
+        self._conv_backward(f"{name}.conv3", g)          # dy(a2) = g
+        a1 = self.tape[f"{name}.conv3"].srcs[0]
+        # s receives g (residual) + dgrad of conv2; reuse g as its gradient buffer
+        s.grad = g
+        self._conv_backward(f"{name}.conv2", a1.grad)
+        a1.grad = None
+        if first:
+            _, x, s_act = self.tape[f"{name}.conv1"]
+            dz, pz = ops.bn_bwd_apply(s.grad, s.t, 32, 2)
+            ops.sums_to_f32(ops.stat_reduce(pz, 32), 0, self.grads[f"{name}.conv1.bias"])
+            ops.conv_in5_wgrad(x, dz, self.grads[f"{name}.conv1.weight"])
+        else:
+            self._conv_backward(f"{name}.conv1", s.grad)
+        s.grad = None
+
+    def _res_backward(self, name):
+        short, a5, res_a, res_b, mask, pooling = self.tape[f"{name}.tail"]
+        if res_b is res_a:
+            d = res_a.grad
+        else:
+            d = ops.maskpool_bwd(res_b.grad, mask, res_a.grad, tuple(res_a.t.shape), pooling)
+            res_b.grad = None
+        res_a.grad = None
+        self._conv_backward(f"{name}.conv5", d)
+        r1, r2, r3 = self.tape[f"{name}.conv5"].srcs
+        self._conv_backward(f"{name}.conv4", r3.grad)
+        r3.grad = None
+        self._conv_backward(f"{name}.conv3", r2.grad)
+        r2.grad = None
+        self._conv_backward(f"{name}.conv2", r1.grad)
+        r1.grad = None
+        self._conv_backward(f"{name}.conv1", d)
+
+    def _up_backward(self, name):
+        xin, skip, up_b, m1, m2 = self.tape[f"{name}.head"]
+        a4 = self.tape[f"{name}.conv4"].out
+        self._conv_backward(f"{name}.conv4", a4.grad)
+        e1, e2, e3 = self.tape[f"{name}.conv4"].srcs
+        self._conv_backward(f"{name}.conv3", e3.grad)
+        e3.grad = None
+        self._conv_backward(f"{name}.conv2", e2.grad)
+        e2.grad = None
+        self._conv_backward(f"{name}.conv1", e1.grad)
+        e1.grad = None
+        if skip.grad is None:
+            skip.grad = torch.empty_like(skip.t)
+            acc = False
+        else:
+            acc = True
+        dxa = ops.pixshuf_cat_bwd(up_b.grad, xin.mask, m1, m2, tuple(xin.t.shape), skip.t.shape[3], skip.grad, acc)
+        up_b.grad = None
+        self._accum(xin, dxa)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, d_prob=None, d_feat=None, grads=None):
+        """d_prob [B,Ho,Wo,C], d_feat [B,Ho,Wo,256] (NHWC, either may be None).  ``grads``: optional
+        dict name -> preallocated gradient tensor (reference layout); returned filled."""
+        P = self.P
+        if grads is None:
+            grads = {k: torch.zeros_like(v) for k, v in P.items()
+                     if v.is_floating_point() and v.dim() > 0 and not k.endswith(("running_mean", "running_var"))
+                     and k not in ("prototypes", "feat_norm.weight", "feat_norm.bias", "mask_norm.weight",
+                                   "mask_norm.bias")}
+        self.grads = grads
+        d0b, d1b, d2b, d3b = self.skips
+        # ---- embedding branch first: it scatters (atomics) into zero-initialised skip gradients
+        if d_feat is not None and self.return_feat:
+            feat_a, z0, emb, embn, norm = self.tape["embed"]
+            d_embn = torch.zeros_like(embn)
+            ops.bilinear_bwd(d_embn, d_feat.contiguous())
+            d_emb = ops.l2norm_bwd(embn, norm, d_embn, 1e-12)
+            self._conv_backward("projector.proj.3", d_emb)
+            self._conv_backward("projector.proj.0", z0.grad)
+            z0.grad = None
+            off = 0
+            for s in self.skips:
+                s.grad = torch.zeros_like(s.t)
+                ops.bilinear_bwd(s.grad, feat_a.grad, dcoff=off, c=s.t.shape[3])
+                off += s.t.shape[3]
+            feat_a.grad = None
+        else:
+            for n in ("projector.proj.0", "projector.proj.1", "projector.proj.3"):
+                for suffix in ("weight", "bias"):
+                    grads[f"{n}.{suffix}"].zero_()
+        # ---- segmentation head
+        logits = self.tape["cls_head"].out
+        if d_prob is None:
+            raise ValueError("backward needs d_prob (the segmentation losses always produce it)")
+        dl = ops.softmax_bwd(self._prob, d_prob.contiguous(), tuple(logits.t.shape))
+        self._conv_backward("cls_head", dl)
+        for name in ("upBlock4", "upBlock3", "upBlock2", "upBlock1"):
+            self._up_backward(name)
+        for name in ("resBlock5", "resBlock4", "resBlock3", "resBlock2", "resBlock1"):
+            self._res_backward(name)
+        self._ctx_backward("downCntx3")
+        self._ctx_backward("downCntx2")
+        self._ctx_backward("downCntx", first=True)
+        self.tape = None
+        return grads

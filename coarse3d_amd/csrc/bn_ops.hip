@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
       ps = *reinterpret_cast<const f32x4*>(p.pre_scale + c);
       psh = *reinterpret_cast<const f32x4*>(p.pre_shift + c);
     }
-    if (APPLY && p.mode != 2) {
+    if (APPLY && p.mode < 2) {
       k1 = *reinterpret_cast<const f32x4*>(p.k1 + c);
       k2 = *reinterpret_cast<const f32x4*>(p.k2 + c);
       k3 = *reinterpret_cast<const f32x4*>(p.k3 + c);
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float da = k1[q] * dy[q] + k2[q] * a[q] + k3[q];
-          if (p.mode != 1) da *= (a[q] > 0.f) ? 1.f : C3D_LRELU_SLOPE;
+          if (p.mode == 0 || p.mode == 2) da *= (a[q] > 0.f) ? 1.f : C3D_LRELU_SLOPE;
           dz[q] = da;
         }
         *reinterpret_cast<f32x4*>(p.dz + (size_t)i * p.dz_cs + c) = dz;

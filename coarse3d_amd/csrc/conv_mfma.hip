@@ -201,7 +201,7 @@ int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const size_t lds = ((size_t)(TR + 2 * HALO) * (32 + 2 * HALO) + (size_t)a.T * 32 * NT) * CS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TR, NT, CK, HALO>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TR, NT, CK, HALO>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }

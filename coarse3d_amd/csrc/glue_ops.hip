@@ -1,0 +1,611 @@
+// HBM-bound glue of the SalsaNext blocks (gfx950): everything between the convolutions.
+// All tensors NHWC fp32; kernels are float4-vectorised along channels and grid-strided.
+// Reference (pc_processor/models/salsanext_proto.py unless noted):
+//   input_norm            tasks/weak_segmentation/trainer.py:599-609
+//   conv_in5              downCntx.conv1 (5 -> 32, 1x1) + LeakyReLU, :41-42,53-54
+//   affine_add            shortcut + BN(a)   :64, :133
+//   avgpool3s2            Dropout2d mask + AvgPool2d(3, stride 2, pad 1)  :108-109,135-142
+//   pixshuf_cat           PixelShuffle(2) + Dropout2d + cat(skip) + Dropout2d  :185-191
+//   softmax / crop        :456-460
+//   bilinear              F.interpolate(mode="bilinear", align_corners=True)  :470-490
+//   l2norm                F.normalize(dim=channel)  :485
+#include "common.h"
+#include "../../include/coarse3d_hip.h"
+
+namespace {
+
+constexpr int GS_BLOCKS = 2048;
+
+__device__ __forceinline__ size_t gtid() { return (size_t)blockIdx.x * blockDim.x + threadIdx.x; }
+__device__ __forceinline__ size_t gstride() { return (size_t)gridDim.x * blockDim.x; }
+
+inline int nblocks(size_t n, int per = 256) {
+  size_t b = (n + per - 1) / per;
+  return (int)(b > GS_BLOCKS ? GS_BLOCKS : (b < 1 ? 1 : b));
+}
+
+// ---------------------------------------------------------------- input normalisation (T1)
+__global__ void input_norm_kernel(const float* __restrict__ x, const int64_t* __restrict__ eval_label,
+                                  const float* __restrict__ mean, const float* __restrict__ stdv, int B, int Cn,
+                                  int HW, float* __restrict__ out) {
+  const size_t total = (size_t)B * Cn * HW;
+  for (size_t i = gtid(); i < total; i += gstride()) {
+    const int p = i % HW;
+    const int c = (i / HW) % Cn;
+    const int b = i / ((size_t)HW * Cn);
+    const float m = eval_label[(size_t)b * HW + p] > 0 ? 1.f : 0.f;
+    out[i] = (x[i] - mean[c]) / stdv[c] * m;
+  }
+}
+
+// ---------------------------------------------------------------- first conv 5 -> 32 (VALU)
+// x NCHW [B,Cn,H,W] (Cn <= 8), w [32][Cn], out NHWC [B,HW,32]
+__global__ __launch_bounds__(256) void conv_in5_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, int Cn, int HW, int total_pix,
+                                                       float* __restrict__ out) {
+  __shared__ float tile[256][33];
+  __shared__ float sw[32 * 8 + 32];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 32 * Cn; i += 256) sw[i] = w[i];
+  if (tid < 32) sw[256 + tid] = bias[tid];
+  __syncthreads();
+  const size_t p0 = (size_t)blockIdx.x * 256;
+  const size_t p = p0 + tid;
+  if (p < (size_t)total_pix) {
+    const int b = p / HW, hw = p % HW;
+    float xv[8];
+    for (int c = 0; c < Cn; ++c) xv[c] = x[((size_t)b * Cn + c) * HW + hw];
+#pragma unroll 4
+    for (int co = 0; co < 32; ++co) {
+      float acc = sw[256 + co];
+      for (int c = 0; c < Cn; ++c) acc = fmaf(sw[co * Cn + c], xv[c], acc);
+      tile[tid][co] = c3d_lrelu(acc);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 256 * 32; i += 256) {
+    const int pp = i >> 5, co = i & 31;
+    if (p0 + pp < (size_t)total_pix) out[(p0 + pp) * 32 + co] = tile[pp][co];
+  }
+}
+
+// dW partial: [nblk][32][8]
+__global__ __launch_bounds__(256) void conv_in5_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                             int Cn, int HW, int total_pix, int pix_per_block,
+                                                             float* __restrict__ partial) {
+  __shared__ float red[8][32][8];
+  const int tid = threadIdx.x, co = tid & 31, pl = tid >> 5;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, total_pix);
+  for (int p = p0 + pl; p < p1; p += 8) {
+    const int b = p / HW, hw = p % HW;
+    const float g = dz[(size_t)p * 32 + co];
+    for (int c = 0; c < Cn; ++c) acc[c] = fmaf(g, x[((size_t)b * Cn + c) * HW + hw], acc[c]);
+  }
+  for (int c = 0; c < 8; ++c) red[pl][co][c] = acc[c];
+  __syncthreads();
+  if (pl == 0) {
+    for (int c = 0; c < 8; ++c) {
+      float s = 0.f;
+      for (int k = 0; k < 8; ++k) s += red[k][co][c];
+      partial[((size_t)blockIdx.x * 32 + co) * 8 + c] = s;
+    }
+  }
+}
+
+// out[co][c] = sum_blocks partial[blk][co][c]  (fp64 fold)
+__global__ void conv_in5_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int Cn, float* __restrict__ dw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 32 * Cn) return;
+  const int co = i / Cn, c = i % Cn;
+  double s = 0.0;
+  for (int k = 0; k < nblk; ++k) s += (double)partial[((size_t)k * 32 + co) * 8 + c];
+  dw[i] = (float)s;
+}
+
+// ---------------------------------------------------------------- out = x + (a*scale + shift)
+__global__ void affine_add_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                  const float* __restrict__ scale, const float* __restrict__ shift, size_t npix, int C,
+                                  float* __restrict__ out) {
+  const int Q = C >> 2;
+  const size_t total = npix * Q;
+  for (size_t i = gtid(); i < total; i += gstride()) {
+    const int c = (i % Q) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(a + i * 4);
+    if (scale) v = v * *reinterpret_cast<const f32x4*>(scale + c) + *reinterpret_cast<const f32x4*>(shift + c);
+    if (x) v += *reinterpret_cast<const f32x4*>(x + i * 4);
+    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+  }
+}
+
+// y (+)= alpha * x  (flat)
+__global__ void axpy_kernel(const float* __restrict__ x, float alpha, size_t n4, float* __restrict__ y, int accumulate) {
+  for (size_t i = gtid(); i < n4; i += gstride()) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4) * alpha;
+    if (accumulate) v += *reinterpret_cast<const f32x4*>(y + i * 4);
+    *reinterpret_cast<f32x4*>(y + i * 4) = v;
+  }
+}
+
+// ---------------------------------------------------------------- mask (+ 3x3 stride-2 average pool)
+// in [B,H,W,C], mask [B,C] or null; pool: out [B,Ho,Wo,C]; no pool: out = in*mask
+__global__ void maskpool_kernel(const float* __restrict__ in, const float* __restrict__ mask, int B, int H, int W, int C,
+                                int pool, int Ho, int Wo, float* __restrict__ out) {
+  const int Q = C >> 2;
+  const size_t total = (size_t)B * Ho * Wo * Q;
+  for (size_t i = gtid(); i < total; i += gstride()) {
+    const int c = (i % Q) * 4;
+    size_t r = i / Q;
+    const int xo = r % Wo;
+    r /= Wo;
+    const int yo = r % Ho;
+    const int b = r / Ho;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (pool) {
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int y = 2 * yo + dy, x = 2 * xo + dx;
+          if (y >= 0 && y < H && x >= 0 && x < W)
+            acc += *reinterpret_cast<const f32x4*>(in + ((size_t)(b * H + y) * W + x) * C + c);
+        }
+      acc *= (1.f / 9.f);
+    } else {
+      acc = *reinterpret_cast<const f32x4*>(in + ((size_t)(b * H + yo) * W + xo) * C + c);
+    }
+    if (mask) acc *= *reinterpret_cast<const f32x4*>(mask + (size_t)b * C + c);
+    *reinterpret_cast<f32x4*>(out + i * 4) = acc;
+  }
+}
+
+// d_in = (extra ? extra : 0) + mask * poolT(d_out)
+__global__ void maskpool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ mask,
+                                    const float* __restrict__ extra, int B, int H, int W, int C, int pool, int Ho,
+                                    int Wo, float* __restrict__ din) {
+  const int Q = C >> 2;
+  const size_t total = (size_t)B * H * W * Q;
+  for (size_t i = gtid(); i < total; i += gstride()) {
+    const int c = (i % Q) * 4;
+    size_t r = i / Q;
+    const int x = r % W;
+    r /= W;
+    const int y = r % H;
+    const int b = r / H;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (pool) {
+      const int ya = (y & 1) ? (y - 1) / 2 : y / 2, yb = (y & 1) ? (y + 1) / 2 : -1;
+      const int xa = (x & 1) ? (x - 1) / 2 : x / 2, xb = (x & 1) ? (x + 1) / 2 : -1;
+      const int ys[2] = {ya, yb}, xs[2] = {xa, xb};
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const int yo = ys[u], xo = xs[v];
+          if (yo >= 0 && yo < Ho && xo >= 0 && xo < Wo)
+            acc += *reinterpret_cast<const f32x4*>(dout + ((size_t)(b * Ho + yo) * Wo + xo) * C + c);
+        }
+      acc *= (1.f / 9.f);
+    } else {
+      acc = *reinterpret_cast<const f32x4*>(dout + i * 4);
+    }
+    if (mask) acc *= *reinterpret_cast<const f32x4*>(mask + (size_t)b * C + c);
+    if (extra) acc += *reinterpret_cast<const f32x4*>(extra + i * 4);
+    *reinterpret_cast<f32x4*>(din + i * 4) = acc;
+  }
+}
+
+// ---------------------------------------------------------------- PixelShuffle(2) + masks + cat
+struct PsArgs {
+  const float* xa; const float* sc; const float* sh;  // [B,Hs,Ws,Cx], affine [Cx] or null
+  const float* m3;  // [B,Cx] or null (dropout3 of the producer block)
+  const float* m1;  // [B,Cu] or null
+  const float* m2;  // [B,Cu+Cs] or null
+  const float* skip;  // [B,H,W,Cs]
+  int B, Hs, Ws, Cx, Cs;
+  float* out;  // [B,2Hs,2Ws,Cu+Cs]
+};
+
+__global__ void pixshuf_kernel(PsArgs p) {
+  const int Cu = p.Cx >> 2, Ct = Cu + p.Cs, H = 2 * p.Hs, W = 2 * p.Ws;
+  const size_t total = (size_t)p.B * p.Hs * p.Ws * Cu;
+  for (size_t i = gtid(); i < total; i += gstride()) {
+    const int c = i % Cu;
+    size_t r = i / Cu;
+    const int xs = r % p.Ws;
+    r /= p.Ws;
+    const int ys = r % p.Hs;
+    const int b = r / p.Hs;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.xa + ((size_t)(b * p.Hs + ys) * p.Ws + xs) * p.Cx + c * 4);
+    if (p.sc) v = v * *reinterpret_cast<const f32x4*>(p.sc + c * 4) + *reinterpret_cast<const f32x4*>(p.sh + c * 4);
+    if (p.m3) v *= *reinterpret_cast<const f32x4*>(p.m3 + (size_t)b * p.Cx + c * 4);
+    float m = 1.f;
+    if (p.m1) m *= p.m1[(size_t)b * Cu + c];
+    if (p.m2) m *= p.m2[(size_t)b * Ct + c];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = 2 * ys + (k >> 1), x = 2 * xs + (k & 1);
+      p.out[((size_t)(b * H + y) * W + x) * Ct + c] = v[k] * m;
+    }
+  }
+}
+
+__global__ void catskip_kernel(PsArgs p) {
+  const int Cu = p.Cx >> 2, Ct = Cu + p.Cs, H = 2 * p.Hs, W = 2 * p.Ws;
+  const int Q = p.Cs >> 2;
+  const size_t total = (size_t)p.B * H * W * Q;
+  for (size_t i = gtid(); i < total; i += gstride()) {
+    const int c = (i % Q) * 4;
+    const size_t pix = i / Q;
+    const int b = pix / ((size_t)H * W);
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.skip + pix * p.Cs + c);
+    if (p.m2) v *= *reinterpret_cast<const f32x4*>(p.m2 + (size_t)b * Ct + Cu + c);
+    *reinterpret_cast<f32x4*>(p.out + pix * Ct + Cu + c) = v;
+  }
+}
+
+struct PsBwdArgs {
+  const float* dout;  // [B,H,W,Cu+Cs]
+  const float* m3; const float* m1; const float* m2;
+  int B, Hs, Ws, Cx, Cs;
+  float* dxa;    // [B,Hs,Ws,Cx]  gradient w.r.t. the (affine-transformed) producer output
+  float* dskip;  // [B,H,W,Cs]
+  int skip_accumulate;
+};
+
+__global__ void pixshuf_bwd_kernel(PsBwdArgs p) {
+  const int Cu = p.Cx >> 2, Ct = Cu + p.Cs, H = 2 * p.Hs, W = 2 * p.Ws;
+  const size_t total = (size_t)p.B * p.Hs * p.Ws * Cu;
+  for (size_t i = gtid(); i < total; i += gstride()) {
+    const int c = i % Cu;
+    size_t r = i / Cu;
+    const int xs = r % p.Ws;
+    r /= p.Ws;
+    const int ys = r % p.Hs;
+    const int b = r / p.Hs;
+    float m = 1.f;
+    if (p.m1) m *= p.m1[(size_t)b * Cu + c];
+    if (p.m2) m *= p.m2[(size_t)b * Ct + c];
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = 2 * ys + (k >> 1), x = 2 * xs + (k & 1);
+      v[k] = p.dout[((size_t)(b * H + y) * W + x) * Ct + c] * m;
+    }
+    if (p.m3) v *= *reinterpret_cast<const f32x4*>(p.m3 + (size_t)b * p.Cx + c * 4);
+    *reinterpret_cast<f32x4*>(p.dxa + ((size_t)(b * p.Hs + ys) * p.Ws + xs) * p.Cx + c * 4) = v;
+  }
+}
+
+__global__ void catskip_bwd_kernel(PsBwdArgs p) {
+  const int Cu = p.Cx >> 2, Ct = Cu + p.Cs, H = 2 * p.Hs, W = 2 * p.Ws;
+  const int Q = p.Cs >> 2;
+  const size_t total = (size_t)p.B * H * W * Q;
+  for (size_t i = gtid(); i < total; i += gstride()) {
+    const int c = (i % Q) * 4;
+    const size_t pix = i / Q;
+    const int b = pix / ((size_t)H * W);
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.dout + pix * Ct + Cu + c);
+    if (p.m2) v *= *reinterpret_cast<const f32x4*>(p.m2 + (size_t)b * Ct + Cu + c);
+    f32x4* d = reinterpret_cast<f32x4*>(p.dskip + pix * p.Cs + c);
+    *d = p.skip_accumulate ? (*d + v) : v;
+  }
+}
+
+// ---------------------------------------------------------------- channel softmax (+crop)
+// logits [B,H,W,cs] (first C channels used) -> prob [B,Ho,Wo,C]
+__global__ void softmax_kernel(const float* __restrict__ logits, int B, int H, int W, int cs, int C, int Ho, int Wo,
+                               float* __restrict__ prob) {
+  const size_t total = (size_t)B * Ho * Wo;
+  for (size_t i = gtid(); i < total; i += gstride()) {
+    const int x = i % Wo;
+    const int y = (i / Wo) % Ho;
+    const int b = i / ((size_t)Wo * Ho);
+    const float* l = logits + ((size_t)(b * H + y) * W + x) * cs;
+    float v[32];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      v[c] = c < C ? l[c] : -INFINITY;
+      mx = fmaxf(mx, v[c]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      v[c] = c < C ? expf(v[c] - mx) : 0.f;
+      s += v[c];
+    }
+    float* o = prob + i * C;
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c < C) o[c] = v[c] / s;
+  }
+}
+
+// dlogits [B,H,W,cs] = p * (dp - sum(p*dp)) inside the crop, 0 elsewhere (incl. pad channels)
+__global__ void softmax_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ dprob, int B, int H, int W,
+                                   int cs, int C, int Ho, int Wo, float* __restrict__ dlogits) {
+  const size_t total = (size_t)B * H * W;
+  for (size_t i = gtid(); i < total; i += gstride()) {
+    const int x = i % W;
+    const int y = (i / W) % H;
+    const int b = i / ((size_t)W * H);
+    float* d = dlogits + i * cs;
+    if (y < Ho && x < Wo) {
+      const size_t j = ((size_t)(b * Ho + y) * Wo + x) * C;
+      float dot = 0.f;
+      for (int c = 0; c < C; ++c) dot += prob[j + c] * dprob[j + c];
+      for (int c = 0; c < C; ++c) d[c] = prob[j + c] * (dprob[j + c] - dot);
+      for (int c = C; c < cs; ++c) d[c] = 0.f;
+    } else {
+      for (int c = 0; c < cs; ++c) d[c] = 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- bilinear, align_corners=True
+struct BlArgs {
+  const float* src; int Hs, Ws, scs, scoff;
+  float* dst; int Hd, Wd, dcs, dcoff;
+  int B, C;
+  float ry, rx;
+};
+
+__device__ __forceinline__ void bl_coords(int d, float ratio, int n, int& i0, int& i1, float& l1) {
+  const float r = ratio * (float)d;
+  i0 = (int)r;
+  if (i0 > n - 1) i0 = n - 1;
+  i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  l1 = fminf(fmaxf(r - (float)i0, 0.f), 1.f);
+}
+
+__global__ void bilinear_kernel(BlArgs p) {
+  const int Q = p.C >> 2;
+  const size_t total = (size_t)p.B * p.Hd * p.Wd * Q;
+  for (size_t i = gtid(); i < total; i += gstride()) {
+    const int c = (i % Q) * 4;
+    size_t r = i / Q;
+    const int xd = r % p.Wd;
+    r /= p.Wd;
+    const int yd = r % p.Hd;
+    const int b = r / p.Hd;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bl_coords(yd, p.ry, p.Hs, y0, y1, ly);
+    bl_coords(xd, p.rx, p.Ws, x0, x1, lx);
+    const float* s = p.src + (size_t)b * p.Hs * p.Ws * p.scs + p.scoff + c;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(s + ((size_t)y0 * p.Ws + x0) * p.scs);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(s + ((size_t)y0 * p.Ws + x1) * p.scs);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(s + ((size_t)y1 * p.Ws + x0) * p.scs);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(s + ((size_t)y1 * p.Ws + x1) * p.scs);
+    const f32x4 top = v00 * (1.f - lx) + v01 * lx;
+    const f32x4 bot = v10 * (1.f - lx) + v11 * lx;
+    *reinterpret_cast<f32x4*>(p.dst + ((size_t)(b * p.Hd + yd) * p.Wd + xd) * p.dcs + p.dcoff + c) =
+        top * (1.f - ly) + bot * ly;
+  }
+}
+
+// d_src (+)= bilinear^T(d_dst)   (atomic scatter; d_src must hold the running gradient or zeros)
+__global__ void bilinear_bwd_kernel(BlArgs p) {  // src = d_src (written), dst = d_dst (read)
+  const size_t total = (size_t)p.B * p.Hd * p.Wd * p.C;
+  float* dsrc = const_cast<float*>(p.src);
+  for (size_t i = gtid(); i < total; i += gstride()) {
+    const int c = i % p.C;
+    size_t r = i / p.C;
+    const int xd = r % p.Wd;
+    r /= p.Wd;
+    const int yd = r % p.Hd;
+    const int b = r / p.Hd;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bl_coords(yd, p.ry, p.Hs, y0, y1, ly);
+    bl_coords(xd, p.rx, p.Ws, x0, x1, lx);
+    const float g = p.dst[((size_t)(b * p.Hd + yd) * p.Wd + xd) * p.dcs + p.dcoff + c];
+    float* s = dsrc + (size_t)b * p.Hs * p.Ws * p.scs + p.scoff + c;
+    unsafeAtomicAdd(s + ((size_t)y0 * p.Ws + x0) * p.scs, g * (1.f - ly) * (1.f - lx));
+    unsafeAtomicAdd(s + ((size_t)y0 * p.Ws + x1) * p.scs, g * (1.f - ly) * lx);
+    unsafeAtomicAdd(s + ((size_t)y1 * p.Ws + x0) * p.scs, g * ly * (1.f - lx));
+    unsafeAtomicAdd(s + ((size_t)y1 * p.Ws + x1) * p.scs, g * ly * lx);
+  }
+}
+
+// ---------------------------------------------------------------- row-wise L2 normalise (one wave per row)
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, size_t n, int C, float eps,
+                                                     float* __restrict__ y, float* __restrict__ norm) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+  for (size_t r = wave; r < n; r += nw) {
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + c);
+      s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    s = c3d_wave_sum(s);
+    const float nr = sqrtf(s);
+    const float inv = 1.f / fmaxf(nr, eps);
+    for (int c = lane * 4; c < C; c += 256)
+      *reinterpret_cast<f32x4*>(y + r * C + c) = *reinterpret_cast<const f32x4*>(x + r * C + c) * inv;
+    if (norm && lane == 0) norm[r] = nr;
+  }
+}
+
+// dx = (dy - y * sum(y*dy)) / max(norm, eps)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ norm,
+                                                         const float* __restrict__ dy, size_t n, int C, float eps,
+                                                         float* __restrict__ dx) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+  for (size_t r = wave; r < n; r += nw) {
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(y + r * C + c);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + c);
+      s += a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3];
+    }
+    s = c3d_wave_sum(s);
+    const float inv = 1.f / fmaxf(norm[r], eps);
+    for (int c = lane * 4; c < C; c += 256) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(y + r * C + c);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + c);
+      *reinterpret_cast<f32x4*>(dx + r * C + c) = (g - a * s) * inv;
+    }
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int c3d_input_norm(const float* x, const int64_t* eval_label, const float* mean, const float* stdv, int B,
+                              int Cn, int HW, float* out, c3d_stream stream) {
+  hipLaunchKernelGGL(input_norm_kernel, dim3(nblocks((size_t)B * Cn * HW)), dim3(256), 0, ST, x, eval_label, mean, stdv,
+                     B, Cn, HW, out);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_conv_in5(const float* x_nchw, const float* w, const float* bias, int B, int Cn, int HW, float* out,
+                            c3d_stream stream) {
+  C3D_REQUIRE(Cn <= 8, "conv_in5: at most 8 input channels");
+  const int total = B * HW;
+  hipLaunchKernelGGL(conv_in5_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, x_nchw, w, bias, Cn, HW, total, out);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_conv_in5_wgrad(const float* x_nchw, const float* dz, int B, int Cn, int HW, float* partial,
+                                  float* dw, c3d_stream stream) {
+  C3D_REQUIRE(Cn <= 8, "conv_in5: at most 8 input channels");
+  const int total = B * HW;
+  int nb = (total + 511) / 512;
+  if (nb > 1024) nb = 1024;
+  const int ppb = (total + nb - 1) / nb;
+  hipLaunchKernelGGL(conv_in5_wgrad_kernel, dim3(nb), dim3(256), 0, ST, x_nchw, dz, Cn, HW, total, ppb, partial);
+  C3D_CHECK_LAUNCH();
+  hipLaunchKernelGGL(conv_in5_wgrad_reduce_kernel, dim3(1), dim3(256), 0, ST, partial, nb, Cn, dw);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_affine_add(const float* x, const float* a, const float* scale, const float* shift, int64_t npix,
+                              int C, float* out, c3d_stream stream) {
+  C3D_REQUIRE(C % 4 == 0, "affine_add: C must be a multiple of 4");
+  hipLaunchKernelGGL(affine_add_kernel, dim3(nblocks((size_t)npix * C / 4)), dim3(256), 0, ST, x, a, scale, shift,
+                     (size_t)npix, C, out);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_axpy(const float* x, float alpha, int64_t n, float* y, int accumulate, c3d_stream stream) {
+  C3D_REQUIRE(n % 4 == 0, "axpy: n must be a multiple of 4");
+  hipLaunchKernelGGL(axpy_kernel, dim3(nblocks((size_t)n / 4)), dim3(256), 0, ST, x, alpha, (size_t)n / 4, y, accumulate);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_maskpool(const float* in, const float* mask, int B, int H, int W, int C, int pool, float* out,
+                            c3d_stream stream) {
+  C3D_REQUIRE(C % 4 == 0, "maskpool: C must be a multiple of 4");
+  const int Ho = pool ? (H + 1) / 2 : H, Wo = pool ? (W + 1) / 2 : W;
+  hipLaunchKernelGGL(maskpool_kernel, dim3(nblocks((size_t)B * Ho * Wo * C / 4)), dim3(256), 0, ST, in, mask, B, H, W, C,
+                     pool, Ho, Wo, out);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_maskpool_bwd(const float* dout, const float* mask, const float* extra, int B, int H, int W, int C,
+                                int pool, float* din, c3d_stream stream) {
+  C3D_REQUIRE(C % 4 == 0, "maskpool: C must be a multiple of 4");
+  const int Ho = pool ? (H + 1) / 2 : H, Wo = pool ? (W + 1) / 2 : W;
+  hipLaunchKernelGGL(maskpool_bwd_kernel, dim3(nblocks((size_t)B * H * W * C / 4)), dim3(256), 0, ST, dout, mask, extra,
+                     B, H, W, C, pool, Ho, Wo, din);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_pixshuf_cat(const float* xa, const float* sc, const float* sh, const float* m3, const float* m1,
+                               const float* m2, const float* skip, int B, int Hs, int Ws, int Cx, int Cs, float* out,
+                               c3d_stream stream) {
+  C3D_REQUIRE(Cx % 16 == 0 && Cs % 4 == 0, "pixshuf_cat: Cx %% 16 and Cs %% 4 required");
+  PsArgs p{xa, sc, sh, m3, m1, m2, skip, B, Hs, Ws, Cx, Cs, out};
+  hipLaunchKernelGGL(pixshuf_kernel, dim3(nblocks((size_t)B * Hs * Ws * (Cx / 4))), dim3(256), 0, ST, p);
+  C3D_CHECK_LAUNCH();
+  hipLaunchKernelGGL(catskip_kernel, dim3(nblocks((size_t)B * Hs * Ws * 4 * (Cs / 4))), dim3(256), 0, ST, p);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_pixshuf_cat_bwd(const float* dout, const float* m3, const float* m1, const float* m2, int B, int Hs,
+                                   int Ws, int Cx, int Cs, float* dxa, float* dskip, int skip_accumulate,
+                                   c3d_stream stream) {
+  PsBwdArgs p{dout, m3, m1, m2, B, Hs, Ws, Cx, Cs, dxa, dskip, skip_accumulate};
+  hipLaunchKernelGGL(pixshuf_bwd_kernel, dim3(nblocks((size_t)B * Hs * Ws * (Cx / 4))), dim3(256), 0, ST, p);
+  C3D_CHECK_LAUNCH();
+  hipLaunchKernelGGL(catskip_bwd_kernel, dim3(nblocks((size_t)B * Hs * Ws * 4 * (Cs / 4))), dim3(256), 0, ST, p);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_softmax(const float* logits, int B, int H, int W, int cs, int C, int Ho, int Wo, float* prob,
+                           c3d_stream stream) {
+  C3D_REQUIRE(C <= 32 && C <= cs, "softmax: at most 32 classes");
+  hipLaunchKernelGGL(softmax_kernel, dim3(nblocks((size_t)B * Ho * Wo)), dim3(256), 0, ST, logits, B, H, W, cs, C, Ho, Wo,
+                     prob);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_softmax_bwd(const float* prob, const float* dprob, int B, int H, int W, int cs, int C, int Ho,
+                               int Wo, float* dlogits, c3d_stream stream) {
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(nblocks((size_t)B * H * W)), dim3(256), 0, ST, prob, dprob, B, H, W, cs, C,
+                     Ho, Wo, dlogits);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+static BlArgs bl_args(const float* src, int Hs, int Ws, int scs, int scoff, float* dst, int Hd, int Wd, int dcs,
+                      int dcoff, int B, int C) {
+  BlArgs p;
+  p.src = src; p.Hs = Hs; p.Ws = Ws; p.scs = scs; p.scoff = scoff;
+  p.dst = dst; p.Hd = Hd; p.Wd = Wd; p.dcs = dcs; p.dcoff = dcoff;
+  p.B = B; p.C = C;
+  p.ry = Hd > 1 ? (float)(Hs - 1) / (float)(Hd - 1) : 0.f;
+  p.rx = Wd > 1 ? (float)(Ws - 1) / (float)(Wd - 1) : 0.f;
+  return p;
+}
+
+extern "C" int c3d_bilinear(const float* src, int Hs, int Ws, int scs, int scoff, float* dst, int Hd, int Wd, int dcs,
+                            int dcoff, int B, int C, c3d_stream stream) {
+  C3D_REQUIRE(C % 4 == 0 && scs % 4 == 0 && dcs % 4 == 0 && scoff % 4 == 0 && dcoff % 4 == 0,
+              "bilinear: channel counts/strides must be multiples of 4");
+  BlArgs p = bl_args(src, Hs, Ws, scs, scoff, dst, Hd, Wd, dcs, dcoff, B, C);
+  hipLaunchKernelGGL(bilinear_kernel, dim3(nblocks((size_t)B * Hd * Wd * C / 4)), dim3(256), 0, ST, p);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_bilinear_bwd(float* dsrc, int Hs, int Ws, int scs, int scoff, const float* ddst, int Hd, int Wd,
+                                int dcs, int dcoff, int B, int C, c3d_stream stream) {
+  BlArgs p = bl_args(dsrc, Hs, Ws, scs, scoff, const_cast<float*>(ddst), Hd, Wd, dcs, dcoff, B, C);
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(nblocks((size_t)B * Hd * Wd * C)), dim3(256), 0, ST, p);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_l2norm(const float* x, int64_t n, int C, float eps, float* y, float* norm, c3d_stream stream) {
+  C3D_REQUIRE(C % 4 == 0, "l2norm: C must be a multiple of 4");
+  hipLaunchKernelGGL(l2norm_kernel, dim3(nblocks((size_t)n, 4)), dim3(256), 0, ST, x, (size_t)n, C, eps, y, norm);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_l2norm_bwd(const float* y, const float* norm, const float* dy, int64_t n, int C, float eps,
+                              float* dx, c3d_stream stream) {
+  C3D_REQUIRE(C % 4 == 0, "l2norm: C must be a multiple of 4");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(nblocks((size_t)n, 4)), dim3(256), 0, ST, y, norm, dy, (size_t)n, C, eps, dx);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}

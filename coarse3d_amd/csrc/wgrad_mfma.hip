@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
       const int gx = x0 + (p & 31), gy = y0 + (p >> 5);
       const int c = co0 + c4 * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gx < a.W && gy < a.H && c < a.Cout)
+      if (gx < a.W && gy < a.H && c + 3 < a.dz_cstride)
         v = *reinterpret_cast<const f32x4*>(a.dz + ((size_t)(b * a.H + gy) * a.W + gx) * a.dz_cstride + c);
       *reinterpret_cast<f32x4*>(s_dz + p * CO + c4 * 4) = v;
     }
@@ -221,7 +221,7 @@ int launch_wg(const WgradArgs& a, hipStream_t st) {
   if (red > lds) lds = red;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<TMAX, CI_T, CO_T, TRW, HALO>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<TMAX, CI_T, CO_T, TRW, HALO>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
@@ -244,7 +244,6 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   C3D_REQUIRE(d->ntaps == 1 || d->ntaps == 4 || d->ntaps == 9, "wgrad: ntaps must be 1, 4 or 9");
   C3D_REQUIRE(d->x.C % 4 == 0, "wgrad: source channels must be a multiple of 4");
   C3D_REQUIRE(d->dz_cstride % 4 == 0 && d->x.cstride % 4 == 0 && d->x.coff % 4 == 0, "wgrad: strides must be multiples of 4");
-  C3D_REQUIRE(d->Cout % 4 == 0, "wgrad: Cout must be a multiple of 4");
   WgradArgs a;
   a.x = d->x; a.dz = d->dz; a.dz_cstride = d->dz_cstride;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.T = d->ntaps;

@@ -115,3 +115,189 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False):
     d.partial = part.data_ptr()
     L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
     return dw
+
+
+# ---------------------------------------------------------------------------- BatchNorm
+def _call(name, *args):
+    L.check(getattr(L.lib(), name)(*args), name)
+
+
+def _dp(t):
+    return t.data_ptr() if t is not None else None
+
+
+def stat_reduce(partial, c, sums=None):
+    """partial [n,C,2] fp32 -> sums [C,2] fp64."""
+    if sums is None:
+        sums = torch.empty(c, 2, device=partial.device, dtype=torch.float64)
+    _call("c3d_stat_reduce", _dp(partial), partial.shape[0], c, _dp(sums), _stream())
+    return sums
+
+
+def bn_finalize(sums, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
+    c = gamma.shape[0]
+    buf = torch.empty(4, c, device=gamma.device, dtype=torch.float32)
+    _call("c3d_bn_finalize", _dp(sums), float(count), _dp(gamma), _dp(beta), _dp(running_mean),
+          _dp(running_var), momentum, eps, c, _dp(buf[0]), _dp(buf[1]), _dp(buf[2]), _dp(buf[3]), _stream())
+    return buf[0], buf[1], buf[2], buf[3]      # scale, shift, mean, invstd
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps=1e-5):
+    c = gamma.shape[0]
+    buf = torch.empty(2, c, device=gamma.device, dtype=torch.float32)
+    _call("c3d_bn_eval_affine", _dp(gamma), _dp(beta), _dp(running_mean), _dp(running_var), eps, c,
+          _dp(buf[0]), _dp(buf[1]), _stream())
+    return buf[0], buf[1]
+
+
+def bn_bwd_blocks(npix):
+    return L.lib().c3d_bn_bwd_num_blocks(npix)
+
+
+def bn_bwd_reduce(dy, a, c, mode=0, pre_scale=None, pre_shift=None):
+    npix = dy.numel() // dy.shape[-1]
+    part = torch.empty(bn_bwd_blocks(npix), c, 2, device=dy.device, dtype=torch.float32)
+    _call("c3d_bn_bwd_reduce", _dp(dy), dy.shape[-1], _dp(a), a.shape[-1], npix, c, mode, _dp(pre_scale),
+          _dp(pre_shift), _dp(part), _stream())
+    return part
+
+
+def bn_bwd_coeffs(sums, count, mean, invstd, gamma, dgamma, dbeta):
+    c = gamma.shape[0]
+    k = torch.empty(3, c, device=gamma.device, dtype=torch.float32)
+    _call("c3d_bn_bwd_coeffs", _dp(sums), float(count), _dp(mean), _dp(invstd), _dp(gamma), c, _dp(k[0]),
+          _dp(k[1]), _dp(k[2]), _dp(dgamma), _dp(dbeta), _stream())
+    return k
+
+
+def bn_bwd_apply(dy, a, c, mode, k=None, pre_scale=None, pre_shift=None, dz=None):
+    """dz = act'(.) * (k1*dy + k2*a + k3); returns (dz, partial [nblk,C,2] with sum(dz) in col 0)."""
+    npix = dy.numel() // dy.shape[-1]
+    if dz is None:
+        dz = torch.empty(dy.shape[:-1] + (c,), device=dy.device, dtype=torch.float32)
+    part = torch.empty(bn_bwd_blocks(npix), c, 2, device=dy.device, dtype=torch.float32)
+    k1, k2, k3 = (k[0], k[1], k[2]) if k is not None else (None, None, None)
+    _call("c3d_bn_bwd_apply", _dp(dy), dy.shape[-1], _dp(a), a.shape[-1], npix, c, mode, _dp(pre_scale),
+          _dp(pre_shift), _dp(k1), _dp(k2), _dp(k3), _dp(dz), dz.shape[-1], _dp(part), _stream())
+    return dz, part
+
+
+def sums_to_f32(sums, col, out, accumulate=False):
+    _call("c3d_sums_to_f32", _dp(sums), out.shape[0], col, _dp(out), int(accumulate), _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------- glue
+def input_norm(x, eval_label, mean, std):
+    b, cn, h, w = x.shape
+    out = torch.empty_like(x)
+    _call("c3d_input_norm", _dp(x), _dp(eval_label), _dp(mean), _dp(std), b, cn, h * w, _dp(out), _stream())
+    return out
+
+
+def conv_in5(x_nchw, w, bias):
+    b, cn, h, wd = x_nchw.shape
+    out = torch.empty(b, h, wd, 32, device=x_nchw.device, dtype=torch.float32)
+    _call("c3d_conv_in5", _dp(x_nchw), _dp(w), _dp(bias), b, cn, h * wd, _dp(out), _stream())
+    return out
+
+
+def conv_in5_wgrad(x_nchw, dz, dw):
+    b, cn, h, wd = x_nchw.shape
+    part = torch.empty(1024 * 32 * 8, device=dz.device, dtype=torch.float32)
+    _call("c3d_conv_in5_wgrad", _dp(x_nchw), _dp(dz), b, cn, h * wd, _dp(part), _dp(dw), _stream())
+    return dw
+
+
+def affine_add(x, a, scale=None, shift=None, out=None):
+    c = a.shape[-1]
+    if out is None:
+        out = torch.empty_like(a)
+    _call("c3d_affine_add", _dp(x), _dp(a), _dp(scale), _dp(shift), a.numel() // c, c, _dp(out), _stream())
+    return out
+
+
+def axpy(x, y, alpha=1.0, accumulate=True):
+    _call("c3d_axpy", _dp(x), alpha, x.numel(), _dp(y), int(accumulate), _stream())
+    return y
+
+
+def maskpool(x, mask, pool):
+    b, h, w, c = x.shape
+    ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
+    out = torch.empty(b, ho, wo, c, device=x.device, dtype=torch.float32)
+    _call("c3d_maskpool", _dp(x), _dp(mask), b, h, w, c, int(pool), _dp(out), _stream())
+    return out
+
+
+def maskpool_bwd(dout, mask, extra, shape, pool):
+    b, h, w, c = shape
+    din = torch.empty(b, h, w, c, device=dout.device, dtype=torch.float32)
+    _call("c3d_maskpool_bwd", _dp(dout), _dp(mask), _dp(extra), b, h, w, c, int(pool), _dp(din), _stream())
+    return din
+
+
+def pixshuf_cat(xa, sc, sh, m3, m1, m2, skip):
+    b, hs, ws, cx = xa.shape
+    cs = skip.shape[-1]
+    out = torch.empty(b, 2 * hs, 2 * ws, cx // 4 + cs, device=xa.device, dtype=torch.float32)
+    _call("c3d_pixshuf_cat", _dp(xa), _dp(sc), _dp(sh), _dp(m3), _dp(m1), _dp(m2), _dp(skip), b, hs, ws, cx, cs,
+          _dp(out), _stream())
+    return out
+
+
+def pixshuf_cat_bwd(dout, m3, m1, m2, xa_shape, cs, dskip, skip_accumulate):
+    b, hs, ws, cx = xa_shape
+    dxa = torch.empty(b, hs, ws, cx, device=dout.device, dtype=torch.float32)
+    _call("c3d_pixshuf_cat_bwd", _dp(dout), _dp(m3), _dp(m1), _dp(m2), b, hs, ws, cx, cs, _dp(dxa), _dp(dskip),
+          int(skip_accumulate), _stream())
+    return dxa
+
+
+def softmax(logits, c, ho=None, wo=None):
+    b, h, w, cs = logits.shape
+    ho, wo = ho or h, wo or w
+    prob = torch.empty(b, ho, wo, c, device=logits.device, dtype=torch.float32)
+    _call("c3d_softmax", _dp(logits), b, h, w, cs, c, ho, wo, _dp(prob), _stream())
+    return prob
+
+
+def softmax_bwd(prob, dprob, shape):
+    b, h, w, cs = shape
+    _, ho, wo, c = prob.shape
+    dl = torch.empty(b, h, w, cs, device=prob.device, dtype=torch.float32)
+    _call("c3d_softmax_bwd", _dp(prob), _dp(dprob), b, h, w, cs, c, ho, wo, _dp(dl), _stream())
+    return dl
+
+
+def bilinear(src, hd, wd, dst=None, dcoff=0, c=None, scoff=0):
+    b, hs, ws, scs = src.shape
+    c = c or scs
+    if dst is None:
+        dst = torch.empty(b, hd, wd, c, device=src.device, dtype=torch.float32)
+    _call("c3d_bilinear", _dp(src), hs, ws, scs, scoff, _dp(dst), hd, wd, dst.shape[-1], dcoff, b, c, _stream())
+    return dst
+
+
+def bilinear_bwd(dsrc, ddst, dcoff=0, c=None, scoff=0):
+    b, hs, ws, scs = dsrc.shape
+    _, hd, wd, dcs = ddst.shape
+    c = c or scs
+    _call("c3d_bilinear_bwd", _dp(dsrc), hs, ws, scs, scoff, _dp(ddst), hd, wd, dcs, dcoff, b, c, _stream())
+    return dsrc
+
+
+def l2norm(x, eps=1e-12, want_norm=True):
+    c = x.shape[-1]
+    n = x.numel() // c
+    y = torch.empty_like(x)
+    norm = torch.empty(n, device=x.device, dtype=torch.float32) if want_norm else None
+    _call("c3d_l2norm", _dp(x), n, c, eps, _dp(y), _dp(norm), _stream())
+    return y, norm
+
+
+def l2norm_bwd(y, norm, dy, eps=1e-12):
+    c = y.shape[-1]
+    dx = torch.empty_like(y)
+    _call("c3d_l2norm_bwd", _dp(y), _dp(norm), _dp(dy), y.numel() // c, c, eps, _dp(dx), _stream())
+    return dx

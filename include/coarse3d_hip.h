@@ -79,14 +79,14 @@ int c3d_pack_weights(const float* w_oihw, float* dst, int Cout, int Cin, int T, 
                      int c_off, int c_cnt, int Kpad, c3d_stream stream);
 
 /* dW[cout][cin_off + cin][t] (OIHW, full Cin_total) = sum_pixels dz[p][cout] * x[p + tap t][cin]
- * and db[cout] = sum dz.  x is given as ONE transformed source (call once per source).
+ * x is given as ONE transformed source (call once per source of a concatenated input).
  * Replaces autograd's conv weight gradient for the layers listed above.
  * `partial` is scratch of c3d_wgrad_partial_floats() floats.                                 */
 typedef struct {
   c3d_src x;                /* input of the forward conv (same transform as forward)      */
   const float* dz;          /* NHWC [B,H,W,Cout] gradient w.r.t. the conv output (pre-act) */
   int32_t dz_cstride;
-  int32_t B, H, W, Cout;
+  int32_t B, H, W, Cout;   /* Cout = rows of dw; dz channels beyond it must be zero       */
   int32_t ntaps;
   int32_t tap_dy[9];
   int32_t tap_dx[9];
@@ -98,6 +98,89 @@ typedef struct {
 } c3d_wgrad_desc;
 int64_t c3d_wgrad_partial_floats(const c3d_wgrad_desc* d);
 int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream);
+
+/* ------------------------------------------------------------------ BatchNorm2d (train mode)
+ * nn.BatchNorm2d of salsanext_proto.py:46,50,89-105,168-180 and projector.py:20, split so that
+ * the fp64 sums can be all-reduced across ranks in between (SyncBatchNorm, trainer.py:54).   */
+
+/* partial [n][C][2] fp32 (per-tile sum, sumsq) -> sums [C][2] fp64 */
+int c3d_stat_reduce(const float* partial, int n, int C, double* sums, c3d_stream stream);
+/* sums + count -> consumer-side affine scale=gamma*invstd, shift=beta-mean*scale; saves
+ * mean/invstd for backward; updates running stats (momentum, unbiased var) when non-NULL.   */
+int c3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, int C,
+                    float* scale, float* shift, float* save_mean, float* save_invstd,
+                    c3d_stream stream);
+/* eval mode: affine from running statistics */
+int c3d_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int C, float* scale, float* shift,
+                       c3d_stream stream);
+/* Backward of  a -> BN -> (consumers)  where a = LeakyReLU(conv) [mode 0], of
+ * a -> BN -> LeakyReLU [mode 1, projector; pre_scale/pre_shift = the forward affine],
+ * of a = LeakyReLU(conv) without BN [mode 2], or identity [mode 3]; dy/a/dz are [npix][cs].
+ *   reduce : partial [c3d_bn_bwd_num_blocks][C][2] = (sum dy, sum dy*a)
+ *   coeffs : da = k1*dy + k2*a + k3 ; dgamma = sum(dy*xhat) ; dbeta = sum(dy)
+ *   apply  : dz = act'(.) * da ; partial[..][C][0] = sum dz  (conv bias gradient)            */
+int c3d_bn_bwd_num_blocks(int npix);
+int c3d_bn_bwd_reduce(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C,
+                      int mode, const float* pre_scale, const float* pre_shift, float* partial,
+                      c3d_stream stream);
+int c3d_bn_bwd_coeffs(const double* sums, double count, const float* mean, const float* invstd,
+                      const float* gamma, int C, float* k1, float* k2, float* k3, float* dgamma,
+                      float* dbeta, c3d_stream stream);
+int c3d_bn_bwd_apply(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C,
+                     int mode, const float* pre_scale, const float* pre_shift, const float* k1,
+                     const float* k2, const float* k3, float* dz, int dz_cs, float* partial,
+                     c3d_stream stream);
+/* out[c] (+)= (float) sums[c][col] */
+int c3d_sums_to_f32(const double* sums, int C, int col, float* out, int accumulate,
+                    c3d_stream stream);
+
+/* ------------------------------------------------------------------ block glue (HBM-bound) */
+
+/* x = (x - mean[c]) / std[c] * (eval_label > 0)   NCHW  (trainer.py:599-609)                */
+int c3d_input_norm(const float* x, const int64_t* eval_label, const float* mean,
+                   const float* stdv, int B, int Cn, int HW, float* out, c3d_stream stream);
+/* downCntx.conv1: 1x1 conv Cn(<=8) -> 32 + LeakyReLU, NCHW in, NHWC out (salsanext_proto.py:41,53-54) */
+int c3d_conv_in5(const float* x_nchw, const float* w, const float* bias, int B, int Cn, int HW,
+                 float* out, c3d_stream stream);
+/* its weight gradient dw[32][Cn]; partial = scratch of 1024*32*8 floats                      */
+int c3d_conv_in5_wgrad(const float* x_nchw, const float* dz, int B, int Cn, int HW,
+                       float* partial, float* dw, c3d_stream stream);
+/* out = x + (a*scale + shift)  (x, scale may be NULL)   residual adds :64, :133             */
+int c3d_affine_add(const float* x, const float* a, const float* scale, const float* shift,
+                   int64_t npix, int C, float* out, c3d_stream stream);
+/* y (+)= alpha*x, flat                                                                      */
+int c3d_axpy(const float* x, float alpha, int64_t n, float* y, int accumulate, c3d_stream stream);
+/* Dropout2d multiplier mask[B,C] (NULL = none) then AvgPool2d(3,2,1) if pool (:108-109,135-142) */
+int c3d_maskpool(const float* in, const float* mask, int B, int H, int W, int C, int pool,
+                 float* out, c3d_stream stream);
+/* din = extra + mask * pool^T(dout)   (extra may be NULL)                                   */
+int c3d_maskpool_bwd(const float* dout, const float* mask, const float* extra, int B, int H,
+                     int W, int C, int pool, float* din, c3d_stream stream);
+/* out = cat(PixelShuffle2((xa*sc+sh)*m3)*m1, skip) * m2   (:185-191; masks may be NULL)     */
+int c3d_pixshuf_cat(const float* xa, const float* sc, const float* sh, const float* m3,
+                    const float* m1, const float* m2, const float* skip, int B, int Hs, int Ws,
+                    int Cx, int Cs, float* out, c3d_stream stream);
+int c3d_pixshuf_cat_bwd(const float* dout, const float* m3, const float* m1, const float* m2,
+                        int B, int Hs, int Ws, int Cx, int Cs, float* dxa, float* dskip,
+                        int skip_accumulate, c3d_stream stream);
+/* softmax over the first C of cs channels, cropped to [Ho,Wo] (:456-460)                    */
+int c3d_softmax(const float* logits, int B, int H, int W, int cs, int C, int Ho, int Wo,
+                float* prob, c3d_stream stream);
+int c3d_softmax_bwd(const float* prob, const float* dprob, int B, int H, int W, int cs, int C,
+                    int Ho, int Wo, float* dlogits, c3d_stream stream);
+/* F.interpolate(bilinear, align_corners=True) between channel slices of NHWC tensors (:470-490) */
+int c3d_bilinear(const float* src, int Hs, int Ws, int scs, int scoff, float* dst, int Hd,
+                 int Wd, int dcs, int dcoff, int B, int C, c3d_stream stream);
+/* dsrc += bilinear^T(ddst)  (atomic scatter-add)                                            */
+int c3d_bilinear_bwd(float* dsrc, int Hs, int Ws, int scs, int scoff, const float* ddst, int Hd,
+                     int Wd, int dcs, int dcoff, int B, int C, c3d_stream stream);
+/* F.normalize(p=2) over rows of [n][C] (:485; eps 1e-12); norm may be NULL                  */
+int c3d_l2norm(const float* x, int64_t n, int C, float eps, float* y, float* norm,
+               c3d_stream stream);
+int c3d_l2norm_bwd(const float* y, const float* norm, const float* dy, int64_t n, int C,
+                   float eps, float* dx, c3d_stream stream);
 
 #ifdef __cplusplus
 }

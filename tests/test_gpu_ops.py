@@ -1,0 +1,223 @@
+"""Kernel-level parity of the BatchNorm / glue HIP ops against plain PyTorch fp32 on CPU
+(the same ops the oracle is built from).  Tolerance: 1e-4 of max|ref| unless stated."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 64, 128, 32), (2, 8, 16, 256), (1, 3, 113, 64), (2, 16, 32, 704)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_bn_backward(B, H, W, C, mode):
+    """dz of  z -> LeakyReLU -> BN  (mode 0),  z -> BN -> LeakyReLU (mode 1),  z -> LeakyReLU (2)."""
+    from coarse3d_amd import ops
+    g = torch.Generator().manual_seed(C + mode)
+    z = torch.randn(B, C, H, W, generator=g).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.2).requires_grad_(True)
+    dy = torch.randn(B, C, H, W, generator=g)
+    if mode == 0:
+        a = F.leaky_relu(z, 0.01)
+        y = F.batch_norm(a, None, None, gamma, beta, True, 0.1, 1e-5)
+    elif mode == 1:
+        a = z
+        y = F.leaky_relu(F.batch_norm(z, None, None, gamma, beta, True, 0.1, 1e-5), 0.01)
+    else:
+        a = F.leaky_relu(z, 0.01)
+        y = a
+    y.backward(dy)
+    a_d = nhwc(a.detach()).to(DEV)
+    dy_d = nhwc(dy).to(DEV)
+    n = B * H * W
+    if mode == 2:
+        dz, pz = ops.bn_bwd_apply(dy_d, a_d, C, 2)
+    else:
+        mean = a.detach().mean(dim=(0, 2, 3))
+        var = a.detach().var(dim=(0, 2, 3), unbiased=False)
+        invstd = 1.0 / torch.sqrt(var + 1e-5)
+        scale = gamma.detach() * invstd
+        shift = beta.detach() - mean * scale
+        pre = (scale.to(DEV), shift.to(DEV)) if mode == 1 else (None, None)
+        part = ops.bn_bwd_reduce(dy_d, a_d, C, mode, *pre)
+        sums = ops.stat_reduce(part, C)
+        dgamma = torch.empty(C, device=DEV)
+        dbeta = torch.empty(C, device=DEV)
+        k = ops.bn_bwd_coeffs(sums, n, mean.to(DEV), invstd.to(DEV), gamma.detach().to(DEV), dgamma, dbeta)
+        dz, pz = ops.bn_bwd_apply(dy_d, a_d, C, mode, k, *pre)
+        assert rel(dgamma, gamma.grad) < 1e-4
+        assert rel(dbeta, beta.grad) < 1e-4
+    assert rel(nchw(dz), z.grad) < 1e-4
+    db = torch.empty(C, device=DEV)
+    ops.sums_to_f32(ops.stat_reduce(pz, C), 0, db)
+    if mode == 1:   # a bias in front of a BatchNorm has exactly zero gradient: both are rounding noise
+        assert float(db.abs().max()) < 1e-3 * float(z.grad.abs().sum(dim=(0, 2, 3)).max())
+    else:
+        assert rel(db, z.grad.sum(dim=(0, 2, 3))) < 1e-4
+
+
+def test_bn_forward_stats_and_running():
+    from coarse3d_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W = 2, 64, 16, 64
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.5
+    bn = torch.nn.BatchNorm2d(C)
+    bn.weight.data = torch.rand(C, generator=g) + 0.5
+    bn.bias.data = torch.randn(C, generator=g)
+    bn.train()
+    y = bn(x)
+    # per-tile partials as the conv epilogue would leave them: emulate with one "tile" per image row
+    xd = nhwc(x).to(DEV)
+    part = torch.stack([xd.reshape(-1, W, C).sum(1), (xd.reshape(-1, W, C) ** 2).sum(1)], -1).contiguous()
+    sums = ops.stat_reduce(part, C)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    sc, sh, mean, invstd = ops.bn_finalize(sums, B * H * W, bn.weight.data.to(DEV), bn.bias.data.to(DEV), rm, rv)
+    yd = xd * sc + sh
+    assert rel(nchw(yd), y) < 1e-4
+    assert rel(rm, bn.running_mean) < 1e-4 and rel(rv, bn.running_var) < 1e-4
+    bn.eval()
+    sc2, sh2 = ops.bn_eval_affine(bn.weight.data.to(DEV), bn.bias.data.to(DEV), rm, rv)
+    assert rel(nchw(xd * sc2 + sh2), bn(x)) < 1e-4
+
+
+def test_input_norm_and_first_conv():
+    from coarse3d_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 16, 80
+    x = torch.randn(B, 5, H, W, generator=g)
+    ev = torch.randint(0, 3, (B, H, W), generator=g)
+    mean, std = torch.randn(5, generator=g), torch.rand(5, generator=g) + 0.5
+    ref = (x - mean[None, :, None, None]) / std[None, :, None, None] * (ev > 0).unsqueeze(1)
+    xn = ops.input_norm(x.to(DEV), ev.to(DEV), mean.to(DEV), std.to(DEV))
+    assert rel(xn, ref) < 1e-6
+    w = (torch.randn(32, 5, 1, 1, generator=g) * 0.4).requires_grad_(True)
+    bias = torch.randn(32, generator=g)
+    s = F.leaky_relu(F.conv2d(ref, w, bias), 0.01)
+    sd = ops.conv_in5(xn, w.detach().reshape(32, 5).contiguous().to(DEV), bias.to(DEV))
+    assert rel(nchw(sd), s) < 1e-5
+    dz = torch.randn(B, 32, H, W, generator=g)
+    F.conv2d(ref, w, bias).backward(dz)
+    dw = torch.empty(32, 5, 1, 1, device=DEV)
+    ops.conv_in5_wgrad(xn, nhwc(dz).to(DEV), dw)
+    assert rel(dw, w.grad) < 1e-4
+
+
+@pytest.mark.parametrize("pool", [True, False])
+@pytest.mark.parametrize("H,W", [(16, 32), (3, 113), (2, 8)])
+def test_maskpool(pool, H, W):
+    from coarse3d_amd import ops
+    g = torch.Generator().manual_seed(H * W)
+    B, C = 2, 64
+    x = torch.randn(B, C, H, W, generator=g).requires_grad_(True)
+    mask = (torch.rand(B, C, generator=g) > 0.2).float() * 1.25
+    extra = torch.randn(B, C, H, W, generator=g)
+    y = x * mask[:, :, None, None]
+    if pool:
+        y = F.avg_pool2d(y, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    (y * dy).sum().backward()
+    yd = ops.maskpool(nhwc(x.detach()).to(DEV), mask.to(DEV), pool)
+    assert rel(nchw(yd), y) < 1e-5
+    dx = ops.maskpool_bwd(nhwc(dy).to(DEV), mask.to(DEV), nhwc(extra).to(DEV), (B, H, W, C), pool)
+    assert rel(nchw(dx), x.grad + extra) < 1e-5
+
+
+def test_pixshuf_cat():
+    from coarse3d_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, Hs, Ws, Cx, Cs = 2, 4, 8, 64, 32
+    xa = torch.randn(B, Cx, Hs, Ws, generator=g).requires_grad_(True)
+    skip = torch.randn(B, Cs, 2 * Hs, 2 * Ws, generator=g).requires_grad_(True)
+    sc, sh = torch.rand(Cx, generator=g) + 0.5, torch.randn(Cx, generator=g)
+    m3 = (torch.rand(B, Cx, generator=g) > 0.2).float() * 1.25
+    m1 = (torch.rand(B, Cx // 4, generator=g) > 0.2).float() * 1.25
+    m2 = (torch.rand(B, Cx // 4 + Cs, generator=g) > 0.2).float() * 1.25
+    yb = (xa * sc[None, :, None, None] + sh[None, :, None, None])
+    yb.retain_grad()
+    u = F.pixel_shuffle(yb * m3[:, :, None, None], 2) * m1[:, :, None, None]
+    out = torch.cat((u, skip), 1) * m2[:, :, None, None]
+    dout = torch.randn(out.shape, generator=g)
+    (out * dout).sum().backward()
+    od = ops.pixshuf_cat(nhwc(xa.detach()).to(DEV), sc.to(DEV), sh.to(DEV), m3.to(DEV), m1.to(DEV), m2.to(DEV),
+                         nhwc(skip.detach()).to(DEV))
+    assert rel(nchw(od), out) < 1e-5
+    dskip = torch.ones(B, 2 * Hs, 2 * Ws, Cs, device=DEV)
+    dxa = ops.pixshuf_cat_bwd(nhwc(dout).to(DEV), m3.to(DEV), m1.to(DEV), m2.to(DEV), (B, Hs, Ws, Cx), Cs, dskip, True)
+    assert rel(nchw(dxa), yb.grad) < 1e-5
+    assert rel(nchw(dskip), skip.grad + 1) < 1e-5
+
+
+def test_softmax_crop():
+    from coarse3d_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, H, W, C = 2, 16, 24, 14
+    lg = (torch.randn(B, C, H, W, generator=g) * 3).requires_grad_(True)
+    p = F.softmax(lg[:, :, :-8, :-8], 1)
+    dp = torch.randn(p.shape, generator=g)
+    (p * dp).sum().backward()
+    l32 = torch.zeros(B, H, W, 32)
+    l32[..., :C] = nhwc(lg.detach())
+    pd = ops.softmax(l32.to(DEV), C, H - 8, W - 8)
+    assert rel(nchw(pd), p) < 1e-5
+    dl = ops.softmax_bwd(pd, nhwc(dp).to(DEV), (B, H, W, 32))
+    assert rel(nchw(dl[..., :C]), lg.grad) < 1e-4
+    assert float(dl[..., C:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("Hs,Ws,Hd,Wd", [(64, 128, 32, 64), (16, 32, 32, 64), (4, 8, 32, 64), (32, 64, 32, 64),
+                                          (32, 64, 12, 24), (16, 28, 32, 56)])
+def test_bilinear(Hs, Ws, Hd, Wd):
+    from coarse3d_amd import ops
+    g = torch.Generator().manual_seed(Hs + Wd)
+    B, C = 2, 32
+    x = torch.randn(B, C, Hs, Ws, generator=g).requires_grad_(True)
+    y = F.interpolate(x, size=(Hd, Wd), mode="bilinear", align_corners=True)
+    dy = torch.randn(y.shape, generator=g)
+    (y * dy).sum().backward()
+    dst = torch.zeros(B, Hd, Wd, C + 16, device=DEV)
+    ops.bilinear(nhwc(x.detach()).to(DEV), Hd, Wd, dst=dst, dcoff=16, c=C)
+    assert rel(nchw(dst[..., 16:]), y) < 1e-5
+    dsrc = torch.zeros(B, Hs, Ws, C, device=DEV)
+    ddst = torch.zeros(B, Hd, Wd, C + 16, device=DEV)
+    ddst[..., 16:] = nhwc(dy).to(DEV)
+    ops.bilinear_bwd(dsrc, ddst, dcoff=16, c=C)
+    assert rel(nchw(dsrc), x.grad) < 1e-4
+
+
+def test_l2norm_and_residual():
+    from coarse3d_amd import ops
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(500, 256, generator=g).requires_grad_(True)
+    x.data[7] = 0
+    y = F.normalize(x, p=2, dim=1)
+    dy = torch.randn(500, 256, generator=g)
+    (y * dy).sum().backward()
+    yd, norm = ops.l2norm(x.detach().to(DEV))
+    assert rel(yd, y) < 1e-6
+    dx = ops.l2norm_bwd(yd, norm, dy.to(DEV))
+    mask = torch.ones(500, dtype=torch.bool)
+    mask[7] = False
+    assert rel(dx[mask.to(DEV)], x.grad[mask]) < 1e-4
+    a, s = torch.randn(2, 8, 16, 32, generator=g), torch.randn(2, 8, 16, 32, generator=g)
+    sc, sh = torch.rand(32, generator=g), torch.randn(32, generator=g)
+    out = ops.affine_add(s.to(DEV), a.to(DEV), sc.to(DEV), sh.to(DEV))
+    assert rel(out, s + a * sc + sh) < 1e-6
+    yy = torch.ones(2, 8, 16, 32, device=DEV)
+    ops.axpy(a.to(DEV), yy, 0.5, True)
+    assert rel(yy, 1 + 0.5 * a) < 1e-6
