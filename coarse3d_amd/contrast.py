@@ -1,0 +1,112 @@
+"""Pixel-to-prototype contrastive loss and entropy-based pseudo-label selection on HIP kernels.
+
+Reference: pc_processor/loss/contrast_pixel_loss.py:27-195 (``ContrastMEMLoss``) and
+tasks/weak_segmentation/trainer.py:447-518 (``entropy_based_selection``).  Everything is
+shape-static and free of host synchronisation: absent (image, class) pairs are masked on the
+device instead of being skipped by Python loops."""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def _nhwc_rows(t_nchw_like):
+    """[B,C,H,W]-shaped tensor (any strides) -> contiguous [B,H,W,C]."""
+    return t_nchw_like.permute(0, 2, 3, 1).contiguous()
+
+
+def entropy_selection(prob_nhwc, train_label, eval_label, select_ratio, noise=None, ignore_cls=0):
+    """prob [B,H,W,C]; labels [B,H,W] int64.  noise: Exp(1) [B,C,H*W] or None (drawn on device).
+    Returns (labels [B,H,W] int64, mask [B,H,W] bool)."""
+    b, h, w, c = prob_nhwc.shape
+    n = h * w
+    _, w_pl, amax = ops.entropy_stats(prob_nhwc, want_anchor=False)
+    tl = train_label.reshape(b, n).contiguous()
+    ev = eval_label.reshape(b, n).contiguous()
+    tl_counts, _ = ops.group_compact(tl, c)
+    if noise is None:
+        noise = torch.empty(b, c, n, device=prob_nhwc.device, dtype=torch.float32).exponential_()
+    labels, mask = ops.pl_select(w_pl, amax, ev, tl, noise.contiguous(), tl_counts, b, n, c, ignore_cls,
+                                 np.float32(select_ratio))
+    return labels.view(b, h, w), mask.view(b, h, w)
+
+
+class _ContrastFn(torch.autograd.Function):
+    """loss = InfoNCE(anchors sampled from feats, prototype queue); d(loss)/d(feats) is a sparse
+    scatter-add of at most B*(C-1)*A rows (the reference zero-fills a dense [B,HW,D] tensor per
+    (image, class) through SelectBackward)."""
+
+    @staticmethod
+    def forward(ctx, feats, state):
+        feat = state["feat"]            # [B,H,W,D] contiguous
+        b, h, w, d = feat.shape
+        n = h * w
+        ctx.state = state
+        ctx.shape = feats.shape
+        ctx.mark_non_differentiable()
+        return state["loss"].reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        st = ctx.state
+        feat = st["feat"]
+        b, h, w, d = feat.shape
+        n = h * w
+        tmax, a = st["tmax"], st["a"]
+        # d(anchor rows, normalised) = dlogits x queue ; then through the l2 normalisation
+        da = ops.gemm_rows(st["dlogits"], st["wq_t"], d)
+        dx = ops.l2norm_bwd(st["anchors"], st["norm"], da)
+        dfeat = torch.zeros(b, h, w, d, device=feat.device, dtype=torch.float32)
+        gs = g.reshape(1).to(torch.float32).contiguous()
+        ops.scatter_add_rows(dx, st["img"], st["idx"], st["T"], tmax, a, n, dfeat, gs)
+        return dfeat.permute(0, 3, 1, 2), None
+
+
+def contrast_mem_loss(feats, prob, labels, keep_mask, proto_queue, temperature=0.1, base_temperature=0.07,
+                      num_anchor=50, ignore_label=0, uniforms=None, perms=None, return_debug=False):
+    """feats [B,D,H,W]-shaped (channels-last memory preferred), prob [B,C,H,W]-shaped, labels
+    [B,H,W] int64, keep_mask [B,H,W] bool or None, proto_queue [C,M,D].
+
+    uniforms: float64 [B*C, A] draws (row t feeds the t-th present (image,class) pair, exactly
+    the stream torch.multinomial would consume); perms: int64 [C-1, M] queue row orders.
+    Returns the 0-dim loss (autograd-connected to ``feats``)."""
+    b, d, h, w = feats.shape
+    c = prob.shape[1]
+    n = h * w
+    dev = feats.device
+    feat = _nhwc_rows(feats.detach())
+    p = _nhwc_rows(prob.detach())
+    w_anchor, _, _ = ops.entropy_stats(p, want_pl=False, want_amax=False)
+    lab = labels.reshape(b, n).contiguous()
+    keep = keep_mask.reshape(b, n).to(torch.uint8).contiguous() if keep_mask is not None else None
+    counts, idx = ops.group_compact(lab, c, keep)
+    tmax = b * c
+    a = num_anchor
+    if uniforms is None:
+        uniforms = torch.rand(tmax, a, device=dev, dtype=torch.float64)
+    else:
+        u = torch.zeros(tmax, a, device=dev, dtype=torch.float64)
+        u[: uniforms.shape[0]] = uniforms.to(dev)
+        uniforms = u
+    a_idx, a_img, a_cls, t = ops.anchor_sample(w_anchor, counts, idx, uniforms, b, n, c, a, ignore_label)
+    anchors, norm = ops.gather_rows_l2(feat, a_img, a_idx, t, tmax, a, n)
+    # queue: classes 1..C-1, rows permuted, l2-normalised, padded to a multiple of 16 rows
+    m = proto_queue.shape[1]
+    q = proto_queue.detach()[1:]
+    if perms is None:
+        perms = torch.stack([torch.randperm(m, device=dev) for _ in range(c - 1)])
+    q = torch.gather(q, 1, perms.to(dev)[:, :, None].expand(-1, -1, d)).reshape((c - 1) * m, d).contiguous()
+    qn, _ = ops.l2norm(q, 1e-12, want_norm=False)
+    ncols = (c - 1) * m
+    ld = (ncols + 15) // 16 * 16
+    qpad = torch.zeros(ld, d, device=dev, dtype=torch.float32)
+    qpad[:ncols] = qn
+    w_q = qpad.view(ld, d, 1, 1)
+    logits = ops.gemm_rows(anchors, ops.pack_weights(w_q, 0), ld)          # [tmax*a, ld] cosine
+    loss, row_loss = ops.infonce_rows(logits, a_cls, t, tmax, a, m, ncols, temperature, base_temperature)
+    state = dict(feat=feat, anchors=anchors, norm=norm, dlogits=logits, wq_t=ops.pack_weights(w_q, 1),
+                 img=a_img, idx=a_idx, T=t, tmax=tmax, a=a, loss=loss)
+    out = _ContrastFn.apply(feats, state)
+    if return_debug:
+        return out, dict(idx=a_idx, img=a_img, cls=a_cls, T=t, row_loss=row_loss)
+    return out

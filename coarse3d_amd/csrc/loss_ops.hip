@@ -1,0 +1,419 @@
+// Entropy-weighted pseudo-label selection, bit-exact anchor sampling and the pixel-to-prototype
+// InfoNCE loss (gfx950).
+// Reference: pc_processor/loss/contrast_pixel_loss.py:27-195 (ContrastMEMLoss),
+// tasks/weak_segmentation/trainer.py:447-518 (entropy_based_selection).
+//
+// Index contracts (pinned against torch.multinomial in tests/test_oracle_golden.py):
+//  * with replacement    : sequential fp32 running sum of the class weights, divided by the fp32
+//    total, left-bisect of each float64 uniform draw;
+//  * without replacement : top-k of weight / Exp(1) noise (fp32 division).
+// Both samplers run one workgroup per (image, class) pair, all pairs concurrently, with no host
+// synchronisation: absent pairs simply produce no work.
+#include "common.h"
+#include "../../include/coarse3d_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------- entropy weights + argmax
+// prob [N][C] -> w_anchor = exp(-H^2), w_pl = exp(-H), amax (contrast_pixel_loss.py:46-49,
+// trainer.py:459-466)
+__global__ void entropy_stats_kernel(const float* __restrict__ prob, size_t n, int C, float* __restrict__ w_anchor,
+                                     float* __restrict__ w_pl, int32_t* __restrict__ amax) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float* p = prob + i * C;
+    float h = 0.f, best = -INFINITY;
+    int bi = 0;
+    for (int c = 0; c < C; ++c) {
+      const float v = p[c];
+      h += v * logf(v + 1e-10f);
+      if (v > best) {
+        best = v;
+        bi = c;
+      }
+    }
+    h = -h;
+    if (w_anchor) w_anchor[i] = expf(-(h * h));
+    if (w_pl) w_pl[i] = expf(-h);
+    if (amax) amax[i] = bi;
+  }
+}
+
+// ---------------------------------------------------------------- pseudo-label selection (T3)
+struct PlArgs {
+  const float* w_pl;           // [B][n]
+  const int32_t* amax;         // [B][n]
+  const int64_t* eval_label;   // [B][n]
+  const int64_t* train_label;  // [B][n]
+  const float* noise;          // [B][C][n] Exp(1)
+  const int32_t* tl_counts;    // [B][C] number of weak labels of class c in image b
+  int n, C, ignore;
+  float ratio;
+  uint8_t* chosen;             // [B][n], pre-zeroed
+};
+
+__device__ __forceinline__ bool pl_member(const PlArgs& a, int b, int c, int i) {
+  return a.amax[(size_t)b * a.n + i] == c && a.eval_label[(size_t)b * a.n + i] > 0;
+}
+
+// grid (C, B).  Radix select (4 x 8 bits) of the k-th largest key, keys = bits of q = w / noise.
+__global__ __launch_bounds__(256) void pl_select_kernel(PlArgs a) {
+  __shared__ int hist[256];
+  __shared__ unsigned int s_prefix, s_k, s_take;
+  __shared__ int s_cnt;
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  if (c == a.ignore || a.tl_counts[b * a.C + c] == 0) return;
+  const float* w = a.w_pl + (size_t)b * a.n;
+  const float* nz = a.noise + ((size_t)b * a.C + c) * a.n;
+  // count members
+  int local = 0;
+  for (int i = tid; i < a.n; i += 256) local += pl_member(a, b, c, i) ? 1 : 0;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  atomicAdd(&s_cnt, local);
+  __syncthreads();
+  const int cnt = s_cnt;
+  if (cnt == 0) return;
+  const int k = (int)((float)cnt * a.ratio);
+  if (k < 1) return;
+  if (tid == 0) {
+    s_prefix = 0;
+    s_k = (unsigned)k;
+  }
+  __syncthreads();
+  for (int level = 3; level >= 0; --level) {
+    hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    const unsigned mask_hi = level == 3 ? 0u : (0xFFFFFFFFu << ((level + 1) * 8));
+    for (int i = tid; i < a.n; i += 256) {
+      if (pl_member(a, b, c, i)) {
+        const unsigned key = __float_as_uint(w[i] / nz[i]);
+        if ((key & mask_hi) == prefix) atomicAdd(&hist[(key >> (level * 8)) & 255], 1);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned kk = s_k;
+      int bin = 255;
+      for (; bin > 0; --bin) {
+        if ((unsigned)hist[bin] >= kk) break;
+        kk -= hist[bin];
+      }
+      s_prefix = prefix | ((unsigned)bin << (level * 8));
+      s_k = kk;  // rank of the k-th element inside this bin
+    }
+    __syncthreads();
+  }
+  // s_prefix = key of the k-th largest; s_k = how many elements equal to it must be taken
+  const unsigned thr = s_prefix;
+  if (tid == 0) s_take = s_k;
+  __syncthreads();
+  for (int i = tid; i < a.n; i += 256) {
+    if (pl_member(a, b, c, i)) {
+      const unsigned key = __float_as_uint(w[i] / nz[i]);
+      bool take = key > thr;
+      if (key == thr) take = atomicSub(&s_take, 1u) - 1u < 0x80000000u;  // first s_k ties (measure-zero event)
+      if (take) a.chosen[(size_t)b * a.n + i] = 1;
+    }
+  }
+}
+
+// labels_out = chosen ? amax : 0, weak labels override; mask_out = label != ignore (trainer.py:510-516)
+__global__ void pl_finalize_kernel(const int32_t* __restrict__ amax, const uint8_t* __restrict__ chosen,
+                                   const int64_t* __restrict__ eval_label, const int64_t* __restrict__ train_label,
+                                   size_t n, int ignore, int64_t* __restrict__ labels_out, uint8_t* __restrict__ mask_out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int64_t l = (chosen[i] && eval_label[i] > 0) ? (int64_t)amax[i] : 0;
+    if (train_label[i] > 0) l = train_label[i];
+    labels_out[i] = l;
+    mask_out[i] = l != ignore;
+  }
+}
+
+// ---------------------------------------------------------------- anchor sampling (L2)
+// slot[b*C+c] = rank of the pair among present ones in (b, c) order, or -1; T = number present
+__global__ void pair_slots_kernel(const int32_t* __restrict__ counts, int npairs, int C, int ignore,
+                                  int32_t* __restrict__ slot, int32_t* __restrict__ T) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int t = 0;
+    for (int p = 0; p < npairs; ++p) {
+      const bool present = (p % C) != ignore && counts[p] > 0;
+      slot[p] = present ? t : -1;
+      t += present ? 1 : 0;
+    }
+    *T = t;
+  }
+}
+
+struct SampleArgs {
+  const float* weights;    // [B][n]
+  const int32_t* counts;   // [B][C]
+  const int32_t* idx;      // [B][C][n] ordered pixel lists
+  const int32_t* slot;     // [B][C]
+  const double* uniforms;  // [Tmax][A]
+  float* cum;              // [B][C][n] scratch
+  int n, C, A;
+  int32_t* anchor_idx;     // [Tmax][A]
+  int32_t* anchor_img;     // [Tmax]
+  int32_t* anchor_cls;     // [Tmax]
+};
+
+// grid (C, B)
+__global__ __launch_bounds__(256) void anchor_sample_kernel(SampleArgs a) {
+  __shared__ float chunk[2048];
+  __shared__ float s_run;
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int pair = b * a.C + c;
+  const int t = a.slot[pair];
+  if (t < 0) return;
+  const int nc = a.counts[pair];
+  const int32_t* rows = a.idx + (size_t)pair * a.n;
+  const float* w = a.weights + (size_t)b * a.n;
+  float* cum = a.cum + (size_t)pair * a.n;
+  if (tid == 0) s_run = 0.f;
+  __syncthreads();
+  // sequential fp32 running sum in list order (== the CPU kernel's order over the whole image,
+  // because zero weights leave an fp32 running sum unchanged)
+  for (int i0 = 0; i0 < nc; i0 += 2048) {
+    const int m = min(2048, nc - i0);
+    for (int j = tid; j < m; j += 256) chunk[j] = w[rows[i0 + j]];
+    __syncthreads();
+    if (tid == 0) {
+      float run = s_run;
+      for (int j = 0; j < m; ++j) {
+        run = run + chunk[j];
+        chunk[j] = run;
+      }
+      s_run = run;
+    }
+    __syncthreads();
+    for (int j = tid; j < m; j += 256) cum[i0 + j] = chunk[j];
+    __syncthreads();
+  }
+  const float total = s_run;
+  for (int j = tid; j < nc; j += 256) cum[j] = cum[j] / total;
+  __threadfence_block();
+  __syncthreads();
+  for (int s = tid; s < a.A; s += 256) {
+    const double u = a.uniforms[(size_t)t * a.A + s];
+    int lo = 0, hi = nc;
+    while (hi - lo > 0) {
+      const int mid = lo + (hi - lo) / 2;
+      if ((double)cum[mid] < u) lo = mid + 1;
+      else hi = mid;
+    }
+    if (lo > nc - 1) lo = nc - 1;
+    int pix = rows[lo];
+    if (u <= 0.0) pix = 0;
+    a.anchor_idx[(size_t)t * a.A + s] = pix;
+  }
+  if (tid == 0) {
+    a.anchor_img[t] = b;
+    a.anchor_cls[t] = c;
+  }
+}
+
+// ---------------------------------------------------------------- anchor gather / scatter
+// out[t*A + s][:] = l2_normalize(feat[img[t]][idx[t][s]][:]); rows with t >= T are zero
+__global__ __launch_bounds__(256) void gather_l2_kernel(const float* __restrict__ feat, const int32_t* __restrict__ img,
+                                                        const int32_t* __restrict__ idx, const int32_t* __restrict__ T,
+                                                        int Tmax, int A, int n, int D, float eps,
+                                                        float* __restrict__ out, float* __restrict__ norm) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+  const int Tn = *T;
+  for (size_t r = wave; r < (size_t)Tmax * A; r += nw) {
+    const int t = r / A;
+    if (t >= Tn) {
+      for (int d = lane * 4; d < D; d += 256) *reinterpret_cast<f32x4*>(out + r * D + d) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (lane == 0) norm[r] = 1.f;
+      continue;
+    }
+    const float* src = feat + ((size_t)img[t] * n + idx[r]) * D;
+    float s = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + d);
+      s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    const float nr = sqrtf(c3d_wave_sum(s));
+    const float inv = 1.f / fmaxf(nr, eps);
+    for (int d = lane * 4; d < D; d += 256)
+      *reinterpret_cast<f32x4*>(out + r * D + d) = *reinterpret_cast<const f32x4*>(src + d) * inv;
+    if (lane == 0) norm[r] = nr;
+  }
+}
+
+// dfeat[img[t]][idx[t][s]][:] += g * dx[t*A+s][:]  (atomic; anchors repeat)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ dx, const int32_t* __restrict__ img,
+                                                           const int32_t* __restrict__ idx, const int32_t* __restrict__ T,
+                                                           int Tmax, int A, int n, int D, const float* __restrict__ gscale,
+                                                           float* __restrict__ dfeat) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+  const int Tn = *T;
+  const float g = gscale ? *gscale : 1.f;
+  for (size_t r = wave; r < (size_t)Tn * A; r += nw) {
+    const int t = r / A;
+    float* dst = dfeat + ((size_t)img[t] * n + idx[r]) * D;
+    for (int d = lane; d < D; d += 64) unsafeAtomicAdd(dst + d, g * dx[r * D + d]);
+  }
+}
+
+// ---------------------------------------------------------------- InfoNCE rows (L3)
+// logits [R][ld] = a_i . q_j (cosine); columns j < (C-1)*M valid, column class = 1 + j / M.
+// Writes d(loss)/d(logits) in place and per-row losses.  One wave per row.
+__global__ __launch_bounds__(256) void infonce_rows_kernel(float* __restrict__ logits, int ld,
+                                                           const int32_t* __restrict__ row_cls,
+                                                           const int32_t* __restrict__ T, int Tmax, int A, int M,
+                                                           int ncols, float temp, float base_temp,
+                                                           float* __restrict__ row_loss) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+  const int Tn = *T;
+  for (size_t r = wave; r < (size_t)Tmax * A; r += nw) {
+    float* row = logits + r * ld;
+    const int t = r / A;
+    if (t >= Tn) {
+      for (int j = lane; j < ld; j += 64) row[j] = 0.f;
+      if (lane == 0) row_loss[r] = 0.f;
+      continue;
+    }
+    const int cls = row_cls[t];
+    float x[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = lane + q * 64;
+      x[q] = j < ncols ? row[j] / temp : -INFINITY;
+      mx = fmaxf(mx, x[q]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float neg = 0.f;
+    float ex[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = lane + q * 64;
+      x[q] -= mx;
+      ex[q] = j < ncols ? expf(x[q]) : 0.f;
+      const bool pos = j < ncols && (1 + j / M) == cls;
+      if (!pos) neg += ex[q];
+    }
+    neg = c3d_wave_sum(neg);
+    float sum_logp = 0.f, sum_inv = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = lane + q * 64;
+      const bool pos = j < ncols && (1 + j / M) == cls;
+      if (pos) {
+        const float den = ex[q] + neg + 1e-6f;
+        sum_logp += x[q] - logf(den);
+        sum_inv += 1.f / den;
+      }
+    }
+    sum_logp = c3d_wave_sum(sum_logp);
+    sum_inv = c3d_wave_sum(sum_inv);
+    const float coef = -(temp / base_temp) / (float)M;   // loss_row = coef * sum_pos logp
+    const float scale = coef / temp / (float)(Tn * A);    // d(mean loss)/d(logit) = scale * g
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = lane + q * 64;
+      if (j < ld) {
+        float g = 0.f;
+        if (j < ncols) {
+          const bool pos = (1 + j / M) == cls;
+          g = pos ? 1.f - ex[q] / (ex[q] + neg + 1e-6f) : -ex[q] * sum_inv;
+        }
+        row[j] = g * scale;
+      }
+    }
+    if (lane == 0) row_loss[r] = coef * sum_logp;
+  }
+}
+
+// loss = sum(row_loss) / (T*A)   (single block, fp64 fold)
+__global__ __launch_bounds__(256) void infonce_reduce_kernel(const float* __restrict__ row_loss,
+                                                             const int32_t* __restrict__ T, int A,
+                                                             float* __restrict__ loss) {
+  __shared__ double red[4];
+  const int Tn = *T;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < Tn * A; i += 256) s += (double)row_loss[i];
+  s = c3d_wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *loss = Tn > 0 ? (float)((red[0] + red[1] + red[2] + red[3]) / ((double)Tn * A)) : 0.f;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+static inline int nb_for(size_t n, int per) {
+  size_t b = (n + per - 1) / per;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+extern "C" int c3d_entropy_stats(const float* prob, int64_t n, int C, float* w_anchor, float* w_pl, int32_t* amax,
+                                 c3d_stream stream) {
+  hipLaunchKernelGGL(entropy_stats_kernel, dim3(nb_for((size_t)n, 256)), dim3(256), 0, ST, prob, (size_t)n, C, w_anchor,
+                     w_pl, amax);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_pl_select(const float* w_pl, const int32_t* amax, const int64_t* eval_label,
+                             const int64_t* train_label, const float* noise, const int32_t* tl_counts, int B, int n,
+                             int C, int ignore_label, float ratio, uint8_t* chosen, int64_t* labels_out,
+                             uint8_t* mask_out, c3d_stream stream) {
+  PlArgs a{w_pl, amax, eval_label, train_label, noise, tl_counts, n, C, ignore_label, ratio, chosen};
+  hipLaunchKernelGGL(pl_select_kernel, dim3(C, B), dim3(256), 0, ST, a);
+  C3D_CHECK_LAUNCH();
+  hipLaunchKernelGGL(pl_finalize_kernel, dim3(nb_for((size_t)B * n, 256)), dim3(256), 0, ST, amax, chosen, eval_label,
+                     train_label, (size_t)B * n, ignore_label, labels_out, mask_out);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_anchor_sample(const float* weights, const int32_t* counts, const int32_t* idx,
+                                 const double* uniforms, int B, int n, int C, int A, int ignore_label, int32_t* slot,
+                                 float* cum, int32_t* anchor_idx, int32_t* anchor_img, int32_t* anchor_cls, int32_t* T,
+                                 c3d_stream stream) {
+  hipLaunchKernelGGL(pair_slots_kernel, dim3(1), dim3(64), 0, ST, counts, B * C, C, ignore_label, slot, T);
+  C3D_CHECK_LAUNCH();
+  SampleArgs a{weights, counts, idx, slot, uniforms, cum, n, C, A, anchor_idx, anchor_img, anchor_cls};
+  hipLaunchKernelGGL(anchor_sample_kernel, dim3(C, B), dim3(256), 0, ST, a);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_gather_rows_l2(const float* feat, const int32_t* img, const int32_t* idx, const int32_t* T, int Tmax,
+                                  int A, int n, int D, float eps, float* out, float* norm, c3d_stream stream) {
+  C3D_REQUIRE(D % 4 == 0, "gather: D must be a multiple of 4");
+  hipLaunchKernelGGL(gather_l2_kernel, dim3(nb_for((size_t)Tmax * A, 4)), dim3(256), 0, ST, feat, img, idx, T, Tmax, A, n,
+                     D, eps, out, norm);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_scatter_add_rows(const float* dx, const int32_t* img, const int32_t* idx, const int32_t* T, int Tmax,
+                                    int A, int n, int D, const float* gscale, float* dfeat, c3d_stream stream) {
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(nb_for((size_t)Tmax * A, 4)), dim3(256), 0, ST, dx, img, idx, T, Tmax, A,
+                     n, D, gscale, dfeat);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_infonce_rows(float* logits, int ld, const int32_t* row_cls, const int32_t* T, int Tmax, int A, int M,
+                                int ncols, float temperature, float base_temperature, float* row_loss, float* loss,
+                                c3d_stream stream) {
+  C3D_REQUIRE(ld <= 512, "infonce: at most 512 queue columns");
+  hipLaunchKernelGGL(infonce_rows_kernel, dim3(nb_for((size_t)Tmax * A, 4)), dim3(256), 0, ST, logits, ld, row_cls, T,
+                     Tmax, A, M, ncols, temperature, base_temperature, row_loss);
+  C3D_CHECK_LAUNCH();
+  hipLaunchKernelGGL(infonce_reduce_kernel, dim3(1), dim3(256), 0, ST, row_loss, T, A, loss);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}

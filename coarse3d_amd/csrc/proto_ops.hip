@@ -1,0 +1,304 @@
+// Prototype memory bank pipeline (gfx950): pixel-to-prototype similarity, Sinkhorn assignment,
+// per-class masked feature reduction, EMA update.
+// Reference: pc_processor/models/salsanext_proto.py:494-510 (similarity), :337-402
+// (prototype_learning), pc_processor/models/sinkhorn.py:5-33.
+// The [N,256] x [256, M*C] similarity GEMM itself runs on the MFMA conv engine (1x1 "conv").
+#include "common.h"
+#include "../../include/coarse3d_hip.h"
+
+namespace {
+
+// out = l2_normalize(LayerNorm(x))  per row; one wave per row (salsanext_proto.py:497-501)
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, size_t n, int C,
+                                                      const float* __restrict__ w, const float* __restrict__ b,
+                                                      float ln_eps, float l2_eps, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+  for (size_t r = wave; r < n; r += nw) {
+    float v[16];  // up to C = 1024
+    int cnt = 0;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(x + r * C + c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[cnt * 4 + q] = t[q];
+        s += t[q];
+      }
+      ++cnt;
+    }
+    const float mean = c3d_wave_sum(s) / (float)C;
+    float ss = 0.f;
+    for (int i = 0; i < cnt * 4; ++i) {
+      const float d = v[i] - mean;
+      ss += d * d;
+    }
+    const float rstd = rsqrtf(c3d_wave_sum(ss) / (float)C + ln_eps);
+    float nn = 0.f;
+    int i = 0;
+    for (int c = lane * 4; c < C; c += 256) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float y = (v[i * 4 + q] - mean) * rstd * w[c + q] + b[c + q];
+        v[i * 4 + q] = y;
+        nn += y * y;
+      }
+      ++i;
+    }
+    const float inv = 1.f / fmaxf(sqrtf(c3d_wave_sum(nn)), l2_eps);
+    i = 0;
+    for (int c = lane * 4; c < C; c += 256) {
+      f32x4 t;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t[q] = v[i * 4 + q] * inv;
+      *reinterpret_cast<f32x4*>(out + r * C + c) = t;
+      ++i;
+    }
+  }
+}
+
+// sim [N][M*C] (column m*C+k) -> nearest[N][C] = LayerNorm_C(max_m sim), pred[N] = argmax_k
+// one wave per row, row staged in LDS  (salsanext_proto.py:506-507, :340)
+__global__ __launch_bounds__(256) void proto_nearest_kernel(const float* __restrict__ sim, size_t n, int M, int C,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            float eps, float* __restrict__ nearest,
+                                                            int32_t* __restrict__ pred) {
+  extern __shared__ float srow[];  // [4][M*C]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int MC = M * C;
+  float* row = srow + wv * MC;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+  for (size_t r = wave; r < n; r += nw) {
+    for (int j = lane; j < MC; j += 64) row[j] = sim[r * MC + j];
+    __builtin_amdgcn_wave_barrier();
+    float mx = -INFINITY;
+    if (lane < C)
+      for (int m = 0; m < M; ++m) mx = fmaxf(mx, row[m * C + lane]);
+    const float val = lane < C ? mx : 0.f;
+    const float mean = c3d_wave_sum(val) / (float)C;
+    const float d = lane < C ? (mx - mean) : 0.f;
+    const float rstd = rsqrtf(c3d_wave_sum(d * d) / (float)C + eps);
+    float y = lane < C ? d * rstd * w[lane] + b[lane] : -INFINITY;
+    if (nearest && lane < C) nearest[r * C + lane] = y;
+    // argmax over lanes (first index on ties)
+    float best = y;
+    int bi = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) pred[r] = bi;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Ordered compaction: for group g and class c list the positions i (ascending) with
+// labels[g][i] == c.  grid = (ncls, groups); idx [groups][ncls][n], counts [groups][ncls].
+__global__ __launch_bounds__(256) void group_compact_kernel(const int64_t* __restrict__ labels,
+                                                            const uint8_t* __restrict__ keep, int n, int ncls,
+                                                            int32_t* __restrict__ counts, int32_t* __restrict__ idx) {
+  __shared__ int wtot[4];
+  __shared__ int base_s;
+  const int c = blockIdx.x, g = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t* lab = labels + (size_t)g * n;
+  const uint8_t* kp = keep ? keep + (size_t)g * n : nullptr;
+  int32_t* out = idx + ((size_t)g * ncls + c) * n;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + tid;
+    bool f = false;
+    if (i < n) {
+      int64_t l = lab[i];
+      if (kp && !kp[i]) l = 0;
+      f = (l == c);
+    }
+    const unsigned long long bal = __ballot(f);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wtot[wv] = __popcll(bal);
+    __syncthreads();
+    int off = base_s;
+    for (int k = 0; k < wv; ++k) off += wtot[k];
+    if (f) out[off + before] = i;
+    __syncthreads();
+    if (tid == 0) base_s += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();
+  }
+  if (tid == 0) counts[g * ncls + c] = base_s;
+}
+
+struct LearnArgs {
+  const float* sim;      // [N][M*C]
+  const float* feat;     // [N][D]  (LayerNorm + l2 rows)
+  const int32_t* pred;   // [N] argmax class of the nearest-prototype map
+  const int32_t* counts; // [ncls]
+  const int32_t* idx;    // [ncls][N]
+  const float* noise;    // [N][M] Exp(1) variates (gumbel = -log), indexed by pixel
+  const float* protos;   // [ncls][M][D] l2-normalised bank (input)
+  float* protos_out;     // [ncls][M][D]
+  float* target;         // [N]  (pre-zeroed)
+  int32_t* assign;       // [N] scratch
+  int N, M, C, D, ignore;
+  float momentum;
+};
+
+// one workgroup per class
+__global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
+  extern __shared__ float sm[];
+  double* red = reinterpret_cast<double*>(sm);          // [4][32] wave partials
+  float* u = sm + 256;                                  // [32] row scalings
+  float* f = sm + 256 + 32;                             // [M][D]
+  float* cnt = f + a.M * a.D;                           // [M]
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int M = a.M, D = a.D, MC = a.M * a.C;
+  const int nc = (c == a.ignore) ? 0 : a.counts[c];
+  const int32_t* rows = a.idx + (size_t)c * a.N;
+  const float* pin = a.protos + (size_t)c * M * D;
+  float* pout = a.protos_out + (size_t)c * M * D;
+
+  if (nc > 0) {
+    // ---- Sinkhorn scalings: Q[i][m] = E[i][m] * u[m] * v[i],  E = exp(sim/0.05)
+    for (int m = tid; m < 32; m += 256) u[m] = 1.f;
+    __syncthreads();
+    for (int it = 0; it < 3; ++it) {
+      double acc[32];
+#pragma unroll
+      for (int m = 0; m < 32; ++m) acc[m] = 0.0;
+      for (int i = tid; i < nc; i += 256) {
+        const float* s = a.sim + (size_t)rows[i] * MC + c;
+        float e[32];
+        float colsum = 0.f;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+          e[m] = m < M ? expf(s[m * a.C] / 0.05f) : 0.f;
+          colsum += e[m] * u[m];
+        }
+        // v[i] of the previous column step (it == 0: uniform, cancels in the row step)
+        const float v = it == 0 ? 1.f : 1.f / colsum;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) acc[m] += (double)(e[m] * v);
+      }
+      // block reduce acc[m]
+#pragma unroll
+      for (int m = 0; m < 32; ++m) {
+        const double t = c3d_wave_sum_d(acc[m]);
+        if (lane == 0) red[wv * 32 + m] = t;
+      }
+      __syncthreads();
+      if (tid < 32) {
+        const double t = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
+        // row step: u[m] = 1 / (K * sum_i E[i][m] v[i])  (independent of the previous u)
+        u[tid] = tid < M ? (float)(1.0 / ((double)M * t)) : 0.f;
+      }
+      __syncthreads();
+    }
+    // ---- assignment per labelled pixel
+    for (int i = tid; i < nc; i += 256) {
+      const int r = rows[i];
+      const float* s = a.sim + (size_t)r * MC + c;
+      float colsum = 0.f;
+      for (int m = 0; m < M; ++m) colsum += expf(s[m * a.C] / 0.05f) * u[m];
+      int best = 0, hot = 0;
+      float bq = -INFINITY, bh = -INFINITY;
+      for (int m = 0; m < M; ++m) {
+        const float qq = expf(s[m * a.C] / 0.05f) * u[m] / colsum;
+        if (qq > bq) {
+          bq = qq;
+          best = m;
+        }
+        const float hh = (qq - logf(a.noise[(size_t)r * M + m])) / 0.5f;
+        if (hh > bh) {
+          bh = hh;
+          hot = m;
+        }
+      }
+      a.target[r] = (float)(best + M * c);
+      a.assign[r] = (a.pred[r] == c) ? hot : -1;
+    }
+  }
+  // ---- masked reduction f[m][:] = sum feat rows, cnt[m]
+  for (int j = tid; j < M * D; j += 256) f[j] = 0.f;
+  if (tid < M) cnt[tid] = 0.f;
+  __threadfence_block();
+  __syncthreads();
+  for (int i = 0; i < nc; ++i) {
+    const int r = rows[i];
+    const int m = a.assign[r];
+    if (m >= 0) {
+      for (int d = tid; d < D; d += 256) f[m * D + d] += a.feat[(size_t)r * D + d];
+      if (tid == 0) cnt[m] += 1.f;
+    }
+  }
+  __syncthreads();
+  float tot = 0.f;
+  for (int m = 0; m < M; ++m) tot += cnt[m];
+  // ---- EMA + final l2 normalisation, one wave per prototype
+  for (int m = wv; m < M; m += 4) {
+    float ss = 0.f;
+    for (int d = lane; d < D; d += 64) ss += f[m * D + d] * f[m * D + d];
+    const float inv = 1.f / fmaxf(sqrtf(c3d_wave_sum(ss)), 1e-12f);
+    const bool upd = nc > 0 && tot > 0.f && cnt[m] != 0.f;
+    float nn = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      float v = pin[m * D + d];
+      if (upd) v = a.momentum * v + (1.f - a.momentum) * (f[m * D + d] * inv);
+      f[m * D + d] = v;
+      nn += v * v;
+    }
+    const float inv2 = 1.f / fmaxf(sqrtf(c3d_wave_sum(nn)), 1e-12f);
+    for (int d = lane; d < D; d += 64) pout[m * D + d] = f[m * D + d] * inv2;
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int c3d_rownorm_ln_l2(const float* x, int64_t n, int C, const float* ln_w, const float* ln_b, float ln_eps,
+                                 float l2_eps, float* out, c3d_stream stream) {
+  C3D_REQUIRE(C % 4 == 0 && C <= 1024, "rownorm: C must be a multiple of 4 and <= 1024");
+  size_t nb = ((size_t)n + 3) / 4;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(rownorm_kernel, dim3((int)nb), dim3(256), 0, ST, x, (size_t)n, C, ln_w, ln_b, ln_eps, l2_eps, out);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_proto_nearest(const float* sim, int64_t n, int M, int C, const float* ln_w, const float* ln_b,
+                                 float eps, float* nearest, int32_t* pred, c3d_stream stream) {
+  C3D_REQUIRE(C <= 64, "proto_nearest: at most 64 classes");
+  size_t nb = ((size_t)n + 3) / 4;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(proto_nearest_kernel, dim3((int)nb), dim3(256), (size_t)4 * M * C * sizeof(float), ST, sim,
+                     (size_t)n, M, C, ln_w, ln_b, eps, nearest, pred);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_group_compact(const int64_t* labels, const uint8_t* keep, int groups, int n, int ncls,
+                                 int32_t* counts, int32_t* idx, c3d_stream stream) {
+  hipLaunchKernelGGL(group_compact_kernel, dim3(ncls, groups), dim3(256), 0, ST, labels, keep, n, ncls, counts, idx);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_proto_learn(const float* sim, const float* feat, const int32_t* pred, const int32_t* counts,
+                               const int32_t* idx, const float* noise, const float* protos, float* protos_out,
+                               float* target, int32_t* assign, int N, int M, int C, int D, int ignore_label,
+                               float momentum, c3d_stream stream) {
+  C3D_REQUIRE(M <= 32, "proto_learn: at most 32 sub-prototypes per class");
+  LearnArgs a{sim, feat, pred, counts, idx, noise, protos, protos_out, target, assign, N, M, C, D, ignore_label, momentum};
+  const size_t lds = (256 + 32 + (size_t)M * D + M) * sizeof(float);
+  hipLaunchKernelGGL(proto_learn_kernel, dim3(C), dim3(256), lds, ST, a);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,95 @@
+"""Data-parallel exchange points of the hot path, one process per GPU over torch.distributed
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+Reference semantics:
+  * gradient mean over ranks                 -- DistributedDataParallel, trainer.py:55-60
+  * SyncBatchNorm statistics                 -- trainer.py:54
+  * prototype bank: mean over ranks of each rank's l2-normalised EMA bank
+                                              -- salsanext_proto.py:397-400
+MI355X-first choices: ONE flat fp32 gradient buffer (29.6 MB) all-reduced in a few large chunks
+on a side stream while the backward of earlier layers is still running; BatchNorm exchanges the
+tiny fp64 (sum, sumsq) vectors the fused conv epilogue already produced; no per-iteration
+barrier or scalar all-reduce (trainer.py:740-743 is logging only).
+"""
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def allreduce_sum_(t):
+    """In-place sum over ranks (used for the fp64 BatchNorm sums)."""
+    if is_dist():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def world_mean(t):
+    """Mean over ranks of a tensor (prototype bank exchange)."""
+    if not is_dist():
+        return t
+    t = t.clone().div_(dist.get_world_size())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+class FlatGradients:
+    """All trainable gradients as views of one flat buffer, laid out in BACKWARD completion
+    order so that finished prefixes can be all-reduced while backward continues."""
+
+    def __init__(self, named_params, device=None, order=None):
+        named = list(named_params)
+        if order is not None:
+            rank = {n: i for i, n in enumerate(order)}
+            named.sort(key=lambda kv: rank.get(kv[0], len(rank)))
+        self.names = [n for n, _ in named]
+        total = sum(p.numel() for _, p in named)
+        dev = device if device is not None else named[0][1].device
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.views, off = {}, 0
+        for n, p in named:
+            self.views[n] = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def all_reduce_mean(self, n_chunks=4, stream=None):
+        if not is_dist():
+            return
+        world = dist.get_world_size()
+        chunk = (self.flat.numel() + n_chunks - 1) // n_chunks
+        works = []
+        for i in range(n_chunks):
+            seg = self.flat[i * chunk:(i + 1) * chunk]
+            if seg.numel():
+                seg.div_(world)
+                works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
+
+
+class DataParallel(torch.nn.Module):
+    """Minimal DDP stand-in exposing ``.module`` (what the reference trainer reads,
+    trainer.py:676-678) and wiring the three exchange points into SalsaNextProto's hooks."""
+
+    def __init__(self, module, sync_bn=True, n_chunks=4):
+        super().__init__()
+        self.module = module
+        self.n_chunks = n_chunks
+        world = dist.get_world_size() if is_dist() else 1
+        module._world = world if sync_bn else 1
+        module._bn_reduce = allreduce_sum_ if (sync_bn and world > 1) else None
+        module._proto_mean = world_mean if world > 1 else None
+        self.flat = FlatGradients(module._trainable())
+        module._flat_grads = self.flat.views
+        if world > 1:                      # identical initial weights on every rank
+            for p in module.parameters():
+                dist.broadcast(p.data, 0)
+            for b in module.buffers():
+                dist.broadcast(b.data, 0)
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    def finish_gradients(self):
+        self.flat.all_reduce_mean(self.n_chunks)

@@ -301,3 +301,108 @@ def l2norm_bwd(y, norm, dy, eps=1e-12):
     dx = torch.empty_like(y)
     _call("c3d_l2norm_bwd", _dp(y), _dp(norm), _dp(dy), y.numel() // c, c, eps, _dp(dx), _stream())
     return dx
+
+
+# ---------------------------------------------------------------------------- prototypes
+def rownorm_ln_l2(x, w, b, ln_eps=1e-5, l2_eps=1e-12):
+    c = x.shape[-1]
+    out = torch.empty_like(x)
+    _call("c3d_rownorm_ln_l2", _dp(x), x.numel() // c, c, _dp(w), _dp(b), ln_eps, l2_eps, _dp(out), _stream())
+    return out
+
+
+def proto_nearest(sim, m, c, w, b, eps=1e-5, want_nearest=False):
+    n = sim.shape[0]
+    nearest = torch.empty(n, c, device=sim.device, dtype=torch.float32) if want_nearest else None
+    pred = torch.empty(n, device=sim.device, dtype=torch.int32)
+    _call("c3d_proto_nearest", _dp(sim), n, m, c, _dp(w), _dp(b), eps, _dp(nearest), _dp(pred), _stream())
+    return nearest, pred
+
+
+def group_compact(labels, ncls, keep=None):
+    """labels int64 [G, n] -> (counts int32 [G, ncls], idx int32 [G, ncls, n])."""
+    g, n = labels.shape
+    counts = torch.empty(g, ncls, device=labels.device, dtype=torch.int32)
+    idx = torch.empty(g, ncls, n, device=labels.device, dtype=torch.int32)
+    _call("c3d_group_compact", _dp(labels), _dp(keep), g, n, ncls, _dp(counts), _dp(idx), _stream())
+    return counts, idx
+
+
+def proto_learn(sim, feat, pred, counts, idx, noise, protos, m, c, ignore_label, momentum):
+    n, d = feat.shape
+    protos_out = torch.empty_like(protos)
+    target = torch.zeros(n, device=feat.device, dtype=torch.float32)
+    assign = torch.empty(n, device=feat.device, dtype=torch.int32)
+    _call("c3d_proto_learn", _dp(sim), _dp(feat), _dp(pred), _dp(counts), _dp(idx), _dp(noise), _dp(protos),
+          _dp(protos_out), _dp(target), _dp(assign), n, m, c, d, ignore_label, momentum, _stream())
+    return protos_out, target
+
+
+# ---------------------------------------------------------------------------- loss path
+def entropy_stats(prob, want_anchor=True, want_pl=True, want_amax=True):
+    c = prob.shape[-1]
+    n = prob.numel() // c
+    dev = prob.device
+    wa = torch.empty(n, device=dev, dtype=torch.float32) if want_anchor else None
+    wp = torch.empty(n, device=dev, dtype=torch.float32) if want_pl else None
+    am = torch.empty(n, device=dev, dtype=torch.int32) if want_amax else None
+    _call("c3d_entropy_stats", _dp(prob), n, c, _dp(wa), _dp(wp), _dp(am), _stream())
+    return wa, wp, am
+
+
+def pl_select(w_pl, amax, eval_label, train_label, noise, tl_counts, b, n, c, ignore_label, ratio):
+    dev = w_pl.device
+    chosen = torch.zeros(b, n, device=dev, dtype=torch.uint8)
+    labels = torch.empty(b, n, device=dev, dtype=torch.int64)
+    mask = torch.empty(b, n, device=dev, dtype=torch.uint8)
+    _call("c3d_pl_select", _dp(w_pl), _dp(amax), _dp(eval_label), _dp(train_label), _dp(noise), _dp(tl_counts), b, n,
+          c, ignore_label, float(ratio), _dp(chosen), _dp(labels), _dp(mask), _stream())
+    return labels, mask.bool()
+
+
+def anchor_sample(weights, counts, idx, uniforms, b, n, c, a, ignore_label):
+    dev = weights.device
+    slot = torch.empty(b * c, device=dev, dtype=torch.int32)
+    cum = torch.empty(b, c, n, device=dev, dtype=torch.float32)
+    a_idx = torch.zeros(b * c, a, device=dev, dtype=torch.int32)
+    a_img = torch.zeros(b * c, device=dev, dtype=torch.int32)
+    a_cls = torch.zeros(b * c, device=dev, dtype=torch.int32)
+    t = torch.zeros(1, device=dev, dtype=torch.int32)
+    _call("c3d_anchor_sample", _dp(weights), _dp(counts), _dp(idx), _dp(uniforms), b, n, c, a, ignore_label,
+          _dp(slot), _dp(cum), _dp(a_idx), _dp(a_img), _dp(a_cls), _dp(t), _stream())
+    return a_idx, a_img, a_cls, t
+
+
+def gather_rows_l2(feat, img, idx, t, tmax, a, n, eps=1e-12):
+    d = feat.shape[-1]
+    out = torch.empty(tmax * a, d, device=feat.device, dtype=torch.float32)
+    norm = torch.empty(tmax * a, device=feat.device, dtype=torch.float32)
+    _call("c3d_gather_rows_l2", _dp(feat), _dp(img), _dp(idx), _dp(t), tmax, a, n, d, eps, _dp(out), _dp(norm),
+          _stream())
+    return out, norm
+
+
+def scatter_add_rows(dx, img, idx, t, tmax, a, n, dfeat, gscale=None):
+    d = dx.shape[-1]
+    _call("c3d_scatter_add_rows", _dp(dx), _dp(img), _dp(idx), _dp(t), tmax, a, n, d, _dp(gscale), _dp(dfeat),
+          _stream())
+    return dfeat
+
+
+def infonce_rows(logits, row_cls, t, tmax, a, m, ncols, temperature, base_temperature=0.07):
+    dev = logits.device
+    row_loss = torch.empty(tmax * a, device=dev, dtype=torch.float32)
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    _call("c3d_infonce_rows", _dp(logits), logits.shape[-1], _dp(row_cls), _dp(t), tmax, a, m, ncols,
+          temperature, base_temperature, _dp(row_loss), _dp(loss), _stream())
+    return loss, row_loss
+
+
+def gemm_rows(x, w_oihw_packed, cout, out=None):
+    """[R, K] x packed weight -> [R, cout] on the MFMA conv engine (R multiple of 32)."""
+    r, k = x.shape
+    assert r % 32 == 0
+    src = Source(x.view(1, r // 32, 32, k))
+    y, _ = conv_forward([src], w_oihw_packed, None, cout, [(0, 0)],
+                        out=None if out is None else out.view(1, r // 32, 32, out.shape[-1]))
+    return y.view(r, -1)

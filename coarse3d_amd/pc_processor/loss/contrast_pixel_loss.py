@@ -1,0 +1,32 @@
+"""ContrastMEMLoss with the reference constructor / forward signature
+(reference pc_processor/loss/contrast_pixel_loss.py:8-75); the work happens in the HIP kernels
+behind ``coarse3d_amd.contrast.contrast_mem_loss``."""
+import torch
+import torch.nn as nn
+
+from ... import contrast
+
+
+class ContrastMEMLoss(nn.Module):
+    def __init__(self, ignore_label=0, temperature=0.1, base_temperature=0.07, num_anchor=50, is_debug=False):
+        super().__init__()
+        self.temperature = temperature
+        self.base_temperature = base_temperature
+        self.num_anchor = num_anchor
+        self.ignore_label = ignore_label
+        self.is_debug = is_debug
+        self.sub_proto = True
+        # test hooks: injected randomness (float64 uniforms [T, A], queue permutations [C-1, M])
+        self.uniforms = None
+        self.perms = None
+
+    def forward(self, feats=None, output=None, labels=None, keep_mask=None, proto_queue=None):
+        assert proto_queue is not None
+        assert output is not None, "entropy weights need the class probabilities"
+        assert labels.shape[-1] == feats.shape[-1], "{} {}".format(labels.shape, feats.shape)
+        queue = proto_queue.squeeze(0)
+        if self.is_debug:
+            print("queue size, max views : ", queue.shape)
+        return contrast.contrast_mem_loss(feats, output, labels, keep_mask, queue, self.temperature,
+                                          self.base_temperature, self.num_anchor, self.ignore_label,
+                                          self.uniforms, self.perms)

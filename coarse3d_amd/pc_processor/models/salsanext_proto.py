@@ -1,0 +1,219 @@
+"""SalsaNextProto with the reference module API (pc_processor/models/salsanext_proto.py:253-532)
+on the MI355X-native HIP backbone.
+
+Drop-in surface kept from the reference:
+  * constructor signature and defaults (:254-267), ``forward`` signature and returned dict keys
+    ``pred_2d`` / ``feat_2d`` / ``contrast_logits`` / ``contrast_target`` (:404-532);
+  * ``state_dict`` key names and OIHW weight layout (released checkpoints load);
+  * ``prototypes`` is re-bound to a fresh ``nn.Parameter`` on every update (:394, :516);
+  * ``nn.BatchNorm2d`` children so ``SyncBatchNorm.convert_sync_batchnorm`` still walks them.
+The child modules below only HOLD parameters (same construction order as the reference, hence
+the same default initialisation under the same seed); the arithmetic runs in
+``coarse3d_amd.backbone.Backbone`` and ``coarse3d_amd.proto``.
+
+Deliberate fixes: the debug lines that overwrite the inputs (:414-421) are
+not replicated (Q1); both H and W are validated (Q4).
+"""
+import torch
+import torch.nn as nn
+
+from ... import proto as proto_ops
+from ...backbone import Backbone
+from .projector import ProjectionV1
+
+DROP_P = 0.2
+
+
+class ResContextBlock(nn.Module):
+    def __init__(self, in_filters, out_filters):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_filters, out_filters, kernel_size=(1, 1), stride=1)
+        self.conv2 = nn.Conv2d(out_filters, out_filters, (3, 3), padding=1)
+        self.bn1 = nn.BatchNorm2d(out_filters)
+        self.conv3 = nn.Conv2d(out_filters, out_filters, (3, 3), dilation=2, padding=2)
+        self.bn2 = nn.BatchNorm2d(out_filters)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_filters, out_filters, dropout_rate, kernel_size=(3, 3), stride=1, pooling=True,
+                 drop_out=True):
+        super().__init__()
+        self.pooling, self.drop_out = pooling, drop_out
+        self.conv1 = nn.Conv2d(in_filters, out_filters, kernel_size=(1, 1), stride=stride)
+        self.conv2 = nn.Conv2d(in_filters, out_filters, kernel_size=(3, 3), padding=1)
+        self.bn1 = nn.BatchNorm2d(out_filters)
+        self.conv3 = nn.Conv2d(out_filters, out_filters, kernel_size=(3, 3), dilation=2, padding=2)
+        self.bn2 = nn.BatchNorm2d(out_filters)
+        self.conv4 = nn.Conv2d(out_filters, out_filters, kernel_size=(2, 2), dilation=2, padding=1)
+        self.bn3 = nn.BatchNorm2d(out_filters)
+        self.conv5 = nn.Conv2d(out_filters * 3, out_filters, kernel_size=(1, 1))
+        self.bn4 = nn.BatchNorm2d(out_filters)
+        self.dropout = nn.Dropout2d(p=dropout_rate)
+
+
+class UpBlock(nn.Module):
+    def __init__(self, in_filters, out_filters, dropout_rate, drop_out=True, inplace=False):
+        super().__init__()
+        self.drop_out = drop_out
+        self.in_filters, self.out_filters = in_filters, out_filters
+        self.dropout1 = nn.Dropout2d(p=dropout_rate)
+        self.dropout2 = nn.Dropout2d(p=dropout_rate)
+        self.conv1 = nn.Conv2d(in_filters // 4 + 2 * out_filters, out_filters, (3, 3), padding=1)
+        self.bn1 = nn.BatchNorm2d(out_filters)
+        self.conv2 = nn.Conv2d(out_filters, out_filters, (3, 3), dilation=2, padding=2)
+        self.bn2 = nn.BatchNorm2d(out_filters)
+        self.conv3 = nn.Conv2d(out_filters, out_filters, (2, 2), dilation=2, padding=1)
+        self.bn3 = nn.BatchNorm2d(out_filters)
+        self.conv4 = nn.Conv2d(out_filters * 3, out_filters, kernel_size=(1, 1))
+        self.bn4 = nn.BatchNorm2d(out_filters)
+        self.dropout3 = nn.Dropout2d(p=dropout_rate)
+
+
+# (site, channels as a multiple of base_channels) of the 13 active Dropout2d layers
+_DROP_SITES = (("resBlock2.dropout", 4), ("resBlock3.dropout", 8), ("resBlock4.dropout", 8),
+               ("resBlock5.dropout", 8),
+               ("upBlock1.dropout1", 2), ("upBlock1.dropout2", 10), ("upBlock1.dropout3", 4),
+               ("upBlock2.dropout1", 1), ("upBlock2.dropout2", 9), ("upBlock2.dropout3", 4),
+               ("upBlock3.dropout1", 1), ("upBlock3.dropout2", 5), ("upBlock3.dropout3", 2))
+
+
+class _BackboneFn(torch.autograd.Function):
+    """x, parameters -> (pred_2d, feat_2d); backward = the explicit HIP backward plan."""
+
+    @staticmethod
+    def forward(ctx, model, x, masks, return_feat, names, *tensors):
+        P = model._tensor_dict()
+        bb = Backbone(P, model.nclasses, model.dataset, model._bn_reduce, model._world)
+        out = bb.forward(x.detach().float(), model.training, masks, return_feat)
+        ctx.bb, ctx.names, ctx.model = bb, names, model
+        ctx.return_feat = return_feat
+        pred = out["prob"].permute(0, 3, 1, 2)
+        feat = out["feat"].permute(0, 3, 1, 2) if return_feat else x.new_zeros(())
+        ctx.mark_non_differentiable(*([] if return_feat else [feat]))
+        return pred, feat
+
+    @staticmethod
+    def backward(ctx, d_pred, d_feat):
+        bb = ctx.bb
+        model = ctx.model
+        prob = bb._prob
+        d_prob = (d_pred.permute(0, 2, 3, 1).contiguous() if d_pred is not None
+                  else torch.zeros_like(prob))
+        d_f = d_feat.permute(0, 2, 3, 1).contiguous() if (ctx.return_feat and d_feat is not None) else None
+        grads = bb.backward(d_prob, d_f, grads=model._grad_buffers(ctx.names))
+        ctx.bb = None
+        if model._grad_ready is not None:
+            model._grad_ready()
+        return (None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
+
+
+class SalsaNextProto(nn.Module):
+    def __init__(self, in_channel=5, nclasses=20, sub_proto_size=20, ignore_label=0, use_prototype=False,
+                 softmax=True, proj_dim=256, projection="v1", classification=False, proto_mom=0.999,
+                 dataset="SemanticKitti"):
+        super().__init__()
+        if classification:
+            raise ValueError("classification=True (ImageNet pre-training head) is outside the accelerated path")
+        if not softmax:
+            raise ValueError("softmax=False is not supported: the head always returns probabilities")
+        self.nclasses = nclasses
+        self.base_channels = 32
+        self.proj_dim = proj_dim
+        self.softmax = softmax
+        self.projection = projection
+        self.classification = classification
+        self.use_prototype = use_prototype
+        self.sub_proto_size = sub_proto_size
+        self.ignore_label = ignore_label
+        self.proto_mom = proto_mom
+        self.dataset = dataset
+        bc = self.base_channels
+
+        self.downCntx = ResContextBlock(in_channel, bc)
+        self.downCntx2 = ResContextBlock(bc, bc)
+        self.downCntx3 = ResContextBlock(bc, bc)
+        self.resBlock1 = ResBlock(bc, 2 * bc, DROP_P, pooling=True, drop_out=False)
+        self.resBlock2 = ResBlock(2 * bc, 4 * bc, DROP_P, pooling=True)
+        self.resBlock3 = ResBlock(4 * bc, 8 * bc, DROP_P, pooling=True)
+        self.resBlock4 = ResBlock(8 * bc, 8 * bc, DROP_P, pooling=True)
+        self.resBlock5 = ResBlock(8 * bc, 8 * bc, DROP_P, pooling=False)
+        self.upBlock1 = UpBlock(8 * bc, 4 * bc, DROP_P)
+        self.upBlock2 = UpBlock(4 * bc, 4 * bc, DROP_P)
+        self.upBlock3 = UpBlock(4 * bc, 2 * bc, DROP_P)
+        self.upBlock4 = UpBlock(2 * bc, bc, DROP_P, drop_out=False)
+        self.cls_head = nn.Conv2d(bc, nclasses, kernel_size=(1, 1))
+        self.projector = ProjectionV1(bc * 22, proj_dim)
+        self.prototypes = nn.Parameter(torch.randn(nclasses, sub_proto_size, proj_dim), requires_grad=False)
+        nn.init.trunc_normal_(self.prototypes, std=0.02)
+        self.feat_norm = nn.LayerNorm(proj_dim)
+        self.mask_norm = nn.LayerNorm(nclasses)
+
+        # hooks (not part of the reference surface)
+        self.dropout_masks = None     # test hook: dict site -> [B, C] multipliers (0 or 1/(1-p))
+        self.gumbel_noise = None      # test hook: Exp(1) variates [N, M] indexed by pixel
+        self._bn_reduce = None        # data parallel: in-place all-reduce of fp64 BN sums
+        self._world = 1
+        self._proto_mean = None       # data parallel: mean of the bank over ranks
+        self._grad_ready = None       # data parallel: called when all gradients are written
+        self._flat_grads = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _tensor_dict(self):
+        d = {k: v.detach() for k, v in self.named_parameters()}
+        d.update({k: v for k, v in self.named_buffers()})
+        return d
+
+    def _trainable(self):
+        skip = ("prototypes", "feat_norm.weight", "feat_norm.bias", "mask_norm.weight", "mask_norm.bias")
+        return [(k, p) for k, p in self.named_parameters() if k not in skip]
+
+    def _grad_buffers(self, names):
+        if self._flat_grads is not None:
+            return self._flat_grads
+        dev = self.cls_head.weight.device
+        P = dict(self.named_parameters())
+        return {n: torch.empty_like(P[n], device=dev) for n in names}
+
+    def _draw_masks(self, b, device):
+        if self.dropout_masks is not None:
+            return self.dropout_masks
+        total = sum(m for _, m in _DROP_SITES) * self.base_channels
+        keep = (torch.rand(b, total, device=device) >= DROP_P).to(torch.float32) * (1.0 / (1.0 - DROP_P))
+        masks, off = {}, 0
+        for name, mult in _DROP_SITES:
+            c = mult * self.base_channels
+            masks[name] = keep[:, off:off + c].contiguous()
+            off += c
+        return masks
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, label=None, eval_mask=None, return_feat=True, proto_loss=False, proto_pl=None):
+        b, c, h, w = x.shape
+        hp, wp = (h + 8, w + 8) if self.dataset == "SemanticPOSS" else (h, w)
+        assert hp % 16 == 0 and wp % 16 == 0, "input height and width must be multiples of 16"
+        masks = self._draw_masks(b, x.device) if self.training else None
+        named = self._trainable()
+        names = tuple(k for k, _ in named)
+        pred, feat = _BackboneFn.apply(self, x, masks, bool(return_feat), names, *[p for _, p in named])
+        out = {"pred_2d": pred}
+        if not return_feat:
+            return out
+        out["feat_2d"] = feat
+        if self.use_prototype and label is not None and eval_mask is not None:
+            with torch.no_grad():
+                P = {"prototypes": self.prototypes.data, "feat_norm.weight": self.feat_norm.weight.data,
+                     "feat_norm.bias": self.feat_norm.bias.data, "mask_norm.weight": self.mask_norm.weight.data,
+                     "mask_norm.bias": self.mask_norm.bias.data}
+                feat_nhwc = feat.detach().permute(0, 2, 3, 1).contiguous()
+                res = proto_ops.prototype_step(
+                    feat_nhwc, P, label.reshape(-1).long() if proto_loss else None, proto_loss,
+                    noise=self.gumbel_noise, momentum=self.proto_mom, ignore_label=self.ignore_label,
+                    world_mean=self._proto_mean, ema_base=proto_pl)
+                self.prototypes.data.copy_(res["bank_l2"])          # in-place renormalisation (:502)
+                if proto_pl is not None:
+                    self.prototypes = nn.Parameter(proto_pl.clone(), requires_grad=False)
+                if proto_loss:
+                    self.prototypes = nn.Parameter(res["new_bank"], requires_grad=False)
+                    out["contrast_logits"] = res["contrast_logits"]
+                    out["contrast_target"] = res["contrast_target"]
+        return out

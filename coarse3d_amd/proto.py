@@ -1,0 +1,62 @@
+"""Prototype memory-bank path on the HIP kernels (no autograd: the reference runs it under
+``requires_grad=False`` parameters and never back-propagates through it).
+
+Reference: pc_processor/models/salsanext_proto.py:494-530 (similarity + LayerNorm) and
+:337-402 (prototype_learning with Sinkhorn, pc_processor/models/sinkhorn.py:5-33)."""
+import torch
+
+from . import ops
+
+
+def l2_bank(protos):
+    """Row-wise l2 normalisation of the [C, M, D] bank (salsanext_proto.py:502)."""
+    out, _ = ops.l2norm(protos.contiguous(), 1e-12, want_norm=False)
+    return out
+
+
+def similarity(feat_nhwc, bank_l2, ln_w, ln_b):
+    """feat [B,H,W,D] -> (rows [N,D] = l2(LN(feat)), sim [N, M*C] with column m*C + k)."""
+    b, h, w, d = feat_nhwc.shape
+    n = b * h * w
+    c, m, _ = bank_l2.shape
+    rows = ops.rownorm_ln_l2(feat_nhwc.view(n, d), ln_w, ln_b)
+    # GEMM weight in "OIHW": output column m*C+k <- prototype (k, m)
+    w_oihw = bank_l2.permute(1, 0, 2).reshape(m * c, d, 1, 1).contiguous()
+    wp = ops.pack_weights(w_oihw, 0)
+    npad = (n + 31) // 32 * 32
+    if npad != n:
+        rows_p = torch.zeros(npad, d, device=rows.device, dtype=torch.float32)
+        rows_p[:n] = rows
+        sim = ops.gemm_rows(rows_p, wp, m * c)[:n]
+    else:
+        sim = ops.gemm_rows(rows, wp, m * c)
+    return rows, sim
+
+
+def prototype_step(feat_nhwc, P, label, proto_loss, noise=None, momentum=0.999, ignore_label=0,
+                   world_mean=None, want_nearest=False, ema_base=None):
+    """One pass of salsanext_proto.py:494-530.
+
+    P: dict with ``prototypes`` [C,M,D], ``feat_norm.*``, ``mask_norm.*``.  label: [N] int64 or
+    None.  noise: Exp(1) variates [N, M] indexed by pixel (None -> drawn on device).
+    Returns dict(bank_l2, [nearest], [contrast_logits, contrast_target, new_bank])."""
+    bank = P["prototypes"]
+    c, m, d = bank.shape
+    bank_l2 = l2_bank(bank)
+    rows, sim = similarity(feat_nhwc, bank_l2, P["feat_norm.weight"], P["feat_norm.bias"])
+    n = rows.shape[0]
+    nearest, pred = ops.proto_nearest(sim, m, c, P["mask_norm.weight"], P["mask_norm.bias"],
+                                      want_nearest=want_nearest)
+    out = {"bank_l2": bank_l2, "nearest": nearest, "pred": pred}
+    if proto_loss and label is not None:
+        lab = label.reshape(1, n).contiguous()
+        counts, idx = ops.group_compact(lab, c)
+        if noise is None:
+            noise = torch.empty(n, m, device=rows.device, dtype=torch.float32).exponential_()
+        base = bank_l2 if ema_base is None else ema_base.contiguous()   # proto_pl replaces the bank (:515-518)
+        new_bank, target = ops.proto_learn(sim, rows, pred, counts.view(-1), idx.view(c, n), noise.contiguous(),
+                                           base, m, c, ignore_label, momentum)
+        if world_mean is not None:       # data parallel: mean over ranks (salsanext_proto.py:397-400)
+            new_bank = world_mean(new_bank)
+        out.update(contrast_logits=sim, contrast_target=target, new_bank=new_bank)
+    return out

@@ -1,0 +1,94 @@
+"""One optimisation step of the weak-segmentation trainer on the HIP path.
+
+Mirrors tasks/weak_segmentation/trainer.py:599-704 (input normalisation, model forward with the
+prototype bank update, focal + Lovasz, entropy-based pseudo-label selection, prototype
+contrastive loss, backward, AdamW, scheduler) with the per-iteration host synchronisations
+(``.item()`` logging :750-802, barrier + scalar all-reduces :740-743) removed from the step.
+Config keys follow tasks/weak_segmentation/option.py:43-49 / config_semantic_kitti.yaml:20-42.
+"""
+import numpy as np
+import torch
+
+from . import contrast, ops
+from .pc_processor.loss import ContrastMEMLoss, FocalSoftmaxLoss, Lovasz_softmax
+
+
+def select_ratio_for(epoch, n_epochs):
+    """trainer.py:655-661."""
+    return float(np.log(1 + (1 + epoch) / n_epochs) / np.log(2) * 0.5)
+
+
+class TrainStep:
+    def __init__(self, model, n_classes, *, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512,
+                 loss_w_ce_2d=1.0, loss_w_lov_2d=1.0, loss_w_contrast=0.1, contrast_warmup=0,
+                 entropy_selection=True, ignore_cls=0, cls_weight=None, feature_mean=None, feature_std=None,
+                 proto_loss=True, optimizer=None, scheduler=None):
+        self.model = model
+        self.net = model.module if hasattr(model, "module") else model
+        self.n_classes = n_classes
+        self.n_epochs = n_epochs
+        self.w_ce, self.w_lov, self.w_con = loss_w_ce_2d, loss_w_lov_2d, loss_w_contrast
+        self.contrast_warmup = contrast_warmup
+        self.entropy_selection = entropy_selection
+        self.ignore_cls = ignore_cls
+        self.proto_loss = proto_loss
+        dev = next(self.net.parameters()).device
+        if cls_weight is None:
+            alpha = np.ones(n_classes, dtype=np.float32)
+        else:                                           # trainer.py:351-354
+            alpha = np.log(1 + np.asarray(cls_weight, dtype=np.float64))
+            alpha = (alpha / alpha.max()).astype(np.float32)
+        alpha[0] = 0
+        self.focal = FocalSoftmaxLoss(n_classes, gamma=2, alpha=alpha, softmax=False)
+        self.lovasz = Lovasz_softmax(ignore=ignore_cls, per_image=False, softmax=False)
+        self.contrast = ContrastMEMLoss(ignore_label=ignore_cls, temperature=temperature, num_anchor=num_anchor)
+        self.mean = torch.as_tensor(feature_mean, dtype=torch.float32, device=dev) if feature_mean is not None else None
+        self.std = torch.as_tensor(feature_std, dtype=torch.float32, device=dev) if feature_std is not None else None
+        # trainer.py:146-151: AdamW(params, lr) -- cfg.weight_decay is NOT passed (default 0.01)
+        self.optimizer = optimizer or torch.optim.AdamW(self.net.parameters(), lr=lr)
+        self.scheduler = scheduler
+        self.pl_noise = None     # test hook: Exp(1) noise [B, C, HW] for the pseudo-label selection
+
+    def step(self, x, train_label, eval_label, epoch=0):
+        """x [B,5,H,W] fp32, labels [B,H,W] int64 (0 = ignore).  Returns dict of 0-dim loss tensors
+        (still on the device: nothing here synchronises with the host except Lovasz' nonzero)."""
+        net = self.net
+        wss_mask = train_label > 0
+        eval_mask = eval_label > 0
+        if self.mean is not None:
+            x = ops.input_norm(x.contiguous(), eval_label.contiguous(), self.mean, self.std)
+        return_feat = epoch >= self.contrast_warmup
+        out = self.model(x, label=train_label if return_feat else None, eval_mask=wss_mask if return_feat else None,
+                         return_feat=return_feat, proto_loss=self.proto_loss)
+        pred = out["pred_2d"]
+        total = pred.new_zeros(())
+        res = {}
+        if self.w_ce > 0:
+            res["ce"] = self.focal(pred, train_label, mask=wss_mask)
+            total = total + self.w_ce * res["ce"]
+        if self.w_lov > 0:
+            res["lov"] = self.lovasz(pred, train_label)
+            total = total + self.w_lov * res["lov"]
+        if self.w_con > 0 and return_feat:
+            if self.entropy_selection:
+                with torch.no_grad():
+                    ratio = select_ratio_for(epoch, self.n_epochs)
+                    lab_c, mask_c = contrast.entropy_selection(
+                        pred.detach().permute(0, 2, 3, 1).contiguous(), train_label, eval_label, ratio,
+                        noise=self.pl_noise, ignore_cls=self.ignore_cls)
+            else:
+                lab_c, mask_c = train_label, wss_mask
+            res["labels_contra"], res["mask_contra"] = lab_c, mask_c
+            queue = net.prototypes.detach().unsqueeze(0)
+            res["contrast"] = self.contrast(feats=out["feat_2d"], output=pred, labels=lab_c, keep_mask=mask_c,
+                                            proto_queue=queue)
+            total = total + self.w_con * res["contrast"]
+        self.optimizer.zero_grad(set_to_none=True)
+        total.backward()
+        if hasattr(self.model, "finish_gradients"):
+            self.model.finish_gradients()
+        self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        res["loss"] = total.detach()
+        return res

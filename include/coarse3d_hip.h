@@ -182,6 +182,66 @@ int c3d_l2norm(const float* x, int64_t n, int C, float eps, float* y, float* nor
 int c3d_l2norm_bwd(const float* y, const float* norm, const float* dy, int64_t n, int C,
                    float eps, float* dx, c3d_stream stream);
 
+/* ------------------------------------------------------------------ prototype memory bank
+ * salsanext_proto.py:494-510 (similarity) and :337-402 (prototype_learning), sinkhorn.py:5-33.
+ * The [N,D] x [D, M*C] similarity GEMM runs on c3d_conv_forward (1x1).                       */
+
+/* out = l2_normalize(LayerNorm(x)) per row of [n][C]   (:497-501)                            */
+int c3d_rownorm_ln_l2(const float* x, int64_t n, int C, const float* ln_w, const float* ln_b,
+                      float ln_eps, float l2_eps, float* out, c3d_stream stream);
+/* sim [n][M*C] (column m*C+k) -> nearest [n][C] = LayerNorm(max_m sim) (may be NULL) and
+ * pred[n] = argmax_k nearest   (:506-507, :340)                                              */
+int c3d_proto_nearest(const float* sim, int64_t n, int M, int C, const float* ln_w,
+                      const float* ln_b, float eps, float* nearest, int32_t* pred,
+                      c3d_stream stream);
+/* Ordered lists: idx[g][c][0..counts[g][c]) = ascending positions i with labels[g][i]==c
+ * (labels masked to 0 where keep[g][i]==0, keep may be NULL).  idx is [groups][ncls][n].     */
+int c3d_group_compact(const int64_t* labels, const uint8_t* keep, int groups, int n, int ncls,
+                      int32_t* counts, int32_t* idx, c3d_stream stream);
+/* Per class: Sinkhorn (3 iters, eps .05) on sim[rows,:,c], argmax -> target, Gumbel-hard
+ * one-hot from Exp(1) `noise` [N][M] (indexed by pixel), masked feature sums, EMA into the
+ * bank and final l2.  counts/idx from c3d_group_compact(groups=1).  target must be zeroed.   */
+int c3d_proto_learn(const float* sim, const float* feat, const int32_t* pred,
+                    const int32_t* counts, const int32_t* idx, const float* noise,
+                    const float* protos, float* protos_out, float* target, int32_t* assign,
+                    int N, int M, int C, int D, int ignore_label, float momentum,
+                    c3d_stream stream);
+
+/* ------------------------------------------------------------------ contrast loss + PL selection
+ * contrast_pixel_loss.py:27-195, trainer.py:447-518                                          */
+
+/* prob [n][C] -> w_anchor = exp(-H^2), w_pl = exp(-H), amax (any output may be NULL)         */
+int c3d_entropy_stats(const float* prob, int64_t n, int C, float* w_anchor, float* w_pl,
+                      int32_t* amax, c3d_stream stream);
+/* entropy_based_selection: per (image b, class c present in train_label): k = int(cnt*ratio)
+ * pixels with the largest w_pl/noise among {amax==c, eval>0}; noise [B][C][n] Exp(1);
+ * tl_counts [B][C] = weak-label counts; chosen [B][n] zeroed scratch.                        */
+int c3d_pl_select(const float* w_pl, const int32_t* amax, const int64_t* eval_label,
+                  const int64_t* train_label, const float* noise, const int32_t* tl_counts,
+                  int B, int n, int C, int ignore_label, float ratio, uint8_t* chosen,
+                  int64_t* labels_out, uint8_t* mask_out, c3d_stream stream);
+/* anchor_sampling: bit-exact torch.multinomial(replacement=True) per present (b,c) pair;
+ * the t-th present pair consumes uniforms[t][0..A).  counts/idx from c3d_group_compact.
+ * slot [B*C], cum [B][C][n] are scratch.  Outputs anchor_idx [B*C][A] (pixel in image),
+ * anchor_img / anchor_cls [B*C], *T = number of present pairs.                               */
+int c3d_anchor_sample(const float* weights, const int32_t* counts, const int32_t* idx,
+                      const double* uniforms, int B, int n, int C, int A, int ignore_label,
+                      int32_t* slot, float* cum, int32_t* anchor_idx, int32_t* anchor_img,
+                      int32_t* anchor_cls, int32_t* T, c3d_stream stream);
+/* out[t*A+s] = l2_normalize(feat[img[t]][idx[t][s]]) for t < *T, zero rows otherwise         */
+int c3d_gather_rows_l2(const float* feat, const int32_t* img, const int32_t* idx,
+                       const int32_t* T, int Tmax, int A, int n, int D, float eps, float* out,
+                       float* norm, c3d_stream stream);
+/* dfeat[img[t]][idx[t][s]] += (*gscale) * dx[t*A+s]   (atomic; gscale may be NULL)           */
+int c3d_scatter_add_rows(const float* dx, const int32_t* img, const int32_t* idx,
+                         const int32_t* T, int Tmax, int A, int n, int D, const float* gscale,
+                         float* dfeat, c3d_stream stream);
+/* InfoNCE over cosine logits [Tmax*A][ld] (first ncols=(C-1)*M columns valid, column class
+ * 1 + j/M): replaces logits by d(mean loss)/d(logits) in place, row_loss per row, *loss.     */
+int c3d_infonce_rows(float* logits, int ld, const int32_t* row_cls, const int32_t* T, int Tmax,
+                     int A, int M, int ncols, float temperature, float base_temperature,
+                     float* row_loss, float* loss, c3d_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,216 @@
+"""Prototype bank, contrast loss, pseudo-label selection and the full training step on the HIP
+path, against (a) golden vectors captured from the real reference and (b) the CPU oracle.
+
+Tolerances: anchor / pseudo-label indices bit-exact when the sampler is fed the golden weights;
+fp32 probabilities and prototype vectors within 1e-4 (north-star); losses within 1e-4."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import weights as W
+from oracle import coarse3d_oracle as oc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, name)).items()}
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def pixel_noise(tr, gold, ncls, m=20):
+    """golden per-class Gumbel noise [n_c, M] (ascending pixel order) -> per-pixel [N, M]."""
+    flat = tr.reshape(-1)
+    out = torch.ones(flat.numel(), m)
+    for c in range(1, ncls):
+        if f"gumbel_{c}" in gold:
+            out[flat == c] = gold[f"gumbel_{c}"]
+    return out
+
+
+def test_multinomial_sampler_bit_exact():
+    """c3d_anchor_sample == torch.multinomial(replacement=True) on the same float64 stream,
+    incl. classes absent from an image (ragged) and zero-weight gaps."""
+    from coarse3d_amd import ops
+    gen = np.random.Generator(np.random.PCG64(17))
+    B, n, C, A = 3, 8192, 7, 512
+    labels = torch.from_numpy(gen.integers(0, C, (B, n)))
+    labels[1][labels[1] == 3] = 0
+    labels[2][:] = 0                                   # an image without any class
+    labels[2][100:5000:7] = 5
+    w = torch.from_numpy(gen.random((B, n)).astype(np.float32))
+    ref_idx, unis = [], []
+    torch.manual_seed(123)
+    for b in range(B):
+        for c in torch.unique(labels[b]).tolist():
+            if c == 0:
+                continue
+            wc = w[b].clone()
+            wc[labels[b] != c] = 0
+            st = torch.random.get_rng_state()
+            ref_idx.append(torch.multinomial(wc, A, replacement=True))
+            torch.random.set_rng_state(st)
+            unis.append(torch.rand(A, dtype=torch.float64))
+    T = len(ref_idx)
+    u = torch.zeros(B * C, A, dtype=torch.float64)
+    u[:T] = torch.stack(unis)
+    counts, idx = ops.group_compact(labels.to(DEV), C)
+    a_idx, a_img, a_cls, t = ops.anchor_sample(w.to(DEV), counts, idx, u.to(DEV), B, n, C, A, 0)
+    assert int(t) == T
+    assert torch.equal(a_idx[:T].cpu().long(), torch.stack(ref_idx))
+
+
+def test_contrast_loss_vs_golden():
+    from coarse3d_amd.pc_processor.loss import ContrastMEMLoss
+    g = load("contrast.npz")
+    feats = g["feats"].to(DEV).requires_grad_(True)
+    crit = ContrastMEMLoss(ignore_label=0, temperature=0.07, num_anchor=64)
+    crit.uniforms, crit.perms = g["uniforms"], g["perms"]
+    from coarse3d_amd import contrast
+    loss, dbg = contrast.contrast_mem_loss(feats, g["prob"].to(DEV), g["labels"].to(DEV), g["keep"].to(DEV),
+                                           g["queue"].to(DEV), 0.07, 0.07, 64, 0, g["uniforms"], g["perms"],
+                                           return_debug=True)
+    T = g["indices"].shape[0]
+    assert int(dbg["T"]) == T
+    got = dbg["idx"][:T].cpu().long()
+    same = (got == g["indices"]).float().mean().item()
+    # weights come from expf/logf on the GPU (<= 1 ulp from the CPU's): a draw that falls within
+    # 1 ulp of a bin edge may move to the neighbouring pixel
+    assert same >= 0.995, same
+    assert rel(loss, g["loss"]) < 1e-4
+    loss.backward()
+    if same == 1.0:
+        assert rel(feats.grad, g["grad_feats"]) < 1e-4
+    # module API gives the same number
+    feats2 = g["feats"].to(DEV).requires_grad_(True)
+    l2 = crit(feats=feats2, output=g["prob"].to(DEV), labels=g["labels"].to(DEV), keep_mask=g["keep"].to(DEV),
+              proto_queue=g["queue"].to(DEV).unsqueeze(0))
+    assert rel(l2, g["loss"]) < 1e-4
+
+
+def test_entropy_selection_vs_golden():
+    from coarse3d_amd import contrast
+    g = load("pl_select.npz")
+    prob, tr, ev = g["prob"], g["train_label"], g["eval_label"]
+    b, c, h, w = prob.shape
+    # golden noise rows are in (b, class) order of the pairs that reached the multinomial
+    pseudo = prob.argmax(1)
+    pseudo[ev == 0] = 0
+    noise = torch.ones(b, c, h * w)
+    it = iter(g["noise"])
+    ratio = np.float32(float(g["ratio"]))
+    for bi in range(b):
+        for cls in torch.unique(tr[bi]).tolist():
+            if cls == 0:
+                continue
+            cnt = int(((pseudo[bi] == cls) & (ev[bi] > 0)).sum())
+            if cnt == 0 or int(np.float32(cnt) * ratio) < 1:
+                continue
+            noise[bi, cls] = next(it)
+    lab, mask = contrast.entropy_selection(prob.permute(0, 2, 3, 1).contiguous().to(DEV), tr.to(DEV), ev.to(DEV),
+                                           float(g["ratio"]), noise=noise.to(DEV))
+    agree = (lab.cpu() == g["labels"]).float().mean().item()
+    assert agree >= 0.9995, agree          # expf/logf ulp differences can flip a borderline pixel
+    assert (mask.cpu() == g["mask"]).float().mean().item() >= 0.9995
+
+
+@pytest.mark.parametrize("tag,b,h,w,ncls,dataset,seed", [
+    ("kitti_small", 2, 32, 64, 20, "SemanticKitti", 101),
+    ("poss_small", 1, 24, 56, 14, "SemanticPOSS", 201),
+])
+def test_module_forward_and_bank_vs_golden(tag, b, h, w, ncls, dataset, seed):
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    g = load(f"model_{tag}.npz")
+    x, tr, ev = W.synthetic_batch(b, h, w, ncls, seed, 0.02, gh=8, gw=16)
+    m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True, dataset=dataset)
+    m.load_state_dict(W.closed_form_state(nclasses=ncls))
+    m.to(DEV).train()
+    m.dropout_masks = {k: v.to(DEV) for k, v in W.dropout_masks_for(None, b, seed + 1).items()}
+    m.gumbel_noise = pixel_noise(tr, g, ncls).to(DEV)
+    out = m(x.to(DEV), label=tr.to(DEV), eval_mask=(tr > 0).to(DEV), return_feat=True, proto_loss=True)
+    assert out["pred_2d"].shape == (b, ncls, h, w) and out["feat_2d"].shape == (b, 256, h, w)
+    assert rel(out["pred_2d"], g["pred_2d"]) < 1e-4
+    assert rel(out["feat_2d"][:, :, ::2, ::4], g["feat_2d_sub"]) < 1e-4
+    assert rel(out["contrast_logits"][::16], g["contrast_logits_sub"]) < 1e-4
+    tgt = out["contrast_target"].cpu()
+    assert (tgt == g["contrast_target"]).float().mean().item() >= 0.999
+    assert rel(m.prototypes, g["new_prototypes"]) < 1e-4
+    sd = m.state_dict()
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert rel(sd[k], g[f"run/{k}"]) < 2e-4, k
+    # eval mode runs, uses running statistics, leaves them untouched
+    m.eval()
+    rm = sd["resBlock3.bn2.running_mean"].clone()
+    with torch.no_grad():
+        ev_out = m(x.to(DEV))
+    assert torch.isfinite(ev_out["pred_2d"]).all()
+    assert torch.equal(m.state_dict()["resBlock3.bn2.running_mean"], rm)
+
+
+def test_full_training_step_vs_golden():
+    """trainer.py:621-704 order with the prototype path on: golden = the reference modules."""
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    from coarse3d_amd.trainer import TrainStep
+    g = load("step.npz")
+    b, h, w, ncls = 2, 64, 128, 20
+    x, tr, ev = W.synthetic_batch(b, h, w, ncls, 77, 0.02, gh=8, gw=16)
+    m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True)
+    m.load_state_dict(W.closed_form_state(nclasses=ncls))
+    m.to(DEV).train()
+    m.dropout_masks = {k: v.to(DEV) for k, v in W.dropout_masks_for(None, b, 78).items()}
+    m.gumbel_noise = pixel_noise(tr, g, ncls).to(DEV)
+    ts = TrainStep(m, ncls, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=64)
+    # pseudo-label noise: rows in (b, class) order of the pairs that reached the multinomial
+    pred_g = g["pred_2d"]
+    pseudo = pred_g.argmax(1)
+    pseudo[ev == 0] = 0
+    ratio = np.float32(oc.select_ratio_for(10, 100))
+    noise = torch.ones(b, ncls, h * w)
+    it = iter(g["pl_noise"])
+    for bi in range(b):
+        for cls in torch.unique(tr[bi]).tolist():
+            if cls == 0:
+                continue
+            cnt = int(((pseudo[bi] == cls) & (ev[bi] > 0)).sum())
+            if cnt == 0 or int(np.float32(cnt) * ratio) < 1:
+                continue
+            noise[bi, cls] = next(it)
+    ts.pl_noise = noise.to(DEV)
+    ts.contrast.uniforms, ts.contrast.perms = g["uniforms"], g["perms"]
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    res = ts.step(x.to(DEV), tr.to(DEV), ev.to(DEV), epoch=10)
+    torch.cuda.synchronize()
+    assert rel(res["ce"], g["ce"]) < 1e-4
+    assert rel(res["lov"], g["lov"]) < 1e-4
+    assert (res["labels_contra"].cpu() == g["labels_contra"]).float().mean().item() >= 0.9995
+    assert rel(m.prototypes, g["new_prototypes"]) < 1e-4
+    assert rel(res["contrast"], g["contrast"]) < 2e-3      # a few anchors may differ (ulp-level weights)
+    assert rel(res["loss"], g["loss"]) < 1e-3
+    # gradients: same noise-calibrated criterion as tests/test_oracle_golden.py
+    errs = []
+    for k, p in m.named_parameters():
+        if f"gnorm/{k}" not in g or k == "projector.proj.0.bias":
+            continue
+        gr = p.grad.detach().cpu()
+        ref = g[f"grad/{k}"]
+        sub = gr if gr.numel() <= 4096 else gr.reshape(-1)[:: max(gr.numel() // 2048, 1)]
+        errs.append(float((sub - ref).abs().max()) / (float(ref.abs().max()) + 1e-12))
+        assert abs(float(gr.norm()) - float(g[f"gnorm/{k}"])) <= 5e-2 * float(g[f"gnorm/{k}"]) + 1e-9, k
+    assert np.median(errs) < 3e-2 and max(errs) < 0.35, (np.median(errs), max(errs))
+    # AdamW moved every trainable tensor; non-trainable ones untouched
+    moved = sum(int(not torch.equal(before[k], p.detach())) for k, p in m.named_parameters() if p.requires_grad)
+    assert moved >= 190
+    for k in ("downCntx.conv1.weight", "cls_head.weight"):
+        p = before[k].cpu().clone()
+        oc.adamw_update(p, dict(m.named_parameters())[k].grad.cpu(), torch.zeros_like(p), torch.zeros_like(p), 1, 1e-3)
+        assert rel(dict(m.named_parameters())[k], p) < 1e-5
