@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: range-images/sec of one COARSE3D training step (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = input normalisation -> SalsaNextProto forward (return_feat, use_prototype, proto_loss)
+-> focal + Lovasz -> entropy-based pseudo-label selection -> prototype contrastive loss
+(512 anchors/class, T=0.07) -> backward -> AdamW, on synthetic 64x2048x5 range images, bs=8 per
+GPU, fp32 (BASELINE.json configs[1]; BASELINE.md section 3 input recipe).  Inputs are resident in
+HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+`roofline`: the dominant kernel is the fp32-MFMA implicit-GEMM convolution; every launch of it is
+bracketed by HIP events on the launch stream during the timed steps, and `achieved` = algorithmic
+FLOPs of those launches / their summed duration, for the template instance with the largest
+total time (name in roofline.kernel; the rocprofv3 summary in profiles/ lists the same name).
+`cpu_baseline`: the CPU oracle (a port: oracle/coarse3d_oracle.py) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FEATURE_MEAN = [12.12, 10.88, 0.23, -1.04, 0.21]     # config_semantic_kitti.yaml sensor.img_means
+FEATURE_STD = [12.32, 11.47, 6.91, 0.86, 0.16]       # config_semantic_kitti.yaml:148-153
+PEAK_FP32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md chip-level parameters
+
+
+def synth_batch(b, h, w, ncls, seed, device, label_rate=1e-3):
+    """x ~ N(0,1); blocky eval labels on an (H/8)x(W/64) grid; weak labels
+    = eval * Bernoulli(rate)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn(b, 5, h, w, generator=g, device=device)
+    grid = torch.randint(0, ncls, (b, h // 8, w // 64), generator=g, device=device)
+    ev = grid.repeat_interleave(8, 1).repeat_interleave(64, 2)
+    keep = torch.rand(b, h, w, generator=g, device=device) < label_rate
+    return x, (ev * keep).long(), ev.long()
+
+
+def cpu_baseline(ncls, h, w, budget_s=150.0):
+    """Oracle train step on the host cores, bounded sample: bs=1, one warm-up + timed steps."""
+    from oracle import coarse3d_oracle as oc
+    cores = torch.get_num_threads()
+    st = oc.init_state(nclasses=ncls, seed=1)
+    for k in oc.trainable_names(st):
+        st[k].requires_grad_(True)
+    mean, std = torch.tensor(FEATURE_MEAN), torch.tensor(FEATURE_STD)
+    times = []
+    t_all = time.time()
+    for s in range(3):
+        x, tr, ev = synth_batch(1, h, w, ncls, 1000 + s, "cpu")
+        masks = {k: (torch.rand(1, c) >= 0.2).float() * 1.25 for k, c in (
+            ("resBlock2.dropout", 128), ("resBlock3.dropout", 256), ("resBlock4.dropout", 256),
+            ("resBlock5.dropout", 256), ("upBlock1.dropout1", 64), ("upBlock1.dropout2", 320),
+            ("upBlock1.dropout3", 128), ("upBlock2.dropout1", 32), ("upBlock2.dropout2", 288),
+            ("upBlock2.dropout3", 128), ("upBlock3.dropout1", 32), ("upBlock3.dropout2", 160),
+            ("upBlock3.dropout3", 64))}
+        t0 = time.time()
+        info, grads = oc.train_step(st, x, tr, ev, None, temperature=0.07, num_anchor=512, dropout_masks=masks,
+                                    mean=mean, std=std)
+        with torch.no_grad():
+            for k, g in grads.items():
+                if g is not None:
+                    oc.adamw_update(st[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, 1e-3)
+        times.append(time.time() - t0)
+        if time.time() - t_all > budget_s:
+            break
+    timed = times[1:] if len(times) > 1 else times
+    sec = float(np.median(timed))
+    return {"value": round(1.0 / sec, 4), "unit": "range-images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle train step, bs=1, {h}x{w}x5, C={ncls}, fp32, {len(timed)} timed step(s) after "
+                      f"{len(times) - len(timed)} warm-up (first step {times[0]:.1f} s incl. oneDNN warm-up)",
+            "sec_per_image": round(sec, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--height", type=int, default=64)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--classes", type=int, default=20)
+    ap.add_argument("--dataset", default="SemanticKitti")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from coarse3d_amd import dist as D
+    from coarse3d_amd import ops
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    from coarse3d_amd.trainer import TrainStep
+
+    torch.manual_seed(1)
+    model = SalsaNextProto(5, args.classes, 20, 0, use_prototype=True, dataset=args.dataset).to(dev).train()
+    wrapped = D.DataParallel(model) if world > 1 else model
+    ts = TrainStep(wrapped, args.classes, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512,
+                   loss_w_ce_2d=1.0, loss_w_lov_2d=1.0, loss_w_contrast=0.1, feature_mean=FEATURE_MEAN,
+                   feature_std=FEATURE_STD, proto_loss=True)
+    rate = 1e-4 if args.dataset == "SemanticPOSS" else 1e-3
+    total_steps = args.warmup + args.steps
+    batches = [synth_batch(args.batch, args.height, args.width, args.classes, 1000 + s + 7919 * rank, dev, rate)
+               for s in range(total_steps)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        ts.step(*batches[s], epoch=10)
+    if not args.no_kernel_events:
+        ops.KERNEL_EVENTS = []
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total_steps):
+        res = ts.step(*batches[s], epoch=10)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    loss = float(res["loss"])
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    roofline = None
+    if ops.KERNEL_EVENTS:
+        per = {}
+        for name, flops, e0, e1 in ops.KERNEL_EVENTS:
+            d = per.setdefault(name, [0.0, 0.0, 0])
+            d[0] += flops
+            d[1] += e0.elapsed_time(e1) * 1e-3
+            d[2] += 1
+        name, (fl, sec, n) = max(per.items(), key=lambda kv: kv[1][1])
+        all_fl = sum(v[0] for v in per.values())
+        all_sec = sum(v[1] for v in per.values())
+        roofline = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2),
+                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "traffic": None, "launches_per_step": n // args.steps,
+                    "avg_launch_us": round(sec / n * 1e6, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
+                    "all_mfma_kernels": {"achieved": round(all_fl / all_sec / 1e12, 2),
+                                         "frac": round(all_fl / all_sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                         "ms_per_step": round(all_sec / args.steps * 1e3, 2)}}
+    ops.KERNEL_EVENTS = None
+
+    if rank == 0:
+        images = args.batch * world * args.steps
+        out = {
+            "metric": "range-images/sec training step, 64x2048x5, bs=8/GPU",
+            "value": round(images / elapsed, 3), "unit": "range-images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.dataset} {args.height}x{args.width}x5 range image, C={args.classes}, "
+                                   f"bs={args.batch}/GPU, SalsaNextProto fwd+bwd + prototype bank + contrast "
+                                   f"loss + AdamW (BASELINE.json configs[1])",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.classes, args.height, args.width)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

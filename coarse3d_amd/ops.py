@@ -9,8 +9,30 @@ import torch
 from . import _lib as L
 
 
+# bench.py sets this to a list to bracket every MFMA-engine launch with HIP events on the launch
+# stream: entries are (kernel instance name, algorithmic FLOPs, start event, end event).
+KERNEL_EVENTS = None
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Timed:
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if KERNEL_EVENTS is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if KERNEL_EVENTS is not None:
+            self.e1.record()
+            KERNEL_EVENTS.append((self.name, self.flops, self.e0, self.e1))
 
 
 def _p(t):
@@ -94,7 +116,11 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     if stats and stat_partial is None:
         stat_partial = torch.empty(num_mtiles(b, h, w), cout, 2, device=wpack.device, dtype=torch.float32)
     d.stat_partial = stat_partial.data_ptr() if stat_partial is not None else None
-    L.check(L.lib().c3d_conv_forward(C.byref(d), _stream()), "c3d_conv_forward")
+    tr = 8 if h >= 8 else (4 if h >= 4 else 2)
+    halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
+    name = f"conv_mfma_kernel<{tr},{2 if (cout > 32 or tr == 2) else 1},16,{halo}>"
+    with _Timed(name, 2.0 * b * h * w * cout * len(taps) * sum(s.C for s in srcs)):
+        L.check(L.lib().c3d_conv_forward(C.byref(d), _stream()), "c3d_conv_forward")
     return out, stat_partial
 
 
@@ -113,7 +139,11 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False):
     n = L.lib().c3d_wgrad_partial_floats(C.byref(d))
     part = torch.empty(n, device=dz.device, dtype=torch.float32)
     d.partial = part.data_ptr()
-    L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
+    halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
+    name = {1: "wgrad_mfma_kernel<1,2,4,2,0>", 4: "wgrad_mfma_kernel<4,1,2,4,1>"}.get(
+        len(taps), f"wgrad_mfma_kernel<9,1,1,4,{1 if halo <= 1 else 2}>")
+    with _Timed(name, 2.0 * b * h * w * dw.shape[0] * len(taps) * src.C):
+        L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
     return dw
 
 

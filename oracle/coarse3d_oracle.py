@@ -335,7 +335,8 @@ def prototype_learning(protos_l2, rows, nearest, label, sim, exp_noise, ignore_l
         sel = label == cls
         if int(sel.sum()) == 0:
             continue
-        q, index = sinkhorn_assign(sim[sel][:, :, cls], exp_noise[cls])
+        noise = exp_noise[cls] if exp_noise is not None else torch.empty(int(sel.sum()), m).exponential_()
+        q, index = sinkhorn_assign(sim[sel][:, :, cls], noise)
         keep = hit[sel].float()
         qm = q * keep[:, None]
         f = qm.t() @ (rows[sel] * keep[:, None])
@@ -400,7 +401,7 @@ def entropy_selection(prob, wss_mask, eval_mask, train_label, select_ratio, exp_
     pseudo = prob.argmax(dim=1)
     pseudo[~eval_mask] = ignore_cls
     chosen = torch.zeros(bs, h * w, dtype=torch.bool)
-    it = iter(exp_noise)
+    it = iter(exp_noise) if exp_noise is not None else None
     ratio32 = np.float32(select_ratio)
     for b in range(bs):
         for cls in torch.unique(train_label[b]).tolist():
@@ -415,7 +416,8 @@ def entropy_selection(prob, wss_mask, eval_mask, train_label, select_ratio, exp_
                 continue
             wc = weight[b].reshape(-1).clone()
             wc[~cmask] = 0
-            idx = multinomial_noreplace_set(wc.numpy(), k, next(it).numpy())
+            q = next(it) if it is not None else torch.empty(h * w).exponential_()
+            idx = multinomial_noreplace_set(wc.numpy(), k, q.numpy())
             chosen[b, torch.from_numpy(idx)] |= True
     chosen = chosen.reshape(bs, h, w)
     labels = (pseudo * chosen).long()
@@ -443,7 +445,8 @@ def sample_anchors(labels, weights, uniforms, num_anchor, ignore_label=0):
                 continue
             wc = weights[b].clone()
             wc[labels[b] != cls] = 0
-            idx = multinomial_replace(wc.numpy(), np.asarray(uniforms[t]))
+            u = uniforms[t] if uniforms is not None else torch.rand(num_anchor, dtype=torch.float64)
+            idx = multinomial_replace(wc.numpy(), np.asarray(u))
             imgs.append(b)
             clss.append(cls)
             idxs.append(torch.from_numpy(idx))
@@ -459,6 +462,8 @@ def info_nce(anchors, anchor_cls, queue, perms, temperature, base_temperature=0.
     Class 0 never enters the queue (contrast_pixel_loss.py:139-140)."""
     t_, a_, d_ = anchors.shape
     ncls, m, _ = queue.shape
+    if perms is None:
+        perms = torch.stack([torch.randperm(m) for _ in range(ncls - 1)])
     bank = torch.cat([queue[c][perms[c - 1]] for c in range(1, ncls)], 0)
     bank_cls = torch.arange(1, ncls).repeat_interleave(m)
     af = anchors.permute(1, 0, 2).reshape(a_ * t_, d_)          # anchor-major order
@@ -553,9 +558,12 @@ def train_step(state, x, train_label, eval_label, rng, *, epoch=10, n_epochs=100
     """Forward + losses + backward of one step; returns (loss dict, grads dict).
 
     ``rng`` supplies the injected randomness: keys gumbel (dict cls -> noise), pl_noise
-    (list), uniforms [T_max,A] f64, perms [C-1,M].  Parameters in ``state`` that need
+    (list), uniforms [T_max,A] f64, perms [C-1,M]; ``rng=None`` draws everything from the
+    global torch generator (used by the CPU baseline timing).  Parameters in ``state`` that need
     gradients must be leaf tensors with requires_grad=True."""
     ncls = state["cls_head.weight"].shape[0]
+    if rng is None:
+        rng = dict(gumbel=None, pl_noise=None, uniforms=None, perms=None)
     wss = train_label > 0
     evm = eval_label > 0
     if mean is not None:
