@@ -229,7 +229,7 @@ class Backbone:
             dz, pz = ops.bn_bwd_apply(dy, a, c, 2)
         else:
             dz, pz = ops.bn_bwd_apply(dy, dy, cpad, 3, dz=dy)
-        ops.sums_to_f32(ops.stat_reduce(pz, pz.shape[1]), 0, G[f"{name}.bias"])
+        ops.sums_to_f32(ops.stat_reduce(pz, pz.shape[0]), 0, G[f"{name}.bias"])
         w = self.P[f"{name}.weight"]
         dw = G[f"{name}.weight"]
         ntaps = ops.negate_taps(rec.taps)
@@ -317,10 +317,10 @@ class Backbone:
                                    "mask_norm.bias")}
         self.grads = grads
         d0b, d1b, d2b, d3b = self.skips
-        # ---- embedding branch first: it scatters (atomics) into zero-initialised skip gradients
+        # ---- embedding branch first: it initialises the skip gradients (gather-form transposes)
         if d_feat is not None and self.return_feat:
             feat_a, z0, emb, embn, norm = self.tape["embed"]
-            d_embn = torch.zeros_like(embn)
+            d_embn = torch.empty_like(embn)
             ops.bilinear_bwd(d_embn, d_feat.contiguous())
             d_emb = ops.l2norm_bwd(embn, norm, d_embn, 1e-12)
             self._conv_backward("projector.proj.3", d_emb)
@@ -328,7 +328,7 @@ class Backbone:
             z0.grad = None
             off = 0
             for s in self.skips:
-                s.grad = torch.zeros_like(s.t)
+                s.grad = torch.empty_like(s.t)
                 ops.bilinear_bwd(s.grad, feat_a.grad, dcoff=off, c=s.t.shape[3])
                 off += s.t.shape[3]
             feat_a.grad = None

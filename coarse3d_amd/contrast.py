@@ -23,7 +23,7 @@ def entropy_selection(prob_nhwc, train_label, eval_label, select_ratio, noise=No
     _, w_pl, amax = ops.entropy_stats(prob_nhwc, want_anchor=False)
     tl = train_label.reshape(b, n).contiguous()
     ev = eval_label.reshape(b, n).contiguous()
-    tl_counts, _ = ops.group_compact(tl, c)
+    tl_counts = ops.label_hist(tl, c)
     if noise is None:
         noise = torch.empty(b, c, n, device=prob_nhwc.device, dtype=torch.float32).exponential_()
     labels, mask = ops.pl_select(w_pl, amax, ev, tl, noise.contiguous(), tl_counts, b, n, c, ignore_cls,

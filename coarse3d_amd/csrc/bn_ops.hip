@@ -16,31 +16,27 @@
 
 namespace {
 
-// partial [n][C][2] fp32  ->  sums [C][2] fp64.  block = 8 row-lanes x 32 channels
+// partial [C][2][n] fp32  ->  sums [C][2] fp64.  One block per channel, contiguous reads.
 __global__ __launch_bounds__(256) void stat_reduce_kernel(const float* __restrict__ partial, int n, int C,
                                                          double* __restrict__ sums) {
-  __shared__ double red[8][32][2];
-  const int ch = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + ch;
+  __shared__ double red[2][4];
+  const int c = blockIdx.x;
+  const float* p = partial + (size_t)c * 2 * n;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C) {
-    for (int t = rl; t < n; t += 8) {
-      const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)t * C + c) * 2);
-      s1 += (double)v.x;
-      s2 += (double)v.y;
-    }
+  for (int t = threadIdx.x; t < n; t += 256) {
+    s1 += (double)p[t];
+    s2 += (double)p[n + t];
   }
-  red[rl][ch][0] = s1;
-  red[rl][ch][1] = s2;
+  s1 = c3d_wave_sum_d(s1);
+  s2 = c3d_wave_sum_d(s2);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s1;
+    red[1][threadIdx.x >> 6] = s2;
+  }
   __syncthreads();
-  if (rl == 0 && c < C) {
-#pragma unroll
-    for (int k = 1; k < 8; ++k) {
-      s1 += red[k][ch][0];
-      s2 += red[k][ch][1];
-    }
-    sums[c * 2 + 0] = s1;
-    sums[c * 2 + 1] = s2;
+  if (threadIdx.x == 0) {
+    sums[c * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    sums[c * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   }
 }
 
@@ -84,7 +80,7 @@ struct BwdArgs {
   const float* pre_scale; const float* pre_shift;   // mode 1: y = a*pre_scale + pre_shift
   const float* k1; const float* k2; const float* k3;
   float* dz; int dz_cs;
-  float* partial;            // [gridDim.x][C][2]
+  float* partial;            // [C][2][gridDim.x]
   int pix_per_block;
 };
 
@@ -147,9 +143,9 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
       t1 += red[(k * p.C + ch) * 2 + 0];
       t2 += red[(k * p.C + ch) * 2 + 1];
     }
-    float* o = p.partial + ((size_t)blockIdx.x * p.C + ch) * 2;
+    float* o = p.partial + (size_t)ch * 2 * gridDim.x + blockIdx.x;   // [C][2][nblk]
     o[0] = t1;
-    o[1] = t2;
+    o[gridDim.x] = t2;
   }
 }
 
@@ -184,7 +180,7 @@ __global__ void sums_to_f32_kernel(const double* __restrict__ sums, int C, int c
 }  // namespace
 
 extern "C" int c3d_stat_reduce(const float* partial, int n, int C, double* sums, c3d_stream stream) {
-  hipLaunchKernelGGL(stat_reduce_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, n, C, sums);
+  hipLaunchKernelGGL(stat_reduce_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, n, C, sums);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -187,9 +187,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
           t1 += red[(w * TN + n) * 2 + 0];
           t2 += red[(w * TN + n) * 2 + 1];
         }
-        float* sp = a.stat_partial + ((size_t)mt * a.Cout + n0 + n) * 2;
+        float* sp = a.stat_partial + (size_t)(n0 + n) * 2 * ntile + mt;   // [C][2][ntile]
         sp[0] = t1;
-        sp[1] = t2;
+        sp[ntile] = t2;
       }
     }
   }
@@ -261,6 +261,17 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   a.tiles_y = (d->H + tr - 1) / tr;
   a.Kq = K / 4;
   hipStream_t st = (hipStream_t)stream;
+  if (tr == 8 && halo == 0) {
+    // pointwise convs are plain GEMMs: deeper K chunk (32) and up to 128 output channels per
+    // workgroup so that each barrier pair covers 128 MFMAs per wave
+    bool k32 = true;
+    for (int s = 0; s < d->nsrc; ++s) k32 = k32 && (d->src[s].C % 32 == 0);
+    if (k32) {
+      if (d->Cout > 64) return launch_cfg<8, 4, 32, 0>(a, st);
+      if (d->Cout > 32) return launch_cfg<8, 2, 32, 0>(a, st);
+      return launch_cfg<8, 1, 32, 0>(a, st);
+    }
+  }
   const bool wide = d->Cout > 32;
   if (tr == 8) return wide ? launch_halo<8, 2>(a, halo, st) : launch_halo<8, 1>(a, halo, st);
   if (tr == 4) return wide ? launch_halo<4, 2>(a, halo, st) : launch_halo<4, 1>(a, halo, st);

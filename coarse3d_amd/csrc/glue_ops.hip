@@ -386,27 +386,60 @@ __global__ void bilinear_kernel(BlArgs p) {
   }
 }
 
-// d_src (+)= bilinear^T(d_dst)   (atomic scatter; d_src must hold the running gradient or zeros)
-__global__ void bilinear_bwd_kernel(BlArgs p) {  // src = d_src (written), dst = d_dst (read)
-  const size_t total = (size_t)p.B * p.Hd * p.Wd * p.C;
+// Range of destination indices d whose interpolation touches source index s:
+// floor(ratio*d) in {s-1, s}  <=>  (s-1)/ratio <= d < (s+1)/ratio   (+-1 slack, exact test inside)
+__device__ __forceinline__ void bl_dst_range(int s, float ratio, int nd, int& lo, int& hi) {
+  if (ratio <= 0.f) {
+    lo = 0;
+    hi = nd - 1;
+    return;
+  }
+  lo = (int)floorf((float)(s - 1) / ratio) - 1;
+  hi = (int)ceilf((float)(s + 1) / ratio) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > nd - 1) hi = nd - 1;
+}
+
+// weight with which destination index d reads source index s along one axis
+__device__ __forceinline__ float bl_weight(int d, int s, float ratio, int n) {
+  int i0, i1;
+  float l1;
+  bl_coords(d, ratio, n, i0, i1, l1);
+  float w = 0.f;
+  if (i0 == s) w += 1.f - l1;
+  if (i1 == s) w += l1;
+  return w;
+}
+
+// d_src (+)= bilinear^T(d_dst) as a GATHER over the destination pixels that read each source
+// pixel: deterministic, no atomics.  src = d_src (written), dst = d_dst (read).
+__global__ void bilinear_bwd_kernel(BlArgs p, int accumulate) {
+  const int Q = p.C >> 2;
+  const size_t total = (size_t)p.B * p.Hs * p.Ws * Q;
   float* dsrc = const_cast<float*>(p.src);
   for (size_t i = gtid(); i < total; i += gstride()) {
-    const int c = i % p.C;
-    size_t r = i / p.C;
-    const int xd = r % p.Wd;
-    r /= p.Wd;
-    const int yd = r % p.Hd;
-    const int b = r / p.Hd;
-    int y0, y1, x0, x1;
-    float ly, lx;
-    bl_coords(yd, p.ry, p.Hs, y0, y1, ly);
-    bl_coords(xd, p.rx, p.Ws, x0, x1, lx);
-    const float g = p.dst[((size_t)(b * p.Hd + yd) * p.Wd + xd) * p.dcs + p.dcoff + c];
-    float* s = dsrc + (size_t)b * p.Hs * p.Ws * p.scs + p.scoff + c;
-    unsafeAtomicAdd(s + ((size_t)y0 * p.Ws + x0) * p.scs, g * (1.f - ly) * (1.f - lx));
-    unsafeAtomicAdd(s + ((size_t)y0 * p.Ws + x1) * p.scs, g * (1.f - ly) * lx);
-    unsafeAtomicAdd(s + ((size_t)y1 * p.Ws + x0) * p.scs, g * ly * (1.f - lx));
-    unsafeAtomicAdd(s + ((size_t)y1 * p.Ws + x1) * p.scs, g * ly * lx);
+    const int c = (i % Q) * 4;
+    size_t r = i / Q;
+    const int xs = r % p.Ws;
+    r /= p.Ws;
+    const int ys = r % p.Hs;
+    const int b = r / p.Hs;
+    int ylo, yhi, xlo, xhi;
+    bl_dst_range(ys, p.ry, p.Hd, ylo, yhi);
+    bl_dst_range(xs, p.rx, p.Wd, xlo, xhi);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int yd = ylo; yd <= yhi; ++yd) {
+      const float wy = bl_weight(yd, ys, p.ry, p.Hs);
+      if (wy == 0.f) continue;
+      for (int xd = xlo; xd <= xhi; ++xd) {
+        const float wx = bl_weight(xd, xs, p.rx, p.Ws);
+        if (wx == 0.f) continue;
+        acc += *reinterpret_cast<const f32x4*>(p.dst + ((size_t)(b * p.Hd + yd) * p.Wd + xd) * p.dcs + p.dcoff + c) *
+               (wy * wx);
+      }
+    }
+    f32x4* o = reinterpret_cast<f32x4*>(dsrc + ((size_t)(b * p.Hs + ys) * p.Ws + xs) * p.scs + p.scoff + c);
+    *o = accumulate ? (*o + acc) : acc;
   }
 }
 
@@ -588,9 +621,11 @@ extern "C" int c3d_bilinear(const float* src, int Hs, int Ws, int scs, int scoff
 }
 
 extern "C" int c3d_bilinear_bwd(float* dsrc, int Hs, int Ws, int scs, int scoff, const float* ddst, int Hd, int Wd,
-                                int dcs, int dcoff, int B, int C, c3d_stream stream) {
+                                int dcs, int dcoff, int B, int C, int accumulate, c3d_stream stream) {
+  C3D_REQUIRE(C % 4 == 0 && scs % 4 == 0 && dcs % 4 == 0 && scoff % 4 == 0 && dcoff % 4 == 0,
+              "bilinear_bwd: channel counts/strides must be multiples of 4");
   BlArgs p = bl_args(dsrc, Hs, Ws, scs, scoff, const_cast<float*>(ddst), Hd, Wd, dcs, dcoff, B, C);
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(nblocks((size_t)B * Hd * Wd * C)), dim3(256), 0, ST, p);
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(nblocks((size_t)B * Hs * Ws * C / 4)), dim3(256), 0, ST, p, accumulate);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -101,46 +101,74 @@ __global__ __launch_bounds__(256) void proto_nearest_kernel(const float* __restr
 
 // Ordered compaction: for group g and class c list the positions i (ascending) with
 // labels[g][i] == c.  grid = (ncls, groups); idx [groups][ncls][n], counts [groups][ncls].
+// 1024 labels per iteration (4 consecutive per thread), one barrier per iteration.
 __global__ __launch_bounds__(256) void group_compact_kernel(const int64_t* __restrict__ labels,
                                                             const uint8_t* __restrict__ keep, int n, int ncls,
                                                             int32_t* __restrict__ counts, int32_t* __restrict__ idx) {
-  __shared__ int wtot[4];
-  __shared__ int base_s;
+  __shared__ int wtot[2][4];
   const int c = blockIdx.x, g = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t* lab = labels + (size_t)g * n;
   const uint8_t* kp = keep ? keep + (size_t)g * n : nullptr;
   int32_t* out = idx + ((size_t)g * ncls + c) * n;
-  if (tid == 0) base_s = 0;
-  __syncthreads();
-  for (int i0 = 0; i0 < n; i0 += 256) {
-    const int i = i0 + tid;
-    bool f = false;
-    if (i < n) {
-      int64_t l = lab[i];
-      if (kp && !kp[i]) l = 0;
-      f = (l == c);
+  int base = 0, buf = 0;
+  for (int i0 = 0; i0 < n; i0 += 1024, buf ^= 1) {
+    const int i = i0 + tid * 4;
+    bool f[4];
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f[q] = false;
+      if (i + q < n) {
+        int64_t l = lab[i + q];
+        if (kp && !kp[i + q]) l = 0;
+        f[q] = (l == c);
+      }
+      cnt += f[q] ? 1 : 0;
     }
-    const unsigned long long bal = __ballot(f);
-    const int before = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wtot[wv] = __popcll(bal);
+    // inclusive scan of cnt over the wave
+    int scan = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(scan, o, 64);
+      if (lane >= o) scan += v;
+    }
+    if (lane == 63) wtot[buf][wv] = scan;
     __syncthreads();
-    int off = base_s;
-    for (int k = 0; k < wv; ++k) off += wtot[k];
-    if (f) out[off + before] = i;
-    __syncthreads();
-    if (tid == 0) base_s += wtot[0] + wtot[1] + wtot[2] + wtot[3];
-    __syncthreads();
+    int off = base + scan - cnt;
+    for (int k = 0; k < wv; ++k) off += wtot[buf][k];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (f[q]) out[off++] = i + q;
+    base += wtot[buf][0] + wtot[buf][1] + wtot[buf][2] + wtot[buf][3];
   }
-  if (tid == 0) counts[g * ncls + c] = base_s;
+  if (tid == 0) counts[g * ncls + c] = base;
+}
+
+// counts[g][c] = #{i : labels[g][i] == c}   (class presence for the pseudo-label selection)
+__global__ __launch_bounds__(256) void label_hist_kernel(const int64_t* __restrict__ labels, int n, int ncls,
+                                                         int32_t* __restrict__ counts) {
+  __shared__ int h[64];
+  const int g = blockIdx.y;
+  if (threadIdx.x < 64) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t* lab = labels + (size_t)g * n;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int64_t l = lab[i];
+    if (l > 0 && l < ncls) atomicAdd(&h[(int)l], 1);     // class 0 (ignore) is never queried
+  }
+  __syncthreads();
+  if (threadIdx.x < ncls && h[threadIdx.x]) atomicAdd(&counts[g * ncls + threadIdx.x], h[threadIdx.x]);
 }
 
 struct LearnArgs {
   const float* sim;      // [N][M*C]
   const float* feat;     // [N][D]  (LayerNorm + l2 rows)
   const int32_t* pred;   // [N] argmax class of the nearest-prototype map
-  const int32_t* counts; // [ncls]
-  const int32_t* idx;    // [ncls][N]
+  const int32_t* counts; // [B][ncls]   per-image ordered lists from c3d_group_compact
+  const int32_t* idx;    // [B][ncls][n]
+  int32_t* rows;         // [ncls][N] scratch: flat (image-major) row list of each class
+  int B, n;
   const float* noise;    // [N][M] Exp(1) variates (gumbel = -log), indexed by pixel
   const float* protos;   // [ncls][M][D] l2-normalised bank (input)
   float* protos_out;     // [ncls][M][D]
@@ -160,8 +188,18 @@ __global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
   const int c = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int M = a.M, D = a.D, MC = a.M * a.C;
-  const int nc = (c == a.ignore) ? 0 : a.counts[c];
-  const int32_t* rows = a.idx + (size_t)c * a.N;
+  int32_t* rows = a.rows + (size_t)c * a.N;
+  int nc = 0;
+  if (c != a.ignore) {
+    for (int b = 0; b < a.B; ++b) {
+      const int cb = a.counts[b * a.C + c];
+      const int32_t* src = a.idx + ((size_t)b * a.C + c) * a.n;
+      for (int i = tid; i < cb; i += 256) rows[nc + i] = src[i] + b * a.n;
+      nc += cb;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
   const float* pin = a.protos + (size_t)c * M * D;
   float* pout = a.protos_out + (size_t)c * M * D;
 
@@ -291,12 +329,24 @@ extern "C" int c3d_group_compact(const int64_t* labels, const uint8_t* keep, int
   return 0;
 }
 
+extern "C" int c3d_label_hist(const int64_t* labels, int groups, int n, int ncls, int32_t* counts, c3d_stream stream) {
+  C3D_REQUIRE(ncls <= 64, "label_hist: at most 64 classes");
+  (void)hipMemsetAsync(counts, 0, sizeof(int32_t) * groups * ncls, ST);
+  int bx = (n + 256 * 16 - 1) / (256 * 16);
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(label_hist_kernel, dim3(bx, groups), dim3(256), 0, ST, labels, n, ncls, counts);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int c3d_proto_learn(const float* sim, const float* feat, const int32_t* pred, const int32_t* counts,
-                               const int32_t* idx, const float* noise, const float* protos, float* protos_out,
-                               float* target, int32_t* assign, int N, int M, int C, int D, int ignore_label,
-                               float momentum, c3d_stream stream) {
+                               const int32_t* idx, int32_t* rows, const float* noise, const float* protos,
+                               float* protos_out, float* target, int32_t* assign, int B, int n, int M, int C, int D,
+                               int ignore_label, float momentum, c3d_stream stream) {
   C3D_REQUIRE(M <= 32, "proto_learn: at most 32 sub-prototypes per class");
-  LearnArgs a{sim, feat, pred, counts, idx, noise, protos, protos_out, target, assign, N, M, C, D, ignore_label, momentum};
+  const int N = B * n;
+  LearnArgs a{sim, feat, pred, counts, idx, rows, B, n, noise, protos, protos_out, target, assign, N, M, C, D,
+              ignore_label, momentum};
   const size_t lds = (256 + 32 + (size_t)M * D + M) * sizeof(float);
   hipLaunchKernelGGL(proto_learn_kernel, dim3(C), dim3(256), lds, ST, a);
   C3D_CHECK_LAUNCH();

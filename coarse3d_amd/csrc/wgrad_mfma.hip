@@ -5,9 +5,14 @@
 // 164-208, 318 and projector.py:18-23).  GEMM view: M = cin, N = cout, K = pixels.  A workgroup
 // owns a (cin slice, cout slice) pair and a strip of pixel tiles; it keeps one 32x32 accumulator
 // per (tap, cin tile, cout tile) in registers across the whole strip, so the only HBM writes
-// are one partial per workgroup, reduced by a second tiny kernel (deterministic, no atomics).
+// are one partial per workgroup, folded by a second small kernel (deterministic, no atomics).
 // x is transformed on load exactly like the forward conv (BatchNorm affine of the producer,
 // zero padding afterwards).
+//
+// The 4 waves of a workgroup are arranged WCI x WCO x WK: WCI/WCO split the cin/cout slice,
+// WK splits the pixel rows of the tile (K split, reduced through LDS at the end).  Small channel
+// counts (HBM-bound layers) use a 32x32 / 64x64 slice with WK = 4; the big 1x1 GEMMs of the
+// projector use 128x256 slices with WK = 1.
 //
 // LDS images are [pixel][channel]; lane l reads channel (l&31) of pixel k + (l>>5): every
 // ds_read_b32 is conflict-free and feeds one MFMA operand (A = x, B = dz).
@@ -29,21 +34,22 @@ struct WgradArgs {
   int ci_slices, co_slices;
 };
 
-// TMAX taps, wave tile CI_T x CO_T (32x32 each), TRW tile rows (split between wave pairs)
-template <int TMAX, int CI_T, int CO_T, int TRW, int HALO>
+template <int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
-  constexpr int CI = 32 * CI_T;        // cin slice of the workgroup
-  constexpr int CO = 64 * CO_T;        // cout slice of the workgroup (2 waves along cout)
+  constexpr int WK = 4 / (WCI * WCO);
+  constexpr int CI = 32 * CI_T * WCI;  // cin slice of the workgroup
+  constexpr int CO = 32 * CO_T * WCO;  // cout slice of the workgroup
   constexpr int TWh = 32 + 2 * HALO;
   constexpr int THh = TRW + 2 * HALO;
-  constexpr int RPW = TRW / 2;         // rows per wave
+  constexpr int RPW = TRW / WK;        // tile rows per wave
+  static_assert(TRW % WK == 0 && RPW >= 1, "tile rows must split across the K waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_x = smem;                   // [THh][TWh][CI]
   float* s_dz = smem + THh * TWh * CI; // [TRW*32][CO]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int wc = wave & 1, wr = wave >> 1;
+  const int wci = wave % WCI, wco = (wave / WCI) % WCO, wk = wave / (WCI * WCO);
 
   const int nsl = a.ci_slices * a.co_slices;
   const int logical = c3d_xcd_remap(blockIdx.x, a.strips * nsl);
@@ -108,17 +114,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     // ---- K loop over this wave's pixels: k-step = pixel pair (2s + half)
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
-      const int row = wr * RPW + rr;
+      const int row = wk * RPW + rr;
 #pragma unroll 4
       for (int s = 0; s < 16; ++s) {
         const int col = 2 * s + half;
         float bv[CO_T];
 #pragma unroll
-        for (int j = 0; j < CO_T; ++j) bv[j] = s_dz[(row * 32 + col) * CO + (wc * CO_T + j) * 32 + l31];
+        for (int j = 0; j < CO_T; ++j) bv[j] = s_dz[(row * 32 + col) * CO + (wco * CO_T + j) * 32 + l31];
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) {
           if (t < a.T) {
-            const float* xp = s_x + ((row + HALO + a.dy[t]) * TWh + (col + HALO + a.dx[t])) * CI + l31;
+            const float* xp =
+                s_x + ((row + HALO + a.dy[t]) * TWh + (col + HALO + a.dx[t])) * CI + wci * CI_T * 32 + l31;
 #pragma unroll
             for (int i = 0; i < CI_T; ++i) {
               const float av = xp[i * 32];
@@ -131,102 +138,133 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
       }
     }
   }
-  // ---- reduce the two row-halves through LDS, write the workgroup partial
-  //      partial layout: [strip][t][cin (slice-local CI)][cout (slice-local CO)] per slice
-  __syncthreads();
-  float* red = smem;  // [2 (wc)][CI_T*CO_T tiles][16][64]  of one tap at a time
+  // ---- fold the WK pixel-row groups through LDS, write the workgroup partial
+  //      partial layout per (slice, strip): [t][cin (slice-local CI)][cout (slice-local CO)]
   const size_t slice_floats = (size_t)a.T * CI * CO;
   float* pout = a.partial + ((size_t)(sl * a.strips + strip)) * slice_floats;
+  float* red = smem;  // [WK-1][WCI*WCO][CI_T*CO_T][16][64], one tap at a time
 #pragma unroll
   for (int t = 0; t < TMAX; ++t) {
     if (t < a.T) {
-      if (wr == 1) {
+      if (WK > 1) {
+        __syncthreads();
+        if (wk > 0) {
 #pragma unroll
-        for (int i = 0; i < CI_T; ++i)
+          for (int i = 0; i < CI_T; ++i)
 #pragma unroll
-          for (int j = 0; j < CO_T; ++j)
+            for (int j = 0; j < CO_T; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              red[(((wc * CI_T + i) * CO_T + j) * 16 + r) * 64 + lane] = acc[t][i][j][r];
+              for (int r = 0; r < 16; ++r)
+                red[(((((wk - 1) * WCO + wco) * WCI + wci) * CI_T + i) * CO_T + j) * 1024 + r * 64 + lane] =
+                    acc[t][i][j][r];
+        }
+        __syncthreads();
       }
-      __syncthreads();
-      if (wr == 0) {
+      if (wk == 0) {
 #pragma unroll
         for (int i = 0; i < CI_T; ++i)
 #pragma unroll
           for (int j = 0; j < CO_T; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float v = acc[t][i][j][r] + red[(((wc * CI_T + i) * CO_T + j) * 16 + r) * 64 + lane];
-              const int ci = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-              const int co = (wc * CO_T + j) * 32 + l31;
+              float v = acc[t][i][j][r];
+#pragma unroll
+              for (int k = 1; k < WK; ++k)
+                v += red[(((((k - 1) * WCO + wco) * WCI + wci) * CI_T + i) * CO_T + j) * 1024 + r * 64 + lane];
+              const int ci = (wci * CI_T + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              const int co = (wco * CO_T + j) * 32 + l31;
               pout[((size_t)t * CI + ci) * CO + co] = v;
             }
       }
-      __syncthreads();
     }
   }
 }
 
-// dw[cout][cin_off + cin][t] (+)= sum_strips partial
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int strips, int T,
-                                    int CI, int CO, int ci_slices, int co_slices, int Cin_src, int Cout,
-                                    int Cin_total, int cin_off, int accumulate) {
-  const size_t total = (size_t)Cout * Cin_src * T;
+// dw[cout][cin_off + cin][t] (+)= sum_strips partial.  Block = 64 outputs x 4 strip lanes.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                           int strips, int T, int CI, int CO, int ci_slices,
+                                                           int co_slices, int Cin_src, int Cout, int Cin_total,
+                                                           int cin_off, int accumulate) {
+  __shared__ double red[4][64];
   const size_t slice_floats = (size_t)T * CI * CO;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    // thread index ordered (t, cin, cout) with cout fastest: coalesced partial reads
-    const int co = i % Cout;
-    size_t r = i / Cout;
-    const int ci = r % Cin_src;
-    const int t = r / Cin_src;
-    const int sl = (co / CO) * ci_slices + (ci / CI);
-    const float* p = partial + (size_t)sl * strips * slice_floats + ((size_t)t * CI + (ci % CI)) * CO + (co % CO);
+  const int nsl = ci_slices * co_slices;
+  const size_t total = slice_floats * nsl;
+  const int o = threadIdx.x & 63, lanek = threadIdx.x >> 6;
+  for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+    const size_t e = base + o;
     double s = 0.0;
-    for (int k = 0; k < strips; ++k) s += (double)p[(size_t)k * slice_floats];
-    float* d = dw + ((size_t)co * Cin_total + cin_off + ci) * T + t;
-    *d = accumulate ? (*d + (float)s) : (float)s;
+    int sl = 0, t = 0, ci = 0, co = 0;
+    bool valid = false;
+    if (e < total) {
+      sl = e / slice_floats;
+      const size_t r = e % slice_floats;
+      co = r % CO;
+      ci = (r / CO) % CI;
+      t = r / ((size_t)CO * CI);
+      ci += (sl % ci_slices) * CI;
+      co += (sl / ci_slices) * CO;
+      valid = ci < Cin_src && co < Cout;
+      if (valid) {
+        const float* p = partial + (size_t)sl * strips * slice_floats + r;
+        for (int k = lanek; k < strips; k += 4) s += (double)p[(size_t)k * slice_floats];
+      }
+    }
+    red[lanek][o] = s;
+    __syncthreads();
+    if (lanek == 0 && valid) {
+      const double v = red[0][o] + red[1][o] + red[2][o] + red[3][o];
+      float* d = dw + ((size_t)co * Cin_total + cin_off + ci) * T + t;
+      *d = accumulate ? (*d + (float)v) : (float)v;
+    }
+    __syncthreads();
   }
 }
 
 struct WgCfg {
-  int CI, CO, TRW;
+  int id, CI, CO, TRW;
 };
-WgCfg cfg_for(int T) {
-  if (T == 1) return {64, 256, 2};
-  if (T <= 4) return {32, 128, 4};
-  return {32, 64, 4};
+// id: 0..3 = 1x1 {A,A2,B,C}; 4,5 = 2x2 {CO64,CO32}; 6,7 = 3x3 {CO64,CO32}
+WgCfg cfg_for(int T, int Cin, int Cout) {
+  if (T == 1) {
+    if (Cin >= 96 && Cout >= 192) return {0, 128, 256, 1};
+    if (Cin >= 96 && Cout >= 96) return {1, 128, 128, 1};
+    if (Cout > 32) return {2, 64, 64, 4};
+    return {3, 32, 32, 4};
+  }
+  if (T <= 4) return Cout > 32 ? WgCfg{4, 32, 64, 4} : WgCfg{5, 32, 32, 4};
+  return Cout > 32 ? WgCfg{6, 32, 64, 4} : WgCfg{7, 32, 32, 4};
 }
 
-void plan(const c3d_wgrad_desc* d, WgradArgs& a) {
-  const WgCfg c = cfg_for(d->ntaps);
+void plan(const c3d_wgrad_desc* d, WgradArgs& a, WgCfg& c) {
+  c = cfg_for(d->ntaps, d->x.C, d->Cout);
   a.tiles_x = (d->W + 31) / 32;
   a.tiles_y = (d->H + c.TRW - 1) / c.TRW;
   a.ntiles = d->B * a.tiles_x * a.tiles_y;
   a.ci_slices = (d->x.C + c.CI - 1) / c.CI;
   a.co_slices = (d->Cout + c.CO - 1) / c.CO;
   const int nsl = a.ci_slices * a.co_slices;
-  int strips = (1024 + nsl - 1) / nsl;
+  int strips = (512 + nsl - 1) / nsl;
   if (strips > a.ntiles) strips = a.ntiles;
   if (strips < 1) strips = 1;
   a.tiles_per_strip = (a.ntiles + strips - 1) / strips;
   a.strips = (a.ntiles + a.tiles_per_strip - 1) / a.tiles_per_strip;
 }
 
-template <int TMAX, int CI_T, int CO_T, int TRW, int HALO>
+template <int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO>
 int launch_wg(const WgradArgs& a, hipStream_t st) {
-  constexpr int CI = 32 * CI_T, CO = 64 * CO_T;
+  constexpr int WK = 4 / (WCI * WCO);
+  constexpr int CI = 32 * CI_T * WCI, CO = 32 * CO_T * WCO;
   size_t lds = ((size_t)(TRW + 2 * HALO) * (32 + 2 * HALO) * CI + (size_t)TRW * 32 * CO) * sizeof(float);
-  const size_t red = (size_t)2 * CI_T * CO_T * 16 * 64 * sizeof(float);
+  const size_t red = (size_t)(WK - 1) * WCI * WCO * CI_T * CO_T * 1024 * sizeof(float);
   if (red > lds) lds = red;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<TMAX, CI_T, CO_T, TRW, HALO>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   dim3 grid(a.strips * a.ci_slices * a.co_slices);
-  hipLaunchKernelGGL((wgrad_mfma_kernel<TMAX, CI_T, CO_T, TRW, HALO>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((wgrad_mfma_kernel<TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO>), grid, dim3(256), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -235,8 +273,8 @@ int launch_wg(const WgradArgs& a, hipStream_t st) {
 
 extern "C" int64_t c3d_wgrad_partial_floats(const c3d_wgrad_desc* d) {
   WgradArgs a;
-  plan(d, a);
-  const WgCfg c = cfg_for(d->ntaps);
+  WgCfg c;
+  plan(d, a, c);
   return (int64_t)a.strips * a.ci_slices * a.co_slices * d->ntaps * c.CI * c.CO;
 }
 
@@ -255,25 +293,30 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
     if (m > halo) halo = m;
   }
   C3D_REQUIRE(halo <= 2, "wgrad: tap offsets beyond +-2 are not supported");
+  C3D_REQUIRE(d->ntaps != 1 || halo == 0, "wgrad: a single tap must have zero offset");
+  C3D_REQUIRE(d->ntaps != 4 || halo <= 1, "wgrad: 4-tap kernels support offsets of +-1");
   a.partial = d->partial;
-  plan(d, a);
+  WgCfg c;
+  plan(d, a, c);
   hipStream_t st = (hipStream_t)stream;
-  int rc;
-  if (d->ntaps == 1) {
-    rc = launch_wg<1, 2, 4, 2, 0>(a, st);
-  } else if (d->ntaps == 4) {
-    rc = launch_wg<4, 1, 2, 4, 1>(a, st);
-  } else {
-    rc = (halo <= 1) ? launch_wg<9, 1, 1, 4, 1>(a, st) : launch_wg<9, 1, 1, 4, 2>(a, st);
+  int rc = 0;
+  switch (c.id) {
+    //                 TMAX CI_T CO_T WCI WCO TRW HALO
+    case 0: rc = launch_wg<1, 2, 4, 2, 2, 1, 0>(a, st); break;
+    case 1: rc = launch_wg<1, 2, 2, 2, 2, 1, 0>(a, st); break;
+    case 2: rc = launch_wg<1, 2, 2, 1, 1, 4, 0>(a, st); break;
+    case 3: rc = launch_wg<1, 1, 1, 1, 1, 4, 0>(a, st); break;
+    case 4: rc = launch_wg<4, 1, 2, 1, 1, 4, 1>(a, st); break;
+    case 5: rc = launch_wg<4, 1, 1, 1, 1, 4, 1>(a, st); break;
+    case 6: rc = halo <= 1 ? launch_wg<9, 1, 1, 1, 2, 4, 1>(a, st) : launch_wg<9, 1, 1, 1, 2, 4, 2>(a, st); break;
+    default: rc = halo <= 1 ? launch_wg<9, 1, 1, 1, 1, 4, 1>(a, st) : launch_wg<9, 1, 1, 1, 1, 4, 2>(a, st); break;
   }
   if (rc) return rc;
-  const WgCfg c = cfg_for(d->ntaps);
-  const size_t total = (size_t)d->Cout * d->x.C * d->ntaps;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.partial, d->dw, a.strips, d->ntaps,
-                     c.CI, c.CO, a.ci_slices, a.co_slices, d->x.C, d->Cout, d->Cin_total, d->cin_off,
-                     d->accumulate);
+  const size_t total = (size_t)d->ntaps * c.CI * c.CO * a.ci_slices * a.co_slices;
+  int blocks = (int)((total + 63) / 64);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.partial, d->dw, a.strips, d->ntaps, c.CI,
+                     c.CO, a.ci_slices, a.co_slices, d->x.C, d->Cout, d->Cin_total, d->cin_off, d->accumulate);
   C3D_CHECK_LAUNCH();
   return 0;
 }

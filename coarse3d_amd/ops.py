@@ -114,11 +114,14 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         out = torch.empty(b, h, w, cout, device=wpack.device, dtype=torch.float32)
     d.out, d.out_cstride, d.out_coff, d.accumulate = out.data_ptr(), out.shape[3], out_coff, int(accumulate)
     if stats and stat_partial is None:
-        stat_partial = torch.empty(num_mtiles(b, h, w), cout, 2, device=wpack.device, dtype=torch.float32)
+        stat_partial = torch.empty(cout, 2, num_mtiles(b, h, w), device=wpack.device, dtype=torch.float32)
     d.stat_partial = stat_partial.data_ptr() if stat_partial is not None else None
     tr = 8 if h >= 8 else (4 if h >= 4 else 2)
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
-    name = f"conv_mfma_kernel<{tr},{2 if (cout > 32 or tr == 2) else 1},16,{halo}>"
+    if tr == 8 and halo == 0 and all(s.C % 32 == 0 for s in srcs):
+        name = f"conv_mfma_kernel<8, {4 if cout > 64 else (2 if cout > 32 else 1)}, 32, 0>"
+    else:
+        name = f"conv_mfma_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {halo}>"
     with _Timed(name, 2.0 * b * h * w * cout * len(taps) * sum(s.C for s in srcs)):
         L.check(L.lib().c3d_conv_forward(C.byref(d), _stream()), "c3d_conv_forward")
     return out, stat_partial
@@ -140,8 +143,15 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False):
     part = torch.empty(n, device=dz.device, dtype=torch.float32)
     d.partial = part.data_ptr()
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
-    name = {1: "wgrad_mfma_kernel<1,2,4,2,0>", 4: "wgrad_mfma_kernel<4,1,2,4,1>"}.get(
-        len(taps), f"wgrad_mfma_kernel<9,1,1,4,{1 if halo <= 1 else 2}>")
+    co, ci, nt = dw.shape[0], src.C, len(taps)
+    if nt == 1:      # mirrors cfg_for() in csrc/wgrad_mfma.hip
+        cfg = ("1, 2, 4, 2, 2, 1, 0" if (ci >= 96 and co >= 192) else "1, 2, 2, 2, 2, 1, 0" if (ci >= 96 and co >= 96)
+               else "1, 2, 2, 1, 1, 4, 0" if co > 32 else "1, 1, 1, 1, 1, 4, 0")
+    elif nt == 4:
+        cfg = "4, 1, 2, 1, 1, 4, 1" if co > 32 else "4, 1, 1, 1, 1, 4, 1"
+    else:
+        cfg = f"9, 1, 1, 1, {2 if co > 32 else 1}, 4, {1 if halo <= 1 else 2}"
+    name = f"wgrad_mfma_kernel<{cfg}>"
     with _Timed(name, 2.0 * b * h * w * dw.shape[0] * len(taps) * src.C):
         L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
     return dw
@@ -157,10 +167,10 @@ def _dp(t):
 
 
 def stat_reduce(partial, c, sums=None):
-    """partial [n,C,2] fp32 -> sums [C,2] fp64."""
+    """partial [C,2,n] fp32 -> sums [C,2] fp64."""
     if sums is None:
         sums = torch.empty(c, 2, device=partial.device, dtype=torch.float64)
-    _call("c3d_stat_reduce", _dp(partial), partial.shape[0], c, _dp(sums), _stream())
+    _call("c3d_stat_reduce", _dp(partial), partial.shape[2], c, _dp(sums), _stream())
     return sums
 
 
@@ -186,7 +196,7 @@ def bn_bwd_blocks(npix):
 
 def bn_bwd_reduce(dy, a, c, mode=0, pre_scale=None, pre_shift=None):
     npix = dy.numel() // dy.shape[-1]
-    part = torch.empty(bn_bwd_blocks(npix), c, 2, device=dy.device, dtype=torch.float32)
+    part = torch.empty(c, 2, bn_bwd_blocks(npix), device=dy.device, dtype=torch.float32)
     _call("c3d_bn_bwd_reduce", _dp(dy), dy.shape[-1], _dp(a), a.shape[-1], npix, c, mode, _dp(pre_scale),
           _dp(pre_shift), _dp(part), _stream())
     return part
@@ -201,11 +211,11 @@ def bn_bwd_coeffs(sums, count, mean, invstd, gamma, dgamma, dbeta):
 
 
 def bn_bwd_apply(dy, a, c, mode, k=None, pre_scale=None, pre_shift=None, dz=None):
-    """dz = act'(.) * (k1*dy + k2*a + k3); returns (dz, partial [nblk,C,2] with sum(dz) in col 0)."""
+    """dz = act'(.) * (k1*dy + k2*a + k3); returns (dz, partial [C,2,nblk] with sum(dz) in row 0)."""
     npix = dy.numel() // dy.shape[-1]
     if dz is None:
         dz = torch.empty(dy.shape[:-1] + (c,), device=dy.device, dtype=torch.float32)
-    part = torch.empty(bn_bwd_blocks(npix), c, 2, device=dy.device, dtype=torch.float32)
+    part = torch.empty(c, 2, bn_bwd_blocks(npix), device=dy.device, dtype=torch.float32)
     k1, k2, k3 = (k[0], k[1], k[2]) if k is not None else (None, None, None)
     _call("c3d_bn_bwd_apply", _dp(dy), dy.shape[-1], _dp(a), a.shape[-1], npix, c, mode, _dp(pre_scale),
           _dp(pre_shift), _dp(k1), _dp(k2), _dp(k3), _dp(dz), dz.shape[-1], _dp(part), _stream())
@@ -309,11 +319,12 @@ def bilinear(src, hd, wd, dst=None, dcoff=0, c=None, scoff=0):
     return dst
 
 
-def bilinear_bwd(dsrc, ddst, dcoff=0, c=None, scoff=0):
+def bilinear_bwd(dsrc, ddst, dcoff=0, c=None, scoff=0, accumulate=False):
     b, hs, ws, scs = dsrc.shape
     _, hd, wd, dcs = ddst.shape
     c = c or scs
-    _call("c3d_bilinear_bwd", _dp(dsrc), hs, ws, scs, scoff, _dp(ddst), hd, wd, dcs, dcoff, b, c, _stream())
+    _call("c3d_bilinear_bwd", _dp(dsrc), hs, ws, scs, scoff, _dp(ddst), hd, wd, dcs, dcoff, b, c, int(accumulate),
+          _stream())
     return dsrc
 
 
@@ -358,13 +369,24 @@ def group_compact(labels, ncls, keep=None):
     return counts, idx
 
 
+def label_hist(labels, ncls):
+    """labels int64 [G, n] -> counts int32 [G, ncls] (classes >= 1)."""
+    g, n = labels.shape
+    counts = torch.empty(g, ncls, device=labels.device, dtype=torch.int32)
+    _call("c3d_label_hist", _dp(labels), g, n, ncls, _dp(counts), _stream())
+    return counts
+
+
 def proto_learn(sim, feat, pred, counts, idx, noise, protos, m, c, ignore_label, momentum):
-    n, d = feat.shape
+    """counts [B, C], idx [B, C, n]: per-image ordered pixel lists of each class."""
+    ntot, d = feat.shape
+    b, _, n = idx.shape
     protos_out = torch.empty_like(protos)
-    target = torch.zeros(n, device=feat.device, dtype=torch.float32)
-    assign = torch.empty(n, device=feat.device, dtype=torch.int32)
-    _call("c3d_proto_learn", _dp(sim), _dp(feat), _dp(pred), _dp(counts), _dp(idx), _dp(noise), _dp(protos),
-          _dp(protos_out), _dp(target), _dp(assign), n, m, c, d, ignore_label, momentum, _stream())
+    target = torch.zeros(ntot, device=feat.device, dtype=torch.float32)
+    assign = torch.empty(ntot, device=feat.device, dtype=torch.int32)
+    rows = torch.empty(c, ntot, device=feat.device, dtype=torch.int32)
+    _call("c3d_proto_learn", _dp(sim), _dp(feat), _dp(pred), _dp(counts), _dp(idx), _dp(rows), _dp(noise),
+          _dp(protos), _dp(protos_out), _dp(target), _dp(assign), b, n, m, c, d, ignore_label, momentum, _stream())
     return protos_out, target
 
 

@@ -17,8 +17,8 @@ def distributed_sinkhorn(out, sinkhorn_iterations=3, epsilon=0.05):
     sim = out.detach().float().contiguous()                # [n, K*1], class 0 of 1
     rows = torch.zeros(n, 4, device=dev)
     pred = torch.zeros(n, device=dev, dtype=torch.int32)
-    counts = torch.tensor([n], device=dev, dtype=torch.int32)
-    idx = torch.arange(n, device=dev, dtype=torch.int32)
+    counts = torch.tensor([[n]], device=dev, dtype=torch.int32)
+    idx = torch.arange(n, device=dev, dtype=torch.int32).view(1, 1, n)
     noise = torch.empty(n, k, device=dev).exponential_()
     bank = torch.zeros(1, k, 4, device=dev)
     _, target = ops.proto_learn(sim, rows, pred, counts, idx, noise, bank, k, 1, -1, 0.999)

@@ -34,7 +34,7 @@ def similarity(feat_nhwc, bank_l2, ln_w, ln_b):
 
 
 def prototype_step(feat_nhwc, P, label, proto_loss, noise=None, momentum=0.999, ignore_label=0,
-                   world_mean=None, want_nearest=False, ema_base=None):
+                   world_mean=None, want_nearest=False, ema_base=None):  # label: [B, H*W] int64
     """One pass of salsanext_proto.py:494-530.
 
     P: dict with ``prototypes`` [C,M,D], ``feat_norm.*``, ``mask_norm.*``.  label: [N] int64 or
@@ -49,12 +49,13 @@ def prototype_step(feat_nhwc, P, label, proto_loss, noise=None, momentum=0.999, 
                                       want_nearest=want_nearest)
     out = {"bank_l2": bank_l2, "nearest": nearest, "pred": pred}
     if proto_loss and label is not None:
-        lab = label.reshape(1, n).contiguous()
+        b = feat_nhwc.shape[0]
+        lab = label.reshape(b, n // b).contiguous()
         counts, idx = ops.group_compact(lab, c)
         if noise is None:
             noise = torch.empty(n, m, device=rows.device, dtype=torch.float32).exponential_()
         base = bank_l2 if ema_base is None else ema_base.contiguous()   # proto_pl replaces the bank (:515-518)
-        new_bank, target = ops.proto_learn(sim, rows, pred, counts.view(-1), idx.view(c, n), noise.contiguous(),
+        new_bank, target = ops.proto_learn(sim, rows, pred, counts, idx, noise.contiguous(),
                                            base, m, c, ignore_label, momentum)
         if world_mean is not None:       # data parallel: mean over ranks (salsanext_proto.py:397-400)
             new_bank = world_mean(new_bank)

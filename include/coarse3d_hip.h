@@ -61,7 +61,7 @@ typedef struct {
   int32_t out_cstride;
   int32_t out_coff;
   int32_t accumulate;       /* out += result (gradient accumulation)                     */
-  float* stat_partial;      /* NULL or [c3d_conv_num_mtiles][Cout][2]: per-tile sum,sumsq */
+  float* stat_partial;      /* NULL or [Cout][2][c3d_conv_num_mtiles]: per-tile sum,sumsq */
 } c3d_conv_desc;
 
 /* y = epilogue(conv(transform(cat(src)))) as an implicit GEMM on fp32 MFMA.
@@ -103,7 +103,7 @@ int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream);
  * nn.BatchNorm2d of salsanext_proto.py:46,50,89-105,168-180 and projector.py:20, split so that
  * the fp64 sums can be all-reduced across ranks in between (SyncBatchNorm, trainer.py:54).   */
 
-/* partial [n][C][2] fp32 (per-tile sum, sumsq) -> sums [C][2] fp64 */
+/* partial [C][2][n] fp32 (per-tile sum, sumsq) -> sums [C][2] fp64 */
 int c3d_stat_reduce(const float* partial, int n, int C, double* sums, c3d_stream stream);
 /* sums + count -> consumer-side affine scale=gamma*invstd, shift=beta-mean*scale; saves
  * mean/invstd for backward; updates running stats (momentum, unbiased var) when non-NULL.   */
@@ -118,9 +118,9 @@ int c3d_bn_eval_affine(const float* gamma, const float* beta, const float* runni
 /* Backward of  a -> BN -> (consumers)  where a = LeakyReLU(conv) [mode 0], of
  * a -> BN -> LeakyReLU [mode 1, projector; pre_scale/pre_shift = the forward affine],
  * of a = LeakyReLU(conv) without BN [mode 2], or identity [mode 3]; dy/a/dz are [npix][cs].
- *   reduce : partial [c3d_bn_bwd_num_blocks][C][2] = (sum dy, sum dy*a)
+ *   reduce : partial [C][2][c3d_bn_bwd_num_blocks] = (sum dy, sum dy*a)
  *   coeffs : da = k1*dy + k2*a + k3 ; dgamma = sum(dy*xhat) ; dbeta = sum(dy)
- *   apply  : dz = act'(.) * da ; partial[..][C][0] = sum dz  (conv bias gradient)            */
+ *   apply  : dz = act'(.) * da ; partial[C][0][..] = sum dz  (conv bias gradient)            */
 int c3d_bn_bwd_num_blocks(int npix);
 int c3d_bn_bwd_reduce(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C,
                       int mode, const float* pre_scale, const float* pre_shift, float* partial,
@@ -173,9 +173,10 @@ int c3d_softmax_bwd(const float* prob, const float* dprob, int B, int H, int W, 
 /* F.interpolate(bilinear, align_corners=True) between channel slices of NHWC tensors (:470-490) */
 int c3d_bilinear(const float* src, int Hs, int Ws, int scs, int scoff, float* dst, int Hd,
                  int Wd, int dcs, int dcoff, int B, int C, c3d_stream stream);
-/* dsrc += bilinear^T(ddst)  (atomic scatter-add)                                            */
+/* dsrc (+)= bilinear^T(ddst): deterministic gather over the destination pixels that read each
+ * source pixel (no atomics); accumulate != 0 adds to the existing dsrc                        */
 int c3d_bilinear_bwd(float* dsrc, int Hs, int Ws, int scs, int scoff, const float* ddst, int Hd,
-                     int Wd, int dcs, int dcoff, int B, int C, c3d_stream stream);
+                     int Wd, int dcs, int dcoff, int B, int C, int accumulate, c3d_stream stream);
 /* F.normalize(p=2) over rows of [n][C] (:485; eps 1e-12); norm may be NULL                  */
 int c3d_l2norm(const float* x, int64_t n, int C, float eps, float* y, float* norm,
                c3d_stream stream);
@@ -198,13 +199,17 @@ int c3d_proto_nearest(const float* sim, int64_t n, int M, int C, const float* ln
  * (labels masked to 0 where keep[g][i]==0, keep may be NULL).  idx is [groups][ncls][n].     */
 int c3d_group_compact(const int64_t* labels, const uint8_t* keep, int groups, int n, int ncls,
                       int32_t* counts, int32_t* idx, c3d_stream stream);
+/* counts[g][c] = number of labels equal to c (c >= 1) in group g                             */
+int c3d_label_hist(const int64_t* labels, int groups, int n, int ncls, int32_t* counts,
+                   c3d_stream stream);
 /* Per class: Sinkhorn (3 iters, eps .05) on sim[rows,:,c], argmax -> target, Gumbel-hard
- * one-hot from Exp(1) `noise` [N][M] (indexed by pixel), masked feature sums, EMA into the
- * bank and final l2.  counts/idx from c3d_group_compact(groups=1).  target must be zeroed.   */
+ * one-hot from Exp(1) `noise` [B*n][M] (indexed by pixel), masked feature sums, EMA into the
+ * bank and final l2.  counts [B][C] / idx [B][C][n] from c3d_group_compact(groups=B) on the
+ * labels of the B images; rows [C][B*n] and assign [B*n] are scratch; target must be zeroed. */
 int c3d_proto_learn(const float* sim, const float* feat, const int32_t* pred,
-                    const int32_t* counts, const int32_t* idx, const float* noise,
+                    const int32_t* counts, const int32_t* idx, int32_t* rows, const float* noise,
                     const float* protos, float* protos_out, float* target, int32_t* assign,
-                    int N, int M, int C, int D, int ignore_label, float momentum,
+                    int B, int n, int M, int C, int D, int ignore_label, float momentum,
                     c3d_stream stream);
 
 /* ------------------------------------------------------------------ contrast loss + PL selection

@@ -52,7 +52,7 @@ def test_conv_forward_and_grads(B, H, W, srcC, Cout, k, dil, pad):
     y_cpu = ops.from_nhwc(y.cpu())
     assert rel_err(y_cpu, y_ref.detach()) < 1e-4
     # per-tile statistics sum up to the channel sums
-    sums = partial.double().sum(0).cpu()
+    sums = partial.double().sum(-1).cpu()
     ref1 = y_ref.detach().double().sum(dim=(0, 2, 3))
     ref2 = (y_ref.detach().double() ** 2).sum(dim=(0, 2, 3))
     assert float((sums[:, 0] - ref1).abs().max()) < 1e-4 * float(ref2.max()) ** 0.5 * (B * H * W) ** 0.5

@@ -84,7 +84,7 @@ def test_bn_forward_stats_and_running():
     y = bn(x)
     # per-tile partials as the conv epilogue would leave them: emulate with one "tile" per image row
     xd = nhwc(x).to(DEV)
-    part = torch.stack([xd.reshape(-1, W, C).sum(1), (xd.reshape(-1, W, C) ** 2).sum(1)], -1).contiguous()
+    part = torch.stack([xd.reshape(-1, W, C).sum(1).t(), (xd.reshape(-1, W, C) ** 2).sum(1).t()], 1).contiguous()
     sums = ops.stat_reduce(part, C)
     rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     sc, sh, mean, invstd = ops.bn_finalize(sums, B * H * W, bn.weight.data.to(DEV), bn.bias.data.to(DEV), rm, rv)
@@ -193,11 +193,13 @@ def test_bilinear(Hs, Ws, Hd, Wd):
     dst = torch.zeros(B, Hd, Wd, C + 16, device=DEV)
     ops.bilinear(nhwc(x.detach()).to(DEV), Hd, Wd, dst=dst, dcoff=16, c=C)
     assert rel(nchw(dst[..., 16:]), y) < 1e-5
-    dsrc = torch.zeros(B, Hs, Ws, C, device=DEV)
+    dsrc = torch.full((B, Hs, Ws, C), 7.0, device=DEV)
     ddst = torch.zeros(B, Hd, Wd, C + 16, device=DEV)
     ddst[..., 16:] = nhwc(dy).to(DEV)
     ops.bilinear_bwd(dsrc, ddst, dcoff=16, c=C)
     assert rel(nchw(dsrc), x.grad) < 1e-4
+    ops.bilinear_bwd(dsrc, ddst, dcoff=16, c=C, accumulate=True)
+    assert rel(nchw(dsrc), 2 * x.grad) < 1e-4
 
 
 def test_l2norm_and_residual():
