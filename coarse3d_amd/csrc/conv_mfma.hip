@@ -9,11 +9,16 @@
 // workgroup), K = taps x Cin.  Per Cin chunk of CK channels the input tile (+halo) and the
 // weight slab of every tap are staged in LDS; the BatchNorm affine of the PRODUCER layer is
 // applied while staging (zero padding afterwards), so normalised tensors never exist in HBM.
-// LDS rows are padded to CK+4 floats: ds_read_b128 / ds_write_b128 conflict-free.
+// Staging is software-pipelined through registers: the global loads of chunk k+1 are issued
+// before the MFMA loop of chunk k and written to LDS after it (one LDS buffer, loads in flight
+// across the whole compute phase).  LDS rows are padded to CK+4 floats: ds_read_b128 /
+// ds_write_b128 conflict-free.
 //   A fragment: lane l reads 4 consecutive k of pixel (l&31), k-half (l>>5)
 //   B fragment: lane l reads 4 consecutive k of cout  (l&31), same k-half
 // so one b128 read per operand feeds 4 MFMAs.  Accumulator (32x32): lane holds cout l&31 for
 // 16 pixels -> stores are 128 B contiguous per pixel.
+// Grid: 1-D, cout tile fastest, XCD-remapped: the workgroups that share one input tile (and
+// neighbouring tiles that share halos) run on the same XCD and hit its L2.
 #include "common.h"
 #include "../../include/coarse3d_hip.h"
 
@@ -33,9 +38,10 @@ struct ConvArgs {
   int out_cstride, out_coff, accumulate;
   float* stat_partial;
   int tiles_x, tiles_y, Kq;  // Kq = padded K / 4 (rows of the packed weight per tap)
+  int ntn;                   // number of cout tiles
 };
 
-template <int TR, int NT, int CK, int HALO>
+template <int TR, int NT, int CK, int HALO, int TT>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   constexpr int CS = CK + 4;
   constexpr int TWh = 32 + 2 * HALO;
@@ -47,10 +53,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   constexpr int NPW = NT / WN;
   static_assert(NT % WN == 0, "NT must split across waves");
   constexpr int CQ = CK / 4;
+  constexpr int IN_UNITS = THh * TWh * CQ;
+  constexpr int IN_PT = (IN_UNITS + 255) / 256;
+  constexpr int W_UNITS = TT * TN * CQ;
+  constexpr int W_PT = (W_UNITS + 255) / 256;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_in = smem;                    // [THh][TWh][CS]
-  float* s_w = smem + THh * TWh * CS;    // [T][TN][CS]
+  float* s_w = smem + THh * TWh * CS;    // [TT][TN][CS]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -58,12 +68,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   const int wm = wave % WM, wn = wave / WM;
 
   const int ntile = a.B * a.tiles_y * a.tiles_x;
-  int mt = c3d_xcd_remap(blockIdx.x, ntile);
+  const int logical = c3d_xcd_remap(blockIdx.x, ntile * a.ntn);
+  const int mt = logical / a.ntn;
+  const int n0 = (logical % a.ntn) * TN;
   const int tx = mt % a.tiles_x;
   const int ty = (mt / a.tiles_x) % a.tiles_y;
   const int b = mt / (a.tiles_x * a.tiles_y);
   const int x0 = tx * 32, y0 = ty * TR;
-  const int n0 = blockIdx.y * TN;
 
   f32x16 acc[RPW][NPW];
 #pragma unroll
@@ -73,80 +84,133 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  int kbase = 0;  // first k (input channel) of the current source inside the packed weights
-  for (int s = 0; s < a.nsrc; ++s) {
-    const c3d_src sr = a.src[s];
-    for (int c0 = 0; c0 < sr.C; c0 += CK) {
-      __syncthreads();
-      // ---- stage input tile: (THh x TWh) pixels x CK channels, transform on load
-      for (int u = tid; u < THh * TWh * CQ; u += 256) {
-        const int c4 = u % CQ;
+  // ---- register staging (prefetch) state
+  f32x4 pin[IN_PT], pw[W_PT];
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  unsigned inb = 0;                      // bit i: unit i of this thread lies inside the image
+  const int c4 = tid % CQ;               // 256 % CQ == 0: the channel quad of a thread is fixed
+
+  auto load_chunk = [&](int s, int c0, int kbase) {
+    const c3d_src& sr = a.src[s];
+    inb = 0;
+#pragma unroll
+    for (int i = 0; i < IN_PT; ++i) {
+      const int u = tid + i * 256;
+      pin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (u < IN_UNITS) {
         const int p = u / CQ;
         const int px = p % TWh, py = p / TWh;
         const int gx = x0 + px - HALO, gy = y0 + py - HALO;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H) {
           const size_t off = ((size_t)(b * a.H + gy) * a.W + gx) * sr.cstride + sr.coff + c0 + c4 * 4;
-          v = *reinterpret_cast<const f32x4*>(sr.ptr + off);
-          if (sr.scale) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(sr.scale + c0 + c4 * 4);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(sr.shift + c0 + c4 * 4);
-            v = v * sc + sh;
-          }
-          if (sr.lrelu) {
+          pin[i] = *reinterpret_cast<const f32x4*>(sr.ptr + off);
+          inb |= 1u << i;
+        }
+      }
+    }
+    if (sr.scale) {
+      psc = *reinterpret_cast<const f32x4*>(sr.scale + c0 + c4 * 4);
+      psh = *reinterpret_cast<const f32x4*>(sr.shift + c0 + c4 * 4);
+    }
+    const int kq0 = (kbase + c0) >> 2;
+#pragma unroll
+    for (int i = 0; i < W_PT; ++i) {
+      const int u = tid + i * 256;
+      pw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (u < W_UNITS) {
+        const int n = u % TN;
+        const int r = u / TN;
+        const int kq = r % CQ, t = r / CQ;
+        if (n0 + n < a.Cout)
+          pw[i] = *reinterpret_cast<const f32x4*>(a.wpack + (((size_t)t * a.Kq + kq0 + kq) * a.Cout + n0 + n) * 4);
+      }
+    }
+  };
+
+  auto store_chunk = [&](int s) {
+    const c3d_src& sr = a.src[s];
+    const bool aff = sr.scale != nullptr;
+    const bool lr = sr.lrelu != 0;
+#pragma unroll
+    for (int i = 0; i < IN_PT; ++i) {
+      const int u = tid + i * 256;
+      if (u < IN_UNITS) {
+        f32x4 v = pin[i];
+        if ((inb >> i) & 1u) {
+          if (aff) v = v * psc + psh;
+          if (lr) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q]);
           }
         }
-        *reinterpret_cast<f32x4*>(s_in + p * CS + c4 * 4) = v;
+        *reinterpret_cast<f32x4*>(s_in + (u / CQ) * CS + c4 * 4) = v;
       }
-      // ---- stage weights of all taps for this K chunk: [t][n][k]
-      const int kq0 = (kbase + c0) >> 2;
-      for (int u = tid; u < a.T * TN * CQ; u += 256) {
+    }
+#pragma unroll
+    for (int i = 0; i < W_PT; ++i) {
+      const int u = tid + i * 256;
+      if (u < W_UNITS) {
         const int n = u % TN;
         const int r = u / TN;
         const int kq = r % CQ, t = r / CQ;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n0 + n < a.Cout)
-          v = *reinterpret_cast<const f32x4*>(a.wpack + (((size_t)t * a.Kq + kq0 + kq) * a.Cout + n0 + n) * 4);
-        *reinterpret_cast<f32x4*>(s_w + (t * TN + n) * CS + kq * 4) = v;
-      }
-      __syncthreads();
-      // ---- MFMA over taps x k
-      for (int t = 0; t < a.T; ++t) {
-        const int tap_off = ((HALO + a.dy[t]) * TWh + (HALO + a.dx[t]) + l31) * CS + half * 4;
-        const float* wb = s_w + (t * TN + wn * NPW * 32 + l31) * CS + half * 4;
-#pragma unroll
-        for (int kk = 0; kk < CK / 8; ++kk) {
-          f32x4 av[RPW], bv[NPW];
-#pragma unroll
-          for (int i = 0; i < RPW; ++i)
-            av[i] = *reinterpret_cast<const f32x4*>(s_in + (wm + i * WM) * TWh * CS + tap_off + kk * 8);
-#pragma unroll
-          for (int j = 0; j < NPW; ++j)
-            bv[j] = *reinterpret_cast<const f32x4*>(wb + j * 32 * CS + kk * 8);
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int i = 0; i < RPW; ++i)
-#pragma unroll
-              for (int j = 0; j < NPW; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
-        }
+        *reinterpret_cast<f32x4*>(s_w + (t * TN + n) * CS + kq * 4) = pw[i];
       }
     }
-    kbase += sr.C;
+  };
+
+  int s = 0, c0 = 0, kbase = 0;
+  load_chunk(s, c0, kbase);
+  while (true) {
+    __syncthreads();      // previous chunk fully consumed
+    store_chunk(s);
+    __syncthreads();
+    // issue the next chunk's global loads; they stay in flight during the MFMA loop
+    int s2 = s, c2 = c0 + CK, kb2 = kbase;
+    if (c2 >= a.src[s].C) {
+      kb2 += a.src[s].C;
+      s2 = s + 1;
+      c2 = 0;
+    }
+    const bool more = s2 < a.nsrc;
+    if (more) load_chunk(s2, c2, kb2);
+    // ---- MFMA over taps x k
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      const int tap_off = ((HALO + a.dy[t]) * TWh + (HALO + a.dx[t]) + l31) * CS + half * 4;
+      const float* wb = s_w + (t * TN + wn * NPW * 32 + l31) * CS + half * 4;
+#pragma unroll
+      for (int kk = 0; kk < CK / 8; ++kk) {
+        f32x4 av[RPW], bv[NPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+          av[i] = *reinterpret_cast<const f32x4*>(s_in + (wm + i * WM) * TWh * CS + tap_off + kk * 8);
+#pragma unroll
+        for (int j = 0; j < NPW; ++j)
+          bv[j] = *reinterpret_cast<const f32x4*>(wb + j * 32 * CS + kk * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int j = 0; j < NPW; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (!more) break;
+    s = s2;
+    c0 = c2;
+    kbase = kb2;
   }
 
   // ---- epilogue: bias, LeakyReLU, store, per-tile channel statistics
-  float s1[NPW], s2[NPW];
+  float s1[NPW], s2v[NPW];
 #pragma unroll
   for (int j = 0; j < NPW; ++j) {
     const int co = n0 + (wn * NPW + j) * 32 + l31;
     const bool cok = co < a.Cout;
     const float bias = (a.bias && cok) ? a.bias[co] : 0.f;
     s1[j] = 0.f;
-    s2[j] = 0.f;
+    s2v[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int gy = y0 + wm + i * WM;
@@ -160,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
           if (a.accumulate) v += *o;
           *o = v;
           s1[j] += v;
-          s2[j] += v * v;
+          s2v[j] += v * v;
         }
       }
     }
@@ -171,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
       float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
-      float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+      float t2 = s2v[j] + __shfl_xor(s2v[j], 32, 64);
       if (half == 0) {
         const int n = (wn * NPW + j) * 32 + l31;
         red[(wm * TN + n) * 2 + 0] = t1;
@@ -195,29 +259,30 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   }
 }
 
-template <int TR, int NT, int CK, int HALO>
-int launch_cfg(const ConvArgs& a, hipStream_t st) {
+template <int TR, int NT, int CK, int HALO, int TT>
+int launch_cfg(ConvArgs& a, hipStream_t st) {
   constexpr int CS = CK + 4;
-  const size_t lds = ((size_t)(TR + 2 * HALO) * (32 + 2 * HALO) + (size_t)a.T * 32 * NT) * CS * sizeof(float);
+  const size_t lds = ((size_t)(TR + 2 * HALO) * (32 + 2 * HALO) + (size_t)TT * 32 * NT) * CS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TR, NT, CK, HALO>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TR, NT, CK, HALO, TT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  dim3 grid(a.B * a.tiles_x * a.tiles_y, (a.Cout + 32 * NT - 1) / (32 * NT));
-  hipLaunchKernelGGL((conv_mfma_kernel<TR, NT, CK, HALO>), grid, dim3(256), lds, st, a);
+  a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
+  dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
+  hipLaunchKernelGGL((conv_mfma_kernel<TR, NT, CK, HALO, TT>), grid, dim3(256), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
+// halo / tap-count dispatch: 1 tap (pointwise), 4 taps (2x2 dilated, halo 1), 9 taps (halo 1|2)
 template <int TR, int NT>
-int launch_halo(const ConvArgs& a, int halo, hipStream_t st) {
-  switch (halo) {
-    case 0: return launch_cfg<TR, NT, 16, 0>(a, st);
-    case 1: return launch_cfg<TR, NT, 16, 1>(a, st);
-    default: return launch_cfg<TR, NT, 16, 2>(a, st);
-  }
+int launch_taps(ConvArgs& a, int halo, hipStream_t st) {
+  if (a.T == 1) return launch_cfg<TR, NT, 16, 0, 1>(a, st);
+  if (a.T == 4) return launch_cfg<TR, NT, 16, 1, 4>(a, st);
+  if (halo <= 1) return launch_cfg<TR, NT, 16, 1, 9>(a, st);
+  return launch_cfg<TR, NT, 16, 2, 9>(a, st);
 }
 
 }  // namespace
@@ -233,7 +298,7 @@ extern "C" int c3d_conv_num_mtiles(int B, int H, int W) {
 
 extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   C3D_REQUIRE(d->nsrc >= 1 && d->nsrc <= C3D_MAX_SRC, "conv: nsrc must be 1..3");
-  C3D_REQUIRE(d->ntaps >= 1 && d->ntaps <= C3D_MAX_TAPS, "conv: ntaps must be 1..9");
+  C3D_REQUIRE(d->ntaps == 1 || d->ntaps == 4 || d->ntaps == 9, "conv: ntaps must be 1, 4 or 9");
   ConvArgs a;
   int K = 0, halo = 0;
   for (int s = 0; s < d->nsrc; ++s) {
@@ -249,6 +314,8 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
     if (m > halo) halo = m;
   }
   C3D_REQUIRE(halo <= 2, "conv: tap offsets beyond +-2 are not supported");
+  C3D_REQUIRE(d->ntaps != 1 || halo == 0, "conv: a single tap must have zero offset");
+  C3D_REQUIRE(d->ntaps != 4 || halo <= 1, "conv: 4-tap kernels support offsets of +-1");
   a.nsrc = d->nsrc;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
   a.T = d->ntaps;
@@ -260,22 +327,23 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   a.tiles_x = (d->W + 31) / 32;
   a.tiles_y = (d->H + tr - 1) / tr;
   a.Kq = K / 4;
+  a.ntn = 1;
   hipStream_t st = (hipStream_t)stream;
-  if (tr == 8 && halo == 0) {
+  if (tr == 8 && d->ntaps == 1) {
     // pointwise convs are plain GEMMs: deeper K chunk (32) and up to 128 output channels per
     // workgroup so that each barrier pair covers 128 MFMAs per wave
     bool k32 = true;
     for (int s = 0; s < d->nsrc; ++s) k32 = k32 && (d->src[s].C % 32 == 0);
     if (k32) {
-      if (d->Cout > 64) return launch_cfg<8, 4, 32, 0>(a, st);
-      if (d->Cout > 32) return launch_cfg<8, 2, 32, 0>(a, st);
-      return launch_cfg<8, 1, 32, 0>(a, st);
+      if (d->Cout > 64) return launch_cfg<8, 4, 32, 0, 1>(a, st);
+      if (d->Cout > 32) return launch_cfg<8, 2, 32, 0, 1>(a, st);
+      return launch_cfg<8, 1, 32, 0, 1>(a, st);
     }
   }
   const bool wide = d->Cout > 32;
-  if (tr == 8) return wide ? launch_halo<8, 2>(a, halo, st) : launch_halo<8, 1>(a, halo, st);
-  if (tr == 4) return wide ? launch_halo<4, 2>(a, halo, st) : launch_halo<4, 1>(a, halo, st);
-  return launch_halo<2, 2>(a, halo, st);
+  if (tr == 8) return wide ? launch_taps<8, 2>(a, halo, st) : launch_taps<8, 1>(a, halo, st);
+  if (tr == 4) return wide ? launch_taps<4, 2>(a, halo, st) : launch_taps<4, 1>(a, halo, st);
+  return launch_taps<2, 2>(a, halo, st);
 }
 
 // ------------------------------------------------------------------ weight repack

@@ -7,7 +7,8 @@
 // per (tap, cin tile, cout tile) in registers across the whole strip, so the only HBM writes
 // are one partial per workgroup, folded by a second small kernel (deterministic, no atomics).
 // x is transformed on load exactly like the forward conv (BatchNorm affine of the producer,
-// zero padding afterwards).
+// zero padding afterwards).  Pixel tiles are software-pipelined through registers: the global
+// loads of tile k+1 are in flight during the MFMA loop of tile k.
 //
 // The 4 waves of a workgroup are arranged WCI x WCO x WK: WCI/WCO split the cin/cout slice,
 // WK splits the pixel rows of the tile (K split, reduced through LDS at the end).  Small channel
@@ -68,49 +69,89 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
 
-  const int t_begin = strip * a.tiles_per_strip;
-  const int t_end = min(t_begin + a.tiles_per_strip, a.ntiles);
-  for (int mt = t_begin; mt < t_end; ++mt) {
+  // ---- register staging (prefetch) of the next pixel tile while the current one is consumed
+  constexpr int X_UNITS = THh * TWh * (CI / 4);
+  constexpr int X_PT = (X_UNITS + 255) / 256;
+  constexpr int D_UNITS = TRW * 32 * (CO / 4);
+  constexpr int D_PT = (D_UNITS + 255) / 256;
+  f32x4 px_[X_PT], pd_[D_PT];
+  unsigned inb = 0;
+  const int xc4 = tid % (CI / 4);          // 256 % (CI/4) == 0: fixed channel quad per thread
+  const int xc = ci0 + xc4 * 4;
+  const bool xc_ok = xc < a.x.C;
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  if (a.x.scale && xc_ok) {
+    psc = *reinterpret_cast<const f32x4*>(a.x.scale + xc);
+    psh = *reinterpret_cast<const f32x4*>(a.x.shift + xc);
+  }
+  const bool aff = a.x.scale != nullptr, lr = a.x.lrelu != 0;
+
+  auto load_tile = [&](int mt) {
     const int tx = mt % a.tiles_x;
     const int ty = (mt / a.tiles_x) % a.tiles_y;
     const int b = mt / (a.tiles_x * a.tiles_y);
     const int x0 = tx * 32, y0 = ty * TRW;
-    __syncthreads();
-    // ---- stage x tile (+halo), transformed
-    for (int u = tid; u < THh * TWh * (CI / 4); u += 256) {
-      const int c4 = u % (CI / 4);
-      const int p = u / (CI / 4);
-      const int px = p % TWh, py = p / TWh;
-      const int gx = x0 + px - HALO, gy = y0 + py - HALO;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const int c = ci0 + c4 * 4;
-      if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && c < a.x.C) {
-        const size_t off = ((size_t)(b * a.H + gy) * a.W + gx) * a.x.cstride + a.x.coff + c;
-        v = *reinterpret_cast<const f32x4*>(a.x.ptr + off);
-        if (a.x.scale) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(a.x.scale + c);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(a.x.shift + c);
-          v = v * sc + sh;
-        }
-        if (a.x.lrelu) {
+    inb = 0;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q]);
+    for (int i = 0; i < X_PT; ++i) {
+      const int u = tid + i * 256;
+      px_[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (u < X_UNITS) {
+        const int p = u / (CI / 4);
+        const int px = p % TWh, py = p / TWh;
+        const int gx = x0 + px - HALO, gy = y0 + py - HALO;
+        if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && xc_ok) {
+          px_[i] = *reinterpret_cast<const f32x4*>(a.x.ptr + ((size_t)(b * a.H + gy) * a.W + gx) * a.x.cstride +
+                                                   a.x.coff + xc);
+          inb |= 1u << i;
         }
       }
-      *reinterpret_cast<f32x4*>(s_x + p * CI + c4 * 4) = v;
     }
-    // ---- stage dz tile
-    for (int u = tid; u < TRW * 32 * (CO / 4); u += 256) {
-      const int c4 = u % (CO / 4);
-      const int p = u / (CO / 4);
-      const int gx = x0 + (p & 31), gy = y0 + (p >> 5);
-      const int c = co0 + c4 * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gx < a.W && gy < a.H && c + 3 < a.dz_cstride)
-        v = *reinterpret_cast<const f32x4*>(a.dz + ((size_t)(b * a.H + gy) * a.W + gx) * a.dz_cstride + c);
-      *reinterpret_cast<f32x4*>(s_dz + p * CO + c4 * 4) = v;
+#pragma unroll
+    for (int i = 0; i < D_PT; ++i) {
+      const int u = tid + i * 256;
+      pd_[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (u < D_UNITS) {
+        const int c4 = u % (CO / 4);
+        const int p = u / (CO / 4);
+        const int gx = x0 + (p & 31), gy = y0 + (p >> 5);
+        const int c = co0 + c4 * 4;
+        if (gx < a.W && gy < a.H && c + 3 < a.dz_cstride)
+          pd_[i] = *reinterpret_cast<const f32x4*>(a.dz + ((size_t)(b * a.H + gy) * a.W + gx) * a.dz_cstride + c);
+      }
     }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < X_PT; ++i) {
+      const int u = tid + i * 256;
+      if (u < X_UNITS) {
+        f32x4 v = px_[i];
+        if ((inb >> i) & 1u) {
+          if (aff) v = v * psc + psh;
+          if (lr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q]);
+          }
+        }
+        *reinterpret_cast<f32x4*>(s_x + (u / (CI / 4)) * CI + xc4 * 4) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < D_PT; ++i) {
+      const int u = tid + i * 256;
+      if (u < D_UNITS) *reinterpret_cast<f32x4*>(s_dz + (u / (CO / 4)) * CO + (u % (CO / 4)) * 4) = pd_[i];
+    }
+  };
+
+  const int t_begin = strip * a.tiles_per_strip;
+  const int t_end = min(t_begin + a.tiles_per_strip, a.ntiles);
+  if (t_begin < t_end) load_tile(t_begin);
+  for (int mt = t_begin; mt < t_end; ++mt) {
     __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (mt + 1 < t_end) load_tile(mt + 1);
     // ---- K loop over this wave's pixels: k-step = pixel pair (2s + half)
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
@@ -232,7 +273,7 @@ WgCfg cfg_for(int T, int Cin, int Cout) {
     return {3, 32, 32, 4};
   }
   if (T <= 4) return Cout > 32 ? WgCfg{4, 32, 64, 4} : WgCfg{5, 32, 32, 4};
-  return Cout > 32 ? WgCfg{6, 32, 64, 4} : WgCfg{7, 32, 32, 4};
+  return Cout > 32 ? WgCfg{6, 32, 64, 2} : WgCfg{7, 32, 32, 4};
 }
 
 void plan(const c3d_wgrad_desc* d, WgradArgs& a, WgCfg& c) {
@@ -308,7 +349,7 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
     case 3: rc = launch_wg<1, 1, 1, 1, 1, 4, 0>(a, st); break;
     case 4: rc = launch_wg<4, 1, 2, 1, 1, 4, 1>(a, st); break;
     case 5: rc = launch_wg<4, 1, 1, 1, 1, 4, 1>(a, st); break;
-    case 6: rc = halo <= 1 ? launch_wg<9, 1, 1, 1, 2, 4, 1>(a, st) : launch_wg<9, 1, 1, 1, 2, 4, 2>(a, st); break;
+    case 6: rc = halo <= 1 ? launch_wg<9, 1, 1, 1, 2, 2, 1>(a, st) : launch_wg<9, 1, 1, 1, 2, 2, 2>(a, st); break;
     default: rc = halo <= 1 ? launch_wg<9, 1, 1, 1, 1, 4, 1>(a, st) : launch_wg<9, 1, 1, 1, 1, 4, 2>(a, st); break;
   }
   if (rc) return rc;

@@ -118,10 +118,12 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     d.stat_partial = stat_partial.data_ptr() if stat_partial is not None else None
     tr = 8 if h >= 8 else (4 if h >= 4 else 2)
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
-    if tr == 8 and halo == 0 and all(s.C % 32 == 0 for s in srcs):
-        name = f"conv_mfma_kernel<8, {4 if cout > 64 else (2 if cout > 32 else 1)}, 32, 0>"
-    else:
-        name = f"conv_mfma_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {halo}>"
+    nt_ = len(taps)
+    if tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs):
+        name = f"conv_mfma_kernel<8, {4 if cout > 64 else (2 if cout > 32 else 1)}, 32, 0, 1>"
+    else:    # mirrors launch_taps() in csrc/conv_mfma.hip
+        hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
+        name = f"conv_mfma_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}>"
     with _Timed(name, 2.0 * b * h * w * cout * len(taps) * sum(s.C for s in srcs)):
         L.check(L.lib().c3d_conv_forward(C.byref(d), _stream()), "c3d_conv_forward")
     return out, stat_partial
@@ -150,7 +152,7 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False):
     elif nt == 4:
         cfg = "4, 1, 2, 1, 1, 4, 1" if co > 32 else "4, 1, 1, 1, 1, 4, 1"
     else:
-        cfg = f"9, 1, 1, 1, {2 if co > 32 else 1}, 4, {1 if halo <= 1 else 2}"
+        cfg = f"9, 1, 1, 1, {2 if co > 32 else 1}, {2 if co > 32 else 4}, {1 if halo <= 1 else 2}"
     name = f"wgrad_mfma_kernel<{cfg}>"
     with _Timed(name, 2.0 * b * h * w * dw.shape[0] * len(taps) * src.C):
         L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
