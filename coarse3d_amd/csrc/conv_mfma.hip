@@ -19,6 +19,8 @@
 // 16 pixels -> stores are 128 B contiguous per pixel.
 // Grid: 1-D, cout tile fastest, XCD-remapped: the workgroups that share one input tile (and
 // neighbouring tiles that share halos) run on the same XCD and hit its L2.
+#include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "../../include/coarse3d_hip.h"
 
@@ -42,7 +44,7 @@ struct ConvArgs {
 };
 
 template <int TR, int NT, int CK, int HALO, int TT>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ? 2 : 3) void conv_mfma_kernel(ConvArgs a) {
   constexpr int CS = CK + 4;
   constexpr int TWh = 32 + 2 * HALO;
   constexpr int THh = TR + 2 * HALO;
@@ -87,43 +89,54 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   // ---- register staging (prefetch) state
   f32x4 pin[IN_PT], pw[W_PT];
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
-  unsigned inb = 0;                      // bit i: unit i of this thread lies inside the image
   const int c4 = tid % CQ;               // 256 % CQ == 0: the channel quad of a thread is fixed
+  // chunk-invariant staging indices, computed once: pixel offset of each unit relative to the
+  // tile origin (32-bit), in-image mask, and the weight unit's (row, column) offset
+  unsigned inb = 0;                      // bit i: unit i of this thread lies inside the image
+  int pixrel[IN_PT];
+#pragma unroll
+  for (int i = 0; i < IN_PT; ++i) {
+    const int u = tid + i * 256;
+    pixrel[i] = 0;
+    if (u < IN_UNITS) {
+      const int p = u / CQ;
+      const int px = p % TWh, py = p / TWh;
+      const int gx = x0 + px - HALO, gy = y0 + py - HALO;
+      pixrel[i] = (py - HALO) * a.W + (px - HALO);
+      if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H) inb |= 1u << i;
+    }
+  }
+  int wrel[W_PT];                        // (t*Kq + kq)*Cout + n  of each weight unit, or -1
+#pragma unroll
+  for (int i = 0; i < W_PT; ++i) {
+    const int u = tid + i * 256;
+    wrel[i] = -1;
+    if (u < W_UNITS) {
+      const int n = u % TN;
+      const int r = u / TN;
+      const int kq = r % CQ, t = r / CQ;
+      if (n0 + n < a.Cout) wrel[i] = (t * a.Kq + kq) * a.Cout + n0 + n;
+    }
+  }
+  const size_t tile_pix = (size_t)(b * a.H + y0) * a.W + x0;   // wave-uniform
 
   auto load_chunk = [&](int s, int c0, int kbase) {
     const c3d_src& sr = a.src[s];
-    inb = 0;
+    const float* base = sr.ptr + tile_pix * sr.cstride + sr.coff + c0 + c4 * 4;
 #pragma unroll
     for (int i = 0; i < IN_PT; ++i) {
-      const int u = tid + i * 256;
       pin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (u < IN_UNITS) {
-        const int p = u / CQ;
-        const int px = p % TWh, py = p / TWh;
-        const int gx = x0 + px - HALO, gy = y0 + py - HALO;
-        if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H) {
-          const size_t off = ((size_t)(b * a.H + gy) * a.W + gx) * sr.cstride + sr.coff + c0 + c4 * 4;
-          pin[i] = *reinterpret_cast<const f32x4*>(sr.ptr + off);
-          inb |= 1u << i;
-        }
-      }
+      if ((inb >> i) & 1u) pin[i] = *reinterpret_cast<const f32x4*>(base + (ptrdiff_t)pixrel[i] * sr.cstride);
     }
     if (sr.scale) {
       psc = *reinterpret_cast<const f32x4*>(sr.scale + c0 + c4 * 4);
       psh = *reinterpret_cast<const f32x4*>(sr.shift + c0 + c4 * 4);
     }
-    const int kq0 = (kbase + c0) >> 2;
+    const float* wbase = a.wpack + (size_t)((kbase + c0) >> 2) * a.Cout * 4;
 #pragma unroll
     for (int i = 0; i < W_PT; ++i) {
-      const int u = tid + i * 256;
       pw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (u < W_UNITS) {
-        const int n = u % TN;
-        const int r = u / TN;
-        const int kq = r % CQ, t = r / CQ;
-        if (n0 + n < a.Cout)
-          pw[i] = *reinterpret_cast<const f32x4*>(a.wpack + (((size_t)t * a.Kq + kq0 + kq) * a.Cout + n0 + n) * 4);
-      }
+      if (wrel[i] >= 0) pw[i] = *reinterpret_cast<const f32x4*>(wbase + (size_t)wrel[i] * 4);
     }
   };
 
@@ -204,27 +217,65 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 
   // ---- epilogue: bias, LeakyReLU, store, per-tile channel statistics
   float s1[NPW], s2v[NPW];
+  const bool full_tile = (x0 + 32 <= a.W) && (y0 + TR <= a.H) && (n0 + TN <= a.Cout);
+  float* obase = a.out + tile_pix * a.out_cstride + a.out_coff + n0 + l31;   // + per-lane cout
+  const int ocs = a.out_cstride;
+  // fast path (interior tiles): straight-line, no per-element predicates
+  auto fast_epilogue = [&](auto accumulate_tag) {
+    constexpr bool ACC = decltype(accumulate_tag)::value;
 #pragma unroll
-  for (int j = 0; j < NPW; ++j) {
-    const int co = n0 + (wn * NPW + j) * 32 + l31;
-    const bool cok = co < a.Cout;
-    const float bias = (a.bias && cok) ? a.bias[co] : 0.f;
-    s1[j] = 0.f;
-    s2v[j] = 0.f;
+    for (int j = 0; j < NPW; ++j) {
+      const int cl = (wn * NPW + j) * 32;
+      const float bias = a.bias ? a.bias[n0 + cl + l31] : 0.f;
+      s1[j] = 0.f;
+      s2v[j] = 0.f;
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int gy = y0 + wm + i * WM;
+      for (int i = 0; i < RPW; ++i) {
+        float* orow = obase + (ptrdiff_t)((wm + i * WM) * a.W + 4 * half) * ocs + cl;
+        float old[16];
+        if constexpr (ACC) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = acc[i][j][r] + bias;
-        if (a.epi_lrelu) v = c3d_lrelu(v);
-        if (cok && gy < a.H && gx < a.W) {
-          float* o = a.out + ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co;
-          if (a.accumulate) v += *o;
-          *o = v;
+          for (int r = 0; r < 16; ++r) old[r] = orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bias;
+          if (a.epi_lrelu) v = c3d_lrelu(v);
+          if constexpr (ACC) v += old[r];
+          orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs] = v;
           s1[j] += v;
           s2v[j] += v * v;
+        }
+      }
+    }
+  };
+  if (full_tile && !a.accumulate) {
+    fast_epilogue(std::false_type{});
+  } else if (full_tile) {
+    fast_epilogue(std::true_type{});
+  } else {
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+      const int co = n0 + (wn * NPW + j) * 32 + l31;
+      const bool cok = co < a.Cout;
+      const float bias = (a.bias && cok) ? a.bias[co] : 0.f;
+      s1[j] = 0.f;
+      s2v[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int gy = y0 + wm + i * WM;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = acc[i][j][r] + bias;
+          if (a.epi_lrelu) v = c3d_lrelu(v);
+          if (cok && gy < a.H && gx < a.W) {
+            float* o = a.out + ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co;
+            if (a.accumulate) v += *o;
+            *o = v;
+            s1[j] += v;
+            s2v[j] += v * v;
+          }
         }
       }
     }
@@ -335,7 +386,9 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
     bool k32 = true;
     for (int s = 0; s < d->nsrc; ++s) k32 = k32 && (d->src[s].C % 32 == 0);
     if (k32) {
-      if (d->Cout > 64) return launch_cfg<8, 4, 32, 0, 1>(a, st);
+      static const char* env_nt = getenv("C3D_POINTWISE_NT");
+      if (d->Cout > 64 && env_nt && env_nt[0] == '4') return launch_cfg<8, 4, 16, 0, 1>(a, st);
+      if (d->Cout > 64 && !(env_nt && env_nt[0] == '2')) return launch_cfg<8, 4, 32, 0, 1>(a, st);
       if (d->Cout > 32) return launch_cfg<8, 2, 32, 0, 1>(a, st);
       return launch_cfg<8, 1, 32, 0, 1>(a, st);
     }

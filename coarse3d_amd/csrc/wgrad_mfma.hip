@@ -144,6 +144,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     }
   };
 
+  int tapoff[TMAX];                        // LDS offset of each tap (a.T == TMAX by construction)
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) tapoff[t] = (a.dy[t] * TWh + a.dx[t]) * CI;
+
   const int t_begin = strip * a.tiles_per_strip;
   const int t_end = min(t_begin + a.tiles_per_strip, a.ntiles);
   if (t_begin < t_end) load_tile(t_begin);
@@ -152,29 +156,45 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     store_tile();
     __syncthreads();
     if (mt + 1 < t_end) load_tile(mt + 1);
-    // ---- K loop over this wave's pixels: k-step = pixel pair (2s + half)
+    // ---- K loop over this wave's pixels: k-step = pixel pair (2s + half); the operand
+    //      fragments of step s+1 are read from LDS while the MFMAs of step s issue
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int row = wk * RPW + rr;
-#pragma unroll 4
+      const float* xr = s_x + ((row + HALO) * TWh + HALO + half) * CI + wci * CI_T * 32 + l31;
+      const float* dr = s_dz + (row * 32 + half) * CO + wco * CO_T * 32 + l31;
+      float ac[TMAX][CI_T], bc[CO_T];
+#pragma unroll
+      for (int j = 0; j < CO_T; ++j) bc[j] = dr[j * 32];
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+        for (int i = 0; i < CI_T; ++i) ac[t][i] = xr[tapoff[t] + i * 32];
+#pragma unroll
       for (int s = 0; s < 16; ++s) {
-        const int col = 2 * s + half;
-        float bv[CO_T];
+        float an[TMAX][CI_T], bn[CO_T];
+        if (s < 15) {
 #pragma unroll
-        for (int j = 0; j < CO_T; ++j) bv[j] = s_dz[(row * 32 + col) * CO + (wco * CO_T + j) * 32 + l31];
+          for (int j = 0; j < CO_T; ++j) bn[j] = dr[(2 * s + 2) * CO + j * 32];
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
-          if (t < a.T) {
-            const float* xp =
-                s_x + ((row + HALO + a.dy[t]) * TWh + (col + HALO + a.dx[t])) * CI + wci * CI_T * 32 + l31;
+          for (int t = 0; t < TMAX; ++t)
 #pragma unroll
-            for (int i = 0; i < CI_T; ++i) {
-              const float av = xp[i * 32];
+            for (int i = 0; i < CI_T; ++i) an[t][i] = xr[(2 * s + 2) * CI + tapoff[t] + i * 32];
+        }
 #pragma unroll
-              for (int j = 0; j < CO_T; ++j)
-                acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[t][i][j], 0, 0, 0);
-            }
-          }
+        for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+          for (int i = 0; i < CI_T; ++i)
+#pragma unroll
+            for (int j = 0; j < CO_T; ++j)
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][i], bc[j], acc[t][i][j], 0, 0, 0);
+        if (s < 15) {
+#pragma unroll
+          for (int j = 0; j < CO_T; ++j) bc[j] = bn[j];
+#pragma unroll
+          for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+            for (int i = 0; i < CI_T; ++i) ac[t][i] = an[t][i];
         }
       }
     }
@@ -284,7 +304,9 @@ void plan(const c3d_wgrad_desc* d, WgradArgs& a, WgCfg& c) {
   a.ci_slices = (d->x.C + c.CI - 1) / c.CI;
   a.co_slices = (d->Cout + c.CO - 1) / c.CO;
   const int nsl = a.ci_slices * a.co_slices;
-  int strips = (512 + nsl - 1) / nsl;
+  // one resident round: 256 CUs x 2 workgroups; never exceed it (a 2nd, nearly empty round
+  // would double the kernel time)
+  int strips = 512 / nsl;
   if (strips > a.ntiles) strips = a.ntiles;
   if (strips < 1) strips = 1;
   a.tiles_per_strip = (a.ntiles + strips - 1) / strips;
