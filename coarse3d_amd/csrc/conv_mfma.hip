@@ -186,7 +186,9 @@ __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ?
     }
     const bool more = s2 < a.nsrc;
     if (more) load_chunk(s2, c2, kb2);
-    // ---- MFMA over taps x k
+    // ---- MFMA over taps x k (raised wave priority: the co-resident workgroup on this CU is
+    //      usually in its staging phase and must not steal issue slots from the matrix pipe)
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
       const int tap_off = ((HALO + a.dy[t]) * TWh + (HALO + a.dx[t]) + l31) * CS + half * 4;
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ?
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     if (!more) break;
     s = s2;
     c0 = c2;

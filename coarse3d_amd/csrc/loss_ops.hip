@@ -39,42 +39,80 @@ __global__ void entropy_stats_kernel(const float* __restrict__ prob, size_t n, i
 }
 
 // ---------------------------------------------------------------- pseudo-label selection (T3)
+// Members of pair (b, c): pixels with amax == c and eval_label > 0, for classes c present in the
+// weak labels of image b.  Three light passes bucket the members' keys (bits of w / noise) per
+// pair, then one workgroup per pair radix-selects the k-th largest key of its bucket.
 struct PlArgs {
   const float* w_pl;           // [B][n]
   const int32_t* amax;         // [B][n]
   const int64_t* eval_label;   // [B][n]
-  const int64_t* train_label;  // [B][n]
   const float* noise;          // [B][C][n] Exp(1)
   const int32_t* tl_counts;    // [B][C] number of weak labels of class c in image b
   int n, C, ignore;
   float ratio;
+  int32_t* cnt;                // [B][C] members per pair
+  int32_t* cursor;             // [B][C] fill cursor
+  uint32_t* keys;              // [B][n] bucketed keys (bucket of (b,c) starts at offset[b][c])
+  int32_t* pix;                // [B][n] pixel index of each key
   uint8_t* chosen;             // [B][n], pre-zeroed
 };
 
-__device__ __forceinline__ bool pl_member(const PlArgs& a, int b, int c, int i) {
-  return a.amax[(size_t)b * a.n + i] == c && a.eval_label[(size_t)b * a.n + i] > 0;
+__device__ __forceinline__ int pl_class(const PlArgs& a, int b, int i) {
+  const int c = a.amax[(size_t)b * a.n + i];
+  if (c == a.ignore || a.eval_label[(size_t)b * a.n + i] <= 0 || a.tl_counts[b * a.C + c] == 0) return -1;
+  return c;
 }
 
-// grid (C, B).  Radix select (4 x 8 bits) of the k-th largest key, keys = bits of q = w / noise.
+// grid (chunks, B): FILL == false counts members, FILL == true writes keys into the buckets
+template <bool FILL>
+__global__ __launch_bounds__(256) void pl_bucket_kernel(PlArgs a) {
+  __shared__ int lcnt[64], lbase[64], loff[64];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (tid < 64) lcnt[tid] = 0;
+  __syncthreads();
+  const int per = (a.n + gridDim.x - 1) / gridDim.x;
+  const int i0 = blockIdx.x * per, i1 = min(i0 + per, a.n);
+  for (int i = i0 + tid; i < i1; i += 256) {
+    const int c = pl_class(a, b, i);
+    if (c >= 0) atomicAdd(&lcnt[c], 1);
+  }
+  __syncthreads();
+  if (!FILL) {
+    if (tid < a.C && lcnt[tid]) atomicAdd(&a.cnt[b * a.C + tid], lcnt[tid]);
+    return;
+  }
+  if (tid < a.C) {
+    int off = 0;                                    // bucket start = prefix of the pair counts
+    for (int c = 0; c < tid; ++c) off += a.cnt[b * a.C + c];
+    loff[tid] = off;
+    lbase[tid] = lcnt[tid] ? atomicAdd(&a.cursor[b * a.C + tid], lcnt[tid]) : 0;
+    lcnt[tid] = 0;
+  }
+  __syncthreads();
+  for (int i = i0 + tid; i < i1; i += 256) {
+    const int c = pl_class(a, b, i);
+    if (c >= 0) {
+      const int pos = loff[c] + lbase[c] + atomicAdd(&lcnt[c], 1);
+      const float q = a.w_pl[(size_t)b * a.n + i] / a.noise[((size_t)b * a.C + c) * a.n + i];
+      a.keys[(size_t)b * a.n + pos] = __float_as_uint(q);
+      a.pix[(size_t)b * a.n + pos] = i;
+    }
+  }
+}
+
+// grid (C, B).  Radix select (4 x 8 bits) of the k-th largest key of the pair's bucket.
 __global__ __launch_bounds__(256) void pl_select_kernel(PlArgs a) {
   __shared__ int hist[256];
   __shared__ unsigned int s_prefix, s_k, s_take;
-  __shared__ int s_cnt;
   const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  if (c == a.ignore || a.tl_counts[b * a.C + c] == 0) return;
-  const float* w = a.w_pl + (size_t)b * a.n;
-  const float* nz = a.noise + ((size_t)b * a.C + c) * a.n;
-  // count members
-  int local = 0;
-  for (int i = tid; i < a.n; i += 256) local += pl_member(a, b, c, i) ? 1 : 0;
-  if (tid == 0) s_cnt = 0;
-  __syncthreads();
-  atomicAdd(&s_cnt, local);
-  __syncthreads();
-  const int cnt = s_cnt;
+  const int cnt = a.cnt[b * a.C + c];
   if (cnt == 0) return;
   const int k = (int)((float)cnt * a.ratio);
   if (k < 1) return;
+  int off = 0;
+  for (int cc = 0; cc < c; ++cc) off += a.cnt[b * a.C + cc];
+  const uint32_t* keys = a.keys + (size_t)b * a.n + off;
+  const int32_t* pix = a.pix + (size_t)b * a.n + off;
   if (tid == 0) {
     s_prefix = 0;
     s_k = (unsigned)k;
@@ -85,11 +123,9 @@ __global__ __launch_bounds__(256) void pl_select_kernel(PlArgs a) {
     __syncthreads();
     const unsigned prefix = s_prefix;
     const unsigned mask_hi = level == 3 ? 0u : (0xFFFFFFFFu << ((level + 1) * 8));
-    for (int i = tid; i < a.n; i += 256) {
-      if (pl_member(a, b, c, i)) {
-        const unsigned key = __float_as_uint(w[i] / nz[i]);
-        if ((key & mask_hi) == prefix) atomicAdd(&hist[(key >> (level * 8)) & 255], 1);
-      }
+    for (int i = tid; i < cnt; i += 256) {
+      const unsigned key = keys[i];
+      if ((key & mask_hi) == prefix) atomicAdd(&hist[(key >> (level * 8)) & 255], 1);
     }
     __syncthreads();
     if (tid == 0) {
@@ -108,13 +144,11 @@ __global__ __launch_bounds__(256) void pl_select_kernel(PlArgs a) {
   const unsigned thr = s_prefix;
   if (tid == 0) s_take = s_k;
   __syncthreads();
-  for (int i = tid; i < a.n; i += 256) {
-    if (pl_member(a, b, c, i)) {
-      const unsigned key = __float_as_uint(w[i] / nz[i]);
-      bool take = key > thr;
-      if (key == thr) take = atomicSub(&s_take, 1u) - 1u < 0x80000000u;  // first s_k ties (measure-zero event)
-      if (take) a.chosen[(size_t)b * a.n + i] = 1;
-    }
+  for (int i = tid; i < cnt; i += 256) {
+    const unsigned key = keys[i];
+    bool take = key > thr;
+    if (key == thr) take = atomicSub(&s_take, 1u) - 1u < 0x80000000u;  // ties: measure-zero event
+    if (take) a.chosen[(size_t)b * a.n + pix[i]] = 1;
   }
 }
 
@@ -366,9 +400,22 @@ extern "C" int c3d_entropy_stats(const float* prob, int64_t n, int C, float* w_a
 
 extern "C" int c3d_pl_select(const float* w_pl, const int32_t* amax, const int64_t* eval_label,
                              const int64_t* train_label, const float* noise, const int32_t* tl_counts, int B, int n,
-                             int C, int ignore_label, float ratio, uint8_t* chosen, int64_t* labels_out,
-                             uint8_t* mask_out, c3d_stream stream) {
-  PlArgs a{w_pl, amax, eval_label, train_label, noise, tl_counts, n, C, ignore_label, ratio, chosen};
+                             int C, int ignore_label, float ratio, int32_t* scratch, uint8_t* chosen,
+                             int64_t* labels_out, uint8_t* mask_out, c3d_stream stream) {
+  C3D_REQUIRE(C <= 64, "pl_select: at most 64 classes");
+  // scratch: cnt [B*C] | cursor [B*C] | keys [B*n] | pix [B*n]
+  int32_t* cnt = scratch;
+  int32_t* cursor = scratch + (size_t)B * C;
+  uint32_t* keys = reinterpret_cast<uint32_t*>(scratch + (size_t)2 * B * C);
+  int32_t* pix = scratch + (size_t)2 * B * C + (size_t)B * n;
+  (void)hipMemsetAsync(scratch, 0, sizeof(int32_t) * 2 * B * C, ST);
+  PlArgs a{w_pl, amax, eval_label, noise, tl_counts, n, C, ignore_label, ratio, cnt, cursor, keys, pix, chosen};
+  int chunks = (n + 4095) / 4096;
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(pl_bucket_kernel<false>, dim3(chunks, B), dim3(256), 0, ST, a);
+  C3D_CHECK_LAUNCH();
+  hipLaunchKernelGGL(pl_bucket_kernel<true>, dim3(chunks, B), dim3(256), 0, ST, a);
+  C3D_CHECK_LAUNCH();
   hipLaunchKernelGGL(pl_select_kernel, dim3(C, B), dim3(256), 0, ST, a);
   C3D_CHECK_LAUNCH();
   hipLaunchKernelGGL(pl_finalize_kernel, dim3(nb_for((size_t)B * n, 256)), dim3(256), 0, ST, amax, chosen, eval_label,

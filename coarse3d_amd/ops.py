@@ -409,8 +409,9 @@ def pl_select(w_pl, amax, eval_label, train_label, noise, tl_counts, b, n, c, ig
     chosen = torch.zeros(b, n, device=dev, dtype=torch.uint8)
     labels = torch.empty(b, n, device=dev, dtype=torch.int64)
     mask = torch.empty(b, n, device=dev, dtype=torch.uint8)
+    scratch = torch.empty(2 * b * c + 2 * b * n, device=dev, dtype=torch.int32)
     _call("c3d_pl_select", _dp(w_pl), _dp(amax), _dp(eval_label), _dp(train_label), _dp(noise), _dp(tl_counts), b, n,
-          c, ignore_label, float(ratio), _dp(chosen), _dp(labels), _dp(mask), _stream())
+          c, ignore_label, float(ratio), _dp(scratch), _dp(chosen), _dp(labels), _dp(mask), _stream())
     return labels, mask.bool()
 
 

@@ -220,11 +220,12 @@ int c3d_entropy_stats(const float* prob, int64_t n, int C, float* w_anchor, floa
                       int32_t* amax, c3d_stream stream);
 /* entropy_based_selection: per (image b, class c present in train_label): k = int(cnt*ratio)
  * pixels with the largest w_pl/noise among {amax==c, eval>0}; noise [B][C][n] Exp(1);
- * tl_counts [B][C] = weak-label counts; chosen [B][n] zeroed scratch.                        */
+ * tl_counts [B][C] = weak-label counts; chosen [B][n] zeroed scratch; scratch = 2*B*C + 2*B*n
+ * int32 (bucketed keys).                                                                     */
 int c3d_pl_select(const float* w_pl, const int32_t* amax, const int64_t* eval_label,
                   const int64_t* train_label, const float* noise, const int32_t* tl_counts,
-                  int B, int n, int C, int ignore_label, float ratio, uint8_t* chosen,
-                  int64_t* labels_out, uint8_t* mask_out, c3d_stream stream);
+                  int B, int n, int C, int ignore_label, float ratio, int32_t* scratch,
+                  uint8_t* chosen, int64_t* labels_out, uint8_t* mask_out, c3d_stream stream);
 /* anchor_sampling: bit-exact torch.multinomial(replacement=True) per present (b,c) pair;
  * the t-th present pair consumes uniforms[t][0..A).  counts/idx from c3d_group_compact.
  * slot [B*C], cum [B][C][n] are scratch.  Outputs anchor_idx [B*C][A] (pixel in image),
