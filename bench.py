@@ -99,11 +99,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    local_rank = local_rank % torch.cuda.device_count()       # (2 ranks on a 1-GPU box: debug only)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm; C3D_DIST_BACKEND=gloo lets two ranks share one GPU for testing
+        dist.init_process_group(os.environ.get("C3D_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from coarse3d_amd import dist as D
     from coarse3d_amd import ops
@@ -112,7 +114,7 @@ def main():
 
     torch.manual_seed(1)
     model = SalsaNextProto(5, args.classes, 20, 0, use_prototype=True, dataset=args.dataset).to(dev).train()
-    wrapped = D.DataParallel(model) if world > 1 else model
+    wrapped = D.DataParallel(model) if (world > 1 or os.environ.get("C3D_FORCE_DP")) else model
     ts = TrainStep(wrapped, args.classes, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512,
                    loss_w_ce_2d=1.0, loss_w_lov_2d=1.0, loss_w_contrast=0.1, feature_mean=FEATURE_MEAN,
                    feature_std=FEATURE_STD, proto_loss=True)

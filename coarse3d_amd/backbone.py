@@ -56,6 +56,8 @@ class Backbone:
         self.reduce_fn = reduce_fn
         self.world = world_size
         self.tape = None
+        self.on_block_done = None     # data parallel: called with a block tag as soon as that
+                                      # block's parameter gradients are final (backward order)
 
     # ------------------------------------------------------------------ forward helpers
     def _bn_forward(self, name, partial, c, count):
@@ -341,13 +343,21 @@ class Backbone:
         if d_prob is None:
             raise ValueError("backward needs d_prob (the segmentation losses always produce it)")
         dl = ops.softmax_bwd(self._prob, d_prob.contiguous(), tuple(logits.t.shape))
+        done = self.on_block_done if self.on_block_done is not None else (lambda tag: None)
+        done("projector")
         self._conv_backward("cls_head", dl)
+        done("cls_head")
         for name in ("upBlock4", "upBlock3", "upBlock2", "upBlock1"):
             self._up_backward(name)
+            done(name)
         for name in ("resBlock5", "resBlock4", "resBlock3", "resBlock2", "resBlock1"):
             self._res_backward(name)
+            done(name)
         self._ctx_backward("downCntx3")
+        done("downCntx3")
         self._ctx_backward("downCntx2")
+        done("downCntx2")
         self._ctx_backward("downCntx", first=True)
+        done("downCntx")
         self.tape = None
         return grads

@@ -35,25 +35,68 @@ def world_mean(t):
     return t
 
 
-class FlatGradients:
-    """All trainable gradients as views of one flat buffer, laid out in BACKWARD completion
-    order so that finished prefixes can be all-reduced while backward continues."""
+# parameter-name prefixes in the order in which Backbone.backward finishes them
+BACKWARD_ORDER = ("projector", "cls_head", "upBlock4", "upBlock3", "upBlock2", "upBlock1", "resBlock5", "resBlock4",
+                  "resBlock3", "resBlock2", "resBlock1", "downCntx3", "downCntx2", "downCntx")
 
-    def __init__(self, named_params, device=None, order=None):
+
+def _block_of(name):
+    head = name.split(".")[0]
+    return head
+
+
+class FlatGradients:
+    """All trainable gradients as views of one flat buffer laid out in BACKWARD completion
+    order, so that finished prefixes can be all-reduced while backward continues."""
+
+    def __init__(self, named_params, device=None):
         named = list(named_params)
-        if order is not None:
-            rank = {n: i for i, n in enumerate(order)}
-            named.sort(key=lambda kv: rank.get(kv[0], len(rank)))
+        rank = {b: i for i, b in enumerate(BACKWARD_ORDER)}
+        named.sort(key=lambda kv: rank.get(_block_of(kv[0]), len(rank)))     # stable
         self.names = [n for n, _ in named]
         total = sum(p.numel() for _, p in named)
         dev = device if device is not None else named[0][1].device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.views, off = {}, 0
+        self.block_end = {}           # block tag -> end offset of its parameters in the flat buffer
         for n, p in named:
             self.views[n] = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
+            self.block_end[_block_of(n)] = off
+        self._sent = 0
+        self._works = []
 
-    def all_reduce_mean(self, n_chunks=4, stream=None):
+    # ---- bucketed, overlapped mean over ranks
+    def begin(self):
+        self._sent = 0
+        self._works = []
+
+    def block_done(self, tag, min_bytes=4 << 20):
+        """Gradients of block ``tag`` are final: all-reduce the finished prefix once it is large
+        enough (a few big messages: xGMI is latency-, not bandwidth-limited at 29.6 MB total)."""
+        end = self.block_end.get(tag)
+        if end is None or not is_dist():
+            return
+        if (end - self._sent) * 4 >= min_bytes or end == self.flat.numel():
+            self._launch(end)
+
+    def _launch(self, end):
+        if end <= self._sent:
+            return
+        seg = self.flat[self._sent:end]
+        seg.div_(dist.get_world_size())
+        self._works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+        self._sent = end
+
+    def finish(self):
+        if is_dist():
+            self._launch(self.flat.numel())
+            for w in self._works:
+                w.wait()
+        self._works = []
+
+    def all_reduce_mean(self, n_chunks=4):
+        """Non-overlapped variant (kept for tests): mean over ranks in n_chunks messages."""
         if not is_dist():
             return
         world = dist.get_world_size()
@@ -70,18 +113,22 @@ class FlatGradients:
 
 class DataParallel(torch.nn.Module):
     """Minimal DDP stand-in exposing ``.module`` (what the reference trainer reads,
-    trainer.py:676-678) and wiring the three exchange points into SalsaNextProto's hooks."""
+    trainer.py:676-678) and wiring the three exchange points into SalsaNextProto's hooks.
+    Gradient buckets are all-reduced on torch.distributed's communication stream as soon as
+    the explicit backward has finished the corresponding blocks (overlap with the rest of
+    backward); ``finish_gradients()`` waits for them and re-binds ``param.grad`` to the
+    reduced flat views."""
 
-    def __init__(self, module, sync_bn=True, n_chunks=4):
+    def __init__(self, module, sync_bn=True):
         super().__init__()
         self.module = module
-        self.n_chunks = n_chunks
         world = dist.get_world_size() if is_dist() else 1
         module._world = world if sync_bn else 1
         module._bn_reduce = allreduce_sum_ if (sync_bn and world > 1) else None
         module._proto_mean = world_mean if world > 1 else None
         self.flat = FlatGradients(module._trainable())
         module._flat_grads = self.flat.views
+        module._block_done = self.flat.block_done
         if world > 1:                      # identical initial weights on every rank
             for p in module.parameters():
                 dist.broadcast(p.data, 0)
@@ -89,7 +136,10 @@ class DataParallel(torch.nn.Module):
                 dist.broadcast(b.data, 0)
 
     def forward(self, *a, **k):
+        self.flat.begin()
         return self.module(*a, **k)
 
     def finish_gradients(self):
-        self.flat.all_reduce_mean(self.n_chunks)
+        self.flat.finish()
+        for n, p in self.module._trainable():      # autograd may have cloned the views
+            p.grad = self.flat.views[n]

@@ -84,6 +84,7 @@ class _BackboneFn(torch.autograd.Function):
     def forward(ctx, model, x, masks, return_feat, names, *tensors):
         P = model._tensor_dict()
         bb = Backbone(P, model.nclasses, model.dataset, model._bn_reduce, model._world)
+        bb.on_block_done = model._block_done
         out = bb.forward(x.detach().float(), model.training, masks, return_feat)
         ctx.bb, ctx.names, ctx.model = bb, names, model
         ctx.return_feat = return_feat
@@ -155,6 +156,7 @@ class SalsaNextProto(nn.Module):
         self._world = 1
         self._proto_mean = None       # data parallel: mean of the bank over ranks
         self._grad_ready = None       # data parallel: called when all gradients are written
+        self._block_done = None       # data parallel: called per block in backward order
         self._flat_grads = None
 
     # ------------------------------------------------------------------ plumbing

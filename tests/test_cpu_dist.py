@@ -20,12 +20,19 @@ def _worker(rank, world, port, q):
     bank = torch.nn.functional.normalize(torch.randn(3, 4, 16, generator=g), dim=-1)
     mean_bank = D.world_mean(bank)
     # (3) flat gradient buffer mean
-    params = [("a.weight", torch.zeros(4, 3)), ("b.bias", torch.zeros(5)), ("c.weight", torch.zeros(2, 2, 3, 3))]
-    fg = D.FlatGradients(params, order=["c.weight", "a.weight"])
+    params = [("downCntx.conv1.weight", torch.zeros(4, 3)), ("upBlock4.conv1.bias", torch.zeros(5)),
+              ("projector.proj.0.weight", torch.zeros(2, 2, 3, 3))]
+    fg = D.FlatGradients(params)
+    fg.begin()
     for i, (n, p) in enumerate(params):
         fg.views[n].copy_(torch.full_like(p, float(rank + 1) * (i + 1)))
-    fg.all_reduce_mean(n_chunks=3)
-    q.put((rank, x, sums, bank, mean_bank, {n: v.clone() for n, v in fg.views.items()}, fg.names))
+    # overlapped path: buckets are launched as blocks finish (backward order), then waited for
+    for tag in D.BACKWARD_ORDER:
+        fg.block_done(tag, min_bytes=16)
+    fg.finish()
+    # numpy payloads are pickled by value (no shared-memory handles that die with the worker)
+    q.put((rank, x.numpy(), sums.numpy(), bank.numpy(), mean_bank.numpy(),
+           {n: v.clone().numpy() for n, v in fg.views.items()}, fg.names))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -38,6 +45,8 @@ def test_exchange_points_world2():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    t = torch.from_numpy
+    res = [(r, t(x), t(s_), t(b), t(m), {k: t(v) for k, v in g.items()}, names) for r, x, s_, b, m, g, names in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -48,7 +57,7 @@ def test_exchange_points_world2():
     torch.testing.assert_close(s0, s1)
     torch.testing.assert_close(m0, (b0 + b1) / 2)      # salsanext_proto.py:397-400: mean, NOT renormalised
     torch.testing.assert_close(m0, m1)
-    assert names0[:2] == ["c.weight", "a.weight"]      # backward-completion order first
-    for i, n in enumerate(["a.weight", "b.bias", "c.weight"]):
+    assert names0 == ["projector.proj.0.weight", "upBlock4.conv1.bias", "downCntx.conv1.weight"]   # backward order
+    for i, n in enumerate(["downCntx.conv1.weight", "upBlock4.conv1.bias", "projector.proj.0.weight"]):
         torch.testing.assert_close(g0[n], torch.full_like(g0[n], 1.5 * (i + 1)))
         torch.testing.assert_close(g0[n], g1[n])

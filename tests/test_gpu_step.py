@@ -214,3 +214,32 @@ def test_full_training_step_vs_golden():
         p = before[k].cpu().clone()
         oc.adamw_update(p, dict(m.named_parameters())[k].grad.cpu(), torch.zeros_like(p), torch.zeros_like(p), 1, 1e-3)
         assert rel(dict(m.named_parameters())[k], p) < 1e-5
+
+
+def test_data_parallel_wrapper_single_rank_matches_plain():
+    """DataParallel (flat gradient buffer, block-done hooks, grad re-binding) with one rank gives
+    the same update as the plain module."""
+    from coarse3d_amd import dist as D
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    from coarse3d_amd.trainer import TrainStep
+    b, h, w, ncls = 2, 32, 64, 20
+    x, tr, ev = W.synthetic_batch(b, h, w, ncls, 5, 0.02, gh=8, gw=16)
+    masks = {k: v.to(DEV) for k, v in W.dropout_masks_for(None, b, 6).items()}
+    results = []
+    for wrap in (False, True):
+        torch.manual_seed(3)
+        m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True)
+        m.load_state_dict(W.closed_form_state(nclasses=ncls))
+        m.to(DEV).train()
+        m.dropout_masks = masks
+        m.gumbel_noise = torch.ones(b * h * w, 20, device=DEV)
+        model = D.DataParallel(m) if wrap else m
+        ts = TrainStep(model, ncls, lr=1e-3, num_anchor=64, loss_w_contrast=0.0)
+        res = ts.step(x.to(DEV), tr.to(DEV), ev.to(DEV), epoch=10)
+        if wrap:
+            assert model.module is m
+            assert m.cls_head.weight.grad.data_ptr() == model.flat.views["cls_head.weight"].data_ptr()
+        results.append((float(res["loss"]), {k: p.detach().clone() for k, p in m.named_parameters()}))
+    assert abs(results[0][0] - results[1][0]) < 1e-6
+    for k in results[0][1]:
+        assert torch.equal(results[0][1][k], results[1][1][k]), k
