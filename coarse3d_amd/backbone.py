@@ -222,10 +222,12 @@ class Backbone:
             pre_s, pre_h = (bn.scale, bn.shift) if rec.mode == 1 else (None, None)
             part = ops.bn_bwd_reduce(dy, a, c, rec.mode, pre_s, pre_h)
             sums = ops.stat_reduce(part, c)
+            local = None
             if self.reduce_fn is not None:
+                local = sums.clone()      # dgamma/dbeta stay rank-local (averaged with the other grads)
                 self.reduce_fn(sums)
             k = ops.bn_bwd_coeffs(sums, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
-                                  G[f"{bn.name}.weight"], G[f"{bn.name}.bias"])
+                                  G[f"{bn.name}.weight"], G[f"{bn.name}.bias"], local)
             dz, pz = ops.bn_bwd_apply(dy, a, c, rec.mode, k, pre_s, pre_h)
         elif rec.mode == 2:
             dz, pz = ops.bn_bwd_apply(dy, a, c, 2)

@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
   }
 }
 
-__global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums, double count, const float* __restrict__ mean,
+__global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums, const double* __restrict__ sums_param,
+                                     double count, const float* __restrict__ mean,
                                      const float* __restrict__ invstd, const float* __restrict__ gamma, int C,
                                      float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ k3,
                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
@@ -164,8 +165,11 @@ __global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums, double cou
   k1[c] = (float)kk1;
   k2[c] = (float)kk2;
   k3[c] = (float)kk3;
-  dgamma[c] = (float)sdyx;
-  dbeta[c] = (float)sdy;
+  // parameter gradients come from THIS rank's sums (data parallel averages them afterwards,
+  // as torch.nn.SyncBatchNorm does); the input-gradient coefficients use the global sums
+  const double ldy = sums_param[c * 2], ldya = sums_param[c * 2 + 1];
+  dgamma[c] = (float)(is * (ldya - mu * ldy));
+  dbeta[c] = (float)ldy;
 }
 
 // column `col` of fp64 sums [C][2] -> fp32 vector (bias gradients)
@@ -237,11 +241,12 @@ extern "C" int c3d_bn_bwd_reduce(const float* dy, int dy_cs, const float* a, int
                        nullptr, 0, partial, (hipStream_t)stream);
 }
 
-extern "C" int c3d_bn_bwd_coeffs(const double* sums, double count, const float* mean, const float* invstd,
+extern "C" int c3d_bn_bwd_coeffs(const double* sums, const double* sums_param, double count, const float* mean,
+                                 const float* invstd,
                                  const float* gamma, int C, float* k1, float* k2, float* k3, float* dgamma,
                                  float* dbeta, c3d_stream stream) {
-  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count,
-                     mean, invstd, gamma, C, k1, k2, k3, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums,
+                     sums_param ? sums_param : sums, count, mean, invstd, gamma, C, k1, k2, k3, dgamma, dbeta);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -204,10 +204,10 @@ def bn_bwd_reduce(dy, a, c, mode=0, pre_scale=None, pre_shift=None):
     return part
 
 
-def bn_bwd_coeffs(sums, count, mean, invstd, gamma, dgamma, dbeta):
+def bn_bwd_coeffs(sums, count, mean, invstd, gamma, dgamma, dbeta, sums_param=None):
     c = gamma.shape[0]
     k = torch.empty(3, c, device=gamma.device, dtype=torch.float32)
-    _call("c3d_bn_bwd_coeffs", _dp(sums), float(count), _dp(mean), _dp(invstd), _dp(gamma), c, _dp(k[0]),
+    _call("c3d_bn_bwd_coeffs", _dp(sums), _dp(sums_param), float(count), _dp(mean), _dp(invstd), _dp(gamma), c, _dp(k[0]),
           _dp(k[1]), _dp(k[2]), _dp(dgamma), _dp(dbeta), _stream())
     return k
 

@@ -125,9 +125,12 @@ int c3d_bn_bwd_num_blocks(int npix);
 int c3d_bn_bwd_reduce(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C,
                       int mode, const float* pre_scale, const float* pre_shift, float* partial,
                       c3d_stream stream);
-int c3d_bn_bwd_coeffs(const double* sums, double count, const float* mean, const float* invstd,
-                      const float* gamma, int C, float* k1, float* k2, float* k3, float* dgamma,
-                      float* dbeta, c3d_stream stream);
+/* sums = (all-reduced) statistics for k1..k3; sums_param = this rank's own statistics for
+ * dgamma/dbeta (NULL = same as sums): SyncBatchNorm semantics under data parallelism          */
+int c3d_bn_bwd_coeffs(const double* sums, const double* sums_param, double count,
+                      const float* mean, const float* invstd, const float* gamma, int C,
+                      float* k1, float* k2, float* k3, float* dgamma, float* dbeta,
+                      c3d_stream stream);
 int c3d_bn_bwd_apply(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C,
                      int mode, const float* pre_scale, const float* pre_shift, const float* k1,
                      const float* k2, const float* k3, float* dz, int dz_cs, float* partial,
