@@ -1,0 +1,88 @@
+"""BASELINE.json configs as parity cases at their real spatial sizes (forward vs the CPU oracle,
+1e-4 of max|ref|; module-level API; default-style initialisation):
+  configs[1] SemanticKITTI 64x2048, C=20            (B=2 here: the oracle runs on the CPU)
+  configs[3] nuScenes      32x1024, C=17            (2x64 bottleneck -> TR=2 tile path)
+  configs[4] SemanticPOSS  40x1800 (+8 pad), C=14   (W=1808: partial 32-wide tiles)
+plus size-independent properties of a full step at the benchmark size."""
+import numpy as np
+import pytest
+import torch
+
+import weights as W
+from oracle import coarse3d_oracle as oc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("b,h,w,ncls,dataset", [
+    (2, 64, 2048, 20, "SemanticKitti"),
+    (2, 32, 1024, 17, "nuScenes"),
+    (1, 40, 1800, 14, "SemanticPOSS"),
+])
+def test_forward_parity_at_config_sizes(b, h, w, ncls, dataset):
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    st = oc.init_state(nclasses=ncls, seed=3)
+    g = torch.Generator().manual_seed(h + w)
+    x = torch.randn(b, 5, h, w, generator=g)
+    masks = W.dropout_masks_for(None, b, 9)
+    m = SalsaNextProto(5, ncls, 20, 0, use_prototype=False, dataset=dataset)
+    m.load_state_dict(st)
+    m.to(DEV).train()
+    m.dropout_masks = {k: v.to(DEV) for k, v in masks.items()}
+    with torch.no_grad():
+        out = m(x.to(DEV), return_feat=True)
+        ref = oc.backbone_forward({k: v.clone() for k, v in st.items()}, x, True, masks, True, dataset)
+    assert out["pred_2d"].shape == ref["pred_2d"].shape
+    assert rel(out["pred_2d"], ref["pred_2d"]) < 1e-4
+    assert rel(out["feat_2d"], ref["feat_2d"]) < 1e-4
+    # probabilities sum to one, embedding rows have (interpolated) norm <= 1
+    assert float((out["pred_2d"].sum(1) - 1).abs().max()) < 1e-5
+    assert float(out["feat_2d"].norm(dim=1).max()) < 1 + 1e-4
+
+
+def test_full_step_properties_at_benchmark_size():
+    """bs=8 64x2048 step (the bench workload): finite losses, every trainable tensor receives a
+    finite gradient, the bank stays l2-normalised, anchors respect their class, determinism."""
+    from coarse3d_amd import contrast
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    from coarse3d_amd.trainer import TrainStep
+    import bench
+    b, h, w, ncls = 8, 64, 2048, 20
+    torch.manual_seed(1)
+    m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True).to(DEV).train()
+    ts = TrainStep(m, ncls, lr=1e-3, num_anchor=512, feature_mean=bench.FEATURE_MEAN, feature_std=bench.FEATURE_STD)
+    x, tr, ev = bench.synth_batch(b, h, w, ncls, 1000, DEV)
+    res = ts.step(x, tr, ev, epoch=10)
+    for k in ("ce", "lov", "contrast", "loss"):
+        assert torch.isfinite(res[k]).all(), k
+    for k, p in m.named_parameters():
+        if p.requires_grad and not k.startswith(("feat_norm", "mask_norm")):   # unused in the reference too
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    assert float((m.prototypes.norm(dim=-1) - 1).abs().max()) < 1e-4
+    # pseudo labels: only on evaluated pixels, weak labels preserved, roughly ratio * |class mask|
+    lab, mask = res["labels_contra"], res["mask_contra"]
+    assert bool((lab[ev == 0] == 0).all())
+    assert bool((lab[tr > 0] == tr[tr > 0]).all())
+    frac = float((lab > 0).float().mean())
+    assert 0.01 < frac < 0.2, frac
+    # anchor sampler on the same inputs twice -> identical indices (no atomics on the index path)
+    prob = torch.softmax(torch.randn(2, ncls, 64, 256, device=DEV), 1)
+    feats = torch.randn(2, 256, 64, 256, device=DEV)
+    labels = torch.randint(0, ncls, (2, 64, 256), device=DEV)
+    u = torch.rand(2 * ncls, 512, dtype=torch.float64)
+    perms = torch.stack([torch.randperm(20) for _ in range(ncls - 1)])
+    l1, d1 = contrast.contrast_mem_loss(feats, prob, labels, None, m.prototypes.detach(), 0.07, 0.07, 512, 0, u, perms,
+                                        return_debug=True)
+    l2, d2 = contrast.contrast_mem_loss(feats, prob, labels, None, m.prototypes.detach(), 0.07, 0.07, 512, 0, u, perms,
+                                        return_debug=True)
+    assert torch.equal(d1["idx"], d2["idx"]) and float(l1) == float(l2)
+    T = int(d1["T"])
+    img, cls, idx = d1["img"][:T].long(), d1["cls"][:T].long(), d1["idx"][:T].long()
+    picked = labels.reshape(2, -1)[img[:, None], idx]
+    assert bool((picked == cls[:, None]).all())
