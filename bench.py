@@ -155,9 +155,17 @@ def main():
         name, (fl, sec, n) = max(per.items(), key=lambda kv: kv[1][1])
         all_fl = sum(v[0] for v in per.values())
         all_sec = sum(v[1] for v in per.values())
+        # HBM traffic of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE x2 +
+        # WRITE_SIZE, separate rocprofv3 --pmc runs of this bench; tools/pmc_traffic.py)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
+            traffic = round(pmc[name]["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2),
                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic": None, "launches_per_step": n // args.steps,
+                    "traffic": traffic, "launches_per_step": n // args.steps,
                     "avg_launch_us": round(sec / n * 1e6, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
                     "all_mfma_kernels": {"achieved": round(all_fl / all_sec / 1e12, 2),
                                          "frac": round(all_fl / all_sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
