@@ -19,7 +19,6 @@
 // 16 pixels -> stores are 128 B contiguous per pixel.
 // Grid: 1-D, cout tile fastest, XCD-remapped: the workgroups that share one input tile (and
 // neighbouring tiles that share halos) run on the same XCD and hit its L2.
-#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 #include "../../include/coarse3d_hip.h"
@@ -389,9 +388,10 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
     bool k32 = true;
     for (int s = 0; s < d->nsrc; ++s) k32 = k32 && (d->src[s].C % 32 == 0);
     if (k32) {
-      static const char* env_nt = getenv("C3D_POINTWISE_NT");
-      if (d->Cout > 64 && env_nt && env_nt[0] == '4') return launch_cfg<8, 4, 16, 0, 1>(a, st);
-      if (d->Cout > 64 && !(env_nt && env_nt[0] == '2')) return launch_cfg<8, 4, 32, 0, 1>(a, st);
+      // 128-wide cout tiles unless 64-wide ones waste fewer padded columns (704 -> 11 x 64
+      // instead of 6 x 128, 400 -> 7 x 64 instead of 4 x 128); measured equal MFMA efficiency
+      const int pad128 = (d->Cout + 127) / 128 * 128, pad64 = (d->Cout + 63) / 64 * 64;
+      if (d->Cout > 64 && pad128 <= pad64) return launch_cfg<8, 4, 32, 0, 1>(a, st);
       if (d->Cout > 32) return launch_cfg<8, 2, 32, 0, 1>(a, st);
       return launch_cfg<8, 1, 32, 0, 1>(a, st);
     }

@@ -120,7 +120,8 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
     nt_ = len(taps)
     if tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs):
-        name = f"conv_mfma_kernel<8, {4 if cout > 64 else (2 if cout > 32 else 1)}, 32, 0, 1>"
+        wide = cout > 64 and (cout + 127) // 128 * 128 <= (cout + 63) // 64 * 64
+        name = f"conv_mfma_kernel<8, {4 if wide else (2 if cout > 32 else 1)}, 32, 0, 1>"
     else:    # mirrors launch_taps() in csrc/conv_mfma.hip
         hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
         name = f"conv_mfma_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}>"
