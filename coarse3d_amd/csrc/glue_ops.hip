@@ -94,14 +94,17 @@ __global__ __launch_bounds__(256) void conv_in5_wgrad_kernel(const float* __rest
   }
 }
 
-// out[co][c] = sum_blocks partial[blk][co][c]  (fp64 fold)
-__global__ void conv_in5_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int Cn, float* __restrict__ dw) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// out[co][c] = sum_blocks partial[blk][co][c]  (fp64 fold, one wave per output)
+__global__ __launch_bounds__(256) void conv_in5_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int Cn,
+                                                                    float* __restrict__ dw) {
+  const int lane = threadIdx.x & 63;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (i >= 32 * Cn) return;
   const int co = i / Cn, c = i % Cn;
   double s = 0.0;
-  for (int k = 0; k < nblk; ++k) s += (double)partial[((size_t)k * 32 + co) * 8 + c];
-  dw[i] = (float)s;
+  for (int k = lane; k < nblk; k += 64) s += (double)partial[((size_t)k * 32 + co) * 8 + c];
+  s = c3d_wave_sum_d(s);
+  if (lane == 0) dw[i] = (float)s;
 }
 
 // ---------------------------------------------------------------- out = x + (a*scale + shift)
@@ -294,53 +297,55 @@ __global__ void catskip_bwd_kernel(PsBwdArgs p) {
 }
 
 // ---------------------------------------------------------------- channel softmax (+crop)
+// 32 lanes cooperate on one pixel (lane = channel): every load / store of a wave covers two whole
+// pixels contiguously, reductions over the classes are 5 shuffle steps.
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+  return v;
+}
+__device__ __forceinline__ float half_wave_max(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 32));
+  return v;
+}
+
 // logits [B,H,W,cs] (first C channels used) -> prob [B,Ho,Wo,C]
-__global__ void softmax_kernel(const float* __restrict__ logits, int B, int H, int W, int cs, int C, int Ho, int Wo,
-                               float* __restrict__ prob) {
+__global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ logits, int B, int H, int W, int cs,
+                                                      int C, int Ho, int Wo, float* __restrict__ prob) {
+  const int c = threadIdx.x & 31;
   const size_t total = (size_t)B * Ho * Wo;
-  for (size_t i = gtid(); i < total; i += gstride()) {
+  for (size_t i = gtid() >> 5; i < total; i += gstride() >> 5) {
     const int x = i % Wo;
     const int y = (i / Wo) % Ho;
     const int b = i / ((size_t)Wo * Ho);
-    const float* l = logits + ((size_t)(b * H + y) * W + x) * cs;
-    float v[32];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      v[c] = c < C ? l[c] : -INFINITY;
-      mx = fmaxf(mx, v[c]);
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      v[c] = c < C ? expf(v[c] - mx) : 0.f;
-      s += v[c];
-    }
-    float* o = prob + i * C;
-#pragma unroll
-    for (int c = 0; c < 32; ++c)
-      if (c < C) o[c] = v[c] / s;
+    const float v = c < C ? logits[((size_t)(b * H + y) * W + x) * cs + c] : -INFINITY;
+    const float mx = half_wave_max(v);
+    const float e = c < C ? expf(v - mx) : 0.f;
+    const float s = half_wave_sum(e);
+    if (c < C) prob[i * C + c] = e / s;
   }
 }
 
 // dlogits [B,H,W,cs] = p * (dp - sum(p*dp)) inside the crop, 0 elsewhere (incl. pad channels)
-__global__ void softmax_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ dprob, int B, int H, int W,
-                                   int cs, int C, int Ho, int Wo, float* __restrict__ dlogits) {
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ prob,
+                                                          const float* __restrict__ dprob, int B, int H, int W, int cs,
+                                                          int C, int Ho, int Wo, float* __restrict__ dlogits) {
+  const int c = threadIdx.x & 31;
   const size_t total = (size_t)B * H * W;
-  for (size_t i = gtid(); i < total; i += gstride()) {
+  for (size_t i = gtid() >> 5; i < total; i += gstride() >> 5) {
     const int x = i % W;
     const int y = (i / W) % H;
     const int b = i / ((size_t)W * H);
-    float* d = dlogits + i * cs;
-    if (y < Ho && x < Wo) {
+    float out = 0.f;
+    if (y < Ho && x < Wo) {                      // uniform over the 32 lanes of a pixel
       const size_t j = ((size_t)(b * Ho + y) * Wo + x) * C;
-      float dot = 0.f;
-      for (int c = 0; c < C; ++c) dot += prob[j + c] * dprob[j + c];
-      for (int c = 0; c < C; ++c) d[c] = prob[j + c] * (dprob[j + c] - dot);
-      for (int c = C; c < cs; ++c) d[c] = 0.f;
-    } else {
-      for (int c = 0; c < cs; ++c) d[c] = 0.f;
+      const float p = c < C ? prob[j + c] : 0.f;
+      const float g = c < C ? dprob[j + c] : 0.f;
+      const float dot = half_wave_sum(p * g);
+      out = p * (g - dot);
     }
+    if (c < cs) dlogits[i * cs + c] = out;
   }
 }
 
@@ -518,7 +523,7 @@ extern "C" int c3d_conv_in5_wgrad(const float* x_nchw, const float* dz, int B, i
   const int ppb = (total + nb - 1) / nb;
   hipLaunchKernelGGL(conv_in5_wgrad_kernel, dim3(nb), dim3(256), 0, ST, x_nchw, dz, Cn, HW, total, ppb, partial);
   C3D_CHECK_LAUNCH();
-  hipLaunchKernelGGL(conv_in5_wgrad_reduce_kernel, dim3(1), dim3(256), 0, ST, partial, nb, Cn, dw);
+  hipLaunchKernelGGL(conv_in5_wgrad_reduce_kernel, dim3((32 * Cn * 64 + 255) / 256), dim3(256), 0, ST, partial, nb, Cn, dw);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -585,16 +590,17 @@ extern "C" int c3d_pixshuf_cat_bwd(const float* dout, const float* m3, const flo
 extern "C" int c3d_softmax(const float* logits, int B, int H, int W, int cs, int C, int Ho, int Wo, float* prob,
                            c3d_stream stream) {
   C3D_REQUIRE(C <= 32 && C <= cs, "softmax: at most 32 classes");
-  hipLaunchKernelGGL(softmax_kernel, dim3(nblocks((size_t)B * Ho * Wo)), dim3(256), 0, ST, logits, B, H, W, cs, C, Ho, Wo,
-                     prob);
+  hipLaunchKernelGGL(softmax_kernel, dim3(nblocks((size_t)B * Ho * Wo * 32)), dim3(256), 0, ST, logits, B, H, W, cs, C,
+                     Ho, Wo, prob);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int c3d_softmax_bwd(const float* prob, const float* dprob, int B, int H, int W, int cs, int C, int Ho,
                                int Wo, float* dlogits, c3d_stream stream) {
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(nblocks((size_t)B * H * W)), dim3(256), 0, ST, prob, dprob, B, H, W, cs, C,
-                     Ho, Wo, dlogits);
+  C3D_REQUIRE(C <= 32 && cs <= 32, "softmax_bwd: at most 32 classes / padded channels");
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(nblocks((size_t)B * H * W * 32)), dim3(256), 0, ST, prob, dprob, B, H, W, cs,
+                     C, Ho, Wo, dlogits);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -17,24 +17,36 @@ namespace {
 // ---------------------------------------------------------------- entropy weights + argmax
 // prob [N][C] -> w_anchor = exp(-H^2), w_pl = exp(-H), amax (contrast_pixel_loss.py:46-49,
 // trainer.py:459-466)
-__global__ void entropy_stats_kernel(const float* __restrict__ prob, size_t n, int C, float* __restrict__ w_anchor,
-                                     float* __restrict__ w_pl, int32_t* __restrict__ amax) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float* p = prob + i * C;
-    float h = 0.f, best = -INFINITY;
-    int bi = 0;
-    for (int c = 0; c < C; ++c) {
-      const float v = p[c];
-      h += v * logf(v + 1e-10f);
-      if (v > best) {
-        best = v;
-        bi = c;
+// 32 lanes per pixel (lane = class): coalesced reads, shuffle reductions
+__global__ __launch_bounds__(256) void entropy_stats_kernel(const float* __restrict__ prob, size_t n, int C,
+                                                            float* __restrict__ w_anchor, float* __restrict__ w_pl,
+                                                            int32_t* __restrict__ amax) {
+  const int c = threadIdx.x & 31;
+  const size_t t0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const size_t tstride = ((size_t)gridDim.x * blockDim.x) >> 5;
+  for (size_t i = t0; i < n; i += tstride) {
+    const float v = c < C ? prob[i * C + c] : 0.f;
+    float h = c < C ? v * logf(v + 1e-10f) : 0.f;
+    // the reference sums the classes in order; a tree over 32 lanes differs by rounding only
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) h += __shfl_xor(h, o, 32);
+    h = -h;
+    float best = c < C ? v : -INFINITY;
+    int bi = c;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 32);
+      const int oi = __shfl_xor(bi, o, 32);
+      if (ov > best || (ov == best && oi < bi)) {
+        best = ov;
+        bi = oi;
       }
     }
-    h = -h;
-    if (w_anchor) w_anchor[i] = expf(-(h * h));
-    if (w_pl) w_pl[i] = expf(-h);
-    if (amax) amax[i] = bi;
+    if (c == 0) {
+      if (w_anchor) w_anchor[i] = expf(-(h * h));
+      if (w_pl) w_pl[i] = expf(-h);
+      if (amax) amax[i] = bi;
+    }
   }
 }
 
@@ -392,7 +404,8 @@ static inline int nb_for(size_t n, int per) {
 
 extern "C" int c3d_entropy_stats(const float* prob, int64_t n, int C, float* w_anchor, float* w_pl, int32_t* amax,
                                  c3d_stream stream) {
-  hipLaunchKernelGGL(entropy_stats_kernel, dim3(nb_for((size_t)n, 256)), dim3(256), 0, ST, prob, (size_t)n, C, w_anchor,
+  C3D_REQUIRE(C <= 32, "entropy_stats: at most 32 classes");
+  hipLaunchKernelGGL(entropy_stats_kernel, dim3(nb_for((size_t)n, 8)), dim3(256), 0, ST, prob, (size_t)n, C, w_anchor,
                      w_pl, amax);
   C3D_CHECK_LAUNCH();
   return 0;
