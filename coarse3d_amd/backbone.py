@@ -65,14 +65,17 @@ class Backbone:
         rec = _BNRec()
         rec.name = name
         if self.train:
-            sums = ops.stat_reduce(partial, c)
-            if self.reduce_fn is not None:
+            rm = P[f"{name}.running_mean"] if self.update_running else None
+            rv = P[f"{name}.running_var"] if self.update_running else None
+            if self.reduce_fn is None:      # single rank: fold + finalize in one launch
+                rec.scale, rec.shift, rec.mean, rec.invstd = ops.bn_finalize_partials(
+                    partial, count, P[f"{name}.weight"], P[f"{name}.bias"], rm, rv, BN_MOMENTUM, BN_EPS)
+            else:                           # SyncBN: all-reduce the fp64 sums in between
+                sums = ops.stat_reduce(partial, c)
                 self.reduce_fn(sums)
                 count = count * self.world
-            rec.scale, rec.shift, rec.mean, rec.invstd = ops.bn_finalize(
-                sums, count, P[f"{name}.weight"], P[f"{name}.bias"],
-                P[f"{name}.running_mean"] if self.update_running else None,
-                P[f"{name}.running_var"] if self.update_running else None, BN_MOMENTUM, BN_EPS)
+                rec.scale, rec.shift, rec.mean, rec.invstd = ops.bn_finalize(
+                    sums, count, P[f"{name}.weight"], P[f"{name}.bias"], rm, rv, BN_MOMENTUM, BN_EPS)
             rec.count = count
             self.bn_seen.append(name)
         else:
@@ -221,19 +224,21 @@ class Backbone:
             bn = rec.bn
             pre_s, pre_h = (bn.scale, bn.shift) if rec.mode == 1 else (None, None)
             part = ops.bn_bwd_reduce(dy, a, c, rec.mode, pre_s, pre_h)
-            sums = ops.stat_reduce(part, c)
-            local = None
-            if self.reduce_fn is not None:
+            if self.reduce_fn is None:
+                k = ops.bn_bwd_coeffs_partials(part, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
+                                               G[f"{bn.name}.weight"], G[f"{bn.name}.bias"])
+            else:
+                sums = ops.stat_reduce(part, c)
                 local = sums.clone()      # dgamma/dbeta stay rank-local (averaged with the other grads)
                 self.reduce_fn(sums)
-            k = ops.bn_bwd_coeffs(sums, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
-                                  G[f"{bn.name}.weight"], G[f"{bn.name}.bias"], local)
+                k = ops.bn_bwd_coeffs(sums, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
+                                      G[f"{bn.name}.weight"], G[f"{bn.name}.bias"], local)
             dz, pz = ops.bn_bwd_apply(dy, a, c, rec.mode, k, pre_s, pre_h)
         elif rec.mode == 2:
             dz, pz = ops.bn_bwd_apply(dy, a, c, 2)
         else:
             dz, pz = ops.bn_bwd_apply(dy, dy, cpad, 3, dz=dy)
-        ops.sums_to_f32(ops.stat_reduce(pz, pz.shape[0]), 0, G[f"{name}.bias"])
+        ops.bias_from_partials(pz, G[f"{name}.bias"])
         w = self.P[f"{name}.weight"]
         dw = G[f"{name}.weight"]
         ntaps = ops.negate_taps(rec.taps)
@@ -265,7 +270,7 @@ class Backbone:
         if first:
             _, x, s_act = self.tape[f"{name}.conv1"]
             dz, pz = ops.bn_bwd_apply(s.grad, s.t, 32, 2)
-            ops.sums_to_f32(ops.stat_reduce(pz, 32), 0, self.grads[f"{name}.conv1.bias"])
+            ops.bias_from_partials(pz, self.grads[f"{name}.conv1.bias"])
             ops.conv_in5_wgrad(x, dz, self.grads[f"{name}.conv1.weight"])
         else:
             self._conv_backward(f"{name}.conv1", s.grad)

@@ -40,6 +40,78 @@ __global__ __launch_bounds__(256) void stat_reduce_kernel(const float* __restric
   }
 }
 
+// block-wide fold of one channel's partials [2][n] -> (s1, s2) in fp64, result valid in thread 0
+__device__ __forceinline__ void fold_channel(const float* __restrict__ p, int n, double& s1, double& s2) {
+  __shared__ double red[2][4];
+  s1 = 0.0;
+  s2 = 0.0;
+  for (int t = threadIdx.x; t < n; t += 256) {
+    s1 += (double)p[t];
+    s2 += (double)p[n + t];
+  }
+  s1 = c3d_wave_sum_d(s1);
+  s2 = c3d_wave_sum_d(s2);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s1;
+    red[1][threadIdx.x >> 6] = s2;
+  }
+  __syncthreads();
+  s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+}
+
+// single-rank fast paths: fold the partials and finish in ONE launch (one block per channel)
+__global__ __launch_bounds__(256) void bn_finalize_partials_kernel(
+    const float* __restrict__ partial, int n, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
+    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
+    float* __restrict__ save_invstd) {
+  const int c = blockIdx.x;
+  double s1, s2;
+  fold_channel(partial + (size_t)c * 2 * n, n, s1, s2);
+  if (threadIdx.x != 0) return;
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = invstd;
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_coeffs_partials_kernel(
+    const float* __restrict__ partial, int n, double count, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, float* __restrict__ k1,
+    float* __restrict__ k2, float* __restrict__ k3, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x;
+  double sdy, sdya;
+  fold_channel(partial + (size_t)c * 2 * n, n, sdy, sdya);
+  if (threadIdx.x != 0) return;
+  const double mu = mean[c], is = invstd[c], g = gamma[c];
+  const double sdyx = is * (sdya - mu * sdy);
+  const double kk2 = -g * is * is * sdyx / count;
+  k1[c] = (float)(g * is);
+  k2[c] = (float)kk2;
+  k3[c] = (float)(-g * is * sdy / count - kk2 * mu);
+  dgamma[c] = (float)sdyx;
+  dbeta[c] = (float)sdy;
+}
+
+__global__ __launch_bounds__(256) void bias_from_partials_kernel(const float* __restrict__ partial, int n,
+                                                                 float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x;
+  double s1, s2;
+  fold_channel(partial + (size_t)c * 2 * n, n, s1, s2);
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)s1 : (float)s1;
+}
+
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* running_mean, float* running_var,
                                    float momentum, float eps, int C, float* __restrict__ scale,
@@ -260,6 +332,33 @@ extern "C" int c3d_bn_bwd_apply(const float* dy, int dy_cs, const float* a, int 
 
 extern "C" int c3d_sums_to_f32(const double* sums, int C, int col, float* out, int accumulate, c3d_stream stream) {
   hipLaunchKernelGGL(sums_to_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, col, out,
+                     accumulate);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_bn_finalize_partials(const float* partial, int n, double count, const float* gamma,
+                                        const float* beta, float* running_mean, float* running_var, float momentum,
+                                        float eps, int C, float* scale, float* shift, float* save_mean,
+                                        float* save_invstd, c3d_stream stream) {
+  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, n, count, gamma,
+                     beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_bn_bwd_coeffs_partials(const float* partial, int n, double count, const float* mean,
+                                          const float* invstd, const float* gamma, int C, float* k1, float* k2,
+                                          float* k3, float* dgamma, float* dbeta, c3d_stream stream) {
+  hipLaunchKernelGGL(bn_bwd_coeffs_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, n, count,
+                     mean, invstd, gamma, k1, k2, k3, dgamma, dbeta);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_bias_from_partials(const float* partial, int n, int C, float* out, int accumulate,
+                                      c3d_stream stream) {
+  hipLaunchKernelGGL(bias_from_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, n, out,
                      accumulate);
   C3D_CHECK_LAUNCH();
   return 0;

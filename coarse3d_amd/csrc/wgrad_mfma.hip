@@ -241,23 +241,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   }
 }
 
-// dw[cout][cin_off + cin][t] (+)= sum_strips partial.  Block = 64 outputs x 4 strip lanes.
+// dw[cout][cin_off + cin][t] (+)= sum_strips partial.  Block = 32 outputs x 8 strip lanes.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                            int strips, int T, int CI, int CO, int ci_slices,
                                                            int co_slices, int Cin_src, int Cout, int Cin_total,
                                                            int cin_off, int accumulate) {
-  __shared__ double red[4][64];
+  __shared__ double red[8][32];
   const size_t slice_floats = (size_t)T * CI * CO;
   const int nsl = ci_slices * co_slices;
   const size_t total = slice_floats * nsl;
-  const int o = threadIdx.x & 63, lanek = threadIdx.x >> 6;
-  for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+  const int o = threadIdx.x & 31, lanek = threadIdx.x >> 5;
+  for (size_t base = (size_t)blockIdx.x * 32; base < total; base += (size_t)gridDim.x * 32) {
     const size_t e = base + o;
     double s = 0.0;
-    int sl = 0, t = 0, ci = 0, co = 0;
+    int t = 0, ci = 0, co = 0;
     bool valid = false;
     if (e < total) {
-      sl = e / slice_floats;
+      const int sl = e / slice_floats;
       const size_t r = e % slice_floats;
       co = r % CO;
       ci = (r / CO) % CI;
@@ -267,13 +267,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       valid = ci < Cin_src && co < Cout;
       if (valid) {
         const float* p = partial + (size_t)sl * strips * slice_floats + r;
-        for (int k = lanek; k < strips; k += 4) s += (double)p[(size_t)k * slice_floats];
+        int k = lanek;
+        for (; k + 24 < strips; k += 32) {     // 4 independent loads in flight
+          const float v0 = p[(size_t)k * slice_floats], v1 = p[(size_t)(k + 8) * slice_floats];
+          const float v2 = p[(size_t)(k + 16) * slice_floats], v3 = p[(size_t)(k + 24) * slice_floats];
+          s += (double)v0 + (double)v1 + (double)v2 + (double)v3;
+        }
+        for (; k < strips; k += 8) s += (double)p[(size_t)k * slice_floats];
       }
     }
     red[lanek][o] = s;
     __syncthreads();
     if (lanek == 0 && valid) {
-      const double v = red[0][o] + red[1][o] + red[2][o] + red[3][o];
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v += red[k][o];
       float* d = dw + ((size_t)co * Cin_total + cin_off + ci) * T + t;
       *d = accumulate ? (*d + (float)v) : (float)v;
     }
@@ -376,7 +384,7 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   }
   if (rc) return rc;
   const size_t total = (size_t)d->ntaps * c.CI * c.CO * a.ci_slices * a.co_slices;
-  int blocks = (int)((total + 63) / 64);
+  int blocks = (int)((total + 31) / 32);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.partial, d->dw, a.strips, d->ntaps, c.CI,
                      c.CO, a.ci_slices, a.co_slices, d->x.C, d->Cout, d->Cin_total, d->cin_off, d->accumulate);

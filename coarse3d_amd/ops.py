@@ -185,6 +185,29 @@ def bn_finalize(sums, count, gamma, beta, running_mean, running_var, momentum=0.
     return buf[0], buf[1], buf[2], buf[3]      # scale, shift, mean, invstd
 
 
+def bn_finalize_partials(partial, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
+    """stat_reduce + bn_finalize in one launch (single-rank path)."""
+    c = gamma.shape[0]
+    buf = torch.empty(4, c, device=gamma.device, dtype=torch.float32)
+    _call("c3d_bn_finalize_partials", _dp(partial), partial.shape[2], float(count), _dp(gamma), _dp(beta),
+          _dp(running_mean), _dp(running_var), momentum, eps, c, _dp(buf[0]), _dp(buf[1]), _dp(buf[2]), _dp(buf[3]),
+          _stream())
+    return buf[0], buf[1], buf[2], buf[3]
+
+
+def bn_bwd_coeffs_partials(partial, count, mean, invstd, gamma, dgamma, dbeta):
+    c = gamma.shape[0]
+    k = torch.empty(3, c, device=gamma.device, dtype=torch.float32)
+    _call("c3d_bn_bwd_coeffs_partials", _dp(partial), partial.shape[2], float(count), _dp(mean), _dp(invstd),
+          _dp(gamma), c, _dp(k[0]), _dp(k[1]), _dp(k[2]), _dp(dgamma), _dp(dbeta), _stream())
+    return k
+
+
+def bias_from_partials(partial, out, accumulate=False):
+    _call("c3d_bias_from_partials", _dp(partial), partial.shape[2], out.shape[0], _dp(out), int(accumulate), _stream())
+    return out
+
+
 def bn_eval_affine(gamma, beta, running_mean, running_var, eps=1e-5):
     c = gamma.shape[0]
     buf = torch.empty(2, c, device=gamma.device, dtype=torch.float32)

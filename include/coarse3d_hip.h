@@ -135,6 +135,18 @@ int c3d_bn_bwd_apply(const float* dy, int dy_cs, const float* a, int a_cs, int n
                      int mode, const float* pre_scale, const float* pre_shift, const float* k1,
                      const float* k2, const float* k3, float* dz, int dz_cs, float* partial,
                      c3d_stream stream);
+/* Single-rank fast paths: fold the partials [C][2][n] and finish in one launch (no all-reduce
+ * hook in between): = c3d_stat_reduce + c3d_bn_finalize / + c3d_bn_bwd_coeffs / + column 0.    */
+int c3d_bn_finalize_partials(const float* partial, int n, double count, const float* gamma,
+                             const float* beta, float* running_mean, float* running_var,
+                             float momentum, float eps, int C, float* scale, float* shift,
+                             float* save_mean, float* save_invstd, c3d_stream stream);
+int c3d_bn_bwd_coeffs_partials(const float* partial, int n, double count, const float* mean,
+                               const float* invstd, const float* gamma, int C, float* k1,
+                               float* k2, float* k3, float* dgamma, float* dbeta,
+                               c3d_stream stream);
+int c3d_bias_from_partials(const float* partial, int n, int C, float* out, int accumulate,
+                           c3d_stream stream);
 /* out[c] (+)= (float) sums[c][col] */
 int c3d_sums_to_f32(const double* sums, int C, int col, float* out, int accumulate,
                     c3d_stream stream);
