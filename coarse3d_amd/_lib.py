@@ -34,6 +34,12 @@ class WgradDesc(C.Structure):
                 ("dw", C.c_void_p), ("accumulate", C.c_int32), ("partial", C.c_void_p)]
 
 
+class PackEntry(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32),
+                ("T", C.c_int32), ("mode", C.c_int32), ("c_off", C.c_int32), ("c_cnt", C.c_int32),
+                ("Kpad", C.c_int32), ("reserved", C.c_int32)]
+
+
 _lib = None
 
 

@@ -48,13 +48,14 @@ class _BNRec:
 
 
 class Backbone:
-    def __init__(self, params, nclasses=20, dataset="SemanticKitti", reduce_fn=None, world_size=1):
+    def __init__(self, params, nclasses=20, dataset="SemanticKitti", reduce_fn=None, world_size=1, packs=None):
         """params: mapping name -> CUDA tensor (the module's parameters and buffers)."""
         self.P = params
         self.ncls = nclasses
         self.dataset = dataset
         self.reduce_fn = reduce_fn
         self.world = world_size
+        self.packs = packs if packs is not None else ops.PackCache()
         self.tape = None
         self.on_block_done = None     # data parallel: called with a block tag as soon as that
                                       # block's parameter gradients are final (backward order)
@@ -90,7 +91,7 @@ class Backbone:
         w = self.P[f"{name}.weight"]
         cout = w.shape[0]
         taps = ops.conv_taps(k, k, dil, pad)
-        wp = ops.pack_weights(w, 0)
+        wp = self.packs.get(w, 0)
         b, h, wd = srcs[0].t.shape[:3]
         out = None
         if cout_pad is not None and cout_pad != cout:
@@ -158,6 +159,7 @@ class Backbone:
         """x [B,Cin,H,W] fp32 (NCHW, as the reference feeds it).  Returns dict with NHWC tensors:
         prob [B,Ho,Wo,C], logits [B,H,W,32], feat [B,Ho,Wo,256] (if return_feat)."""
         self.train, self.masks, self.update_running = train, dropout_masks, update_running
+        self.packs.refresh()             # every weight repack of this step in one launch
         self.tape = OrderedDict()
         self.bn_seen = []
         ho, wo = x.shape[2], x.shape[3]
@@ -247,7 +249,7 @@ class Backbone:
             cs = s.t.shape[3]
             ops.conv_wgrad(s.src(rec.src_lrelu), dz, dw, rec.taps, cin_off=off)
             if not getattr(s, "no_grad", False):
-                wd = ops.pack_weights(w, 1, c_off=off, c_cnt=cs, kpad=(dz.shape[3] + 15) // 16 * 16)
+                wd = self.packs.get(w, 1, c_off=off, c_cnt=cs, kpad=(dz.shape[3] + 15) // 16 * 16)
                 if s.grad is None:
                     s.grad = torch.empty_like(s.t)
                     acc = False

@@ -440,3 +440,36 @@ extern "C" int c3d_pack_weights(const float* w_oihw, float* dst, int Cout, int C
   C3D_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------ batched repack
+// One launch for every layer of the model: blockIdx.y selects the table entry.
+namespace {
+__global__ void pack_weights_batch_kernel(const c3d_pack_entry* __restrict__ table) {
+  const c3d_pack_entry e = table[blockIdx.y];
+  const int N = e.mode == 0 ? e.Cout : e.c_cnt;
+  const int K = e.mode == 0 ? e.c_cnt : e.Cout;
+  const size_t total = (size_t)e.T * (e.Kpad / 4) * N * 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 3;
+    size_t r = i >> 2;
+    const int n = r % N;
+    r /= N;
+    const int kq = r % (e.Kpad / 4);
+    const int t = r / (e.Kpad / 4);
+    const int k = kq * 4 + j;
+    float v = 0.f;
+    if (k < K) {
+      if (e.mode == 0) v = e.src[((size_t)n * e.Cin + e.c_off + k) * e.T + t];
+      else v = e.src[((size_t)k * e.Cin + e.c_off + n) * e.T + t];
+    }
+    e.dst[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int c3d_pack_weights_batch(const c3d_pack_entry* table_dev, int n, c3d_stream stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(32, n), dim3(256), 0, (hipStream_t)stream, table_dev);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}

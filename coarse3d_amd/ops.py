@@ -91,6 +91,52 @@ def pack_weights(w, mode=0, c_off=0, c_cnt=None, kpad=None):
     return dst
 
 
+class PackCache:
+    """All weight repacks of a model in ONE launch per step.
+
+    The first step packs layer by layer (and records which (weight, mode, slice) repacks the
+    forward/backward plan asks for); from then on ``refresh()`` repacks every recorded entry with
+    a single batched launch at the start of the forward and ``get()`` just returns the buffer.
+    The table is rebuilt whenever a parameter's storage moves."""
+
+    def __init__(self):
+        self.entries = {}        # key -> (weight tensor, mode, c_off, c_cnt, kpad, dst)
+        self.table = None
+        self.ptrs = None
+        self.fresh = False
+
+    def get(self, w, mode=0, c_off=0, c_cnt=None, kpad=None):
+        key = (w.data_ptr(), tuple(w.shape), mode, c_off, c_cnt, kpad)   # parameter storage is stable across steps
+        ent = self.entries.get(key)
+        if ent is not None and self.fresh:
+            return ent[5]
+        dst = pack_weights(w, mode, c_off, c_cnt, kpad)
+        cc = (w.shape[1] - c_off) if c_cnt is None else c_cnt
+        k = cc if mode == 0 else w.shape[0]
+        self.entries[key] = (w, mode, c_off, cc, (k + 15) // 16 * 16 if kpad is None else kpad, dst)
+        self.table = None
+        return dst
+
+    def refresh(self):
+        """Repack every known entry from the current weights (one launch)."""
+        if not self.entries:
+            self.fresh = False
+            return
+        ptrs = tuple(e[0].data_ptr() for e in self.entries.values())
+        if self.table is None or ptrs != self.ptrs:
+            arr = (L.PackEntry * len(self.entries))()
+            for i, (w, mode, c_off, cc, kpad, dst) in enumerate(self.entries.values()):
+                arr[i].src, arr[i].dst = w.data_ptr(), dst.data_ptr()
+                arr[i].Cout, arr[i].Cin, arr[i].T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+                arr[i].mode, arr[i].c_off, arr[i].c_cnt, arr[i].Kpad = mode, c_off, cc, kpad
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            dev = next(iter(self.entries.values()))[5].device
+            self.table = raw.to(dev)
+            self.ptrs = ptrs
+        _call("c3d_pack_weights_batch", _dp(self.table), len(self.entries), _stream())
+        self.fresh = True
+
+
 def num_mtiles(b, h, w):
     return L.lib().c3d_conv_num_mtiles(b, h, w)
 

@@ -17,6 +17,7 @@ not replicated (Q1); both H and W are validated (Q4).
 import torch
 import torch.nn as nn
 
+from ... import ops as ops_mod
 from ... import proto as proto_ops
 from ...backbone import Backbone
 from .projector import ProjectionV1
@@ -83,7 +84,7 @@ class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, masks, return_feat, names, *tensors):
         P = model._tensor_dict()
-        bb = Backbone(P, model.nclasses, model.dataset, model._bn_reduce, model._world)
+        bb = Backbone(P, model.nclasses, model.dataset, model._bn_reduce, model._world, model._packs)
         bb.on_block_done = model._block_done
         out = bb.forward(x.detach().float(), model.training, masks, return_feat)
         ctx.bb, ctx.names, ctx.model = bb, names, model
@@ -158,6 +159,7 @@ class SalsaNextProto(nn.Module):
         self._grad_ready = None       # data parallel: called when all gradients are written
         self._block_done = None       # data parallel: called per block in backward order
         self._flat_grads = None
+        self._packs = ops_mod.PackCache()   # batched weight repacking (one launch per step)
 
     # ------------------------------------------------------------------ plumbing
     def _tensor_dict(self):

@@ -77,6 +77,13 @@ int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream);
  * K is zero-padded to Kpad (multiple of 16).                                                */
 int c3d_pack_weights(const float* w_oihw, float* dst, int Cout, int Cin, int T, int mode,
                      int c_off, int c_cnt, int Kpad, c3d_stream stream);
+/* The same for a whole model in ONE launch: `table_dev` is a device array of n entries.       */
+typedef struct {
+  const float* src;   /* OIHW weight                                                          */
+  float* dst;         /* packed destination                                                   */
+  int32_t Cout, Cin, T, mode, c_off, c_cnt, Kpad, reserved;
+} c3d_pack_entry;
+int c3d_pack_weights_batch(const c3d_pack_entry* table_dev, int n, c3d_stream stream);
 
 /* dW[cout][cin_off + cin][t] (OIHW, full Cin_total) = sum_pixels dz[p][cout] * x[p + tap t][cin]
  * x is given as ONE transformed source (call once per source of a concatenated input).
