@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256) void label_hist_kernel(const int64_t* __restri
 struct LearnArgs {
   const float* sim;      // [N][M*C]
   const float* feat;     // [N][D]  (LayerNorm + l2 rows)
-  const int32_t* pred;   // [N] argmax class of the nearest-prototype map
+  const int32_t* pred;   // [N] argmax class of the nearest-prototype map, or NULL: computed here
+  const float* ln_w; const float* ln_b; float ln_eps;   // mask_norm LayerNorm (used when pred == NULL)
   const int32_t* counts; // [B][ncls]   per-image ordered lists from c3d_group_compact
   const int32_t* idx;    // [B][ncls][n]
   int32_t* rows;         // [ncls][N] scratch: flat (image-major) row list of each class
@@ -260,7 +261,40 @@ __global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
         }
       }
       a.target[r] = (float)(best + M * c);
-      a.assign[r] = (a.pred[r] == c) ? hot : -1;
+      int pred_r;
+      if (a.pred) {
+        pred_r = a.pred[r];
+      } else {
+        // nearest-prototype class of this labelled pixel, computed here instead of for all N
+        // pixels: argmax_k LayerNorm_C(max_m sim[r][m][k])   (salsanext_proto.py:506-507, :340)
+        const float* row = a.sim + (size_t)r * MC;
+        float mean = 0.f;
+        for (int k = 0; k < a.C; ++k) {
+          float mx = -INFINITY;
+          for (int m = 0; m < M; ++m) mx = fmaxf(mx, row[m * a.C + k]);
+          mean += mx;
+        }
+        mean /= (float)a.C;
+        float var = 0.f;
+        for (int k = 0; k < a.C; ++k) {
+          float mx = -INFINITY;
+          for (int m = 0; m < M; ++m) mx = fmaxf(mx, row[m * a.C + k]);
+          var += (mx - mean) * (mx - mean);
+        }
+        const float rstd = rsqrtf(var / (float)a.C + a.ln_eps);
+        float by = -INFINITY;
+        pred_r = 0;
+        for (int k = 0; k < a.C; ++k) {
+          float mx = -INFINITY;
+          for (int m = 0; m < M; ++m) mx = fmaxf(mx, row[m * a.C + k]);
+          const float y = (mx - mean) * rstd * a.ln_w[k] + a.ln_b[k];
+          if (y > by) {
+            by = y;
+            pred_r = k;
+          }
+        }
+      }
+      a.assign[r] = (pred_r == c) ? hot : -1;
     }
   }
   // ---- masked reduction f[m][:] = sum feat rows, cnt[m]
@@ -339,13 +373,14 @@ extern "C" int c3d_label_hist(const int64_t* labels, int groups, int n, int ncls
   return 0;
 }
 
-extern "C" int c3d_proto_learn(const float* sim, const float* feat, const int32_t* pred, const int32_t* counts,
+extern "C" int c3d_proto_learn(const float* sim, const float* feat, const int32_t* pred, const float* ln_w,
+                               const float* ln_b, float ln_eps, const int32_t* counts,
                                const int32_t* idx, int32_t* rows, const float* noise, const float* protos,
                                float* protos_out, float* target, int32_t* assign, int B, int n, int M, int C, int D,
                                int ignore_label, float momentum, c3d_stream stream) {
   C3D_REQUIRE(M <= 32, "proto_learn: at most 32 sub-prototypes per class");
   const int N = B * n;
-  LearnArgs a{sim, feat, pred, counts, idx, rows, B, n, noise, protos, protos_out, target, assign, N, M, C, D,
+  LearnArgs a{sim, feat, pred, ln_w, ln_b, ln_eps, counts, idx, rows, B, n, noise, protos, protos_out, target, assign, N, M, C, D,
               ignore_label, momentum};
   const size_t lds = (256 + 32 + (size_t)M * D + M) * sizeof(float);
   hipLaunchKernelGGL(proto_learn_kernel, dim3(C), dim3(256), lds, ST, a);

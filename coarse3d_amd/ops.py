@@ -449,7 +449,8 @@ def label_hist(labels, ncls):
     return counts
 
 
-def proto_learn(sim, feat, pred, counts, idx, noise, protos, m, c, ignore_label, momentum):
+def proto_learn(sim, feat, pred, counts, idx, noise, protos, m, c, ignore_label, momentum, ln_w=None, ln_b=None,
+                ln_eps=1e-5):
     """counts [B, C], idx [B, C, n]: per-image ordered pixel lists of each class."""
     ntot, d = feat.shape
     b, _, n = idx.shape
@@ -457,7 +458,9 @@ def proto_learn(sim, feat, pred, counts, idx, noise, protos, m, c, ignore_label,
     target = torch.zeros(ntot, device=feat.device, dtype=torch.float32)
     assign = torch.empty(ntot, device=feat.device, dtype=torch.int32)
     rows = torch.empty(c, ntot, device=feat.device, dtype=torch.int32)
-    _call("c3d_proto_learn", _dp(sim), _dp(feat), _dp(pred), _dp(counts), _dp(idx), _dp(rows), _dp(noise),
+    assert pred is not None or ln_w is not None
+    _call("c3d_proto_learn", _dp(sim), _dp(feat), _dp(pred), _dp(ln_w), _dp(ln_b), ln_eps, _dp(counts), _dp(idx),
+          _dp(rows), _dp(noise),
           _dp(protos), _dp(protos_out), _dp(target), _dp(assign), b, n, m, c, d, ignore_label, momentum, _stream())
     return protos_out, target
 

@@ -21,7 +21,7 @@ def distributed_sinkhorn(out, sinkhorn_iterations=3, epsilon=0.05):
     idx = torch.arange(n, device=dev, dtype=torch.int32).view(1, 1, n)
     noise = torch.empty(n, k, device=dev).exponential_()
     bank = torch.zeros(1, k, 4, device=dev)
-    _, target = ops.proto_learn(sim, rows, pred, counts, idx, noise, bank, k, 1, -1, 0.999)
+    _, target = ops.proto_learn(sim, rows, pred, counts, idx, noise, bank, k, 1, -1, 0.999)   # pred given
     index = target.long()
     # Gumbel-hard draw from the same noise, on the Sinkhorn-normalised scores
     e = torch.exp(sim / epsilon)

@@ -43,12 +43,20 @@ def prototype_step(feat_nhwc, P, label, proto_loss, noise=None, momentum=0.999, 
     bank = P["prototypes"]
     c, m, d = bank.shape
     bank_l2 = l2_bank(bank)
+    learn = proto_loss and label is not None
+    if not (learn or want_nearest):
+        # the similarity map is unobservable in this mode (the reference computes and drops it);
+        # the only side effect is the in-place renormalisation of the bank
+        return {"bank_l2": bank_l2, "nearest": None, "pred": None}
     rows, sim = similarity(feat_nhwc, bank_l2, P["feat_norm.weight"], P["feat_norm.bias"])
     n = rows.shape[0]
-    nearest, pred = ops.proto_nearest(sim, m, c, P["mask_norm.weight"], P["mask_norm.bias"],
-                                      want_nearest=want_nearest)
+    # nearest_proto_distance (:506-510) is only ever consumed through its argmax at LABELLED
+    # pixels (prototype_learning :340-341): the full [N, C] map is materialised on request only
+    nearest = pred = None
+    if want_nearest:
+        nearest, pred = ops.proto_nearest(sim, m, c, P["mask_norm.weight"], P["mask_norm.bias"], want_nearest=True)
     out = {"bank_l2": bank_l2, "nearest": nearest, "pred": pred}
-    if proto_loss and label is not None:
+    if learn:
         b = feat_nhwc.shape[0]
         lab = label.reshape(b, n // b).contiguous()
         counts, idx = ops.group_compact(lab, c)
@@ -56,7 +64,8 @@ def prototype_step(feat_nhwc, P, label, proto_loss, noise=None, momentum=0.999, 
             noise = torch.empty(n, m, device=rows.device, dtype=torch.float32).exponential_()
         base = bank_l2 if ema_base is None else ema_base.contiguous()   # proto_pl replaces the bank (:515-518)
         new_bank, target = ops.proto_learn(sim, rows, pred, counts, idx, noise.contiguous(),
-                                           base, m, c, ignore_label, momentum)
+                                           base, m, c, ignore_label, momentum, P["mask_norm.weight"],
+                                           P["mask_norm.bias"])
         if world_mean is not None:       # data parallel: mean over ranks (salsanext_proto.py:397-400)
             new_bank = world_mean(new_bank)
         out.update(contrast_logits=sim, contrast_target=target, new_bank=new_bank)

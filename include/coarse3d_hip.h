@@ -227,9 +227,11 @@ int c3d_label_hist(const int64_t* labels, int groups, int n, int ncls, int32_t* 
 /* Per class: Sinkhorn (3 iters, eps .05) on sim[rows,:,c], argmax -> target, Gumbel-hard
  * one-hot from Exp(1) `noise` [B*n][M] (indexed by pixel), masked feature sums, EMA into the
  * bank and final l2.  counts [B][C] / idx [B][C][n] from c3d_group_compact(groups=B) on the
- * labels of the B images; rows [C][B*n] and assign [B*n] are scratch; target must be zeroed. */
-int c3d_proto_learn(const float* sim, const float* feat, const int32_t* pred,
-                    const int32_t* counts, const int32_t* idx, int32_t* rows, const float* noise,
+ * labels of the B images; rows [C][B*n] and assign [B*n] are scratch; target must be zeroed.
+ * pred = c3d_proto_nearest's argmax, or NULL to evaluate it (with the mask_norm LayerNorm
+ * ln_w/ln_b/ln_eps) for the labelled pixels only.                                              */
+int c3d_proto_learn(const float* sim, const float* feat, const int32_t* pred, const float* ln_w,
+                    const float* ln_b, float ln_eps, const int32_t* counts, const int32_t* idx, int32_t* rows, const float* noise,
                     const float* protos, float* protos_out, float* target, int32_t* assign,
                     int B, int n, int M, int C, int D, int ignore_label, float momentum,
                     c3d_stream stream);

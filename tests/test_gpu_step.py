@@ -243,3 +243,22 @@ def test_data_parallel_wrapper_single_rank_matches_plain():
     assert abs(results[0][0] - results[1][0]) < 1e-6
     for k in results[0][1]:
         assert torch.equal(results[0][1][k], results[1][1][k]), k
+
+
+def test_prototype_nearest_kernel_matches_oracle():
+    """c3d_proto_nearest (the full nearest-prototype map, computed on request) vs the oracle's
+    prototype_similarity; the fused in-kernel argmax used by proto_learn is covered by the
+    bank / contrast_target checks of test_module_forward_and_bank_vs_golden."""
+    from coarse3d_amd import proto
+    g = torch.Generator().manual_seed(2)
+    b, h, w, ncls = 2, 8, 32, 14
+    st = W.closed_form_state(nclasses=ncls)
+    feat = torch.nn.functional.normalize(torch.randn(b, 256, h, w, generator=g), dim=1)
+    rows, sim, nearest, pl2 = oc.prototype_similarity(st, feat)
+    P = {k: st[k].to(DEV) for k in ("prototypes", "feat_norm.weight", "feat_norm.bias", "mask_norm.weight",
+                                    "mask_norm.bias")}
+    res = proto.prototype_step(feat.permute(0, 2, 3, 1).contiguous().to(DEV), P, None, False, want_nearest=True)
+    assert rel(res["bank_l2"], pl2) < 1e-5
+    got = res["nearest"].reshape(b, h, w, ncls).permute(0, 3, 1, 2)
+    assert rel(got, nearest) < 1e-4
+    assert (res["pred"].cpu().long() == nearest.argmax(1).reshape(-1)).float().mean().item() > 0.999
