@@ -503,8 +503,10 @@ def anchor_sample(weights, counts, idx, uniforms, b, n, c, a, ignore_label):
 
 def gather_rows_l2(feat, img, idx, t, tmax, a, n, eps=1e-12):
     d = feat.shape[-1]
-    out = torch.empty(tmax * a, d, device=feat.device, dtype=torch.float32)
-    norm = torch.empty(tmax * a, device=feat.device, dtype=torch.float32)
+    rows = tmax * a
+    rpad = (rows + 31) // 32 * 32            # the GEMM engine wants a multiple of 32 rows
+    out = (torch.empty if rpad == rows else torch.zeros)(rpad, d, device=feat.device, dtype=torch.float32)
+    norm = torch.ones(rpad, device=feat.device, dtype=torch.float32)
     _call("c3d_gather_rows_l2", _dp(feat), _dp(img), _dp(idx), _dp(t), tmax, a, n, d, eps, _dp(out), _dp(norm),
           _stream())
     return out, norm

@@ -262,3 +262,27 @@ def test_prototype_nearest_kernel_matches_oracle():
     got = res["nearest"].reshape(b, h, w, ncls).permute(0, 3, 1, 2)
     assert rel(got, nearest) < 1e-4
     assert (res["pred"].cpu().long() == nearest.argmax(1).reshape(-1)).float().mean().item() > 0.999
+
+
+def test_contrast_loss_default_anchor_count_matches_oracle():
+    """num_anchor = 50 (the reference default, not a multiple of 32): row padding of the GEMM engine
+    must be invisible.  Loss and gradient vs the oracle on the same draws."""
+    from coarse3d_amd import contrast
+    g = torch.Generator().manual_seed(8)
+    b, ncls, h, w, d = 2, 5, 8, 32, 256
+    feats = torch.randn(b, d, h, w, generator=g)
+    prob = torch.softmax(torch.randn(b, ncls, h, w, generator=g) * 2, 1)
+    labels = torch.randint(0, ncls, (b, h, w), generator=g)
+    queue = torch.randn(ncls, 20, d, generator=g)
+    u = torch.rand(b * ncls, 50, dtype=torch.float64, generator=g)
+    perms = torch.stack([torch.randperm(20, generator=g) for _ in range(ncls - 1)])
+    fo = feats.clone().requires_grad_(True)
+    ref = oc.contrast_mem_loss(fo, prob, labels, torch.ones_like(labels, dtype=torch.bool), queue, u, perms,
+                               temperature=0.1, num_anchor=50)
+    ref.backward()
+    fd = feats.to(DEV).requires_grad_(True)
+    got, dbg = contrast.contrast_mem_loss(fd, prob.to(DEV), labels.to(DEV), None, queue.to(DEV), 0.1, 0.07, 50, 0, u,
+                                          perms, return_debug=True)
+    got.backward()
+    assert rel(got, ref) < 1e-4
+    assert rel(fd.grad, fo.grad) < 1e-3
