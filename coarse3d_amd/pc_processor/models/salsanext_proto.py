@@ -25,49 +25,47 @@ from .projector import ProjectionV1
 DROP_P = 0.2
 
 
-class ResContextBlock(nn.Module):
-    def __init__(self, in_filters, out_filters):
+class _ParamBlock(nn.Module):
+    """Parameter holder: children are registered from a (name, kernel, dilation, pad, cin, cout)
+    table in the order that fixes both the state_dict layout and the RNG consumption of the
+    default initialisation.  It has no forward: the arithmetic lives in coarse3d_amd.backbone."""
+
+    def __init__(self, table):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_filters, out_filters, kernel_size=(1, 1), stride=1)
-        self.conv2 = nn.Conv2d(out_filters, out_filters, (3, 3), padding=1)
-        self.bn1 = nn.BatchNorm2d(out_filters)
-        self.conv3 = nn.Conv2d(out_filters, out_filters, (3, 3), dilation=2, padding=2)
-        self.bn2 = nn.BatchNorm2d(out_filters)
+        for name, k, dil, pad, cin, cout in table:
+            if k == 0:
+                self.add_module(name, nn.BatchNorm2d(cout))
+            else:
+                self.add_module(name, nn.Conv2d(cin, cout, (k, k), dilation=dil, padding=pad))
+
+    def forward(self, *a, **k):
+        raise RuntimeError("parameter container of the HIP backbone; call SalsaNextProto instead")
 
 
-class ResBlock(nn.Module):
-    def __init__(self, in_filters, out_filters, dropout_rate, kernel_size=(3, 3), stride=1, pooling=True,
-                 drop_out=True):
-        super().__init__()
-        self.pooling, self.drop_out = pooling, drop_out
-        self.conv1 = nn.Conv2d(in_filters, out_filters, kernel_size=(1, 1), stride=stride)
-        self.conv2 = nn.Conv2d(in_filters, out_filters, kernel_size=(3, 3), padding=1)
-        self.bn1 = nn.BatchNorm2d(out_filters)
-        self.conv3 = nn.Conv2d(out_filters, out_filters, kernel_size=(3, 3), dilation=2, padding=2)
-        self.bn2 = nn.BatchNorm2d(out_filters)
-        self.conv4 = nn.Conv2d(out_filters, out_filters, kernel_size=(2, 2), dilation=2, padding=1)
-        self.bn3 = nn.BatchNorm2d(out_filters)
-        self.conv5 = nn.Conv2d(out_filters * 3, out_filters, kernel_size=(1, 1))
-        self.bn4 = nn.BatchNorm2d(out_filters)
-        self.dropout = nn.Dropout2d(p=dropout_rate)
+def ResContextBlock(cin, cout):
+    """conv1x1 -> [3x3 -> BN] -> [3x3 d2 -> BN], residual (reference :38-65)."""
+    return _ParamBlock([("conv1", 1, 1, 0, cin, cout), ("conv2", 3, 1, 1, cout, cout), ("bn1", 0, 0, 0, 0, cout),
+                        ("conv3", 3, 2, 2, cout, cout), ("bn2", 0, 0, 0, 0, cout)])
 
 
-class UpBlock(nn.Module):
-    def __init__(self, in_filters, out_filters, dropout_rate, drop_out=True, inplace=False):
-        super().__init__()
-        self.drop_out = drop_out
-        self.in_filters, self.out_filters = in_filters, out_filters
-        self.dropout1 = nn.Dropout2d(p=dropout_rate)
-        self.dropout2 = nn.Dropout2d(p=dropout_rate)
-        self.conv1 = nn.Conv2d(in_filters // 4 + 2 * out_filters, out_filters, (3, 3), padding=1)
-        self.bn1 = nn.BatchNorm2d(out_filters)
-        self.conv2 = nn.Conv2d(out_filters, out_filters, (3, 3), dilation=2, padding=2)
-        self.bn2 = nn.BatchNorm2d(out_filters)
-        self.conv3 = nn.Conv2d(out_filters, out_filters, (2, 2), dilation=2, padding=1)
-        self.bn3 = nn.BatchNorm2d(out_filters)
-        self.conv4 = nn.Conv2d(out_filters * 3, out_filters, kernel_size=(1, 1))
-        self.bn4 = nn.BatchNorm2d(out_filters)
-        self.dropout3 = nn.Dropout2d(p=dropout_rate)
+def ResBlock(cin, cout, dropout_rate=DROP_P, pooling=True, drop_out=True):
+    """shortcut 1x1; 3x3 -> 3x3 d2 -> 2x2 d2 chain, concat 1x1; optional Dropout2d + AvgPool (:68-148)."""
+    blk = _ParamBlock([("conv1", 1, 1, 0, cin, cout), ("conv2", 3, 1, 1, cin, cout), ("bn1", 0, 0, 0, 0, cout),
+                       ("conv3", 3, 2, 2, cout, cout), ("bn2", 0, 0, 0, 0, cout),
+                       ("conv4", 2, 2, 1, cout, cout), ("bn3", 0, 0, 0, 0, cout),
+                       ("conv5", 1, 1, 0, 3 * cout, cout), ("bn4", 0, 0, 0, 0, cout)])
+    blk.pooling, blk.drop_out, blk.dropout_rate = pooling, drop_out, dropout_rate
+    return blk
+
+
+def UpBlock(cin, cout, dropout_rate=DROP_P, drop_out=True):
+    """PixelShuffle(2) + skip concat, 3x3 -> 3x3 d2 -> 2x2 d2 chain, concat 1x1 (:151-212)."""
+    blk = _ParamBlock([("conv1", 3, 1, 1, cin // 4 + 2 * cout, cout), ("bn1", 0, 0, 0, 0, cout),
+                       ("conv2", 3, 2, 2, cout, cout), ("bn2", 0, 0, 0, 0, cout),
+                       ("conv3", 2, 2, 1, cout, cout), ("bn3", 0, 0, 0, 0, cout),
+                       ("conv4", 1, 1, 0, 3 * cout, cout), ("bn4", 0, 0, 0, 0, cout)])
+    blk.drop_out, blk.dropout_rate = drop_out, dropout_rate
+    return blk
 
 
 # (site, channels as a multiple of base_channels) of the 13 active Dropout2d layers

@@ -319,7 +319,21 @@ def gold_step():
     npz("step.npz", **arrs)
 
 
+def gold_init():
+    """Default initialisation of the reference under a fixed seed: per-tensor checksums (the
+    drop-in module must consume the RNG in the same order, salsanext_proto.py:284-328)."""
+    torch.manual_seed(7)
+    m = R.SalsaNextProto(5, 20, 20, 0)
+    arrs = {"keys": np.array(list(m.state_dict().keys()))}
+    for k, v in m.state_dict().items():
+        v = v.double()
+        arrs[f"sum/{k}"] = v.sum()
+        arrs[f"sq/{k}"] = (v * v).sum()
+    npz("init_checksums.npz", **arrs)
+
+
 if __name__ == "__main__":
+    gold_init()
     gold_blocks()
     gold_model("kitti_small", 2, 32, 64, 20, "SemanticKitti", 101, 0.02)
     gold_model("poss_small", 1, 24, 56, 14, "SemanticPOSS", 201, 0.02)

@@ -78,3 +78,17 @@ def test_lovasz_and_focal_match_golden():
     gl, = torch.autograd.grad(ll, prob)
     torch.testing.assert_close(gf, g["grad_focal"], rtol=1e-4, atol=1e-7)
     torch.testing.assert_close(gl, g["grad_lovasz"], rtol=1e-4, atol=1e-7)
+
+
+def test_default_init_matches_reference_checksums():
+    """Same constructor order => same RNG consumption => bit-identical default weights under one
+    seed (golden: per-tensor checksums of the reference's SalsaNextProto under seed 7)."""
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    g = np.load(os.path.join(ROOT, "tests", "golden", "init_checksums.npz"))
+    torch.manual_seed(7)
+    sd = SalsaNextProto(5, 20, 20, 0).state_dict()
+    assert list(sd.keys()) == list(g["keys"])
+    for k, v in sd.items():
+        v = v.double()
+        assert float(v.sum()) == float(g[f"sum/{k}"]), k
+        assert float((v * v).sum()) == float(g[f"sq/{k}"]), k
