@@ -37,5 +37,8 @@ class FocalSoftmaxLoss(nn.Module):
         if mask is None:
             return loss.mean()
         m = mask.reshape(-1).to(loss.dtype)
-        out = (loss * m).sum() / m.sum()
-        return torch.where(torch.isnan(out), torch.zeros_like(out), out)   # reference returns 0 on NaN
+        den = m.sum()
+        # reference: 0/0 -> NaN -> "return torch.tensor(0.0)".  Dividing by max(den, 1) gives the
+        # same 0 without a NaN ever entering the autograd graph (a where() would leak NaN grads)
+        out = (loss * m).sum() / den.clamp(min=1.0)
+        return torch.where(torch.isnan(out.detach()), torch.zeros_like(out), out)

@@ -286,3 +286,30 @@ def test_contrast_loss_default_anchor_count_matches_oracle():
     got.backward()
     assert rel(got, ref) < 1e-4
     assert rel(fd.grad, fo.grad) < 1e-3
+
+
+def test_edge_cases_no_labels_and_no_feat_branch():
+    """(a) a batch without any weak label: focal -> 0, Lovasz -> 0, no pseudo labels, no anchors
+    (the reference would crash in _contrastive; here the contrast loss is 0) -- the step must
+    still run and produce finite, zero gradients for the segmentation losses;
+    (b) return_feat=False (contrast warm-up epochs, trainer.py:625-630): projector gets zero grads."""
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    from coarse3d_amd.trainer import TrainStep
+    b, h, w, ncls = 2, 32, 64, 20
+    x, tr, ev = W.synthetic_batch(b, h, w, ncls, 3, 0.02, gh=8, gw=16)
+    m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True)
+    m.load_state_dict(W.closed_form_state(nclasses=ncls))
+    m.to(DEV).train()
+    ts = TrainStep(m, ncls, lr=1e-3, num_anchor=64)
+    res = ts.step(x.to(DEV), torch.zeros_like(tr).to(DEV), ev.to(DEV), epoch=10)
+    assert float(res["ce"].detach()) == 0.0 and float(res["lov"].detach()) == 0.0 and float(res["contrast"].detach()) == 0.0
+    assert int((res["labels_contra"] != 0).sum()) == 0
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), k
+    # (b) warm-up epoch: no embedding branch
+    ts2 = TrainStep(m, ncls, lr=1e-3, num_anchor=64, contrast_warmup=5)
+    res = ts2.step(x.to(DEV), tr.to(DEV), ev.to(DEV), epoch=0)
+    assert "contrast" not in res and torch.isfinite(res["loss"])
+    assert float(m.projector.proj[0].weight.grad.abs().max()) == 0.0
+    assert float(m.cls_head.weight.grad.abs().max()) > 0.0
