@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 FEATURE_MEAN = [12.12, 10.88, 0.23, -1.04, 0.21]     # config_semantic_kitti.yaml sensor.img_means
 FEATURE_STD = [12.32, 11.47, 6.91, 0.86, 0.16]       # config_semantic_kitti.yaml:148-153
 PEAK_FP32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md chip-level parameters
+PEAK_BF16_MFMA_TFLOPS = 2500.0                       # dense bf16 (no sparsity), same guide
 
 
 def synth_batch(b, h, w, ncls, seed, device, label_rate=1e-3):
@@ -90,8 +91,12 @@ def main():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--classes", type=int, default=20)
     ap.add_argument("--dataset", default="SemanticKitti")
+    ap.add_argument("--matrix-dtype", choices=("f32", "bf16"), default="f32",
+                    help="MFMA operand type: f32 = the parity path and the headline; bf16 = opt-in mixed "
+                         "precision (bf16 operands, fp32 accumulate and storage; BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--kernel-table", default=None, help="write a per-(kernel, layer shape) timing table (JSON) here")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,6 +117,8 @@ def main():
     from coarse3d_amd.pc_processor.models import SalsaNextProto
     from coarse3d_amd.trainer import TrainStep
 
+    ops.set_matrix_precision(args.matrix_dtype)
+    peak_tf = PEAK_FP32_MFMA_TFLOPS if args.matrix_dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     torch.manual_seed(1)
     model = SalsaNextProto(5, args.classes, 20, 0, use_prototype=True, dataset=args.dataset).to(dev).train()
     wrapped = D.DataParallel(model) if (world > 1 or os.environ.get("C3D_FORCE_DP")) else model
@@ -147,11 +154,19 @@ def main():
     roofline = None
     if ops.KERNEL_EVENTS:
         per = {}
-        for name, flops, e0, e1 in ops.KERNEL_EVENTS:
-            d = per.setdefault(name, [0.0, 0.0, 0])
-            d[0] += flops
-            d[1] += e0.elapsed_time(e1) * 1e-3
-            d[2] += 1
+        table = {}
+        for name, flops, e0, e1, detail in ops.KERNEL_EVENTS:
+            sec_ = e0.elapsed_time(e1) * 1e-3
+            for dd, key in ((per, name), (table, (name, detail))):
+                d = dd.setdefault(key, [0.0, 0.0, 0])
+                d[0] += flops
+                d[1] += sec_
+                d[2] += 1
+        if args.kernel_table and rank == 0:
+            rows = [{"kernel": k[0], "h_w_cin_cout_taps_halo_acc": k[1], "launches_per_step": v[2] / args.steps,
+                     "ms_per_step": round(v[1] / args.steps * 1e3, 4), "tflops": round(v[0] / v[1] / 1e12, 2)}
+                    for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])]
+            json.dump(rows, open(args.kernel_table, "w"), indent=0)
         name, (fl, sec, n) = max(per.items(), key=lambda kv: kv[1][1])
         all_fl = sum(v[0] for v in per.values())
         all_sec = sum(v[1] for v in per.values())
@@ -160,15 +175,16 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
-            traffic = round(pmc[name]["hbm_bytes_per_launch"])
+            key = name if name in pmc else name.replace(", false>", ">")
+            traffic = round(pmc[key]["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2),
-                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "peak": peak_tf, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak_tf, 4),
                     "traffic": traffic, "launches_per_step": n // args.steps,
                     "avg_launch_us": round(sec / n * 1e6, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
                     "all_mfma_kernels": {"achieved": round(all_fl / all_sec / 1e12, 2),
-                                         "frac": round(all_fl / all_sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                         "frac": round(all_fl / all_sec / 1e12 / peak_tf, 4),
                                          "ms_per_step": round(all_sec / args.steps * 1e3, 2)}}
     ops.KERNEL_EVENTS = None
 
@@ -179,11 +195,12 @@ def main():
             "value": round(images / elapsed, 3), "unit": "range-images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.matrix_dtype == "f32" else "bf16 MFMA operands, f32 accumulate/storage",
             "data": "synthetic",
             "config": {"workload": f"{args.dataset} {args.height}x{args.width}x5 range image, C={args.classes}, "
                                    f"bs={args.batch}/GPU, SalsaNextProto fwd+bwd + prototype bank + contrast "
-                                   f"loss + AdamW (BASELINE.json configs[1])",
+                                   f"loss + AdamW (BASELINE.json configs[{1 if args.matrix_dtype == 'f32' else 2}])",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
             "roofline": roofline,
         }

@@ -38,12 +38,7 @@ class _ContrastFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feats, state):
-        feat = state["feat"]            # [B,H,W,D] contiguous
-        b, h, w, d = feat.shape
-        n = h * w
         ctx.state = state
-        ctx.shape = feats.shape
-        ctx.mark_non_differentiable()
         return state["loss"].reshape(())
 
     @staticmethod

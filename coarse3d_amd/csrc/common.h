@@ -5,12 +5,22 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define C3D_LRELU_SLOPE 0.01f
 #define C3D_MAX_SRC 3
 #define C3D_MAX_TAPS 9
 
 __device__ __forceinline__ float c3d_lrelu(float v) { return v > 0.f ? v : C3D_LRELU_SLOPE * v; }
+
+// 8 floats -> 8 bf16 (round to nearest even; v_cvt_pk_bf16_f32 on gfx950): one operand of
+// v_mfma_f32_32x32x16_bf16
+__device__ __forceinline__ bf16x8 c3d_pack_bf16x8(f32x4 a, f32x4 b) {
+  bf16x8 r;
+  r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+  r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+  return r;
+}
 
 // Bijective XCD-aware remap: consecutive logical tiles land on the same XCD (block b runs on
 // XCD b % 8 on MI355X), so neighbouring tiles that share halos / weights hit one L2.

@@ -42,7 +42,11 @@ struct ConvArgs {
   int ntn;                   // number of cout tiles
 };
 
-template <int TR, int NT, int CK, int HALO, int TT>
+// BF = true: same staging and LDS image, but the fragments are rounded to bf16 (RNE) when they
+// are read and fed to v_mfma_f32_32x32x16_bf16 (lane l: 8 consecutive k of row l&31, k-group
+// l>>5); accumulation stays fp32.  Opt-in mixed-precision mode (BASELINE config[2]), never the
+// fp32 parity path.
+template <int TR, int NT, int CK, int HALO, int TT, bool BF>
 __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ? 2 : 3) void conv_mfma_kernel(ConvArgs a) {
   constexpr int CS = CK + 4;
   constexpr int TWh = 32 + 2 * HALO;
@@ -188,6 +192,32 @@ __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ?
     // ---- MFMA over taps x k (raised wave priority: the co-resident workgroup on this CU is
     //      usually in its staging phase and must not steal issue slots from the matrix pipe)
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (BF) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        const int tap_off = ((HALO + a.dy[t]) * TWh + (HALO + a.dx[t]) + l31) * CS + half * 8;
+        const float* wb = s_w + (t * TN + wn * NPW * 32 + l31) * CS + half * 8;
+#pragma unroll
+        for (int kk = 0; kk < CK / 16; ++kk) {
+          bf16x8 av[RPW], bv[NPW];
+#pragma unroll
+          for (int i = 0; i < RPW; ++i) {
+            const float* p = s_in + (wm + i * WM) * TWh * CS + tap_off + kk * 16;
+            av[i] = c3d_pack_bf16x8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
+          }
+#pragma unroll
+          for (int j = 0; j < NPW; ++j) {
+            const float* p = wb + j * 32 * CS + kk * 16;
+            bv[j] = c3d_pack_bf16x8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
+          }
+#pragma unroll
+          for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int j = 0; j < NPW; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
       const int tap_off = ((HALO + a.dy[t]) * TWh + (HALO + a.dx[t]) + l31) * CS + half * 4;
@@ -209,6 +239,7 @@ __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ?
             for (int j = 0; j < NPW; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
       }
+    }
     }
     __builtin_amdgcn_s_setprio(0);
     if (!more) break;
@@ -312,30 +343,52 @@ __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ?
   }
 }
 
-template <int TR, int NT, int CK, int HALO, int TT>
+template <int TR, int NT, int CK, int HALO, int TT, bool BF>
 int launch_cfg(ConvArgs& a, hipStream_t st) {
   constexpr int CS = CK + 4;
   const size_t lds = ((size_t)(TR + 2 * HALO) * (32 + 2 * HALO) + (size_t)TT * 32 * NT) * CS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TR, NT, CK, HALO, TT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TR, NT, CK, HALO, TT, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
-  hipLaunchKernelGGL((conv_mfma_kernel<TR, NT, CK, HALO, TT>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<TR, NT, CK, HALO, TT, BF>), grid, dim3(256), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
 // halo / tap-count dispatch: 1 tap (pointwise), 4 taps (2x2 dilated, halo 1), 9 taps (halo 1|2)
-template <int TR, int NT>
+template <int TR, int NT, bool BF>
 int launch_taps(ConvArgs& a, int halo, hipStream_t st) {
-  if (a.T == 1) return launch_cfg<TR, NT, 16, 0, 1>(a, st);
-  if (a.T == 4) return launch_cfg<TR, NT, 16, 1, 4>(a, st);
-  if (halo <= 1) return launch_cfg<TR, NT, 16, 1, 9>(a, st);
-  return launch_cfg<TR, NT, 16, 2, 9>(a, st);
+  if (a.T == 1) return launch_cfg<TR, NT, 16, 0, 1, BF>(a, st);
+  if (a.T == 4) return launch_cfg<TR, NT, 16, 1, 4, BF>(a, st);
+  if (halo <= 1) return launch_cfg<TR, NT, 16, 1, 9, BF>(a, st);
+  return launch_cfg<TR, NT, 16, 2, 9, BF>(a, st);
+}
+
+template <bool BF>
+int dispatch(ConvArgs& a, const c3d_conv_desc* d, int tr, int halo, hipStream_t st) {
+  if (tr == 8 && d->ntaps == 1) {
+    // pointwise convs are plain GEMMs: deeper K chunk (32) and up to 128 output channels per
+    // workgroup so that each barrier pair covers 128 MFMAs per wave
+    bool k32 = true;
+    for (int s = 0; s < d->nsrc; ++s) k32 = k32 && (d->src[s].C % 32 == 0);
+    if (k32) {
+      // 128-wide cout tiles unless 64-wide ones waste fewer padded columns (704 -> 11 x 64
+      // instead of 6 x 128, 400 -> 7 x 64 instead of 4 x 128); measured equal MFMA efficiency
+      const int pad128 = (d->Cout + 127) / 128 * 128, pad64 = (d->Cout + 63) / 64 * 64;
+      if (d->Cout > 64 && pad128 <= pad64) return launch_cfg<8, 4, 32, 0, 1, BF>(a, st);
+      if (d->Cout > 32) return launch_cfg<8, 2, 32, 0, 1, BF>(a, st);
+      return launch_cfg<8, 1, 32, 0, 1, BF>(a, st);
+    }
+  }
+  const bool wide = d->Cout > 32;
+  if (tr == 8) return wide ? launch_taps<8, 2, BF>(a, halo, st) : launch_taps<8, 1, BF>(a, halo, st);
+  if (tr == 4) return wide ? launch_taps<4, 2, BF>(a, halo, st) : launch_taps<4, 1, BF>(a, halo, st);
+  return launch_taps<2, 2, BF>(a, halo, st);
 }
 
 }  // namespace
@@ -382,24 +435,7 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   a.Kq = K / 4;
   a.ntn = 1;
   hipStream_t st = (hipStream_t)stream;
-  if (tr == 8 && d->ntaps == 1) {
-    // pointwise convs are plain GEMMs: deeper K chunk (32) and up to 128 output channels per
-    // workgroup so that each barrier pair covers 128 MFMAs per wave
-    bool k32 = true;
-    for (int s = 0; s < d->nsrc; ++s) k32 = k32 && (d->src[s].C % 32 == 0);
-    if (k32) {
-      // 128-wide cout tiles unless 64-wide ones waste fewer padded columns (704 -> 11 x 64
-      // instead of 6 x 128, 400 -> 7 x 64 instead of 4 x 128); measured equal MFMA efficiency
-      const int pad128 = (d->Cout + 127) / 128 * 128, pad64 = (d->Cout + 63) / 64 * 64;
-      if (d->Cout > 64 && pad128 <= pad64) return launch_cfg<8, 4, 32, 0, 1>(a, st);
-      if (d->Cout > 32) return launch_cfg<8, 2, 32, 0, 1>(a, st);
-      return launch_cfg<8, 1, 32, 0, 1>(a, st);
-    }
-  }
-  const bool wide = d->Cout > 32;
-  if (tr == 8) return wide ? launch_taps<8, 2>(a, halo, st) : launch_taps<8, 1>(a, halo, st);
-  if (tr == 4) return wide ? launch_taps<4, 2>(a, halo, st) : launch_taps<4, 1>(a, halo, st);
-  return launch_taps<2, 2>(a, halo, st);
+  return d->mfma_bf16 ? dispatch<true>(a, d, tr, halo, st) : dispatch<false>(a, d, tr, halo, st);
 }
 
 // ------------------------------------------------------------------ weight repack

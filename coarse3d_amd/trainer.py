@@ -91,4 +91,5 @@ class TrainStep:
         if self.scheduler is not None:
             self.scheduler.step()
         res["loss"] = total.detach()
+        res["pred_2d"] = pred.detach()
         return res

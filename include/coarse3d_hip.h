@@ -62,6 +62,9 @@ typedef struct {
   int32_t out_coff;
   int32_t accumulate;       /* out += result (gradient accumulation)                     */
   float* stat_partial;      /* NULL or [Cout][2][c3d_conv_num_mtiles]: per-tile sum,sumsq */
+  int32_t mfma_bf16;        /* 0: fp32 MFMA (the parity path).  1: operands rounded to bf16
+                               (RNE) in LDS->register reads, v_mfma_f32_32x32x16_bf16, fp32
+                               accumulate/storage -- opt-in mixed precision (BASELINE config 2) */
 } c3d_conv_desc;
 
 /* y = epilogue(conv(transform(cat(src)))) as an implicit GEMM on fp32 MFMA.
@@ -102,6 +105,7 @@ typedef struct {
   float* dw;                /* OIHW gradient [Cout][Cin_total][T]                         */
   int32_t accumulate;
   float* partial;
+  int32_t mfma_bf16;        /* as in c3d_conv_desc                                         */
 } c3d_wgrad_desc;
 int64_t c3d_wgrad_partial_floats(const c3d_wgrad_desc* d);
 int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream);

@@ -80,3 +80,62 @@ def test_conv_forward_and_grads(B, H, W, srcC, Cout, k, dil, pad):
         off += c
     torch.cuda.synchronize()
     assert rel_err(dw.cpu(), w_ref.grad) < 1e-4
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)     # round-to-nearest-even, as v_cvt_pk_bf16_f32
+
+
+@pytest.mark.parametrize("B,H,W,srcC,Cout,k,dil,pad", CASES)
+def test_bf16_operand_mode(B, H, W, srcC, Cout, k, dil, pad):
+    """Opt-in mixed precision (BASELINE config[2]): the MFMA operands are rounded to bf16 after
+    the on-load transform, accumulation is fp32.  Emulated exactly on CPU by rounding the same
+    operands and convolving in fp64.  Tolerance 2e-4 of max|ref|: the kernel's on-load affine is
+    one fused multiply-add, the emulation rounds twice, so a few operands land on the other side
+    of a bf16 rounding boundary (a bf16 ulp is 4e-3; a layout error would be O(1))."""
+    from coarse3d_amd import ops
+    g = torch.Generator().manual_seed(B * 977 + H + W + Cout)
+    Cin = sum(srcC)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in srcC]
+    scs = [torch.rand(c, generator=g) + 0.5 for c in srcC]
+    shs = [torch.randn(c, generator=g) * 0.3 for c in srcC]
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    xin = torch.cat([x * s[None, :, None, None] + t[None, :, None, None] for x, s, t in zip(xs, scs, shs)], 1)
+    xin_b = _bf(xin).double().requires_grad_(True)
+    w_b = _bf(w).double().requires_grad_(True)
+    z = F.conv2d(xin_b, w_b, bias.double(), padding=pad, dilation=dil)
+    y_ref = F.leaky_relu(z, 0.01)
+    dz = torch.randn(z.shape, generator=g)
+    z.backward(_bf(dz).double())
+
+    dev = "cuda"
+    taps = ops.conv_taps(k, k, dil, pad)
+    srcs = [ops.Source(ops.to_nhwc(x).to(dev), s.to(dev), t.to(dev)) for x, s, t in zip(xs, scs, shs)]
+    ops.set_matrix_precision("bf16")
+    try:
+        wp = ops.pack_weights(w.to(dev), mode=0)
+        y, _ = ops.conv_forward(srcs, wp, bias.to(dev), Cout, taps, lrelu=True, stats=True)
+        e = rel_err(ops.from_nhwc(y.cpu()).double(), y_ref.detach())
+        assert e < 2e-4, e
+        dzd = ops.to_nhwc(dz).to(dev)
+        if Cout % 16:
+            dzp = torch.zeros(B, H, W, (Cout + 15) // 16 * 16, device=dev)
+            dzp[..., :Cout] = dzd
+            dzd = dzp
+        off = 0
+        for c in srcC:
+            wd = ops.pack_weights(w.to(dev), mode=1, c_off=off, c_cnt=c)
+            dx, _ = ops.conv_forward([ops.Source(dzd)], wd, None, c, ops.negate_taps(taps))
+            e = rel_err(ops.from_nhwc(dx.cpu()).double(), xin_b.grad[:, off:off + c])
+            assert e < 2e-4, e
+            off += c
+        dw = torch.zeros_like(w, device=dev)
+        off = 0
+        for src, c in zip(srcs, srcC):
+            ops.conv_wgrad(src, dzd, dw, taps, cin_off=off)
+            off += c
+        e = rel_err(dw.cpu().double(), w_b.grad)
+        assert e < 2e-4, e
+    finally:
+        ops.set_matrix_precision("f32")
