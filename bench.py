@@ -91,9 +91,10 @@ def main():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--classes", type=int, default=20)
     ap.add_argument("--dataset", default="SemanticKitti")
-    ap.add_argument("--matrix-dtype", choices=("f32", "bf16"), default="f32",
+    ap.add_argument("--matrix-dtype", choices=("f32", "bf16", "bf16x3"), default="f32",
                     help="MFMA operand type: f32 = the parity path and the headline; bf16 = opt-in mixed "
-                         "precision (bf16 operands, fp32 accumulate and storage; BASELINE configs[2])")
+                         "precision (bf16 operands, fp32 accumulate and storage; BASELINE configs[2]); "
+                         "bf16x3 = opt-in fp32-accurate product on the bf16 matrix pipe (exact 3-way operand split)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--kernel-table", default=None, help="write a per-(kernel, layer shape) timing table (JSON) here")
@@ -118,7 +119,8 @@ def main():
     from coarse3d_amd.trainer import TrainStep
 
     ops.set_matrix_precision(args.matrix_dtype)
-    peak_tf = PEAK_FP32_MFMA_TFLOPS if args.matrix_dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    peak_tf = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS,
+               "bf16x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[args.matrix_dtype]   # 6 bf16 MFMAs per fp32-equivalent one
     torch.manual_seed(1)
     model = SalsaNextProto(5, args.classes, 20, 0, use_prototype=True, dataset=args.dataset).to(dev).train()
     wrapped = D.DataParallel(model) if (world > 1 or os.environ.get("C3D_FORCE_DP")) else model
@@ -175,7 +177,7 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
-            key = name if name in pmc else name.replace(", false>", ">")
+            key = name if name in pmc else name.replace(", 0>", ">")
             traffic = round(pmc[key]["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
@@ -196,11 +198,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.matrix_dtype == "f32" else "bf16 MFMA operands, f32 accumulate/storage",
+            "dtype": {"f32": "f32", "bf16": "bf16 MFMA operands, f32 accumulate/storage",
+                      "bf16x3": "f32 values as 3 bf16 planes on the bf16 MFMA pipe, f32 accumulate/storage"}[args.matrix_dtype],
             "data": "synthetic",
             "config": {"workload": f"{args.dataset} {args.height}x{args.width}x5 range image, C={args.classes}, "
                                    f"bs={args.batch}/GPU, SalsaNextProto fwd+bwd + prototype bank + contrast "
-                                   f"loss + AdamW (BASELINE.json configs[{1 if args.matrix_dtype == 'f32' else 2}])",
+                                   f"loss + AdamW (BASELINE.json configs[{2 if args.matrix_dtype == 'bf16' else 1}])",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
             "roofline": roofline,
         }

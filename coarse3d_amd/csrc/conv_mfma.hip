@@ -42,11 +42,13 @@ struct ConvArgs {
   int ntn;                   // number of cout tiles
 };
 
-// BF = true: same staging and LDS image, but the fragments are rounded to bf16 (RNE) when they
-// are read and fed to v_mfma_f32_32x32x16_bf16 (lane l: 8 consecutive k of row l&31, k-group
-// l>>5); accumulation stays fp32.  Opt-in mixed-precision mode (BASELINE config[2]), never the
-// fp32 parity path.
-template <int TR, int NT, int CK, int HALO, int TT, bool BF>
+// PM (precision mode) 0: fp32 MFMA, the default parity path.
+// PM 1: same staging and LDS image, but the fragments are rounded to bf16 (RNE) when they are
+//   read and fed to v_mfma_f32_32x32x16_bf16 (lane l: 8 consecutive k of row l&31, k-group
+//   l>>5); accumulation stays fp32.  Opt-in mixed precision (BASELINE config[2]).
+// PM 2: fp32-accurate product on the bf16 matrix pipe: each fp32 fragment is split exactly into
+//   three bf16 planes and six of the nine plane products are accumulated (common.h).
+template <int TR, int NT, int CK, int HALO, int TT, int PM>
 __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ? 2 : 3) void conv_mfma_kernel(ConvArgs a) {
   constexpr int CS = CK + 4;
   constexpr int TWh = 32 + 2 * HALO;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ?
     // ---- MFMA over taps x k (raised wave priority: the co-resident workgroup on this CU is
     //      usually in its staging phase and must not steal issue slots from the matrix pipe)
     __builtin_amdgcn_s_setprio(1);
-    if constexpr (BF) {
+    if constexpr (PM == 1) {
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
         const int tap_off = ((HALO + a.dy[t]) * TWh + (HALO + a.dx[t]) + l31) * CS + half * 8;
@@ -215,6 +217,32 @@ __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ?
 #pragma unroll
             for (int j = 0; j < NPW; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    } else if constexpr (PM == 2) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        const int tap_off = ((HALO + a.dy[t]) * TWh + (HALO + a.dx[t]) + l31) * CS + half * 8;
+        const float* wb = s_w + (t * TN + wn * NPW * 32 + l31) * CS + half * 8;
+#pragma unroll
+        for (int kk = 0; kk < CK / 16; ++kk) {
+          bf16x8 ah[RPW], am[RPW], al[RPW], bh[NPW], bm[NPW], bl[NPW];
+#pragma unroll
+          for (int i = 0; i < RPW; ++i) {
+            const float* p = s_in + (wm + i * WM) * TWh * CS + tap_off + kk * 16;
+            c3d_split_bf16x3(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), ah[i], am[i], al[i]);
+          }
+#pragma unroll
+          for (int j = 0; j < NPW; ++j) {
+            const float* p = wb + j * 32 * CS + kk * 16;
+            c3d_split_bf16x3(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), bh[j], bm[j], bl[j]);
+          }
+          // plane pair outermost: consecutive MFMAs hit different accumulators (small terms first)
+#define C3D_PLANE(A_, B_)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < RPW; ++i) _Pragma("unroll") for (int j = 0; j < NPW; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][j], 0, 0, 0);
+          C3D_PLANE(al, bh) C3D_PLANE(ah, bl) C3D_PLANE(am, bm) C3D_PLANE(am, bh) C3D_PLANE(ah, bm) C3D_PLANE(ah, bh)
+#undef C3D_PLANE
         }
       }
     } else {
@@ -343,33 +371,33 @@ __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ?
   }
 }
 
-template <int TR, int NT, int CK, int HALO, int TT, bool BF>
+template <int TR, int NT, int CK, int HALO, int TT, int PM>
 int launch_cfg(ConvArgs& a, hipStream_t st) {
   constexpr int CS = CK + 4;
   const size_t lds = ((size_t)(TR + 2 * HALO) * (32 + 2 * HALO) + (size_t)TT * 32 * NT) * CS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TR, NT, CK, HALO, TT, BF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TR, NT, CK, HALO, TT, PM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
-  hipLaunchKernelGGL((conv_mfma_kernel<TR, NT, CK, HALO, TT, BF>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<TR, NT, CK, HALO, TT, PM>), grid, dim3(256), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
 // halo / tap-count dispatch: 1 tap (pointwise), 4 taps (2x2 dilated, halo 1), 9 taps (halo 1|2)
-template <int TR, int NT, bool BF>
+template <int TR, int NT, int PM>
 int launch_taps(ConvArgs& a, int halo, hipStream_t st) {
-  if (a.T == 1) return launch_cfg<TR, NT, 16, 0, 1, BF>(a, st);
-  if (a.T == 4) return launch_cfg<TR, NT, 16, 1, 4, BF>(a, st);
-  if (halo <= 1) return launch_cfg<TR, NT, 16, 1, 9, BF>(a, st);
-  return launch_cfg<TR, NT, 16, 2, 9, BF>(a, st);
+  if (a.T == 1) return launch_cfg<TR, NT, 16, 0, 1, PM>(a, st);
+  if (a.T == 4) return launch_cfg<TR, NT, 16, 1, 4, PM>(a, st);
+  if (halo <= 1) return launch_cfg<TR, NT, 16, 1, 9, PM>(a, st);
+  return launch_cfg<TR, NT, 16, 2, 9, PM>(a, st);
 }
 
-template <bool BF>
+template <int PM>
 int dispatch(ConvArgs& a, const c3d_conv_desc* d, int tr, int halo, hipStream_t st) {
   if (tr == 8 && d->ntaps == 1) {
     // pointwise convs are plain GEMMs: deeper K chunk (32) and up to 128 output channels per
@@ -380,15 +408,15 @@ int dispatch(ConvArgs& a, const c3d_conv_desc* d, int tr, int halo, hipStream_t 
       // 128-wide cout tiles unless 64-wide ones waste fewer padded columns (704 -> 11 x 64
       // instead of 6 x 128, 400 -> 7 x 64 instead of 4 x 128); measured equal MFMA efficiency
       const int pad128 = (d->Cout + 127) / 128 * 128, pad64 = (d->Cout + 63) / 64 * 64;
-      if (d->Cout > 64 && pad128 <= pad64) return launch_cfg<8, 4, 32, 0, 1, BF>(a, st);
-      if (d->Cout > 32) return launch_cfg<8, 2, 32, 0, 1, BF>(a, st);
-      return launch_cfg<8, 1, 32, 0, 1, BF>(a, st);
+      if (d->Cout > 64 && pad128 <= pad64) return launch_cfg<8, 4, 32, 0, 1, PM>(a, st);
+      if (d->Cout > 32) return launch_cfg<8, 2, 32, 0, 1, PM>(a, st);
+      return launch_cfg<8, 1, 32, 0, 1, PM>(a, st);
     }
   }
   const bool wide = d->Cout > 32;
-  if (tr == 8) return wide ? launch_taps<8, 2, BF>(a, halo, st) : launch_taps<8, 1, BF>(a, halo, st);
-  if (tr == 4) return wide ? launch_taps<4, 2, BF>(a, halo, st) : launch_taps<4, 1, BF>(a, halo, st);
-  return launch_taps<2, 2, BF>(a, halo, st);
+  if (tr == 8) return wide ? launch_taps<8, 2, PM>(a, halo, st) : launch_taps<8, 1, PM>(a, halo, st);
+  if (tr == 4) return wide ? launch_taps<4, 2, PM>(a, halo, st) : launch_taps<4, 1, PM>(a, halo, st);
+  return launch_taps<2, 2, PM>(a, halo, st);
 }
 
 }  // namespace
@@ -435,7 +463,8 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   a.Kq = K / 4;
   a.ntn = 1;
   hipStream_t st = (hipStream_t)stream;
-  return d->mfma_bf16 ? dispatch<true>(a, d, tr, halo, st) : dispatch<false>(a, d, tr, halo, st);
+  if (d->mfma_bf16 == 2) return dispatch<2>(a, d, tr, halo, st);
+  return d->mfma_bf16 ? dispatch<1>(a, d, tr, halo, st) : dispatch<0>(a, d, tr, halo, st);
 }
 
 // ------------------------------------------------------------------ weight repack

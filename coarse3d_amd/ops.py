@@ -12,25 +12,25 @@ from . import _lib as L
 # bench.py sets this to a list to bracket every MFMA-engine launch with HIP events on the launch
 # stream: entries are (kernel instance name, algorithmic FLOPs, start event, end event).
 KERNEL_EVENTS = None
-# Matrix-operand precision of the MFMA engines: False = fp32 MFMA (the parity path, default);
-# True = operands rounded to bf16 inside the kernels, fp32 accumulate/storage (opt-in mixed
-# precision for BASELINE config[2]; see set_matrix_precision).
-MFMA_BF16 = False
+# Matrix-pipe mode of the MFMA engines (c3d_conv_desc.mfma_bf16):
+#   0 "f32"    fp32 MFMA -- the parity path and the default
+#   1 "bf16"   operands rounded to bf16 inside the kernels, fp32 accumulate/storage (opt-in
+#              mixed precision, BASELINE configs[2])
+#   2 "bf16x3" fp32 operands split exactly into three bf16 planes, six plane products per step on
+#              the bf16 matrix pipe: fp32-accurate results (opt-in; see csrc/common.h)
+MFMA_MODE = 0
+_MODES = {"f32": 0, "bf16": 1, "bf16x3": 2}
 
 
 def set_matrix_precision(kind):
-    """'f32' (default, parity path) or 'bf16' (bf16 MFMA operands, fp32 accumulate + storage)."""
-    global MFMA_BF16
-    if kind not in ("f32", "bf16"):
-        raise ValueError(f"matrix precision must be 'f32' or 'bf16', got {kind!r}")
-    MFMA_BF16 = kind == "bf16"
+    global MFMA_MODE
+    if kind not in _MODES:
+        raise ValueError(f"matrix precision must be one of {sorted(_MODES)}, got {kind!r}")
+    MFMA_MODE = _MODES[kind]
 
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
-_BF = {False: "false", True: "true"}
 
 
 class _Timed:
@@ -182,11 +182,11 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     nt_ = len(taps)
     if tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs):
         wide = cout > 64 and (cout + 127) // 128 * 128 <= (cout + 63) // 64 * 64
-        name = f"conv_mfma_kernel<8, {4 if wide else (2 if cout > 32 else 1)}, 32, 0, 1, {_BF[MFMA_BF16]}>"
+        name = f"conv_mfma_kernel<8, {4 if wide else (2 if cout > 32 else 1)}, 32, 0, 1, {MFMA_MODE}>"
     else:    # mirrors launch_taps() in csrc/conv_mfma.hip
         hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
-        name = f"conv_mfma_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}, {_BF[MFMA_BF16]}>"
-    d.mfma_bf16 = int(MFMA_BF16)
+        name = f"conv_mfma_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}, {MFMA_MODE}>"
+    d.mfma_bf16 = MFMA_MODE
     with _Timed(name, 2.0 * b * h * w * cout * len(taps) * sum(s.C for s in srcs),
                 (h, w, sum(s.C for s in srcs), cout, nt_, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_forward(C.byref(d), _stream()), "c3d_conv_forward")
@@ -217,8 +217,8 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False):
         cfg = "4, 1, 2, 1, 1, 4, 1" if co > 32 else "4, 1, 1, 1, 1, 4, 1"
     else:
         cfg = f"9, 1, 1, 1, {2 if co > 32 else 1}, {2 if co > 32 else 4}, {1 if halo <= 1 else 2}"
-    name = f"wgrad_mfma_kernel<{cfg}, {_BF[MFMA_BF16]}>"
-    d.mfma_bf16 = int(MFMA_BF16)
+    name = f"wgrad_mfma_kernel<{cfg}, {MFMA_MODE}>"
+    d.mfma_bf16 = MFMA_MODE
     with _Timed(name, 2.0 * b * h * w * dw.shape[0] * len(taps) * src.C, (h, w, ci, co, nt, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
     return dw
