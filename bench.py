@@ -177,8 +177,7 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
-            key = name if name in pmc else name.replace(", 0>", ">")
-            traffic = round(pmc[key]["hbm_bytes_per_launch"])
+            traffic = round(pmc[name]["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2),

@@ -1,0 +1,274 @@
+// Implicit-GEMM convolution on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16) for gfx950, with
+// fp32 tensors in HBM and fp32 accumulation.  Opt-in precision modes of c3d_conv_forward
+// (c3d_conv_desc.mfma_bf16); the fp32-MFMA kernel in conv_mfma.hip stays the default path.
+//
+//   NP = 1  "bf16":   every operand is rounded once to bf16 (RNE) while it is staged in LDS.
+//   NP = 3  "bf16x3": every fp32 operand is split EXACTLY into three bf16 planes
+//                     x = h + m + l  (h = RNE8(x), m = RNE8(x-h), l = RNE8(x-h-m); both
+//                     residuals are exact in fp32, 3 x 8 significand bits cover all 24) and six
+//                     of the nine plane products are accumulated, smallest first:
+//                     l*h + h*l + m*m + m*h + h*m + h*h.  The dropped terms are < 2^-23 |a||b|,
+//                     i.e. the result is in the accuracy class of an fp32 FMA chain, at 6/16 of
+//                     the fp32-MFMA issue time.
+//
+// Same GEMM view, tile shapes, on-load BatchNorm affine and epilogue as conv_mfma.hip.  The split
+// happens ONCE per staged element (not per fragment read): LDS holds NP bf16 images of the
+// input tile and of the weight slab, rows padded to CK+8 bf16 (48 / 80 B: conflict-free
+// ds_read_b128); a fragment read is one b128 per plane = one MFMA operand (lane l: 8 consecutive
+// k of row l&31, k-group l>>5).
+#include "conv_common.h"
+
+namespace {
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// 4 floats -> NP x (4 bf16 packed in 2 dwords)
+template <int NP>
+__device__ __forceinline__ void split4(f32x4 v, u32x2 (&out)[NP]) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  f32x4 r = v;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    bf16x4 h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h[q] = (__bf16)r[q];
+    out[p] = __builtin_bit_cast(u32x2, h);
+    if (p + 1 < NP) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[q] -= (float)h[q];
+    }
+  }
+}
+
+template <int TR, int NT, int CK, int HALO, int TT, int NP>
+__global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) ? 3 : 2) void conv_bfp_kernel(ConvArgs a) {
+  constexpr int CSB = CK + 8;            // bf16 elements per LDS row
+  constexpr int TWh = 32 + 2 * HALO;
+  constexpr int THh = TR + 2 * HALO;
+  constexpr int TN = 32 * NT;
+  constexpr int WM = (TR >= 4) ? 4 : TR;
+  constexpr int WN = 4 / WM;
+  constexpr int RPW = TR / WM;
+  constexpr int NPW = NT / WN;
+  static_assert(NT % WN == 0, "NT must split across waves");
+  static_assert(CK % 16 == 0, "K chunk must be a multiple of the MFMA K (16)");
+  constexpr int CQ = CK / 4;
+  constexpr int IN_ROWS = THh * TWh;
+  constexpr int W_ROWS = TT * TN;
+  constexpr int IN_UNITS = IN_ROWS * CQ;
+  constexpr int IN_PT = (IN_UNITS + 255) / 256;
+  constexpr int W_UNITS = W_ROWS * CQ;
+  constexpr int W_PT = (W_UNITS + 255) / 256;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short* s_in = reinterpret_cast<unsigned short*>(smem);   // [NP][IN_ROWS][CSB]
+  unsigned short* s_w = s_in + NP * IN_ROWS * CSB;                  // [NP][W_ROWS][CSB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave % WM, wn = wave / WM;
+
+  const int ntile = a.B * a.tiles_y * a.tiles_x;
+  const int logical = c3d_xcd_remap(blockIdx.x, ntile * a.ntn);
+  const int mt = logical / a.ntn;
+  const int n0 = (logical % a.ntn) * TN;
+  const int tx = mt % a.tiles_x;
+  const int ty = (mt / a.tiles_x) % a.tiles_y;
+  const int b = mt / (a.tiles_x * a.tiles_y);
+  const int x0 = tx * 32, y0 = ty * TR;
+
+  f32x16 acc[RPW][NPW];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i)
+#pragma unroll
+    for (int j = 0; j < NPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- register staging (prefetch) state, as in conv_mfma.hip
+  f32x4 pin[IN_PT], pw[W_PT];
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  const int c4 = tid % CQ;
+  unsigned inb = 0;
+  int pixrel[IN_PT];
+#pragma unroll
+  for (int i = 0; i < IN_PT; ++i) {
+    const int u = tid + i * 256;
+    pixrel[i] = 0;
+    if (u < IN_UNITS) {
+      const int p = u / CQ;
+      const int px = p % TWh, py = p / TWh;
+      const int gx = x0 + px - HALO, gy = y0 + py - HALO;
+      pixrel[i] = (py - HALO) * a.W + (px - HALO);
+      if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H) inb |= 1u << i;
+    }
+  }
+  int wrel[W_PT];
+#pragma unroll
+  for (int i = 0; i < W_PT; ++i) {
+    const int u = tid + i * 256;
+    wrel[i] = -1;
+    if (u < W_UNITS) {
+      const int n = u % TN;
+      const int r = u / TN;
+      const int kq = r % CQ, t = r / CQ;
+      if (n0 + n < a.Cout) wrel[i] = (t * a.Kq + kq) * a.Cout + n0 + n;
+    }
+  }
+  const size_t tile_pix = (size_t)(b * a.H + y0) * a.W + x0;
+
+  auto load_chunk = [&](int s, int c0, int kbase) {
+    const c3d_src& sr = a.src[s];
+    const float* base = sr.ptr + tile_pix * sr.cstride + sr.coff + c0 + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < IN_PT; ++i) {
+      pin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if ((inb >> i) & 1u) pin[i] = *reinterpret_cast<const f32x4*>(base + (ptrdiff_t)pixrel[i] * sr.cstride);
+    }
+    if (sr.scale) {
+      psc = *reinterpret_cast<const f32x4*>(sr.scale + c0 + c4 * 4);
+      psh = *reinterpret_cast<const f32x4*>(sr.shift + c0 + c4 * 4);
+    }
+    const float* wbase = a.wpack + (size_t)((kbase + c0) >> 2) * a.Cout * 4;
+#pragma unroll
+    for (int i = 0; i < W_PT; ++i) {
+      pw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (wrel[i] >= 0) pw[i] = *reinterpret_cast<const f32x4*>(wbase + (size_t)wrel[i] * 4);
+    }
+  };
+
+  auto store_chunk = [&](int s) {
+    const c3d_src& sr = a.src[s];
+    const bool aff = sr.scale != nullptr;
+    const bool lr = sr.lrelu != 0;
+#pragma unroll
+    for (int i = 0; i < IN_PT; ++i) {
+      const int u = tid + i * 256;
+      if (u < IN_UNITS) {
+        f32x4 v = pin[i];
+        if ((inb >> i) & 1u) {
+          if (aff) v = v * psc + psh;
+          if (lr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q]);
+          }
+        }
+        u32x2 pl[NP];
+        split4<NP>(v, pl);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          *reinterpret_cast<u32x2*>(s_in + (p * IN_ROWS + u / CQ) * CSB + c4 * 4) = pl[p];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W_PT; ++i) {
+      const int u = tid + i * 256;
+      if (u < W_UNITS) {
+        const int n = u % TN;
+        const int r = u / TN;
+        const int kq = r % CQ, t = r / CQ;
+        u32x2 pl[NP];
+        split4<NP>(pw[i], pl);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          *reinterpret_cast<u32x2*>(s_w + (p * W_ROWS + t * TN + n) * CSB + kq * 4) = pl[p];
+      }
+    }
+  };
+
+  int s = 0, c0 = 0, kbase = 0;
+  load_chunk(s, c0, kbase);
+  while (true) {
+    __syncthreads();
+    store_chunk(s);
+    __syncthreads();
+    int s2 = s, c2 = c0 + CK, kb2 = kbase;
+    if (c2 >= a.src[s].C) {
+      kb2 += a.src[s].C;
+      s2 = s + 1;
+      c2 = 0;
+    }
+    const bool more = s2 < a.nsrc;
+    if (more) load_chunk(s2, c2, kb2);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      const int tap_off = ((HALO + a.dy[t]) * TWh + (HALO + a.dx[t]) + l31) * CSB + half * 8;
+      const unsigned short* wb = s_w + (t * TN + wn * NPW * 32 + l31) * CSB + half * 8;
+#pragma unroll
+      for (int kk = 0; kk < CK / 16; ++kk) {
+        bf16x8 bp[NP][NPW];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int j = 0; j < NPW; ++j)
+            bp[p][j] = *reinterpret_cast<const bf16x8*>(wb + (p * W_ROWS + j * 32) * CSB + kk * 16);
+        bf16x8 ap[NP][RPW];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int i = 0; i < RPW; ++i)
+            ap[p][i] = *reinterpret_cast<const bf16x8*>(s_in + (p * IN_ROWS + (wm + i * WM) * TWh) * CSB + tap_off + kk * 16);
+#define C3D_PLANE(PA, PB)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < RPW; ++i) _Pragma("unroll") for (int j = 0; j < NPW; ++j)  \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA][i], bp[PB][j], acc[i][j], 0, 0, 0);
+        if constexpr (NP == 3) {
+          C3D_PLANE(2, 0) C3D_PLANE(0, 2) C3D_PLANE(1, 1) C3D_PLANE(1, 0) C3D_PLANE(0, 1) C3D_PLANE(0, 0)
+        } else {
+          C3D_PLANE(0, 0)
+        }
+#undef C3D_PLANE
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (!more) break;
+    s = s2;
+    c0 = c2;
+    kbase = kb2;
+  }
+  conv_epilogue<TR, NT, WM, WN>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
+}
+
+template <int TR, int NT, int CK, int HALO, int TT, int NP>
+int launch_bfp(ConvArgs& a, hipStream_t st) {
+  constexpr int CSB = CK + 8;
+  size_t lds = (size_t)NP * ((size_t)(TR + 2 * HALO) * (32 + 2 * HALO) + (size_t)TT * 32 * NT) * CSB * 2;
+  const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
+  if (lds < red) lds = red;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bfp_kernel<TR, NT, CK, HALO, TT, NP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
+  dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
+  hipLaunchKernelGGL((conv_bfp_kernel<TR, NT, CK, HALO, TT, NP>), grid, dim3(256), lds, st, a);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int TR, int NT, int NP>
+int launch_bfp_taps(ConvArgs& a, int halo, hipStream_t st) {
+  if (a.T == 1) return launch_bfp<TR, NT, 16, 0, 1, NP>(a, st);
+  if (a.T == 4) return launch_bfp<TR, NT, 16, 1, 4, NP>(a, st);
+  if (halo <= 1) return launch_bfp<TR, NT, 16, 1, 9, NP>(a, st);
+  return launch_bfp<TR, NT, 16, 2, 9, NP>(a, st);
+}
+
+template <int NP>
+int dispatch_bfp(ConvArgs& a, int tr, int halo, bool k32, hipStream_t st) {
+  const bool wide = a.Cout > 32;
+  if (tr == 8 && a.T == 1 && k32) return wide ? launch_bfp<8, 2, 32, 0, 1, NP>(a, st) : launch_bfp<8, 1, 32, 0, 1, NP>(a, st);
+  if (tr == 8) return wide ? launch_bfp_taps<8, 2, NP>(a, halo, st) : launch_bfp_taps<8, 1, NP>(a, halo, st);
+  if (tr == 4) return wide ? launch_bfp_taps<4, 2, NP>(a, halo, st) : launch_bfp_taps<4, 1, NP>(a, halo, st);
+  return launch_bfp_taps<2, 2, NP>(a, halo, st);
+}
+
+}  // namespace
+
+// called by c3d_conv_forward (conv_mfma.hip) for mfma_bf16 = 1 (planes = 1) or 2 (planes = 3)
+int c3d_conv_forward_bfp(ConvArgs& a, int planes, int tr, int halo, bool k32, hipStream_t st) {
+  return planes == 3 ? dispatch_bfp<3>(a, tr, halo, k32, st) : dispatch_bfp<1>(a, tr, halo, k32, st);
+}

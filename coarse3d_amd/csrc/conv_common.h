@@ -1,0 +1,133 @@
+// Pieces shared by the fp32-MFMA and the bf16-plane convolution kernels.
+#pragma once
+#include <type_traits>
+#include "common.h"
+#include "../../include/coarse3d_hip.h"
+
+struct ConvArgs {
+  c3d_src src[C3D_MAX_SRC];
+  int nsrc;
+  int B, H, W, Cout;
+  int T;
+  int dy[C3D_MAX_TAPS];
+  int dx[C3D_MAX_TAPS];
+  const float* wpack;
+  const float* bias;
+  int epi_lrelu;
+  float* out;
+  int out_cstride, out_coff, accumulate;
+  float* stat_partial;
+  int tiles_x, tiles_y, Kq;  // Kq = padded K / 4 (rows of the packed weight per tap)
+  int ntn;                   // number of cout tiles
+};
+
+// bf16-plane kernels (conv_bfp.hip): planes = 1 (bf16) or 3 (bf16x3)
+int c3d_conv_forward_bfp(ConvArgs& a, int planes, int tr, int halo, bool k32, hipStream_t st);
+
+namespace {
+
+// Epilogue of one workgroup tile: bias, LeakyReLU, (accumulating) store, per-tile channel
+// statistics [C][2][ntile].  acc[i][j] is the 32x32 MFMA accumulator of tile row wm + i*WM and
+// cout tile wn*NPW + j (lane l: cout l&31, pixels (r&3) + 8*(r>>2) + 4*(l>>5)).
+template <int TR, int NT, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TR / WM][NT / WN], float* smem, int tid,
+                                              int lane, int half, int l31, int wm, int wn, int b, int x0, int y0,
+                                              int n0, int mt, int ntile, size_t tile_pix) {
+  constexpr int RPW = TR / WM;
+  constexpr int NPW = NT / WN;
+  constexpr int TN = 32 * NT;
+  float s1[NPW], s2v[NPW];
+  const bool full_tile = (x0 + 32 <= a.W) && (y0 + TR <= a.H) && (n0 + TN <= a.Cout);
+  float* obase = a.out + tile_pix * a.out_cstride + a.out_coff + n0 + l31;   // + per-lane cout
+  const int ocs = a.out_cstride;
+  // fast path (interior tiles): straight-line, no per-element predicates
+  auto fast_epilogue = [&](auto accumulate_tag) {
+    constexpr bool ACC = decltype(accumulate_tag)::value;
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+      const int cl = (wn * NPW + j) * 32;
+      const float bias = a.bias ? a.bias[n0 + cl + l31] : 0.f;
+      s1[j] = 0.f;
+      s2v[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        float* orow = obase + (ptrdiff_t)((wm + i * WM) * a.W + 4 * half) * ocs + cl;
+        float old[16];
+        if constexpr (ACC) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) old[r] = orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bias;
+          if (a.epi_lrelu) v = c3d_lrelu(v);
+          if constexpr (ACC) v += old[r];
+          orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs] = v;
+          s1[j] += v;
+          s2v[j] += v * v;
+        }
+      }
+    }
+  };
+  if (full_tile && !a.accumulate) {
+    fast_epilogue(std::false_type{});
+  } else if (full_tile) {
+    fast_epilogue(std::true_type{});
+  } else {
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+      const int co = n0 + (wn * NPW + j) * 32 + l31;
+      const bool cok = co < a.Cout;
+      const float bias = (a.bias && cok) ? a.bias[co] : 0.f;
+      s1[j] = 0.f;
+      s2v[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int gy = y0 + wm + i * WM;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = acc[i][j][r] + bias;
+          if (a.epi_lrelu) v = c3d_lrelu(v);
+          if (cok && gy < a.H && gx < a.W) {
+            float* o = a.out + ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co;
+            if (a.accumulate) v += *o;
+            *o = v;
+            s1[j] += v;
+            s2v[j] += v * v;
+          }
+        }
+      }
+    }
+  }
+  if (a.stat_partial) {
+    __syncthreads();
+    float* red = smem;  // [WM][TN][2]
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+      float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+      float t2 = s2v[j] + __shfl_xor(s2v[j], 32, 64);
+      if (half == 0) {
+        const int n = (wn * NPW + j) * 32 + l31;
+        red[(wm * TN + n) * 2 + 0] = t1;
+        red[(wm * TN + n) * 2 + 1] = t2;
+      }
+    }
+    __syncthreads();
+    for (int n = tid; n < TN; n += 256) {
+      if (n0 + n < a.Cout) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          t1 += red[(w * TN + n) * 2 + 0];
+          t2 += red[(w * TN + n) * 2 + 1];
+        }
+        float* sp = a.stat_partial + (size_t)(n0 + n) * 2 * ntile + mt;   // [C][2][ntile]
+        sp[0] = t1;
+        sp[ntile] = t2;
+      }
+    }
+  }
+}
+
+}  // namespace

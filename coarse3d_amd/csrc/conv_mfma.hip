@@ -20,35 +20,12 @@
 // Grid: 1-D, cout tile fastest, XCD-remapped: the workgroups that share one input tile (and
 // neighbouring tiles that share halos) run on the same XCD and hit its L2.
 #include <type_traits>
-#include "common.h"
-#include "../../include/coarse3d_hip.h"
+#include "conv_common.h"
 
 namespace {
 
-struct ConvArgs {
-  c3d_src src[C3D_MAX_SRC];
-  int nsrc;
-  int B, H, W, Cout;
-  int T;
-  int dy[C3D_MAX_TAPS];
-  int dx[C3D_MAX_TAPS];
-  const float* wpack;
-  const float* bias;
-  int epi_lrelu;
-  float* out;
-  int out_cstride, out_coff, accumulate;
-  float* stat_partial;
-  int tiles_x, tiles_y, Kq;  // Kq = padded K / 4 (rows of the packed weight per tap)
-  int ntn;                   // number of cout tiles
-};
 
-// PM (precision mode) 0: fp32 MFMA, the default parity path.
-// PM 1: same staging and LDS image, but the fragments are rounded to bf16 (RNE) when they are
-//   read and fed to v_mfma_f32_32x32x16_bf16 (lane l: 8 consecutive k of row l&31, k-group
-//   l>>5); accumulation stays fp32.  Opt-in mixed precision (BASELINE config[2]).
-// PM 2: fp32-accurate product on the bf16 matrix pipe: each fp32 fragment is split exactly into
-//   three bf16 planes and six of the nine plane products are accumulated (common.h).
-template <int TR, int NT, int CK, int HALO, int TT, int PM>
+template <int TR, int NT, int CK, int HALO, int TT>
 __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ? 2 : 3) void conv_mfma_kernel(ConvArgs a) {
   constexpr int CS = CK + 4;
   constexpr int TWh = 32 + 2 * HALO;
@@ -194,58 +171,6 @@ __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ?
     // ---- MFMA over taps x k (raised wave priority: the co-resident workgroup on this CU is
     //      usually in its staging phase and must not steal issue slots from the matrix pipe)
     __builtin_amdgcn_s_setprio(1);
-    if constexpr (PM == 1) {
-#pragma unroll
-      for (int t = 0; t < TT; ++t) {
-        const int tap_off = ((HALO + a.dy[t]) * TWh + (HALO + a.dx[t]) + l31) * CS + half * 8;
-        const float* wb = s_w + (t * TN + wn * NPW * 32 + l31) * CS + half * 8;
-#pragma unroll
-        for (int kk = 0; kk < CK / 16; ++kk) {
-          bf16x8 av[RPW], bv[NPW];
-#pragma unroll
-          for (int i = 0; i < RPW; ++i) {
-            const float* p = s_in + (wm + i * WM) * TWh * CS + tap_off + kk * 16;
-            av[i] = c3d_pack_bf16x8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
-          }
-#pragma unroll
-          for (int j = 0; j < NPW; ++j) {
-            const float* p = wb + j * 32 * CS + kk * 16;
-            bv[j] = c3d_pack_bf16x8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
-          }
-#pragma unroll
-          for (int i = 0; i < RPW; ++i)
-#pragma unroll
-            for (int j = 0; j < NPW; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-      }
-    } else if constexpr (PM == 2) {
-#pragma unroll
-      for (int t = 0; t < TT; ++t) {
-        const int tap_off = ((HALO + a.dy[t]) * TWh + (HALO + a.dx[t]) + l31) * CS + half * 8;
-        const float* wb = s_w + (t * TN + wn * NPW * 32 + l31) * CS + half * 8;
-#pragma unroll
-        for (int kk = 0; kk < CK / 16; ++kk) {
-          bf16x8 ah[RPW], am[RPW], al[RPW], bh[NPW], bm[NPW], bl[NPW];
-#pragma unroll
-          for (int i = 0; i < RPW; ++i) {
-            const float* p = s_in + (wm + i * WM) * TWh * CS + tap_off + kk * 16;
-            c3d_split_bf16x3(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), ah[i], am[i], al[i]);
-          }
-#pragma unroll
-          for (int j = 0; j < NPW; ++j) {
-            const float* p = wb + j * 32 * CS + kk * 16;
-            c3d_split_bf16x3(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), bh[j], bm[j], bl[j]);
-          }
-          // plane pair outermost: consecutive MFMAs hit different accumulators (small terms first)
-#define C3D_PLANE(A_, B_)                                                                          \
-  _Pragma("unroll") for (int i = 0; i < RPW; ++i) _Pragma("unroll") for (int j = 0; j < NPW; ++j) \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][j], 0, 0, 0);
-          C3D_PLANE(al, bh) C3D_PLANE(ah, bl) C3D_PLANE(am, bm) C3D_PLANE(am, bh) C3D_PLANE(ah, bm) C3D_PLANE(ah, bh)
-#undef C3D_PLANE
-        }
-      }
-    } else {
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
       const int tap_off = ((HALO + a.dy[t]) * TWh + (HALO + a.dx[t]) + l31) * CS + half * 4;
@@ -268,7 +193,6 @@ __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ?
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
       }
     }
-    }
     __builtin_amdgcn_s_setprio(0);
     if (!more) break;
     s = s2;
@@ -276,147 +200,33 @@ __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ?
     kbase = kb2;
   }
 
-  // ---- epilogue: bias, LeakyReLU, store, per-tile channel statistics
-  float s1[NPW], s2v[NPW];
-  const bool full_tile = (x0 + 32 <= a.W) && (y0 + TR <= a.H) && (n0 + TN <= a.Cout);
-  float* obase = a.out + tile_pix * a.out_cstride + a.out_coff + n0 + l31;   // + per-lane cout
-  const int ocs = a.out_cstride;
-  // fast path (interior tiles): straight-line, no per-element predicates
-  auto fast_epilogue = [&](auto accumulate_tag) {
-    constexpr bool ACC = decltype(accumulate_tag)::value;
-#pragma unroll
-    for (int j = 0; j < NPW; ++j) {
-      const int cl = (wn * NPW + j) * 32;
-      const float bias = a.bias ? a.bias[n0 + cl + l31] : 0.f;
-      s1[j] = 0.f;
-      s2v[j] = 0.f;
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        float* orow = obase + (ptrdiff_t)((wm + i * WM) * a.W + 4 * half) * ocs + cl;
-        float old[16];
-        if constexpr (ACC) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) old[r] = orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r] + bias;
-          if (a.epi_lrelu) v = c3d_lrelu(v);
-          if constexpr (ACC) v += old[r];
-          orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs] = v;
-          s1[j] += v;
-          s2v[j] += v * v;
-        }
-      }
-    }
-  };
-  if (full_tile && !a.accumulate) {
-    fast_epilogue(std::false_type{});
-  } else if (full_tile) {
-    fast_epilogue(std::true_type{});
-  } else {
-#pragma unroll
-    for (int j = 0; j < NPW; ++j) {
-      const int co = n0 + (wn * NPW + j) * 32 + l31;
-      const bool cok = co < a.Cout;
-      const float bias = (a.bias && cok) ? a.bias[co] : 0.f;
-      s1[j] = 0.f;
-      s2v[j] = 0.f;
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const int gy = y0 + wm + i * WM;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          float v = acc[i][j][r] + bias;
-          if (a.epi_lrelu) v = c3d_lrelu(v);
-          if (cok && gy < a.H && gx < a.W) {
-            float* o = a.out + ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co;
-            if (a.accumulate) v += *o;
-            *o = v;
-            s1[j] += v;
-            s2v[j] += v * v;
-          }
-        }
-      }
-    }
-  }
-  if (a.stat_partial) {
-    __syncthreads();
-    float* red = smem;  // [WM][TN][2]
-#pragma unroll
-    for (int j = 0; j < NPW; ++j) {
-      float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
-      float t2 = s2v[j] + __shfl_xor(s2v[j], 32, 64);
-      if (half == 0) {
-        const int n = (wn * NPW + j) * 32 + l31;
-        red[(wm * TN + n) * 2 + 0] = t1;
-        red[(wm * TN + n) * 2 + 1] = t2;
-      }
-    }
-    __syncthreads();
-    for (int n = tid; n < TN; n += 256) {
-      if (n0 + n < a.Cout) {
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) {
-          t1 += red[(w * TN + n) * 2 + 0];
-          t2 += red[(w * TN + n) * 2 + 1];
-        }
-        float* sp = a.stat_partial + (size_t)(n0 + n) * 2 * ntile + mt;   // [C][2][ntile]
-        sp[0] = t1;
-        sp[ntile] = t2;
-      }
-    }
-  }
+  conv_epilogue<TR, NT, WM, WN>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
 }
 
-template <int TR, int NT, int CK, int HALO, int TT, int PM>
+template <int TR, int NT, int CK, int HALO, int TT>
 int launch_cfg(ConvArgs& a, hipStream_t st) {
   constexpr int CS = CK + 4;
   const size_t lds = ((size_t)(TR + 2 * HALO) * (32 + 2 * HALO) + (size_t)TT * 32 * NT) * CS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TR, NT, CK, HALO, TT, PM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TR, NT, CK, HALO, TT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
-  hipLaunchKernelGGL((conv_mfma_kernel<TR, NT, CK, HALO, TT, PM>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<TR, NT, CK, HALO, TT>), grid, dim3(256), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
 // halo / tap-count dispatch: 1 tap (pointwise), 4 taps (2x2 dilated, halo 1), 9 taps (halo 1|2)
-template <int TR, int NT, int PM>
+template <int TR, int NT>
 int launch_taps(ConvArgs& a, int halo, hipStream_t st) {
-  if (a.T == 1) return launch_cfg<TR, NT, 16, 0, 1, PM>(a, st);
-  if (a.T == 4) return launch_cfg<TR, NT, 16, 1, 4, PM>(a, st);
-  if (halo <= 1) return launch_cfg<TR, NT, 16, 1, 9, PM>(a, st);
-  return launch_cfg<TR, NT, 16, 2, 9, PM>(a, st);
-}
-
-template <int PM>
-int dispatch(ConvArgs& a, const c3d_conv_desc* d, int tr, int halo, hipStream_t st) {
-  if (tr == 8 && d->ntaps == 1) {
-    // pointwise convs are plain GEMMs: deeper K chunk (32) and up to 128 output channels per
-    // workgroup so that each barrier pair covers 128 MFMAs per wave
-    bool k32 = true;
-    for (int s = 0; s < d->nsrc; ++s) k32 = k32 && (d->src[s].C % 32 == 0);
-    if (k32) {
-      // 128-wide cout tiles unless 64-wide ones waste fewer padded columns (704 -> 11 x 64
-      // instead of 6 x 128, 400 -> 7 x 64 instead of 4 x 128); measured equal MFMA efficiency
-      const int pad128 = (d->Cout + 127) / 128 * 128, pad64 = (d->Cout + 63) / 64 * 64;
-      if (d->Cout > 64 && pad128 <= pad64) return launch_cfg<8, 4, 32, 0, 1, PM>(a, st);
-      if (d->Cout > 32) return launch_cfg<8, 2, 32, 0, 1, PM>(a, st);
-      return launch_cfg<8, 1, 32, 0, 1, PM>(a, st);
-    }
-  }
-  const bool wide = d->Cout > 32;
-  if (tr == 8) return wide ? launch_taps<8, 2, PM>(a, halo, st) : launch_taps<8, 1, PM>(a, halo, st);
-  if (tr == 4) return wide ? launch_taps<4, 2, PM>(a, halo, st) : launch_taps<4, 1, PM>(a, halo, st);
-  return launch_taps<2, 2, PM>(a, halo, st);
+  if (a.T == 1) return launch_cfg<TR, NT, 16, 0, 1>(a, st);
+  if (a.T == 4) return launch_cfg<TR, NT, 16, 1, 4>(a, st);
+  if (halo <= 1) return launch_cfg<TR, NT, 16, 1, 9>(a, st);
+  return launch_cfg<TR, NT, 16, 2, 9>(a, st);
 }
 
 }  // namespace
@@ -463,8 +273,30 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   a.Kq = K / 4;
   a.ntn = 1;
   hipStream_t st = (hipStream_t)stream;
-  if (d->mfma_bf16 == 2) return dispatch<2>(a, d, tr, halo, st);
-  return d->mfma_bf16 ? dispatch<1>(a, d, tr, halo, st) : dispatch<0>(a, d, tr, halo, st);
+  if (d->mfma_bf16) {      // opt-in precision modes on the bf16 matrix pipe (conv_bfp.hip)
+    C3D_REQUIRE(d->mfma_bf16 == 1 || d->mfma_bf16 == 2, "conv: mfma_bf16 must be 0, 1 or 2");
+    bool k32 = true;
+    for (int s = 0; s < d->nsrc; ++s) k32 = k32 && (d->src[s].C % 32 == 0);
+    return c3d_conv_forward_bfp(a, d->mfma_bf16 == 2 ? 3 : 1, tr, halo, k32, st);
+  }
+  if (tr == 8 && d->ntaps == 1) {
+    // pointwise convs are plain GEMMs: deeper K chunk (32) and up to 128 output channels per
+    // workgroup so that each barrier pair covers 128 MFMAs per wave
+    bool k32 = true;
+    for (int s = 0; s < d->nsrc; ++s) k32 = k32 && (d->src[s].C % 32 == 0);
+    if (k32) {
+      // 128-wide cout tiles unless 64-wide ones waste fewer padded columns (704 -> 11 x 64
+      // instead of 6 x 128, 400 -> 7 x 64 instead of 4 x 128); measured equal MFMA efficiency
+      const int pad128 = (d->Cout + 127) / 128 * 128, pad64 = (d->Cout + 63) / 64 * 64;
+      if (d->Cout > 64 && pad128 <= pad64) return launch_cfg<8, 4, 32, 0, 1>(a, st);
+      if (d->Cout > 32) return launch_cfg<8, 2, 32, 0, 1>(a, st);
+      return launch_cfg<8, 1, 32, 0, 1>(a, st);
+    }
+  }
+  const bool wide = d->Cout > 32;
+  if (tr == 8) return wide ? launch_taps<8, 2>(a, halo, st) : launch_taps<8, 1>(a, halo, st);
+  if (tr == 4) return wide ? launch_taps<4, 2>(a, halo, st) : launch_taps<4, 1>(a, halo, st);
+  return launch_taps<2, 2>(a, halo, st);
 }
 
 // ------------------------------------------------------------------ weight repack

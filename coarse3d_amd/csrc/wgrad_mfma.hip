@@ -432,8 +432,9 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   WgCfg c;
   plan(d, a, c);
   hipStream_t st = (hipStream_t)stream;
-  const int rc = d->mfma_bf16 == 2 ? launch_id<2>(c.id, halo, a, st)
-                 : d->mfma_bf16   ? launch_id<1>(c.id, halo, a, st) : launch_id<0>(c.id, halo, a, st);
+  // bf16x3 (mode 2) keeps the fp32-MFMA weight gradient: splitting K = pixel fragments at read
+  // time costs more VALU time than the fp32 matrix pipe saves
+  const int rc = d->mfma_bf16 == 1 ? launch_id<1>(c.id, halo, a, st) : launch_id<0>(c.id, halo, a, st);
   if (rc) return rc;
   const size_t total = (size_t)d->ntaps * c.CI * c.CO * a.ci_slices * a.co_slices;
   int blocks = (int)((total + 31) / 32);

@@ -180,12 +180,17 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     tr = 8 if h >= 8 else (4 if h >= 4 else 2)
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
     nt_ = len(taps)
-    if tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs):
+    hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
+    k32 = tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs)
+    if MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
+        np_ = 3 if MFMA_MODE == 2 else 1
+        name = (f"conv_bfp_kernel<8, {2 if cout > 32 else 1}, 32, 0, 1, {np_}>" if k32 else
+                f"conv_bfp_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}, {np_}>")
+    elif k32:         # mirrors c3d_conv_forward / launch_taps() in csrc/conv_mfma.hip
         wide = cout > 64 and (cout + 127) // 128 * 128 <= (cout + 63) // 64 * 64
-        name = f"conv_mfma_kernel<8, {4 if wide else (2 if cout > 32 else 1)}, 32, 0, 1, {MFMA_MODE}>"
-    else:    # mirrors launch_taps() in csrc/conv_mfma.hip
-        hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
-        name = f"conv_mfma_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}, {MFMA_MODE}>"
+        name = f"conv_mfma_kernel<8, {4 if wide else (2 if cout > 32 else 1)}, 32, 0, 1>"
+    else:
+        name = f"conv_mfma_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}>"
     d.mfma_bf16 = MFMA_MODE
     with _Timed(name, 2.0 * b * h * w * cout * len(taps) * sum(s.C for s in srcs),
                 (h, w, sum(s.C for s in srcs), cout, nt_, halo, int(accumulate))):
