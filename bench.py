@@ -173,10 +173,11 @@ def main():
         all_fl = sum(v[0] for v in per.values())
         all_sec = sum(v[1] for v in per.values())
         # HBM traffic of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE x2 +
-        # WRITE_SIZE, separate rocprofv3 --pmc runs of this bench; tools/pmc_traffic.py)
+        # WRITE_SIZE, separate rocprofv3 --pmc runs of this bench; tools/profile_round.sh, tools/hbm_report.py)
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
+            tag = {"f32": "", "bf16": "_bf16", "bf16x3": "_bf16x3"}[args.matrix_dtype]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", f"round1_f{tag}_hbm.json")))
             traffic = round(pmc[name]["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from coarse3d_amd import ops
 dev = "cuda"
+if len(sys.argv) > 1:
+    ops.set_matrix_precision(sys.argv[1])
 shapes = [(8, 64, 2048, 32, 32, 3, 1, 1), (8, 64, 2048, 64, 64, 3, 2, 2), (8, 16, 512, 256, 256, 3, 1, 1),
           (8, 32, 1024, 704, 704, 1, 1, 0), (8, 64, 2048, 192, 64, 1, 1, 0)]
 for (B, H, W, Ci, Co, k, dil, pad) in shapes:
