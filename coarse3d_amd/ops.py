@@ -559,3 +559,36 @@ def gemm_rows(x, w_oihw_packed, cout, out=None):
     y, _ = conv_forward([src], w_oihw_packed, None, cout, [(0, 0)],
                         out=None if out is None else out.view(1, r // 32, 32, out.shape[-1]))
     return y.view(r, -1)
+
+
+# ---------------------------------------------------------------------------- metrics (N1)
+def confusion_add(pred, label, conf):
+    """conf[pred[i]][label[i]] += 1 (int64 [C,C], in place)."""
+    _call("c3d_confusion_add", _dp(pred), _dp(label), pred.numel(), conf.shape[0], _dp(conf), _stream())
+    return conf
+
+
+def unproject_confusion(pred_2d, uy, ux, labels, conf, n_points=None):
+    """pred_2d [C,H,W]-shaped probabilities of one scan (read in place when its memory is
+    channels-last, i.e. a view of an NHWC buffer); uy/ux pixel coordinates per point (ux None:
+    uy is the flat pixel index, SemanticPOSS); labels int64 [n].  Returns argmax per point."""
+    c, h, w = pred_2d.shape
+    p = pred_2d.permute(1, 2, 0)
+    if not (p.stride(2) == 1 and p.stride(1) >= c and p.stride(0) == w * p.stride(1)):
+        p = p.contiguous()
+    dev = p.device
+    uy = uy.to(dev, torch.int32).contiguous()
+    uxp = ux.to(dev, torch.int32).contiguous() if ux is not None else None
+    labels = labels.to(dev, torch.long).reshape(-1).contiguous()
+    n = labels.numel() if n_points is None else n_points
+    if labels.numel() != n:
+        raise ValueError(f"labels has {labels.numel()} entries, expected {n}")
+    nv = uy.numel()
+    if ux is not None and ux.numel() != nv:
+        raise ValueError("uproj_x_idx and uproj_y_idx differ in length")
+    if nv > n:
+        raise ValueError("more un-projection indices than points")
+    out = torch.empty(n, device=dev, dtype=torch.int32)
+    _call("c3d_unproject_confusion", _dp(p), h, w, c, p.stride(1), _dp(uy), _dp(uxp), _dp(labels), n, nv, _dp(conf),
+          _dp(out), _stream())
+    return out

@@ -276,6 +276,22 @@ int c3d_infonce_rows(float* logits, int ld, const int32_t* row_cls, const int32_
                      int A, int M, int ncols, float temperature, float base_temperature,
                      float* row_loss, float* loss, c3d_stream stream);
 
+/* ------------------------------------------------------------------ per-iteration metrics
+ * tasks/weak_segmentation/trainer.py:713-730, pc_processor/metrics/iou_eval.py:35-58          */
+
+/* For each of the n points of ONE scan: pred = argmax_c prob[pix][c] (first maximum) with
+ * pix = uy[i]*W + ux[i] (SemanticKitti / nuScenes, trainer.py:718-719) or pix = uy[i] when
+ * ux == NULL (SemanticPOSS, trainer.py:720-726: points i >= n_valid predict class 0), then
+ * conf[pred][labels[i]] += 1 (int64 [C][C], accumulated).  prob is the NHWC image of that scan
+ * with channel stride cstride; pred_out (int32 [n]) may be NULL.                               */
+int c3d_unproject_confusion(const float* prob, int H, int W, int C, int cstride,
+                            const int32_t* uy, const int32_t* ux, const int64_t* labels,
+                            int64_t n, int64_t n_valid, int64_t* conf, int32_t* pred_out,
+                            c3d_stream stream);
+/* IOUEval.addBatch: conf[pred[i]][label[i]] += 1                                               */
+int c3d_confusion_add(const int64_t* pred, const int64_t* label, int64_t n, int C, int64_t* conf,
+                      c3d_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

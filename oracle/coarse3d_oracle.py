@@ -539,6 +539,48 @@ def lovasz_loss(prob, labels, ignore=0):
     return sum(losses) / len(losses)
 
 
+# --------------------------------------------------------------------------------------
+# per-iteration metrics
+# --------------------------------------------------------------------------------------
+def unproject_argmax(pred_2d, uy, ux=None, n_points=None):
+    """pred_2d [C,H,W] -> class per point.  trainer.py:713-726: ``argmax(dim=1)`` then either
+    ``argmax_2d[ii, uproj_y_idx, uproj_x_idx]`` (SemanticKitti / nuScenes) or, with ``ux=None``
+    (SemanticPOSS), ``argmax.reshape(-1)[uproj_y_idx]`` written into the head of a zero vector
+    of ``n_points`` entries."""
+    am = pred_2d.argmax(dim=0)
+    if ux is not None:
+        return am[uy.long(), ux.long()]
+    temp = am.reshape(-1)[uy.long()]
+    out = torch.zeros(n_points, dtype=torch.long)
+    out[: temp.shape[0]] = temp
+    return out
+
+
+def confusion_add(conf, pred, label):
+    """IOUEval.addBatch (iou_eval.py:35-58): conf[pred][label] += 1 (int64, in place)."""
+    idx = pred.reshape(-1).long() * conf.shape[1] + label.reshape(-1).long()
+    conf += torch.bincount(idx, minlength=conf.numel()).reshape(conf.shape)
+    return conf
+
+
+def iou_stats(conf, ignore):
+    """IOUEval.getStats/getIoU/getAcc/getRecall (iou_eval.py:60-119).  Returns dict of
+    (mean over the included classes, per-class vector)."""
+    ncls = conf.shape[0]
+    include = torch.tensor([n for n in range(ncls) if n not in ignore], dtype=torch.long)
+    c = conf.clone().double()
+    c[list(ignore)] = 0
+    c[:, list(ignore)] = 0
+    tp = c.diag()
+    fp = c.sum(dim=1) - tp
+    fn = c.sum(dim=0) - tp
+    out = {}
+    for name, den in (("iou", tp + fp + fn + 1e-15), ("acc", tp + fp + 1e-15), ("recall", tp + fn + 1e-15)):
+        per = tp / den
+        out[name] = ((tp[include] / den[include]).mean(), per)
+    return out
+
+
 def normalise_input(x, eval_label, mean, std):
     m = (eval_label > 0).unsqueeze(1).to(x.dtype)
     return (x - mean[None, :, None, None]) / std[None, :, None, None] * m

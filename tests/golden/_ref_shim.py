@@ -35,7 +35,8 @@ def load_reference():
     # bare package objects: skip the heavy __init__ files
     for name, sub in (("pc_processor", "pc_processor"),
                       ("pc_processor.models", "pc_processor/models"),
-                      ("pc_processor.loss", "pc_processor/loss")):
+                      ("pc_processor.loss", "pc_processor/loss"),
+                      ("pc_processor.metrics", "pc_processor/metrics")):
         if name not in sys.modules:
             pkg = types.ModuleType(name)
             pkg.__path__ = [f"{REF_ROOT}/{sub}"]
@@ -52,6 +53,7 @@ def load_reference():
     m_contrast = importlib.import_module("pc_processor.loss.contrast_pixel_loss")  # reseeds RNG
     m_focal = importlib.import_module("pc_processor.loss.focal_softmax")
     m_lovasz = importlib.import_module("pc_processor.loss.lovasz_softmax")
+    m_iou = importlib.import_module("pc_processor.metrics.iou_eval")
     torch.random.set_rng_state(rng_state)
 
     # strip the debug lines that overwrite x/label/eval_mask
@@ -88,5 +90,6 @@ def load_reference():
         FocalSoftmaxLoss=m_focal.FocalSoftmaxLoss,
         Lovasz_softmax=m_lovasz.Lovasz_softmax,
         entropy_based_selection=ns["entropy_based_selection"],
+        IOUEval=m_iou.IOUEval,
     )
     return out

@@ -260,6 +260,40 @@ def gold_losses():
         lovasz=ll.detach(), grad_focal=gf, grad_lovasz=gl)
 
 
+def gold_metrics():
+    """Per-iteration metrics: argmax + un-projection exactly as trainer.py:713-726 (both dataset
+    conventions), accumulated and summarised by the reference IOUEval (iou_eval.py:35-119)."""
+    g = np.random.Generator(np.random.PCG64(77))
+    arrs = {}
+    for tag, ncls, h, w, npts, poss in (("kitti", 20, 16, 64, 1500, False), ("poss", 14, 8, 36, 8 * 36, True)):
+        ev = R.IOUEval(ncls, ignore=[0])
+        scans = 3
+        pred = torch.softmax(torch.from_numpy(g.standard_normal((scans, ncls, h, w)).astype(np.float32)) * 3, 1)
+        pred[0, :, 0, 0] = 0.05                       # an exact tie: argmax must return the first class
+        argmax_2d = pred.argmax(dim=1)
+        arrs[f"{tag}/pred_2d"] = pred
+        for ii in range(scans):
+            if not poss:                              # trainer.py:718-719
+                uy = torch.from_numpy(g.integers(0, h, npts))
+                ux = torch.from_numpy(g.integers(0, w, npts))
+                labels = torch.from_numpy(g.integers(0, ncls, npts))
+                unproj = argmax_2d[ii, uy, ux]
+                arrs[f"{tag}/ux{ii}"] = ux
+            else:                                     # trainer.py:720-726 (40*1800 -> h*w here)
+                nvalid = int(g.integers(npts // 2, npts))
+                uy = torch.from_numpy(g.integers(0, h * w, nvalid))
+                labels = torch.from_numpy(g.integers(0, ncls, npts))
+                temp = argmax_2d[ii, :].reshape(-1)[uy]
+                unproj = torch.zeros(npts).long()
+                unproj[: temp.shape[0]] = temp
+            ev.addBatch(unproj, labels)
+            arrs[f"{tag}/uy{ii}"], arrs[f"{tag}/labels{ii}"], arrs[f"{tag}/unproj{ii}"] = uy, labels, unproj
+        arrs[f"{tag}/conf"] = ev.conf_matrix
+        for name, (mean, per) in (("iou", ev.getIoU()), ("acc", ev.getAcc()), ("recall", ev.getRecall())):
+            arrs[f"{tag}/{name}_mean"], arrs[f"{tag}/{name}"] = mean, per
+    npz("metrics.npz", **arrs)
+
+
 # ----------------------------------------------------------------------------- full step
 def gold_step():
     """One optimisation step of the reference modules, trainer.py:621-704 order, with
@@ -340,4 +374,5 @@ if __name__ == "__main__":
     gold_contrast()
     gold_pl_select()
     gold_losses()
+    gold_metrics()
     gold_step()

@@ -173,3 +173,24 @@ def test_full_step_gradients():
         p = st[k].detach().clone()
         oc.adamw_update(p, g[f"grad/{k}"].reshape(p.shape), torch.zeros_like(p), torch.zeros_like(p), 1, 1e-3)
         close(p, g[f"after/{k}"], rtol=1e-5, atol=1e-7)
+
+
+def test_metrics_argmax_unproject_confusion():
+    """N1 metrics: oracle restatement of trainer.py:713-726 + IOUEval vs the reference (exact
+    integers; ratios to 1e-12)."""
+    d = np.load(os.path.join(GOLD, "metrics.npz"))
+    for tag, ncls, poss in (("kitti", 20, False), ("poss", 14, True)):
+        pred = torch.from_numpy(d[f"{tag}/pred_2d"])
+        conf = torch.zeros(ncls, ncls, dtype=torch.long)
+        for ii in range(pred.shape[0]):
+            uy = torch.from_numpy(d[f"{tag}/uy{ii}"])
+            labels = torch.from_numpy(d[f"{tag}/labels{ii}"])
+            ux = None if poss else torch.from_numpy(d[f"{tag}/ux{ii}"])
+            un = oc.unproject_argmax(pred[ii], uy, ux, labels.numel())
+            assert torch.equal(un, torch.from_numpy(d[f"{tag}/unproj{ii}"]))
+            oc.confusion_add(conf, un, labels)
+        assert torch.equal(conf, torch.from_numpy(d[f"{tag}/conf"]))
+        st = oc.iou_stats(conf, [0])
+        for name in ("iou", "acc", "recall"):
+            assert abs(float(st[name][0]) - float(d[f"{tag}/{name}_mean"])) < 1e-12
+            assert float((st[name][1] - torch.from_numpy(d[f"{tag}/{name}"])).abs().max()) < 1e-12
