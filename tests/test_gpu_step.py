@@ -313,3 +313,27 @@ def test_edge_cases_no_labels_and_no_feat_branch():
     assert "contrast" not in res and torch.isfinite(res["loss"])
     assert float(m.projector.proj[0].weight.grad.abs().max()) == 0.0
     assert float(m.cls_head.weight.grad.abs().max()) > 0.0
+
+
+def test_eval_mode_forward_parity():
+    """Validation path (trainer.py:706-709: ``model(pcd_feature)`` under no_grad in eval mode):
+    BatchNorm uses the running statistics, no dropout, no prototype update.  1e-4 of max|ref|
+    against the CPU oracle; a second call returns the same bits (deterministic kernels)."""
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    b, h, w, ncls = 2, 32, 96, 20
+    st = W.closed_form_state(nclasses=ncls)
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(b, 5, h, w, generator=g)
+    m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True)
+    m.load_state_dict(st)
+    m.to(DEV).eval()
+    protos = m.prototypes.detach().clone()
+    with torch.no_grad():
+        out = m(x.to(DEV))
+        out2 = m(x.to(DEV))
+        ref = oc.backbone_forward({k: v.clone() for k, v in st.items()}, x, False, None, True, "SemanticKitti")
+    assert rel(out["pred_2d"], ref["pred_2d"]) < 1e-4
+    assert rel(out["feat_2d"], ref["feat_2d"]) < 1e-4
+    assert torch.equal(out["pred_2d"], out2["pred_2d"]) and torch.equal(out["feat_2d"], out2["feat_2d"])
+    assert torch.equal(m.prototypes.detach(), protos)
+    assert "contrast_logits" not in out
