@@ -109,9 +109,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    single_rank_group = world == 1 and bool(os.environ.get("C3D_SINGLE_RANK_COLLECTIVES"))   # RCCL smoke test
+    if world > 1 or single_rank_group:
         # "nccl" is RCCL on ROCm; C3D_DIST_BACKEND=gloo lets two ranks share one GPU for testing
-        dist.init_process_group(os.environ.get("C3D_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        backend = os.environ.get("C3D_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
 
     from coarse3d_amd import dist as D
     from coarse3d_amd import ops
@@ -123,7 +127,7 @@ def main():
                "bf16x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[args.matrix_dtype]   # 6 bf16 MFMAs per fp32-equivalent one
     torch.manual_seed(1)
     model = SalsaNextProto(5, args.classes, 20, 0, use_prototype=True, dataset=args.dataset).to(dev).train()
-    wrapped = D.DataParallel(model) if (world > 1 or os.environ.get("C3D_FORCE_DP")) else model
+    wrapped = D.DataParallel(model) if (world > 1 or single_rank_group or os.environ.get("C3D_FORCE_DP")) else model
     ts = TrainStep(wrapped, args.classes, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512,
                    loss_w_ce_2d=1.0, loss_w_lov_2d=1.0, loss_w_contrast=0.1, feature_mean=FEATURE_MEAN,
                    feature_std=FEATURE_STD, proto_loss=True)
@@ -137,10 +141,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def summarise(events, nsteps):
+        """{kernel instance: [flops, seconds, launches]} and the per-(instance, layer shape) table."""
+        per, table = {}, {}
+        for name, flops, e0, e1, detail in events:
+            sec_ = e0.elapsed_time(e1) * 1e-3
+            for dd, key in ((per, name), (table, (name, detail))):
+                d = dd.setdefault(key, [0.0, 0.0, 0])
+                d[0] += flops
+                d[1] += sec_
+                d[2] += 1
+        return per, table
+
+    # Warm-up.  The LAST warm-up step brackets EVERY MFMA launch with HIP events on the launch
+    # stream: that picks the dominant kernel instance and gives the all-kernel summary.  The timed
+    # steps then bracket only the launches of that dominant instance (bracketing all ~300 launches
+    # per step costs ~2 % of the step, which would distort `value`).
+    survey = None
     for s in range(args.warmup):
+        last = s == args.warmup - 1 and not args.no_kernel_events
+        if last:
+            ops.KERNEL_EVENTS = []
         ts.step(*batches[s], epoch=10)
+        if last:
+            torch.cuda.synchronize()
+            survey = summarise(ops.KERNEL_EVENTS, 1)
+            ops.KERNEL_EVENTS = None
+    # RCCL prints a version banner through C stdio on first use; push it out now so that the
+    # JSON line below is the last thing this process writes to stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
     if not args.no_kernel_events:
         ops.KERNEL_EVENTS = []
+        if survey is not None:
+            ops.KERNEL_EVENT_FILTER = max(survey[0].items(), key=lambda kv: kv[1][1])[0]
     barrier()
     t0 = time.perf_counter()
     for s in range(args.warmup, total_steps):
@@ -155,24 +189,20 @@ def main():
 
     roofline = None
     if ops.KERNEL_EVENTS:
-        per = {}
-        table = {}
-        for name, flops, e0, e1, detail in ops.KERNEL_EVENTS:
-            sec_ = e0.elapsed_time(e1) * 1e-3
-            for dd, key in ((per, name), (table, (name, detail))):
-                d = dd.setdefault(key, [0.0, 0.0, 0])
-                d[0] += flops
-                d[1] += sec_
-                d[2] += 1
-        if args.kernel_table and rank == 0:
-            rows = [{"kernel": k[0], "h_w_cin_cout_taps_halo_acc": k[1], "launches_per_step": v[2] / args.steps,
-                     "ms_per_step": round(v[1] / args.steps * 1e3, 4), "tflops": round(v[0] / v[1] / 1e12, 2)}
-                    for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])]
-            json.dump(rows, open(args.kernel_table, "w"), indent=0)
+        per, table = summarise(ops.KERNEL_EVENTS, args.steps)
         name, (fl, sec, n) = max(per.items(), key=lambda kv: kv[1][1])
-        all_fl = sum(v[0] for v in per.values())
-        all_sec = sum(v[1] for v in per.values())
-        # HBM traffic of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE x2 +
+        if survey is None:                   # no warm-up step: everything was bracketed in the timed region
+            survey, all_steps = (per, table), args.steps
+        else:
+            all_steps = 1
+        all_fl = sum(v[0] for v in survey[0].values())
+        all_sec = sum(v[1] for v in survey[0].values())
+        if args.kernel_table and rank == 0:
+            rows = [{"kernel": k[0], "h_w_cin_cout_taps_halo_acc": k[1], "launches_per_step": v[2] / all_steps,
+                     "ms_per_step": round(v[1] / all_steps * 1e3, 4), "tflops": round(v[0] / v[1] / 1e12, 2)}
+                    for k, v in sorted(survey[1].items(), key=lambda kv: -kv[1][1])]
+            json.dump(rows, open(args.kernel_table, "w"), indent=0)
+        # HBM traffic of the same kernel from the PMC passes kept under profiles/ (2*FETCH_SIZE +
         # WRITE_SIZE, separate rocprofv3 --pmc runs of this bench; tools/profile_round.sh, tools/hbm_report.py)
         traffic = None
         try:
@@ -187,8 +217,10 @@ def main():
                     "avg_launch_us": round(sec / n * 1e6, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
                     "all_mfma_kernels": {"achieved": round(all_fl / all_sec / 1e12, 2),
                                          "frac": round(all_fl / all_sec / 1e12 / peak_tf, 4),
-                                         "ms_per_step": round(all_sec / args.steps * 1e3, 2)}}
+                                         "ms_per_step": round(all_sec / all_steps * 1e3, 2),
+                                         "measured_in": "last warm-up step" if all_steps == 1 else "timed steps"}}
     ops.KERNEL_EVENTS = None
+    ops.KERNEL_EVENT_FILTER = None
 
     if rank == 0:
         images = args.batch * world * args.steps
@@ -211,10 +243,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.classes, args.height, args.width)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        line = json.dumps(out)
+    if world > 1 or single_rank_group:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        ctypes.CDLL(None).fflush(None)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -11,12 +11,21 @@ on a side stream while the backward of earlier layers is still running; BatchNor
 tiny fp64 (sum, sumsq) vectors the fused conv epilogue already produced; no per-iteration
 barrier or scalar all-reduce (trainer.py:740-743 is logging only).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
+def _min_world():
+    # C3D_SINGLE_RANK_COLLECTIVES=1: issue every collective even in a 1-rank group, so that the
+    # RCCL calls (dtypes, streams, async handles) of the exchange points can be exercised on a
+    # single-GPU box (tests/test_gpu_dp.py)
+    return 1 if os.environ.get("C3D_SINGLE_RANK_COLLECTIVES") else 2
+
+
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() >= _min_world()
 
 
 def allreduce_sum_(t):
@@ -124,12 +133,12 @@ class DataParallel(torch.nn.Module):
         self.module = module
         world = dist.get_world_size() if is_dist() else 1
         module._world = world if sync_bn else 1
-        module._bn_reduce = allreduce_sum_ if (sync_bn and world > 1) else None
-        module._proto_mean = world_mean if world > 1 else None
+        module._bn_reduce = allreduce_sum_ if (sync_bn and is_dist()) else None
+        module._proto_mean = world_mean if is_dist() else None
         self.flat = FlatGradients(module._trainable())
         module._flat_grads = self.flat.views
         module._block_done = self.flat.block_done
-        if world > 1:                      # identical initial weights on every rank
+        if is_dist():                      # identical initial weights on every rank
             for p in module.parameters():
                 dist.broadcast(p.data, 0)
             for b in module.buffers():

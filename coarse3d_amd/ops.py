@@ -12,6 +12,7 @@ from . import _lib as L
 # bench.py sets this to a list to bracket every MFMA-engine launch with HIP events on the launch
 # stream: entries are (kernel instance name, algorithmic FLOPs, start event, end event).
 KERNEL_EVENTS = None
+KERNEL_EVENT_FILTER = None       # None = every MFMA launch; else only launches of this kernel instance
 # Matrix-pipe mode of the MFMA engines (c3d_conv_desc.mfma_bf16):
 #   0 "f32"    fp32 MFMA -- the parity path and the default
 #   1 "bf16"   operands rounded to bf16 inside the kernels, fp32 accumulate/storage (opt-in
@@ -38,14 +39,15 @@ class _Timed:
         self.name, self.flops, self.detail = name, flops, detail
 
     def __enter__(self):
-        if KERNEL_EVENTS is not None:
+        self.on = KERNEL_EVENTS is not None and (KERNEL_EVENT_FILTER is None or KERNEL_EVENT_FILTER == self.name)
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
         return self
 
     def __exit__(self, *a):
-        if KERNEL_EVENTS is not None:
+        if self.on:
             self.e1.record()
             KERNEL_EVENTS.append((self.name, self.flops, self.e0, self.e1, self.detail))
 

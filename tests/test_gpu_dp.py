@@ -91,3 +91,26 @@ def test_two_ranks_match_full_batch():
     assert (res[0]["protos"] == res[1]["protos"]).all()
     n = torch.from_numpy(res[0]["protos"]).norm(dim=-1)
     assert float(n.min()) > 0.9 and float(n.max()) < 1.0 + 1e-5
+
+
+def test_rccl_exchange_points_in_a_single_rank_group():
+    """The box has one GPU, so the RCCL (backend "nccl") code path cannot run with two ranks.
+    C3D_SINGLE_RANK_COLLECTIVES=1 makes every exchange point -- fp64 SyncBN sums in forward and
+    backward, the bucketed async gradient all-reduce on the communication stream, the prototype
+    bank mean, parameter broadcast -- issue its real RCCL call in a 1-rank group.  The step must
+    then reproduce the plain single-process step bit for bit (sum over one rank = identity)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--height", "32",
+           "--width", "256", "--no-cpu-baseline", "--no-kernel-events"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    plain = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    rccl = subprocess.run(cmd, env=dict(env, C3D_SINGLE_RANK_COLLECTIVES="1"), capture_output=True, text=True, timeout=600)
+    assert rccl.returncode == 0, rccl.stderr[-2000:]
+    a = json.loads(plain.stdout.strip().splitlines()[-1])
+    b = json.loads(rccl.stdout.strip().splitlines()[-1])      # the JSON line must be the LAST stdout line
+    assert a["config"]["final_loss"] == b["config"]["final_loss"]
+    assert b["n_gpus"] == 1 and b["value"] > 0
