@@ -231,9 +231,21 @@ int launch_taps(ConvArgs& a, int halo, hipStream_t st) {
 
 }  // namespace
 
-// tile rows chosen from the image height only, so that every conv over the same [B,H,W]
-// produces the same number of statistic partials
-static int c3d_tile_rows(int H) { return H >= 8 ? 8 : (H >= 4 ? 4 : 2); }
+// Tile rows: the candidate (8, 4, 2) that pads H the least, larger tiles on ties (H = 12 -> 4,
+// not 8: the SemanticPOSS pyramid 48/24/12/6/3 would otherwise waste 25 % of the rows at two
+// levels).  A function of the image height only, so that every conv over the same [B,H,W]
+// produces the same number of statistic partials.
+static int c3d_tile_rows(int H) {
+  int best = 8, best_pad = (H + 7) / 8 * 8;
+  for (int tr = 4; tr >= 2; tr /= 2) {
+    const int pad = (H + tr - 1) / tr * tr;
+    if (pad < best_pad) {
+      best = tr;
+      best_pad = pad;
+    }
+  }
+  return best;
+}
 
 extern "C" int c3d_conv_num_mtiles(int B, int H, int W) {
   const int tr = c3d_tile_rows(H);

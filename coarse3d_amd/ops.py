@@ -179,7 +179,7 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     if stats and stat_partial is None:
         stat_partial = torch.empty(cout, 2, num_mtiles(b, h, w), device=wpack.device, dtype=torch.float32)
     d.stat_partial = stat_partial.data_ptr() if stat_partial is not None else None
-    tr = 8 if h >= 8 else (4 if h >= 4 else 2)
+    tr = min((8, 4, 2), key=lambda t: ((h + t - 1) // t * t, -t))       # c3d_tile_rows() in csrc/conv_mfma.hip
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
     nt_ = len(taps)
     hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
