@@ -11,6 +11,7 @@ import torch
 
 from . import contrast, ops
 from .pc_processor.loss import ContrastMEMLoss, FocalSoftmaxLoss, Lovasz_softmax
+from .pc_processor.loss.lovasz_softmax import valid_indices
 
 
 def select_ratio_for(epoch, n_epochs):
@@ -22,7 +23,7 @@ class TrainStep:
     def __init__(self, model, n_classes, *, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512,
                  loss_w_ce_2d=1.0, loss_w_lov_2d=1.0, loss_w_contrast=0.1, contrast_warmup=0,
                  entropy_selection=True, ignore_cls=0, cls_weight=None, feature_mean=None, feature_std=None,
-                 proto_loss=True, optimizer=None, scheduler=None):
+                 proto_loss=True, optimizer=None, scheduler=None, inputs_resident=False):
         self.model = model
         self.net = model.module if hasattr(model, "module") else model
         self.n_classes = n_classes
@@ -47,12 +48,30 @@ class TrainStep:
         # trainer.py:146-151: AdamW(params, lr) -- cfg.weight_decay is NOT passed (default 0.01)
         self.optimizer = optimizer or torch.optim.AdamW(self.net.parameters(), lr=lr)
         self.scheduler = scheduler
+        self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        # True: the caller guarantees that the label tensors handed to step() are complete in HBM
+        # (e.g. delivered by a prefetcher on its own copy stream and synchronised) -- the side
+        # stream may then read them without waiting for the main stream.
+        self.inputs_resident = inputs_resident
         self.pl_noise = None     # test hook: Exp(1) noise [B, C, HW] for the pseudo-label selection
 
     def step(self, x, train_label, eval_label, epoch=0):
         """x [B,5,H,W] fp32, labels [B,H,W] int64 (0 = ignore).  Returns dict of 0-dim loss tensors
         (still on the device: nothing here synchronises with the host except Lovasz' nonzero)."""
         net = self.net
+        lov_valid = None
+        if self.w_lov > 0 and self._side is not None:
+            # The Lovasz loss needs the list of labelled pixels, whose length is data dependent (the
+            # only host synchronisation of the step).  It depends on the labels alone: compute it now
+            # on a side stream; with ``inputs_resident`` it does not wait for the previous step still
+            # running on the main stream, so the host blocks for microseconds and the main stream
+            # never drains.
+            if not self.inputs_resident:
+                self._side.wait_stream(torch.cuda.current_stream())   # labels may still be in flight on the main stream
+            with torch.cuda.stream(self._side):
+                lov_valid = valid_indices(train_label, self.ignore_cls)
+            torch.cuda.current_stream().wait_stream(self._side)
+            lov_valid.record_stream(torch.cuda.current_stream())
         wss_mask = train_label > 0
         eval_mask = eval_label > 0
         if self.mean is not None:
@@ -67,7 +86,7 @@ class TrainStep:
             res["ce"] = self.focal(pred, train_label, mask=wss_mask)
             total = total + self.w_ce * res["ce"]
         if self.w_lov > 0:
-            res["lov"] = self.lovasz(pred, train_label)
+            res["lov"] = self.lovasz(pred, train_label, valid=lov_valid)
             total = total + self.w_lov * res["lov"]
         if self.w_con > 0 and return_feat:
             if self.entropy_selection:
