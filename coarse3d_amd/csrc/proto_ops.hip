@@ -100,33 +100,71 @@ __global__ __launch_bounds__(256) void proto_nearest_kernel(const float* __restr
 }
 
 // Ordered compaction: for group g and class c list the positions i (ascending) with
-// labels[g][i] == c.  grid = (ncls, groups); idx [groups][ncls][n], counts [groups][ncls].
-// 1024 labels per iteration (4 consecutive per thread), one barrier per iteration.
+// labels[g][i] == c.  idx [groups][ncls][n], counts [groups][ncls].
+// Two passes over SEG segments of each label row, so that groups*ncls*SEG workgroups share the
+// work: (1) per-(group, segment) class histogram (all classes in one read of the labels);
+// (2) each (class, group, segment) workgroup derives its output offset from the histograms of the
+// earlier segments and compacts its own segment, 4096 labels per iteration (16 consecutive per
+// thread, fetched coalesced through LDS), one wave scan + one barrier pair per iteration.
+constexpr int CSEG = 8;
+
+__global__ __launch_bounds__(256) void compact_hist_kernel(const int64_t* __restrict__ labels,
+                                                           const uint8_t* __restrict__ keep, int n, int ncls, int seg_len,
+                                                           int32_t* __restrict__ seg_counts) {   // [groups][CSEG][ncls]
+  __shared__ int h[64];
+  const int sg = blockIdx.x, g = blockIdx.y;
+  if (threadIdx.x < 64) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t* lab = labels + (size_t)g * n;
+  const uint8_t* kp = keep ? keep + (size_t)g * n : nullptr;
+  const int e = min(n, (sg + 1) * seg_len);
+  for (int i = sg * seg_len + threadIdx.x; i < e; i += 256) {
+    int64_t l = lab[i];
+    if (kp && !kp[i]) l = 0;
+    if (l >= 0 && l < ncls) atomicAdd(&h[(int)l], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < ncls) seg_counts[((size_t)g * CSEG + sg) * ncls + threadIdx.x] = h[threadIdx.x];
+}
+
 __global__ __launch_bounds__(256) void group_compact_kernel(const int64_t* __restrict__ labels,
-                                                            const uint8_t* __restrict__ keep, int n, int ncls,
+                                                            const uint8_t* __restrict__ keep, int n, int ncls, int seg_len,
+                                                            const int32_t* __restrict__ seg_counts,
                                                             int32_t* __restrict__ counts, int32_t* __restrict__ idx) {
+  constexpr int PT = 16;
   __shared__ int wtot[2][4];
-  const int c = blockIdx.x, g = blockIdx.y;
+  __shared__ unsigned char flag[256 * PT];
+  const int c = blockIdx.x, g = blockIdx.y, sg = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t* lab = labels + (size_t)g * n;
   const uint8_t* kp = keep ? keep + (size_t)g * n : nullptr;
   int32_t* out = idx + ((size_t)g * ncls + c) * n;
-  int base = 0, buf = 0;
-  for (int i0 = 0; i0 < n; i0 += 1024, buf ^= 1) {
-    const int i = i0 + tid * 4;
-    bool f[4];
-    int cnt = 0;
+  int base = 0, total = 0;
+  for (int k = 0; k < CSEG; ++k) {
+    const int v = seg_counts[((size_t)g * CSEG + k) * ncls + c];
+    if (k < sg) base += v;
+    total += v;
+  }
+  if (sg == 0 && tid == 0) counts[g * ncls + c] = total;
+  const int e = min(n, (sg + 1) * seg_len);
+  int buf = 0;
+  for (int i0 = sg * seg_len; i0 < e; i0 += 256 * PT, buf ^= 1) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f[q] = false;
-      if (i + q < n) {
-        int64_t l = lab[i + q];
-        if (kp && !kp[i + q]) l = 0;
-        f[q] = (l == c);
+    for (int q = 0; q < PT; ++q) {           // coalesced fetch -> per-label flag byte
+      const int i = i0 + q * 256 + tid;
+      unsigned char fl = 0;
+      if (i < e) {
+        int64_t l = lab[i];
+        if (kp && !kp[i]) l = 0;
+        fl = (l == c);
       }
-      cnt += f[q] ? 1 : 0;
+      flag[q * 256 + tid] = fl;
     }
-    // inclusive scan of cnt over the wave
+    __syncthreads();
+    unsigned f = 0;
+#pragma unroll
+    for (int q = 0; q < PT; ++q) f |= (unsigned)flag[tid * PT + q] << q;
+    const int cnt = __popc(f);
     int scan = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -137,12 +175,14 @@ __global__ __launch_bounds__(256) void group_compact_kernel(const int64_t* __res
     __syncthreads();
     int off = base + scan - cnt;
     for (int k = 0; k < wv; ++k) off += wtot[buf][k];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (f[q]) out[off++] = i + q;
+    const int i = i0 + tid * PT;
+    while (f) {
+      const int q = __ffs(f) - 1;
+      out[off++] = i + q;
+      f &= f - 1;
+    }
     base += wtot[buf][0] + wtot[buf][1] + wtot[buf][2] + wtot[buf][3];
   }
-  if (tid == 0) counts[g * ncls + c] = base;
 }
 
 // counts[g][c] = #{i : labels[g][i] == c}   (class presence for the pseudo-label selection)
@@ -179,15 +219,39 @@ struct LearnArgs {
   float momentum;
 };
 
-// one workgroup per class
+// 32-lane group helpers (a wave holds two independent groups; xor offsets < 32 stay inside one)
+__device__ __forceinline__ float group32_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// argmax with the smallest index on ties (torch.argmax), result in every lane of the group
+__device__ __forceinline__ int group32_argmax(float v, int idx) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > v || (ov == v && oi < idx)) {
+      v = ov;
+      idx = oi;
+    }
+  }
+  return idx;
+}
+
+// one workgroup per class; 8 labelled pixels in flight, 32 lanes (sub-prototype m, or class k for
+// the nearest-prototype vote) per pixel
 __global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
   extern __shared__ float sm[];
-  double* red = reinterpret_cast<double*>(sm);          // [4][32] wave partials
-  float* u = sm + 256;                                  // [32] row scalings
-  float* f = sm + 256 + 32;                             // [M][D]
+  double* red = reinterpret_cast<double*>(sm);          // [8][32] slot partials
+  float* u = sm + 512;                                  // [32] row scalings
+  int* s_r = reinterpret_cast<int*>(sm + 512 + 32);     // [256] staged pixel rows
+  int* s_m = s_r + 256;                                 // [256] staged assignments
+  float* f = sm + 512 + 32 + 512;                       // [M][D]
   float* cnt = f + a.M * a.D;                           // [M]
   const int c = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int sub = tid >> 5, m = tid & 31;
   const int M = a.M, D = a.D, MC = a.M * a.C;
   int32_t* rows = a.rows + (size_t)c * a.N;
   int nc = 0;
@@ -206,61 +270,41 @@ __global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
 
   if (nc > 0) {
     // ---- Sinkhorn scalings: Q[i][m] = E[i][m] * u[m] * v[i],  E = exp(sim/0.05)
-    for (int m = tid; m < 32; m += 256) u[m] = 1.f;
+    if (tid < 32) u[tid] = 1.f;
     __syncthreads();
     for (int it = 0; it < 3; ++it) {
-      double acc[32];
-#pragma unroll
-      for (int m = 0; m < 32; ++m) acc[m] = 0.0;
-      for (int i = tid; i < nc; i += 256) {
+      double acc = 0.0;
+      const float um = u[m];
+      for (int i = sub; i < nc; i += 8) {
         const float* s = a.sim + (size_t)rows[i] * MC + c;
-        float e[32];
-        float colsum = 0.f;
-#pragma unroll
-        for (int m = 0; m < 32; ++m) {
-          e[m] = m < M ? expf(s[m * a.C] / 0.05f) : 0.f;
-          colsum += e[m] * u[m];
-        }
+        const float e = m < M ? expf(s[m * a.C] / 0.05f) : 0.f;
+        const float colsum = group32_sum(e * um);
         // v[i] of the previous column step (it == 0: uniform, cancels in the row step)
         const float v = it == 0 ? 1.f : 1.f / colsum;
-#pragma unroll
-        for (int m = 0; m < 32; ++m) acc[m] += (double)(e[m] * v);
+        acc += (double)(e * v);
       }
-      // block reduce acc[m]
-#pragma unroll
-      for (int m = 0; m < 32; ++m) {
-        const double t = c3d_wave_sum_d(acc[m]);
-        if (lane == 0) red[wv * 32 + m] = t;
-      }
+      red[sub * 32 + m] = acc;
       __syncthreads();
       if (tid < 32) {
-        const double t = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k * 32 + tid];
         // row step: u[m] = 1 / (K * sum_i E[i][m] v[i])  (independent of the previous u)
         u[tid] = tid < M ? (float)(1.0 / ((double)M * t)) : 0.f;
       }
       __syncthreads();
     }
     // ---- assignment per labelled pixel
-    for (int i = tid; i < nc; i += 256) {
+    const float um = u[m];
+    for (int i = sub; i < nc; i += 8) {
       const int r = rows[i];
       const float* s = a.sim + (size_t)r * MC + c;
-      float colsum = 0.f;
-      for (int m = 0; m < M; ++m) colsum += expf(s[m * a.C] / 0.05f) * u[m];
-      int best = 0, hot = 0;
-      float bq = -INFINITY, bh = -INFINITY;
-      for (int m = 0; m < M; ++m) {
-        const float qq = expf(s[m * a.C] / 0.05f) * u[m] / colsum;
-        if (qq > bq) {
-          bq = qq;
-          best = m;
-        }
-        const float hh = (qq - logf(a.noise[(size_t)r * M + m])) / 0.5f;
-        if (hh > bh) {
-          bh = hh;
-          hot = m;
-        }
-      }
-      a.target[r] = (float)(best + M * c);
+      const float e = m < M ? expf(s[m * a.C] / 0.05f) * um : 0.f;
+      const float colsum = group32_sum(e);
+      const float qq = m < M ? e / colsum : -INFINITY;
+      const int best = group32_argmax(qq, m);
+      const float hh = m < M ? (qq - logf(a.noise[(size_t)r * M + m])) / 0.5f : -INFINITY;
+      const int hot = group32_argmax(hh, m);
       int pred_r;
       if (a.pred) {
         pred_r = a.pred[r];
@@ -268,33 +312,20 @@ __global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
         // nearest-prototype class of this labelled pixel, computed here instead of for all N
         // pixels: argmax_k LayerNorm_C(max_m sim[r][m][k])   (salsanext_proto.py:506-507, :340)
         const float* row = a.sim + (size_t)r * MC;
-        float mean = 0.f;
-        for (int k = 0; k < a.C; ++k) {
-          float mx = -INFINITY;
-          for (int m = 0; m < M; ++m) mx = fmaxf(mx, row[m * a.C + k]);
-          mean += mx;
-        }
-        mean /= (float)a.C;
-        float var = 0.f;
-        for (int k = 0; k < a.C; ++k) {
-          float mx = -INFINITY;
-          for (int m = 0; m < M; ++m) mx = fmaxf(mx, row[m * a.C + k]);
-          var += (mx - mean) * (mx - mean);
-        }
-        const float rstd = rsqrtf(var / (float)a.C + a.ln_eps);
-        float by = -INFINITY;
-        pred_r = 0;
-        for (int k = 0; k < a.C; ++k) {
-          float mx = -INFINITY;
-          for (int m = 0; m < M; ++m) mx = fmaxf(mx, row[m * a.C + k]);
-          const float y = (mx - mean) * rstd * a.ln_w[k] + a.ln_b[k];
-          if (y > by) {
-            by = y;
-            pred_r = k;
-          }
-        }
+        const int k = m;                    // lane = class
+        float mx = -INFINITY;
+        if (k < a.C)
+          for (int mm = 0; mm < M; ++mm) mx = fmaxf(mx, row[mm * a.C + k]);
+        const float mean = group32_sum(k < a.C ? mx : 0.f) / (float)a.C;
+        const float dv = k < a.C ? mx - mean : 0.f;
+        const float rstd = rsqrtf(group32_sum(dv * dv) / (float)a.C + a.ln_eps);
+        const float y = k < a.C ? dv * rstd * a.ln_w[k] + a.ln_b[k] : -INFINITY;
+        pred_r = group32_argmax(y, k);
       }
-      a.assign[r] = (pred_r == c) ? hot : -1;
+      if (m == 0) {
+        a.target[r] = (float)(best + M * c);
+        a.assign[r] = (pred_r == c) ? hot : -1;
+      }
     }
   }
   // ---- masked reduction f[m][:] = sum feat rows, cnt[m]
@@ -302,15 +333,33 @@ __global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
   if (tid < M) cnt[tid] = 0.f;
   __threadfence_block();
   __syncthreads();
-  for (int i = 0; i < nc; ++i) {
-    const int r = rows[i];
-    const int m = a.assign[r];
-    if (m >= 0) {
-      for (int d = tid; d < D; d += 256) f[m * D + d] += a.feat[(size_t)r * D + d];
-      if (tid == 0) cnt[m] += 1.f;
+  for (int i0 = 0; i0 < nc; i0 += 256) {
+    const int cn = min(256, nc - i0);
+    if (tid < cn) {
+      const int r = rows[i0 + tid];
+      s_r[tid] = r;
+      s_m[tid] = a.assign[r];
     }
+    __syncthreads();
+    for (int d = tid; d < D; d += 256) {
+      for (int ii = 0; ii < cn; ii += 8) {      // 8 feature rows in flight per thread
+        float v[8];
+        int mm[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          mm[q] = ii + q < cn ? s_m[ii + q] : -1;
+          v[q] = mm[q] >= 0 ? a.feat[(size_t)s_r[ii + q] * D + d] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (mm[q] >= 0) f[mm[q] * D + d] += v[q];
+      }
+    }
+    if (tid == 0)
+      for (int ii = 0; ii < cn; ++ii)
+        if (s_m[ii] >= 0) cnt[s_m[ii]] += 1.f;
+    __syncthreads();
   }
-  __syncthreads();
   float tot = 0.f;
   for (int m = 0; m < M; ++m) tot += cnt[m];
   // ---- EMA + final l2 normalisation, one wave per prototype
@@ -357,8 +406,14 @@ extern "C" int c3d_proto_nearest(const float* sim, int64_t n, int M, int C, cons
 }
 
 extern "C" int c3d_group_compact(const int64_t* labels, const uint8_t* keep, int groups, int n, int ncls,
-                                 int32_t* counts, int32_t* idx, c3d_stream stream) {
-  hipLaunchKernelGGL(group_compact_kernel, dim3(ncls, groups), dim3(256), 0, ST, labels, keep, n, ncls, counts, idx);
+                                 int32_t* counts, int32_t* idx, int32_t* seg_scratch, c3d_stream stream) {
+  C3D_REQUIRE(ncls <= 64, "group_compact: at most 64 classes");
+  C3D_REQUIRE(seg_scratch != nullptr, "group_compact: scratch of groups*8*ncls int32 required");
+  int seg_len = ((n + CSEG - 1) / CSEG + 4095) / 4096 * 4096;      // whole 4096-label iterations per segment
+  hipLaunchKernelGGL(compact_hist_kernel, dim3(CSEG, groups), dim3(256), 0, ST, labels, keep, n, ncls, seg_len, seg_scratch);
+  C3D_CHECK_LAUNCH();
+  hipLaunchKernelGGL(group_compact_kernel, dim3(ncls, groups, CSEG), dim3(256), 0, ST, labels, keep, n, ncls, seg_len,
+                     seg_scratch, counts, idx);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -382,7 +437,7 @@ extern "C" int c3d_proto_learn(const float* sim, const float* feat, const int32_
   const int N = B * n;
   LearnArgs a{sim, feat, pred, ln_w, ln_b, ln_eps, counts, idx, rows, B, n, noise, protos, protos_out, target, assign, N, M, C, D,
               ignore_label, momentum};
-  const size_t lds = (256 + 32 + (size_t)M * D + M) * sizeof(float);
+  const size_t lds = (512 + 32 + 512 + (size_t)M * D + M) * sizeof(float);
   hipLaunchKernelGGL(proto_learn_kernel, dim3(C), dim3(256), lds, ST, a);
   C3D_CHECK_LAUNCH();
   return 0;

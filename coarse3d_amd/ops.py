@@ -462,7 +462,8 @@ def group_compact(labels, ncls, keep=None):
     g, n = labels.shape
     counts = torch.empty(g, ncls, device=labels.device, dtype=torch.int32)
     idx = torch.empty(g, ncls, n, device=labels.device, dtype=torch.int32)
-    _call("c3d_group_compact", _dp(labels), _dp(keep), g, n, ncls, _dp(counts), _dp(idx), _stream())
+    seg = torch.empty(g * 8 * ncls, device=labels.device, dtype=torch.int32)
+    _call("c3d_group_compact", _dp(labels), _dp(keep), g, n, ncls, _dp(counts), _dp(idx), _dp(seg), _stream())
     return counts, idx
 
 

@@ -222,9 +222,10 @@ int c3d_proto_nearest(const float* sim, int64_t n, int M, int C, const float* ln
                       const float* ln_b, float eps, float* nearest, int32_t* pred,
                       c3d_stream stream);
 /* Ordered lists: idx[g][c][0..counts[g][c]) = ascending positions i with labels[g][i]==c
- * (labels masked to 0 where keep[g][i]==0, keep may be NULL).  idx is [groups][ncls][n].     */
+ * (labels masked to 0 where keep[g][i]==0, keep may be NULL).  idx is [groups][ncls][n];
+ * seg_scratch = groups*8*ncls int32 (per-segment class histograms).                          */
 int c3d_group_compact(const int64_t* labels, const uint8_t* keep, int groups, int n, int ncls,
-                      int32_t* counts, int32_t* idx, c3d_stream stream);
+                      int32_t* counts, int32_t* idx, int32_t* seg_scratch, c3d_stream stream);
 /* counts[g][c] = number of labels equal to c (c >= 1) in group g                             */
 int c3d_label_hist(const int64_t* labels, int groups, int n, int ncls, int32_t* counts,
                    c3d_stream stream);
