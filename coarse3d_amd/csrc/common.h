@@ -22,35 +22,6 @@ __device__ __forceinline__ bf16x8 c3d_pack_bf16x8(f32x4 a, f32x4 b) {
   return r;
 }
 
-// Exact 3-way bf16 split of 8 fp32 values: x = h + m + l with h = RNE8(x), m = RNE8(x - h),
-// l = RNE8(x - h - m) (both residuals are exact in fp32; 3 x 8 significand bits cover all 24).
-// Six bf16 MFMAs over (h,m,l) x (h,m,l) minus the three smallest cross terms reproduce the fp32
-// product sum to ~2^-23 relative of |a||b| -- the accuracy class of an fp32 FMA chain.
-__device__ __forceinline__ void c3d_split_bf16x3(f32x4 a, f32x4 b, bf16x8& h, bf16x8& m, bf16x8& l) {
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const float x = q < 4 ? a[q] : b[q - 4];
-    const __bf16 hq = (__bf16)x;
-    const float r = x - (float)hq;
-    const __bf16 mq = (__bf16)r;
-    const float r2 = r - (float)mq;
-    h[q] = hq;
-    m[q] = mq;
-    l[q] = (__bf16)r2;
-  }
-}
-// acc += A*B for one 32x32x16 step with split operands (small terms first)
-__device__ __forceinline__ f32x16 c3d_mfma_split(const bf16x8& ah, const bf16x8& am, const bf16x8& al,
-                                                 const bf16x8& bh, const bf16x8& bm, const bf16x8& bl, f32x16 acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-  return acc;
-}
-
 // Bijective XCD-aware remap: consecutive logical tiles land on the same XCD (block b runs on
 // XCD b % 8 on MI355X), so neighbouring tiles that share halos / weights hit one L2.
 __device__ __forceinline__ int c3d_xcd_remap(int bid, int n) {

@@ -35,11 +35,11 @@ struct WgradArgs {
   int ci_slices, co_slices;
 };
 
-// PM 0: fp32 MFMA (default parity path).  PM 1: operands rounded to bf16 (RNE) when read from
-// LDS, v_mfma_f32_32x32x16_bf16 with k = 16 consecutive pixels per step (lane l: channel l&31,
-// pixels 8*(l>>5)..+7), fp32 accumulation -- opt-in mixed precision.  PM 2: exact 3-way bf16
-// split of both operands, six plane products per step (fp32-accurate, see common.h).
-template <int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, int PM>
+// BF = false: fp32 MFMA (default parity path).  BF = true: operands rounded to bf16 (RNE) when
+// read from LDS, v_mfma_f32_32x32x16_bf16 with k = 16 consecutive pixels per step (lane l:
+// channel l&31, pixels 8*(l>>5)..+7), fp32 accumulation -- the opt-in "bf16" mode.  The
+// fp32-accurate "bf16x3" mode keeps the fp32-MFMA weight gradient.
+template <int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool BF>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   constexpr int WK = 4 / (WCI * WCO);
   constexpr int CI = 32 * CI_T * WCI;  // cin slice of the workgroup
@@ -165,12 +165,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
       const int row = wk * RPW + rr;
-      if constexpr (PM != 0) {
+      if constexpr (BF) {
         const float* xr8 = s_x + ((row + HALO) * TWh + HALO + 8 * half) * CI + wci * CI_T * 32 + l31;
         const float* dr8 = s_dz + (row * 32 + 8 * half) * CO + wco * CO_T * 32 + l31;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          bf16x8 bh[CO_T], bm[CO_T], bl[CO_T];
+          bf16x8 bh[CO_T];
 #pragma unroll
           for (int j = 0; j < CO_T; ++j) {
             f32x4 v0, v1;
@@ -179,8 +179,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
               v0[q] = dr8[(16 * s + q) * CO + j * 32];
               v1[q] = dr8[(16 * s + 4 + q) * CO + j * 32];
             }
-            if constexpr (PM == 2) c3d_split_bf16x3(v0, v1, bh[j], bm[j], bl[j]);
-            else bh[j] = c3d_pack_bf16x8(v0, v1);
+            bh[j] = c3d_pack_bf16x8(v0, v1);
           }
 #pragma unroll
           for (int t = 0; t < TMAX; ++t)
@@ -192,18 +191,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
                 v0[q] = xr8[(16 * s + q) * CI + tapoff[t] + i * 32];
                 v1[q] = xr8[(16 * s + 4 + q) * CI + tapoff[t] + i * 32];
               }
-              if constexpr (PM == 2) {
-                bf16x8 ah, am, al;
-                c3d_split_bf16x3(v0, v1, ah, am, al);
+              const bf16x8 ac = c3d_pack_bf16x8(v0, v1);
 #pragma unroll
-                for (int j = 0; j < CO_T; ++j)
-                  acc[t][i][j] = c3d_mfma_split(ah, am, al, bh[j], bm[j], bl[j], acc[t][i][j]);
-              } else {
-                const bf16x8 ac = c3d_pack_bf16x8(v0, v1);
-#pragma unroll
-                for (int j = 0; j < CO_T; ++j)
-                  acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac, bh[j], acc[t][i][j], 0, 0, 0);
-              }
+              for (int j = 0; j < CO_T; ++j)
+                acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac, bh[j], acc[t][i][j], 0, 0, 0);
             }
         }
         continue;
@@ -368,7 +359,7 @@ void plan(const c3d_wgrad_desc* d, WgradArgs& a, WgCfg& c) {
   a.strips = (a.ntiles + a.tiles_per_strip - 1) / a.tiles_per_strip;
 }
 
-template <int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, int PM>
+template <int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool BF>
 int launch_wg(const WgradArgs& a, hipStream_t st) {
   constexpr int WK = 4 / (WCI * WCO);
   constexpr int CI = 32 * CI_T * WCI, CO = 32 * CO_T * WCO;
@@ -377,28 +368,28 @@ int launch_wg(const WgradArgs& a, hipStream_t st) {
   if (red > lds) lds = red;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, PM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   dim3 grid(a.strips * a.ci_slices * a.co_slices);
-  hipLaunchKernelGGL((wgrad_mfma_kernel<TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, PM>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((wgrad_mfma_kernel<TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, BF>), grid, dim3(256), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
-template <int PM>
+template <bool BF>
 int launch_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
   switch (id) {
     //                     TMAX CI_T CO_T WCI WCO TRW HALO
-    case 0: return launch_wg<1, 2, 4, 2, 2, 1, 0, PM>(a, st);
-    case 1: return launch_wg<1, 2, 2, 2, 2, 1, 0, PM>(a, st);
-    case 2: return launch_wg<1, 2, 2, 1, 1, 4, 0, PM>(a, st);
-    case 3: return launch_wg<1, 1, 1, 1, 1, 4, 0, PM>(a, st);
-    case 4: return launch_wg<4, 1, 2, 1, 1, 4, 1, PM>(a, st);
-    case 5: return launch_wg<4, 1, 1, 1, 1, 4, 1, PM>(a, st);
-    case 6: return halo <= 1 ? launch_wg<9, 1, 1, 1, 2, 2, 1, PM>(a, st) : launch_wg<9, 1, 1, 1, 2, 2, 2, PM>(a, st);
-    default: return halo <= 1 ? launch_wg<9, 1, 1, 1, 1, 4, 1, PM>(a, st) : launch_wg<9, 1, 1, 1, 1, 4, 2, PM>(a, st);
+    case 0: return launch_wg<1, 2, 4, 2, 2, 1, 0, BF>(a, st);
+    case 1: return launch_wg<1, 2, 2, 2, 2, 1, 0, BF>(a, st);
+    case 2: return launch_wg<1, 2, 2, 1, 1, 4, 0, BF>(a, st);
+    case 3: return launch_wg<1, 1, 1, 1, 1, 4, 0, BF>(a, st);
+    case 4: return launch_wg<4, 1, 2, 1, 1, 4, 1, BF>(a, st);
+    case 5: return launch_wg<4, 1, 1, 1, 1, 4, 1, BF>(a, st);
+    case 6: return halo <= 1 ? launch_wg<9, 1, 1, 1, 2, 2, 1, BF>(a, st) : launch_wg<9, 1, 1, 1, 2, 2, 2, BF>(a, st);
+    default: return halo <= 1 ? launch_wg<9, 1, 1, 1, 1, 4, 1, BF>(a, st) : launch_wg<9, 1, 1, 1, 1, 4, 2, BF>(a, st);
   }
 }
 
@@ -434,7 +425,7 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   hipStream_t st = (hipStream_t)stream;
   // bf16x3 (mode 2) keeps the fp32-MFMA weight gradient: splitting K = pixel fragments at read
   // time costs more VALU time than the fp32 matrix pipe saves
-  const int rc = d->mfma_bf16 == 1 ? launch_id<1>(c.id, halo, a, st) : launch_id<0>(c.id, halo, a, st);
+  const int rc = d->mfma_bf16 == 1 ? launch_id<true>(c.id, halo, a, st) : launch_id<false>(c.id, halo, a, st);
   if (rc) return rc;
   const size_t total = (size_t)d->ntaps * c.CI * c.CO * a.ci_slices * a.co_slices;
   int blocks = (int)((total + 31) / 32);

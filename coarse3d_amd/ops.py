@@ -224,7 +224,7 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False):
         cfg = "4, 1, 2, 1, 1, 4, 1" if co > 32 else "4, 1, 1, 1, 1, 4, 1"
     else:
         cfg = f"9, 1, 1, 1, {2 if co > 32 else 1}, {2 if co > 32 else 4}, {1 if halo <= 1 else 2}"
-    name = f"wgrad_mfma_kernel<{cfg}, {MFMA_MODE}>"
+    name = f"wgrad_mfma_kernel<{cfg}, {'true' if MFMA_MODE == 1 else 'false'}>"
     d.mfma_bf16 = MFMA_MODE
     with _Timed(name, 2.0 * b * h * w * dw.shape[0] * len(taps) * src.C, (h, w, ci, co, nt, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
