@@ -90,3 +90,269 @@ extern "C" int c3d_confusion_add(const int64_t* pred, const int64_t* label, int6
   C3D_CHECK_LAUNCH();
   return 0;
 }
+
+// ====================================================================== loss head
+// Focal loss on probabilities (pc_processor/loss/focal_softmax.py:30-77) and Lovasz-softmax
+// (pc_processor/loss/lovasz_softmax.py:101-176, classes='present', per_image=False) on the
+// labelled pixels, forward and backward, without the ~40 stock-op launches of the PyTorch path.
+namespace {
+
+// ---- focal: loss_i = -(1-pt)^gamma * log(max(pt,1e-6)) * alpha[t] over pixels with mask != 0
+//      partial[block] = (sum loss_i, count); deterministic two-stage reduction
+__global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict__ prob, int C, int cstride,
+                                                        const int64_t* __restrict__ target, const uint8_t* __restrict__ mask,
+                                                        const float* __restrict__ alpha, float gamma, int64_t n,
+                                                        double* __restrict__ partial) {
+  __shared__ double red[2][4];
+  double s = 0.0, cnt = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if (mask && !mask[i]) continue;
+    const int64_t t = target[i];
+    if (t < 0 || t >= C) continue;
+    const float pt = prob[i * cstride + t];
+    const float l = -powf(1.f - pt, gamma) * logf(fmaxf(pt, 1e-6f)) * alpha[t];
+    s += (double)l;
+    cnt += 1.0;
+  }
+  s = c3d_wave_sum_d(s);
+  cnt = c3d_wave_sum_d(cnt);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wv] = s;
+    red[1][wv] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+// out[0] = sum / count (0 when no pixel is selected: focal_softmax.py:67-73 returns 0 for NaN), out[1] = count
+__global__ void focal_finish_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out) {
+  double s = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 64) {
+    s += partial[2 * i];
+    c += partial[2 * i + 1];
+  }
+  s = c3d_wave_sum_d(s);
+  c = c3d_wave_sum_d(c);
+  if (threadIdx.x == 0) {
+    out[0] = c > 0.0 ? (float)(s / c) : 0.f;
+    out[1] = (float)c;
+  }
+}
+
+// dprob[i][t] += g * d(mean loss)/d pt ;  g = *gscale, count = stats[1]
+__global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict__ prob, int C, int cstride,
+                                                        const int64_t* __restrict__ target, const uint8_t* __restrict__ mask,
+                                                        const float* __restrict__ alpha, float gamma, int64_t n,
+                                                        const float* __restrict__ stats, const float* __restrict__ gscale,
+                                                        float* __restrict__ dprob, int dstride) {
+  const float cnt = stats[1];
+  if (cnt <= 0.f) return;
+  const float g = (gscale ? *gscale : 1.f) / cnt;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if (mask && !mask[i]) continue;
+    const int64_t t = target[i];
+    if (t < 0 || t >= C) continue;
+    const float pt = prob[i * cstride + t];
+    const float om = 1.f - pt;
+    // d/dpt [ -(1-pt)^g * log(clamp(pt)) ] = g (1-pt)^(g-1) log(clamp(pt)) - (1-pt)^g / pt * [pt > 1e-6]
+    const float dl = gamma * powf(om, gamma - 1.f) * logf(fmaxf(pt, 1e-6f)) - (pt > 1e-6f ? powf(om, gamma) / pt : 0.f);
+    dprob[i * dstride + t] += g * dl * alpha[t];
+  }
+}
+
+// ---- Lovasz: one workgroup per class over the P labelled pixels (P <= CAP, LDS-resident)
+template <int CAP>
+__global__ __launch_bounds__(256) void lovasz_class_kernel(const float* __restrict__ prob, int cstride,
+                                                           const int64_t* __restrict__ labels, const int64_t* __restrict__ idx,
+                                                           int P, float* __restrict__ loss_c, float* __restrict__ present,
+                                                           float* __restrict__ grad /* [C][P] */) {
+  extern __shared__ float lsm[];
+  __shared__ float wsum[4];
+  __shared__ double dsum[4];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int npow = 1;
+  while (npow < P) npow <<= 1;                              // <= CAP (checked by the host)
+  float* key = lsm;                                         // [npow] errors, sorted descending
+  unsigned* val = reinterpret_cast<unsigned*>(lsm + npow);  // [npow] 2*p + fg
+  float fgs = 0.f;
+  for (int p = tid; p < npow; p += 256) {
+    float e = -1.f;                                       // padding sorts behind every real error (>= 0)
+    unsigned v = 0;
+    if (p < P) {
+      const int64_t i = idx[p];
+      const unsigned fg = labels[i] == c;
+      e = fabsf((float)fg - prob[i * cstride + c]);
+      v = 2u * (unsigned)p + fg;
+      fgs += (float)fg;
+    }
+    key[p] = e;
+    val[p] = v;
+  }
+  fgs = c3d_wave_sum(fgs);
+  if (lane == 0) wsum[wv] = fgs;
+  __syncthreads();
+  const float gts = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (gts == 0.f) {                                       // class absent: skipped by classes='present'
+    if (tid == 0) {
+      loss_c[c] = 0.f;
+      present[c] = 0.f;
+    }
+    for (int p = tid; p < P; p += 256) grad[(size_t)c * P + p] = 0.f;
+    return;
+  }
+  // bitonic sort, descending by key
+  for (int k = 2; k <= npow; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = tid; i < npow; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool desc = (i & k) == 0;
+          const float a = key[i], b = key[l];
+          if (desc ? (a < b) : (a > b)) {
+            key[i] = b;
+            key[l] = a;
+            const unsigned t = val[i];
+            val[i] = val[l];
+            val[l] = t;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // prefix sums of fg over the sorted order: each thread owns a contiguous run of `per` ranks
+  const int per = (P + 255) / 256;
+  const int r0 = tid * per, r1 = min(P, r0 + per);
+  float run = 0.f;
+  for (int r = r0; r < r1; ++r) run += (float)(val[r] & 1u);
+  float scan = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float v = __shfl_up(scan, o, 64);
+    if (lane >= o) scan += v;
+  }
+  __syncthreads();
+  if (lane == 63) wsum[wv] = scan;
+  __syncthreads();
+  float cum = scan - run;                                 // fg before this thread's run
+  for (int k = 0; k < wv; ++k) cum += wsum[k];
+  // jaccard gradient (lovasz_softmax.py:56-68) + loss + per-pixel gradient
+  float jprev = 0.f;
+  if (r0 > 0 && r0 < P) {                                 // jaccard at rank r0-1
+    const float inter = gts - cum, uni = gts + ((float)r0 - cum);
+    jprev = 1.f - inter / uni;
+  }
+  double acc = 0.0;
+  for (int r = r0; r < r1; ++r) {
+    const unsigned v = val[r];
+    const float fg = (float)(v & 1u);
+    cum += fg;
+    const float inter = gts - cum, uni = gts + ((float)(r + 1) - cum);
+    const float jac = 1.f - inter / uni;
+    const float jd = r == 0 ? jac : jac - jprev;
+    jprev = jac;
+    const float e = key[r];
+    acc += (double)(e * jd);
+    // d|fg - p|/dp = -1 (fg = 1), +1 (fg = 0); 0 where the error is exactly 0 (abs'(0) = 0)
+    const float sgn = e == 0.f ? 0.f : (fg != 0.f ? -1.f : 1.f);
+    grad[(size_t)c * P + (v >> 1)] = jd * sgn;
+  }
+  acc = c3d_wave_sum_d(acc);
+  if (lane == 0) dsum[wv] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    loss_c[c] = (float)(dsum[0] + dsum[1] + dsum[2] + dsum[3]);
+    present[c] = 1.f;
+  }
+}
+
+// out[0] = mean over present classes of loss_c (0 if none), out[1] = number of present classes
+__global__ void lovasz_finish_kernel(const float* __restrict__ loss_c, const float* __restrict__ present, int C,
+                                     float* __restrict__ out) {
+  float s = 0.f, n = 0.f;
+  for (int c = 0; c < C; ++c) {
+    s += loss_c[c] * present[c];
+    n += present[c];
+  }
+  out[0] = n > 0.f ? s / n : 0.f;
+  out[1] = n;
+}
+
+// dprob[idx[p]][c] += g / npresent * grad[c][p]
+__global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict__ grad, const int64_t* __restrict__ idx, int P,
+                                                         int C, const float* __restrict__ stats, const float* __restrict__ gscale,
+                                                         float* __restrict__ dprob, int dstride) {
+  const float np_ = stats[1];
+  if (np_ <= 0.f) return;
+  const float g = (gscale ? *gscale : 1.f) / np_;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)P * C; e += (int64_t)gridDim.x * 256) {
+    const int p = (int)(e / C), c = (int)(e % C);
+    dprob[idx[p] * dstride + c] += g * grad[(size_t)c * P + p];
+  }
+}
+
+}  // namespace
+
+extern "C" int c3d_focal_forward(const float* prob, int C, int cstride, const int64_t* target, const uint8_t* mask,
+                                 const float* alpha, float gamma, int64_t n, double* partial, int nblk, float* out,
+                                 c3d_stream stream) {
+  C3D_REQUIRE(nblk >= 1 && nblk <= 4096, "focal: 1..4096 partial blocks");
+  hipLaunchKernelGGL(focal_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, prob, C, cstride, target, mask, alpha,
+                     gamma, n, partial);
+  C3D_CHECK_LAUNCH();
+  hipLaunchKernelGGL(focal_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nblk, out);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_focal_backward(const float* prob, int C, int cstride, const int64_t* target, const uint8_t* mask,
+                                  const float* alpha, float gamma, int64_t n, const float* stats, const float* gscale,
+                                  float* dprob, int dstride, c3d_stream stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(focal_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, prob, C, cstride, target, mask,
+                     alpha, gamma, n, stats, gscale, dprob, dstride);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_lovasz_max_pixels(void) { return 8192; }
+
+extern "C" int c3d_lovasz_forward(const float* prob, int C, int cstride, const int64_t* labels, const int64_t* idx, int P,
+                                  float* loss_c, float* present, float* grad, float* out, c3d_stream stream) {
+  C3D_REQUIRE(P >= 0 && P <= 8192, "lovasz: at most 8192 labelled pixels on the fused path");
+  C3D_REQUIRE(C >= 1 && C <= 64, "lovasz: 1..64 classes");
+  hipStream_t st = (hipStream_t)stream;
+  if (P == 0) {
+    (void)hipMemsetAsync(loss_c, 0, sizeof(float) * C, st);
+    (void)hipMemsetAsync(present, 0, sizeof(float) * C, st);
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lovasz_class_kernel<8192>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8);
+      attr_set = true;
+    }
+    int npow = 1;
+    while (npow < P) npow <<= 1;
+    hipLaunchKernelGGL(lovasz_class_kernel<8192>, dim3(C), dim3(256), (size_t)npow * 8, st, prob, cstride, labels, idx, P,
+                       loss_c, present, grad);
+    C3D_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(lovasz_finish_kernel, dim3(1), dim3(1), 0, st, loss_c, present, C, out);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_lovasz_backward(const float* grad, const int64_t* idx, int P, int C, const float* stats,
+                                   const float* gscale, float* dprob, int dstride, c3d_stream stream) {
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(lovasz_bwd_kernel, dim3(blocks_for((int64_t)P * C)), dim3(256), 0, (hipStream_t)stream, grad, idx, P, C,
+                     stats, gscale, dprob, dstride);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}

@@ -595,3 +595,59 @@ def unproject_confusion(pred_2d, uy, ux, labels, conf, n_points=None):
     _call("c3d_unproject_confusion", _dp(p), h, w, c, p.stride(1), _dp(uy), _dp(uxp), _dp(labels), n, nv, _dp(conf),
           _dp(out), _stream())
     return out
+
+
+# ---------------------------------------------------------------------------- loss head (N1)
+def _rows(prob_nchw_like):
+    """[B,C,H,W]-shaped probabilities -> ([N, cstride-strided] NHWC tensor, C, cstride): read in
+    place when the memory is channels-last (a view of the backbone's NHWC buffer)."""
+    c = prob_nchw_like.shape[1]
+    p = prob_nchw_like.permute(0, 2, 3, 1)
+    if not p.is_contiguous():
+        p = p.contiguous()
+    return p, c, c
+
+
+def focal_forward(prob, target, mask, alpha, gamma):
+    """prob [B,C,H,W]-shaped, target int64 [B,H,W], mask uint8/bool [B,H,W] or None ->
+    stats float32 [2] = (mean focal loss, selected pixels)."""
+    p, c, cs = _rows(prob)
+    n = p.numel() // c
+    nblk = max(1, min(1024, (n + 2047) // 2048))
+    part = torch.empty(2 * nblk, device=p.device, dtype=torch.float64)
+    out = torch.empty(2, device=p.device, dtype=torch.float32)
+    _call("c3d_focal_forward", _dp(p), c, cs, _dp(target), _dp(mask), _dp(alpha), float(gamma), n, _dp(part), nblk,
+          _dp(out), _stream())
+    return out
+
+
+def focal_backward(prob, target, mask, alpha, gamma, stats, gscale, dprob):
+    """dprob (NHWC [B,H,W,C], accumulated in place) += gscale * d(mean focal)/d prob."""
+    p, c, cs = _rows(prob)
+    _call("c3d_focal_backward", _dp(p), c, cs, _dp(target), _dp(mask), _dp(alpha), float(gamma), p.numel() // c,
+          _dp(stats), _dp(gscale), _dp(dprob), dprob.shape[-1], _stream())
+    return dprob
+
+
+def lovasz_max_pixels():
+    return L.lib().c3d_lovasz_max_pixels()
+
+
+def lovasz_forward(prob, labels, idx):
+    """idx int64 [P]: flat positions of the labelled pixels.  Returns (stats [2] = (loss, present
+    classes), grad [C,P])."""
+    p, c, cs = _rows(prob)
+    n_idx = idx.numel()
+    loss_c = torch.empty(c, device=p.device, dtype=torch.float32)
+    present = torch.empty(c, device=p.device, dtype=torch.float32)
+    grad = torch.empty(c, max(n_idx, 1), device=p.device, dtype=torch.float32)
+    out = torch.empty(2, device=p.device, dtype=torch.float32)
+    _call("c3d_lovasz_forward", _dp(p), c, cs, _dp(labels), _dp(idx), n_idx, _dp(loss_c), _dp(present), _dp(grad),
+          _dp(out), _stream())
+    return out, grad
+
+
+def lovasz_backward(grad, idx, stats, gscale, dprob):
+    _call("c3d_lovasz_backward", _dp(grad), _dp(idx), idx.numel(), grad.shape[0], _dp(stats), _dp(gscale), _dp(dprob),
+          dprob.shape[-1], _stream())
+    return dprob

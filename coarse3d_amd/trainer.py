@@ -9,7 +9,7 @@ Config keys follow tasks/weak_segmentation/option.py:43-49 / config_semantic_kit
 import numpy as np
 import torch
 
-from . import contrast, ops
+from . import contrast, loss_head, ops
 from .pc_processor.loss import ContrastMEMLoss, FocalSoftmaxLoss, Lovasz_softmax
 from .pc_processor.loss.lovasz_softmax import valid_indices
 
@@ -53,6 +53,9 @@ class TrainStep:
         # (e.g. delivered by a prefetcher on its own copy stream and synchronised) -- the side
         # stream may then read them without waiting for the main stream.
         self.inputs_resident = inputs_resident
+        # focal + Lovasz on the fused HIP loss head when the labelled pixels fit its LDS sort
+        # (weak labels: always); otherwise the sync-free PyTorch-op restatements
+        self.fused_loss_head = True
         self.pl_noise = None     # test hook: Exp(1) noise [B, C, HW] for the pseudo-label selection
 
     def step(self, x, train_label, eval_label, epoch=0):
@@ -82,12 +85,25 @@ class TrainStep:
         pred = out["pred_2d"]
         total = pred.new_zeros(())
         res = {}
-        if self.w_ce > 0:
-            res["ce"] = self.focal(pred, train_label, mask=wss_mask)
-            total = total + self.w_ce * res["ce"]
-        if self.w_lov > 0:
-            res["lov"] = self.lovasz(pred, train_label, valid=lov_valid)
-            total = total + self.w_lov * res["lov"]
+        fused = (self.fused_loss_head and lov_valid is not None and self.ignore_cls == 0
+                 and loss_head.fused_available(lov_valid.numel()))
+        if fused:      # focal + Lovasz forward/backward on the HIP loss-head kernels
+            if self.focal.alpha.device != pred.device:       # once: a per-step H2D copy would drain the stream
+                self.focal.alpha = self.focal.alpha.to(pred.device)
+            ce, lov = loss_head.loss_head(pred, train_label, wss_mask, self.focal.alpha,
+                                          self.focal.gamma, lov_valid, self.w_ce > 0, self.w_lov > 0)
+            if self.w_ce > 0:
+                res["ce"] = ce
+                total = total + self.w_ce * ce
+            res["lov"] = lov
+            total = total + self.w_lov * lov
+        else:
+            if self.w_ce > 0:
+                res["ce"] = self.focal(pred, train_label, mask=wss_mask)
+                total = total + self.w_ce * res["ce"]
+            if self.w_lov > 0:
+                res["lov"] = self.lovasz(pred, train_label, valid=lov_valid)
+                total = total + self.w_lov * res["lov"]
         if self.w_con > 0 and return_feat:
             if self.entropy_selection:
                 with torch.no_grad():

@@ -293,6 +293,33 @@ int c3d_unproject_confusion(const float* prob, int H, int W, int C, int cstride,
 int c3d_confusion_add(const int64_t* pred, const int64_t* label, int64_t n, int C, int64_t* conf,
                       c3d_stream stream);
 
+/* ------------------------------------------------------------------ loss head   */
+
+/* FocalSoftmaxLoss on probabilities (pc_processor/loss/focal_softmax.py:30-77, softmax=False):
+ * loss_i = -(1-pt)^gamma * log(max(pt,1e-6)) * alpha[target_i] over the pixels with mask != 0
+ * (mask NULL = all), out[0] = mean (0 when nothing is selected, as the reference's NaN guard),
+ * out[1] = number of selected pixels.  partial = 2*nblk doubles of scratch.                     */
+int c3d_focal_forward(const float* prob, int C, int cstride, const int64_t* target,
+                      const uint8_t* mask, const float* alpha, float gamma, int64_t n,
+                      double* partial, int nblk, float* out, c3d_stream stream);
+/* dprob[i][target_i] += (*gscale) * d out[0] / d prob[i][target_i]   (stats = out of forward)  */
+int c3d_focal_backward(const float* prob, int C, int cstride, const int64_t* target,
+                       const uint8_t* mask, const float* alpha, float gamma, int64_t n,
+                       const float* stats, const float* gscale, float* dprob, int dstride,
+                       c3d_stream stream);
+/* Lovasz_softmax(classes='present', per_image=False) on the P labelled pixels idx[0..P)
+ * (pc_processor/loss/lovasz_softmax.py:56-68,101-176): one workgroup per class sorts the errors
+ * |fg - p| in LDS (P <= c3d_lovasz_max_pixels()), forms the Jaccard gradient and the class loss;
+ * loss_c/present [C], grad [C][P] = d loss_c / d prob[idx[p]][c], out[0] = mean over the present
+ * classes, out[1] = their number.                                                              */
+int c3d_lovasz_max_pixels(void);
+int c3d_lovasz_forward(const float* prob, int C, int cstride, const int64_t* labels,
+                       const int64_t* idx, int P, float* loss_c, float* present, float* grad,
+                       float* out, c3d_stream stream);
+/* dprob[idx[p]][c] += (*gscale) / out[1] * grad[c][p]                                          */
+int c3d_lovasz_backward(const float* grad, const int64_t* idx, int P, int C, const float* stats,
+                        const float* gscale, float* dprob, int dstride, c3d_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

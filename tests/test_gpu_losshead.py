@@ -1,0 +1,72 @@
+"""SURVEY 8f N1, loss head: fused focal + Lovasz forward/backward (csrc/metric_ops.hip,
+coarse3d_amd/loss_head.py) against the golden vectors of the reference FocalSoftmaxLoss /
+Lovasz_softmax (tests/golden/losses.npz) and against the CPU oracle.  fp32: 1e-5 of the value /
+of max|grad| (the reductions run in a different order; everything else is the same arithmetic)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import coarse3d_oracle as oc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _run(prob, labels, alpha, gamma, channels_last):
+    from coarse3d_amd import loss_head
+    p = prob.to(DEV)
+    if channels_last:                      # a [B,C,H,W] view of an NHWC buffer, as the backbone returns it
+        p = p.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    p.requires_grad_(True)
+    lab = labels.to(DEV)
+    idx = torch.nonzero(lab.reshape(-1) != 0).reshape(-1)
+    ce, lov = loss_head.loss_head(p, lab, lab > 0, alpha.to(DEV), gamma, idx)
+    gf, = torch.autograd.grad(ce, p, retain_graph=True)
+    gl, = torch.autograd.grad(lov, p)
+    return ce.detach().cpu(), lov.detach().cpu(), gf.cpu(), gl.cpu()
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_loss_head_vs_reference_golden(channels_last):
+    d = np.load(os.path.join(GOLD, "losses.npz"))
+    prob, tr, alpha = torch.from_numpy(d["prob"]), torch.from_numpy(d["train_label"]), torch.from_numpy(d["alpha"])
+    ce, lov, gf, gl = _run(prob, tr, alpha, 2, channels_last)
+    assert abs(float(ce) - float(d["focal"])) < 1e-5 * abs(float(d["focal"]))
+    assert abs(float(lov) - float(d["lovasz"])) < 1e-5 * abs(float(d["lovasz"]))
+    gfr, glr = torch.from_numpy(d["grad_focal"]), torch.from_numpy(d["grad_lovasz"])
+    assert float((gf - gfr).abs().max()) < 1e-5 * float(gfr.abs().max())
+    assert float((gl - glr).abs().max()) < 1e-5 * float(glr.abs().max())
+
+
+@pytest.mark.parametrize("b,ncls,h,w,rate,seed", [(2, 20, 32, 256, 0.2, 1), (1, 14, 16, 64, 0.9, 2), (2, 20, 8, 64, 0.0, 3)])
+def test_loss_head_vs_oracle(b, ncls, h, w, rate, seed):
+    """Up to ~3300 labelled pixels (several bitonic sizes), absent classes, and the empty case
+    (no labelled pixel: both losses 0, zero gradients, no NaN -- focal_softmax.py:67-73)."""
+    g = torch.Generator().manual_seed(seed)
+    prob = torch.softmax(torch.randn(b, ncls, h, w, generator=g) * 2, 1)
+    lab = torch.randint(0, ncls, (b, h, w), generator=g) * (torch.rand(b, h, w, generator=g) < rate)
+    lab[lab == 3] = 0                                   # class 3 absent
+    alpha = torch.rand(ncls, generator=g) * 0.8 + 0.2
+    alpha[0] = 0
+    ce, lov, gf, gl = _run(prob, lab, alpha, 2, True)
+    pr = prob.clone().requires_grad_(True)
+    ce_r = oc.focal_loss(pr, lab, lab > 0, alpha, 2)
+    lov_r = oc.lovasz_loss(pr, lab)
+    if rate == 0.0:
+        assert float(ce) == 0.0 and float(lov) == 0.0
+        assert float(gf.abs().max()) == 0.0 and float(gl.abs().max()) == 0.0
+        return
+    gfr, = torch.autograd.grad(ce_r, pr, retain_graph=True)
+    glr, = torch.autograd.grad(lov_r, pr)
+    assert abs(float(ce) - float(ce_r.detach())) < 1e-5 * abs(float(ce_r.detach()))
+    assert abs(float(lov) - float(lov_r.detach())) < 1e-5 * abs(float(lov_r.detach()))
+    assert float((gf - gfr).abs().max()) < 1e-5 * float(gfr.abs().max())
+    # Lovasz gradients: ties in the sorted errors may hand two equal-error pixels each other's
+    # Jaccard increment (torch.sort is not stable either); compare the sorted gradient values
+    tol = 1e-5 * float(glr.abs().max())
+    same = float((gl - glr).abs().max()) < tol
+    same_up_to_ties = float((gl.flatten().sort()[0] - glr.flatten().sort()[0]).abs().max()) < tol
+    assert same or same_up_to_ties
