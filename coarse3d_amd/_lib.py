@@ -58,7 +58,7 @@ def lib():
     return _lib
 
 
-_CTYPES = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "float": C.c_float,
+_CTYPES = {"int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "float": C.c_float,
            "double": C.c_double, "c3d_stream": C.c_void_p, "void": None}
 
 

@@ -4,6 +4,7 @@ PyTorch is used for device memory and streams only; every function here launches
 hand-written HIP kernels through ctypes and raises if the library refuses the call."""
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -651,3 +652,44 @@ def lovasz_backward(grad, idx, stats, gscale, dprob):
     _call("c3d_lovasz_backward", _dp(grad), _dp(idx), idx.numel(), grad.shape[0], _dp(stats), _dp(gscale), _dp(dprob),
           dprob.shape[-1], _stream())
     return dprob
+
+
+# ---------------------------------------------------------------------------- scan -> range image (N2)
+def augment_points(pc, sx, sy, trans, rot):
+    """In place: flip (sx, sy = +-1), translation (float32), rotation (3x3 float64, points x rot^T)."""
+    assert pc.is_cuda and pc.dtype == torch.float32 and pc.dim() == 2 and pc.is_contiguous()
+    r = torch.as_tensor(np.asarray(rot, dtype=np.float64).reshape(9)).to(pc.device)
+    _call("c3d_augment_points", _dp(pc), pc.shape[0], pc.shape[1], float(sx), float(sy), float(np.float32(trans[0])),
+          float(np.float32(trans[1])), float(np.float32(trans[2])), _dp(r), _stream())
+    return pc
+
+
+def range_project(pc, depth, fov, w, h, want_image=True, sem=None, weak=None):
+    """pc CUDA float32 [n, c]; fov = (|fov_left|, fov_hori, |fov_down|, fov_vert) as float32 values.
+    Returns a dict of CUDA tensors (see c3d_range_project)."""
+    assert pc.is_cuda and pc.dtype == torch.float32 and pc.dim() == 2 and pc.is_contiguous()
+    n, c = pc.shape
+    dev = pc.device
+    out = {"ux": torch.empty(n, device=dev, dtype=torch.int32), "uy": torch.empty(n, device=dev, dtype=torch.int32),
+           "udepth": torch.empty(n, device=dev, dtype=torch.float32),
+           "proj_idx": torch.empty(h, w, device=dev, dtype=torch.int32),
+           "proj_mask": torch.empty(h, w, device=dev, dtype=torch.int32)}
+    zbuf = torch.empty(h * w, device=dev, dtype=torch.int64)
+    if want_image:
+        out["proj_pc"] = torch.empty(h, w, c, device=dev, dtype=torch.float32)
+        out["proj_range"] = torch.empty(h, w, device=dev, dtype=torch.float32)
+    if sem is not None:
+        sem = sem.to(dev, torch.long).contiguous()
+        weak = weak.to(dev, torch.long).contiguous()
+        assert sem.numel() == n and weak.numel() == n
+        out["feat5"] = torch.empty(5, h, w, device=dev, dtype=torch.float32)
+        out["eval_label"] = torch.empty(h, w, device=dev, dtype=torch.float32)
+        out["train_label"] = torch.empty(h, w, device=dev, dtype=torch.float32)
+    if depth is not None:
+        depth = depth.to(dev, torch.float32).contiguous()
+        assert depth.numel() == n
+    _call("c3d_range_project", _dp(pc), n, c, c, _dp(depth), fov[0], fov[1], fov[2], fov[3], w, h, _dp(out["ux"]),
+          _dp(out["uy"]), _dp(out["udepth"]), _dp(zbuf), _dp(out.get("proj_pc")), _dp(out.get("proj_range")),
+          _dp(out["proj_idx"]), _dp(out["proj_mask"]), _dp(sem), _dp(weak), _dp(out.get("feat5")),
+          _dp(out.get("eval_label")), _dp(out.get("train_label")), _stream())
+    return out

@@ -320,6 +320,29 @@ int c3d_lovasz_forward(const float* prob, int C, int cstride, const int64_t* lab
 int c3d_lovasz_backward(const float* grad, const int64_t* idx, int P, int C, const float* stats,
                         const float* gscale, float* dprob, int dstride, c3d_stream stream);
 
+/* ------------------------------------------------------------------ scan -> range image
+ * pc_processor/dataset/preprocess/projection.py:43-115, augmentor.py:150-230,
+ * pc_processor/dataset/semantic_kitti/wss_sem_kitti_loader.py:113-170                          */
+
+/* In place on pc [n][stride] (x, y, z first): x = sx*x + tx, y = sy*y + ty, z = z + tz (float32),
+ * then xyz = xyz (as float64) x rot^T rounded to float32; rot_dev = 9 doubles (row major) on the
+ * device.  Identity rotation / zero translation / sx = sy = 1 reproduce the input bits.          */
+int c3d_augment_points(float* pc, int n, int stride, float sx, float sy, float tx, float ty,
+                       float tz, const double* rot_dev, c3d_stream stream);
+/* RangeProjection.doProjection: per point depth (or `depth` [n] if not NULL), pixel coordinates
+ * ux/uy [n] and udepth [n] (= cached_data), closest point per pixel through zbuf (H*W uint64 of
+ * scratch).  Any of the image outputs may be NULL: proj_pc [H][W][cols] (-1 where empty),
+ * proj_range [H][W], proj_idx [H][W] (-1), proj_mask [H][W] = (proj_idx > 0); and the loader
+ * tensors of wss_sem_kitti_loader.py: feat5 [5][H][W] = (range, x, y, z, intensity with -1 -> 0),
+ * eval_label / train_label [H][W] float32 = sem / weak label of the winning point (0 if empty).
+ * fov_*: |fov_left|, fov_hori, |fov_down|, fov_vert in radians, as float32.                      */
+int c3d_range_project(const float* pc, int n, int stride, int cols, const float* depth,
+                      float fov_left_abs, float fov_hori, float fov_down_abs, float fov_vert,
+                      int W, int H, int32_t* ux, int32_t* uy, float* udepth, uint64_t* zbuf,
+                      float* proj_pc, float* proj_range, int32_t* proj_idx, int32_t* proj_mask,
+                      const int64_t* sem, const int64_t* weak, float* feat5, float* eval_label,
+                      float* train_label, c3d_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

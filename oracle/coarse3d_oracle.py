@@ -581,6 +581,74 @@ def iou_stats(conf, ignore):
     return out
 
 
+# --------------------------------------------------------------------------------------
+# scan -> range image
+# --------------------------------------------------------------------------------------
+def augment_points(pc, flip_x, flip_y, trans, rot_deg):
+    """augmentor.py:150-174 on a float32 [n, c] array (returns a new array): sign flips, float32
+    translation, then xyz (as float64) times the transposed 'zyx' Euler matrix, cast to float32."""
+    import numpy as np
+    from scipy.spatial.transform import Rotation
+    out = np.array(pc, dtype=np.float32, copy=True)
+    if flip_x:
+        out[:, 0] = -out[:, 0]
+    if flip_y:
+        out[:, 1] = -out[:, 1]
+    for k in range(3):
+        out[:, k] = out[:, k] + np.float32(trans[k])
+    roll, pitch, yaw = rot_deg
+    m = Rotation.from_euler("zyx", [yaw, pitch, roll], degrees=True).as_matrix()
+    out[:, :3] = out[:, :3].astype(np.float64) @ m.T
+    return out
+
+
+def range_projection(pc, fov_up, fov_down, fov_left, fov_right, proj_w, proj_h, depth=None):
+    """projection.py:43-115 restated on numpy float32: pixel of every point, closest point per
+    pixel (points visited by decreasing depth, later writes win).  Returns dict with proj_pc
+    [H,W,c], proj_range, proj_idx, proj_mask, ux, uy, udepth."""
+    import numpy as np
+    pc = np.asarray(pc, dtype=np.float32)
+    up, down = fov_up / 180.0 * np.pi, fov_down / 180.0 * np.pi
+    left, right = fov_left / 180.0 * np.pi, fov_right / 180.0 * np.pi
+    vert, hori = abs(up) + abs(down), abs(left) + abs(right)
+    if depth is None:
+        depth = np.sqrt((pc[:, 0] * pc[:, 0] + pc[:, 1] * pc[:, 1]) + pc[:, 2] * pc[:, 2])
+    depth = np.asarray(depth, dtype=np.float32)
+    yaw = -np.arctan2(pc[:, 1], pc[:, 0])
+    pitch = np.arcsin(pc[:, 2] / depth)
+    fx = (yaw + np.float32(abs(left))) / np.float32(hori) * np.float32(proj_w)
+    fy = (np.float32(1.0) - (pitch + np.float32(abs(down))) / np.float32(vert)) * np.float32(proj_h)
+    ux = np.clip(np.floor(fx), 0, proj_w - 1).astype(np.int32)
+    uy = np.clip(np.floor(fy), 0, proj_h - 1).astype(np.int32)
+    # closest point per pixel; equal depths: the smallest index (the reference's argsort is unstable there)
+    order = np.lexsort((np.arange(len(depth)), depth))[::-1]
+    proj_idx = np.full((proj_h, proj_w), -1, dtype=np.int32)
+    proj_idx[uy[order], ux[order]] = order.astype(np.int32)
+    hit = proj_idx >= 0
+    proj_range = np.full((proj_h, proj_w), -1, dtype=np.float32)
+    proj_range[hit] = depth[proj_idx[hit]]
+    proj_pc = np.full((proj_h, proj_w, pc.shape[1]), -1, dtype=np.float32)
+    proj_pc[hit] = pc[proj_idx[hit]]
+    return dict(proj_pc=proj_pc, proj_range=proj_range, proj_idx=proj_idx, proj_mask=(proj_idx > 0).astype(np.int32),
+                ux=ux, uy=uy, udepth=depth)
+
+
+def loader_tensors(proj, sem_label, weak_label):
+    """wss_sem_kitti_loader.py:121-131,147-164: label images from the winning point of each pixel
+    (0 where empty) and the 5-channel input (range, x, y, z, intensity with -1 -> 0)."""
+    import numpy as np
+    idx = proj["proj_idx"]
+    hit = idx > -1
+    ev = np.zeros(idx.shape, dtype=np.float32)
+    tr = np.zeros(idx.shape, dtype=np.float32)
+    ev[hit] = sem_label[idx[hit]]
+    tr[hit] = weak_label[idx[hit]]
+    inten = proj["proj_pc"][..., 3]
+    feat = np.concatenate([proj["proj_range"][None], proj["proj_pc"][..., :3].transpose(2, 0, 1),
+                           ((inten != -1).astype(np.float32) * inten)[None]], 0)
+    return dict(feature=feat, eval_label=ev, train_label=tr)
+
+
 def normalise_input(x, eval_label, mean, std):
     m = (eval_label > 0).unsqueeze(1).to(x.dtype)
     return (x - mean[None, :, None, None]) / std[None, :, None, None] * m

@@ -294,6 +294,64 @@ def gold_metrics():
     npz("metrics.npz", **arrs)
 
 
+def synthetic_scan(seed, n):
+    """LiDAR-like scan: points on rays inside (and slightly outside) a 3/-25 degree field of view."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    yaw = g.uniform(-np.pi, np.pi, n)
+    pitch = np.deg2rad(g.uniform(-27.0, 4.0, n))
+    rng = g.uniform(2.0, 80.0, n) ** 1.0
+    pc = np.stack([rng * np.cos(pitch) * np.cos(yaw), rng * np.cos(pitch) * np.sin(yaw), rng * np.sin(pitch),
+                   g.uniform(0, 1, n)], 1).astype(np.float32)
+    pc[: n // 50] = pc[n // 50: 2 * (n // 50)]          # exact duplicates: equal depth, same pixel
+    sem = g.integers(0, 20, n)
+    weak = sem * (g.random(n) < 0.01)
+    return pc, sem, weak
+
+
+def gold_projection():
+    """The reference RangeProjection / Augmentor (loaded by file: their package __init__ pulls in
+    the dataset dependencies) on a synthetic scan, plus the loader tensors exactly as
+    wss_sem_kitti_loader.py:113-164 derives them."""
+    import importlib.util
+    import random
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    proj_m = load("_ref_projection", "/root/reference/pc_processor/dataset/preprocess/projection.py")
+    aug_m = load("_ref_augmentor", "/root/reference/pc_processor/dataset/preprocess/augmentor.py")
+    pc, sem, weak = synthetic_scan(5, 12000)
+    arrs = {"pc": pc, "sem": sem, "weak": weak}
+    # augmentation: seeded host draws, then the reference transforms
+    params = aug_m.AugmentParams()
+    params.setFlipProb(0.5, 0.5)
+    params.setTranslationParams(1.0, -5, 5, 1.0, -3, 3, 1.0, -1, 0)
+    params.setRotationParams(1.0, -5, 5, 1.0, -5, 5, 1.0, -180, 180)
+    random.seed(11)
+    aug = aug_m.Augmentor(params).doAugmentation(pc.copy())
+    arrs["aug"] = aug
+    for tag, src, w, h in (("raw", pc, 256, 32), ("aug", aug, 2048, 64)):
+        rp = proj_m.RangeProjection(fov_up=3, fov_down=-25, fov_left=-180, fov_right=180, proj_w=w, proj_h=h)
+        proj_pc, proj_range, proj_idx, proj_mask = rp.doProjection(src.copy())
+        arrs.update({f"{tag}/proj_pc": proj_pc, f"{tag}/proj_range": proj_range, f"{tag}/proj_idx": proj_idx,
+                     f"{tag}/proj_mask": proj_mask, f"{tag}/ux": rp.cached_data["uproj_x_idx"],
+                     f"{tag}/uy": rp.cached_data["uproj_y_idx"], f"{tag}/udepth": rp.cached_data["uproj_depth"]})
+        ev = np.zeros(proj_idx.shape, dtype=np.float32)
+        ev[proj_idx > -1] = sem[proj_idx[proj_idx > -1]]
+        tr = np.zeros(proj_idx.shape, dtype=np.float32)
+        tr[proj_idx > -1] = weak[proj_idx[proj_idx > -1]]
+        inten = torch.from_numpy(proj_pc[..., 3])
+        feat = torch.cat([torch.from_numpy(proj_range).unsqueeze(0), torch.from_numpy(proj_pc[..., :3]).permute(2, 0, 1),
+                          (inten.ne(-1).float() * inten).unsqueeze(0)], 0)
+        arrs.update({f"{tag}/eval_label": ev, f"{tag}/train_label": tr, f"{tag}/feature": feat})
+        if tag == "aug":     # full KITTI width: keep the index-level outputs only (the images follow from them)
+            for k in ("proj_pc", "proj_range", "feature", "udepth"):
+                del arrs[f"{tag}/{k}"]
+    npz("projection.npz", **arrs)
+
+
 # ----------------------------------------------------------------------------- full step
 def gold_step():
     """One optimisation step of the reference modules, trainer.py:621-704 order, with
@@ -375,4 +433,5 @@ if __name__ == "__main__":
     gold_pl_select()
     gold_losses()
     gold_metrics()
+    gold_projection()
     gold_step()

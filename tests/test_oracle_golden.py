@@ -194,3 +194,43 @@ def test_metrics_argmax_unproject_confusion():
         for name in ("iou", "acc", "recall"):
             assert abs(float(st[name][0]) - float(d[f"{tag}/{name}_mean"])) < 1e-12
             assert float((st[name][1] - torch.from_numpy(d[f"{tag}/{name}"])).abs().max()) < 1e-12
+
+
+def test_projection_and_augmentation_vs_reference():
+    """N2: oracle restatement of RangeProjection.doProjection / Augmentor vs the reference run on a
+    synthetic scan.  Pixel indices and the winning point per pixel are integers: exact (both sides
+    are numpy on the same machine); the scan contains exact duplicates, whose winner the reference
+    leaves to an unstable argsort -- those pixels are compared through the winner's depth."""
+    d = np.load(os.path.join(GOLD, "projection.npz"))
+    pc, sem, weak = d["pc"], d["sem"], d["weak"]
+    import random
+    # replay the reference's draw order (augmentor.py:182-228) for the parameters of make_golden.py
+    random.seed(11)
+    flip_x = random.uniform(0, 1) < 0.5
+    flip_y = random.uniform(0, 1) < 0.5
+    trans = []
+    for lo, hi in ((-5, 5), (-3, 3), (-1, 0)):
+        random.uniform(0, 1)
+        trans.append(random.uniform(lo, hi))
+    rot = []
+    for lo, hi in ((-5, 5), (-5, 5), (-180, 180)):
+        random.uniform(0, 1)
+        rot.append(random.uniform(lo, hi))
+    aug = oc.augment_points(pc, flip_x, flip_y, trans, rot)
+    assert np.array_equal(aug, d["aug"])
+    for tag, src, w, h in (("raw", pc, 256, 32), ("aug", aug, 2048, 64)):
+        pr = oc.range_projection(src, 3, -25, -180, 180, w, h)
+        assert np.array_equal(pr["ux"], d[f"{tag}/ux"]) and np.array_equal(pr["uy"], d[f"{tag}/uy"])
+        gi = d[f"{tag}/proj_idx"]
+        assert np.array_equal(pr["proj_idx"] >= 0, gi >= 0)
+        hit = gi >= 0
+        assert np.array_equal(pr["udepth"][pr["proj_idx"][hit]], pr["udepth"][gi[hit]])     # same depth wins
+        assert (pr["proj_idx"][hit] != gi[hit]).mean() < 0.02                               # only among duplicates
+        lt = oc.loader_tensors(pr, sem, weak)
+        same = pr["proj_idx"] == gi
+        assert np.array_equal(lt["eval_label"][same], d[f"{tag}/eval_label"][same])
+        assert np.array_equal(lt["train_label"][same], d[f"{tag}/train_label"][same])
+        if tag == "raw":
+            assert np.array_equal(pr["proj_range"], d["raw/proj_range"])
+            assert np.array_equal(pr["proj_pc"][same], d["raw/proj_pc"][same])
+            assert np.array_equal(lt["feature"][:, same], d["raw/feature"][:, same])
