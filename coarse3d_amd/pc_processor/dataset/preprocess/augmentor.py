@@ -6,8 +6,6 @@ draws the same flips / offsets / angles); the flip + translation + rotation they
 applied to the CUDA point tensor by ONE kernel."""
 import random
 
-import numpy as np
-import torch
 from scipy.spatial.transform import Rotation as R
 
 from .... import ops

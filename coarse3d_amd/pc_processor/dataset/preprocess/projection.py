@@ -6,7 +6,6 @@ un-projection indices are cached in ``cached_data`` exactly as the reference cac
 ``project_scan`` additionally builds the tensors the weak-label loaders hand to the trainer
 (pc_processor/dataset/semantic_kitti/wss_sem_kitti_loader.py:113-170) in the same launch."""
 import numpy as np
-import torch
 
 from .... import ops
 

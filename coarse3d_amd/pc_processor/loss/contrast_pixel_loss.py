@@ -1,7 +1,6 @@
 """ContrastMEMLoss with the reference constructor / forward signature
 (reference pc_processor/loss/contrast_pixel_loss.py:8-75); the work happens in the HIP kernels
 behind ``coarse3d_amd.contrast.contrast_mem_loss``."""
-import torch
 import torch.nn as nn
 
 from ... import contrast

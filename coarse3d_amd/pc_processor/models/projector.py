@@ -3,7 +3,6 @@
 conv1x1(C->C) -> BatchNorm -> LeakyReLU -> conv1x1(C->proj_dim); state_dict keys
 ``proj.0.*, proj.1.*, proj.3.*``.  Inside SalsaNextProto the arithmetic runs in the fused HIP
 backbone; called stand-alone this module runs the same HIP kernels on its own input."""
-import torch
 import torch.nn as nn
 
 from ... import ops

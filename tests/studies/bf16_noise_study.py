@@ -5,7 +5,7 @@ Result (2x64x512, 2 % labels, seed 1): class probabilities move 3.6e-3 on averag
 figures the HIP bf16-operand mode shows (tests/test_gpu_configs.py), i.e. the decorrelation is a
 property of the network at initialisation, not of the kernels.
 Run from the repo root: python tests/studies/bf16_noise_study.py"""
-import sys, torch, numpy as np
+import sys, torch
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))

@@ -1,7 +1,6 @@
 """Data-parallel exchange semantics on CPU with gloo, world_size 2."""
 import os
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

@@ -4,7 +4,6 @@
   configs[3] nuScenes      32x1024, C=17            (2x64 bottleneck -> TR=2 tile path)
   configs[4] SemanticPOSS  40x1800 (+8 pad), C=14   (W=1808: partial 32-wide tiles)
 plus size-independent properties of a full step at the benchmark size."""
-import numpy as np
 import pytest
 import torch
 

@@ -1,6 +1,5 @@
 """conv / wgrad MFMA engines vs plain PyTorch fp32 (F.conv2d on CPU).  Tolerance 1e-4 of
 max|ref| (fp32 MFMA == fmaf chain; only the summation order differs)."""
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F

@@ -1,6 +1,5 @@
 """Kernel-level parity of the BatchNorm / glue HIP ops against plain PyTorch fp32 on CPU
 (the same ops the oracle is built from).  Tolerance: 1e-4 of max|ref| unless stated."""
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmarks of the MFMA engines at the BASELINE shapes (run on the GPU box)."""
-import sys, os, json, time
+import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from coarse3d_amd import ops

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Register / scratch / occupancy of every kernel in a .hip file (compile-time remark parse).
 usage: kernel_resources.py coarse3d_amd/csrc/conv_mfma.hip"""
-import re, subprocess, sys, os
+import re, subprocess, sys
 src = sys.argv[1]
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
        "-fno-fast-math", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
