@@ -180,9 +180,9 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
       k2 = *reinterpret_cast<const f32x4*>(p.k2 + c);
       k3 = *reinterpret_cast<const f32x4*>(p.k3 + c);
     }
-    for (int i = p0 + pl; i < p1; i += PL) {
-      f32x4 dy = *reinterpret_cast<const f32x4*>(p.dy + (size_t)i * p.dy_cs + c);
-      const f32x4 a = *reinterpret_cast<const f32x4*>(p.a + (size_t)i * p.a_cs + c);
+    // UN pixels per trip: all 2*UN loads are issued before the first use (memory-level parallelism)
+    constexpr int UN = 4;
+    auto body = [&](f32x4 dy, const f32x4 a, int i) {
       if (p.mode == 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) dy[q] *= (a[q] * ps[q] + psh[q] > 0.f) ? 1.f : C3D_LRELU_SLOPE;
@@ -201,7 +201,21 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
         *reinterpret_cast<f32x4*>(p.dz + (size_t)i * p.dz_cs + c) = dz;
         s1 += dz;
       }
+    };
+    int i = p0 + pl;
+    for (; i + (UN - 1) * PL < p1; i += UN * PL) {
+      f32x4 dyv[UN], av[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        dyv[u] = *reinterpret_cast<const f32x4*>(p.dy + (size_t)(i + u * PL) * p.dy_cs + c);
+        av[u] = *reinterpret_cast<const f32x4*>(p.a + (size_t)(i + u * PL) * p.a_cs + c);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) body(dyv[u], av[u], i + u * PL);
     }
+    for (; i < p1; i += PL)
+      body(*reinterpret_cast<const f32x4*>(p.dy + (size_t)i * p.dy_cs + c),
+           *reinterpret_cast<const f32x4*>(p.a + (size_t)i * p.a_cs + c), i);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       red[(pl * p.C + c + q) * 2 + 0] = s1[q];
