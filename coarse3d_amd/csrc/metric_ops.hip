@@ -356,3 +356,77 @@ extern "C" int c3d_lovasz_backward(const float* grad, const int64_t* idx, int P,
   C3D_CHECK_LAUNCH();
   return 0;
 }
+
+// ====================================================================== kNN label clean-up
+// pc_processor/postproc/knn.py:36-142 (KNN.forward): every point looks at the S x S window of
+// the range image around its pixel, keeps the K neighbours whose range is closest to its own
+// (differences weighted by 1 - gaussian(offset), the centre replaced by the point itself), and
+// takes the majority label among them (labels 1..C-1; neighbours beyond `cutoff` vote for nothing).
+// One thread per point; the S*S <= 49 candidates live in registers/LDS-free local arrays.
+namespace {
+
+template <int SMAX>
+__global__ __launch_bounds__(256) void knn_vote_kernel(const float* __restrict__ proj_range, const int64_t* __restrict__ proj_argmax,
+                                                       int H, int W, const float* __restrict__ unproj_range,
+                                                       const int64_t* __restrict__ px, const int64_t* __restrict__ py, int64_t n,
+                                                       const float* __restrict__ inv_gauss, int S, int K, float cutoff, int C,
+                                                       int64_t* __restrict__ out) {
+  const int pad = (S - 1) / 2, SS = S * S, center = (SS - 1) / 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)px[i], y = (int)py[i];
+    const float r0 = unproj_range[i];
+    float bd[SMAX];     // K best distances, ascending
+    int bl[SMAX];       // their labels
+    int nb = 0;
+    for (int k = 0; k < SS; ++k) {
+      const int yy = y + k / S - pad, xx = x + k % S - pad;
+      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      float r = in ? proj_range[(size_t)yy * W + xx] : 0.f;          // F.unfold pads with zeros
+      if (r < 0.f) r = INFINITY;                                     // knn.py:88 (invalid pixels)
+      if (k == center) r = r0;                                       // knn.py:92
+      const float d = fabsf(r - r0) * inv_gauss[k];
+      const int lab = in ? (int)proj_argmax[(size_t)yy * W + xx] : 0;
+      // insert into the sorted list of the K smallest (earlier candidate wins ties)
+      if (nb < K || d < bd[nb - 1]) {
+        int j = nb < K ? nb : K - 1;
+        while (j > 0 && bd[j - 1] > d) {
+          bd[j] = bd[j - 1];
+          bl[j] = bl[j - 1];
+          --j;
+        }
+        bd[j] = d;
+        bl[j] = lab;
+        if (nb < K) ++nb;
+      }
+    }
+    // vote over classes 1..C-1 (knn.py:124-133); first maximum wins
+    int best = 1, bestv = -1;
+    for (int c = 1; c < C; ++c) {
+      int v = 0;
+      for (int j = 0; j < nb; ++j) {
+        const bool valid = !(cutoff > 0.f && bd[j] > cutoff);
+        v += (valid && bl[j] == c) ? 1 : 0;
+      }
+      if (v > bestv) {
+        bestv = v;
+        best = c;
+      }
+    }
+    out[i] = best;
+  }
+}
+
+}  // namespace
+
+extern "C" int c3d_knn_vote(const float* proj_range, const int64_t* proj_argmax, int H, int W, const float* unproj_range,
+                            const int64_t* px, const int64_t* py, int64_t n, const float* inv_gauss, int search, int knn,
+                            float cutoff, int nclasses, int64_t* out, c3d_stream stream) {
+  C3D_REQUIRE(search % 2 == 1 && search >= 1 && search <= 7, "knn: search window must be odd and <= 7");
+  C3D_REQUIRE(knn >= 1 && knn <= search * search, "knn: 1 <= knn <= search^2");
+  C3D_REQUIRE(nclasses >= 2, "knn: at least two classes");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(knn_vote_kernel<49>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, proj_range, proj_argmax, H, W,
+                     unproj_range, px, py, n, inv_gauss, search, knn, cutoff, nclasses, out);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}

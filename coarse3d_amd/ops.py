@@ -693,3 +693,18 @@ def range_project(pc, depth, fov, w, h, want_image=True, sem=None, weak=None):
           _dp(out["proj_idx"]), _dp(out["proj_mask"]), _dp(sem), _dp(weak), _dp(out.get("feat5")),
           _dp(out.get("eval_label")), _dp(out.get("train_label")), _stream())
     return out
+
+
+# ---------------------------------------------------------------------------- kNN clean-up (N4)
+def knn_vote(proj_range, proj_argmax, unproj_range, px, py, inv_gauss, search, knn, cutoff, nclasses):
+    h, w = proj_range.shape
+    dev = proj_range.device
+    pr = proj_range.to(torch.float32).contiguous()
+    pa = proj_argmax.to(dev, torch.long).contiguous()
+    ur = unproj_range.to(dev, torch.float32).contiguous()
+    pxl, pyl = px.to(dev, torch.long).contiguous(), py.to(dev, torch.long).contiguous()
+    n = ur.numel()
+    out = torch.empty(n, device=dev, dtype=torch.long)
+    _call("c3d_knn_vote", _dp(pr), _dp(pa), h, w, _dp(ur), _dp(pxl), _dp(pyl), n, _dp(inv_gauss.to(torch.float32).contiguous()),
+          int(search), int(knn), float(cutoff), int(nclasses), _dp(out), _stream())
+    return out

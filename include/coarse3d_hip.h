@@ -320,6 +320,18 @@ int c3d_lovasz_forward(const float* prob, int C, int cstride, const int64_t* lab
 int c3d_lovasz_backward(const float* grad, const int64_t* idx, int P, int C, const float* stats,
                         const float* gscale, float* dprob, int dstride, c3d_stream stream);
 
+/* ------------------------------------------------------------------ kNN label clean-up
+ * pc_processor/postproc/knn.py:36-142 (KNN.forward), un-batched as the reference: for each of
+ * the n points (pixel px,py; range unproj_range) the `knn` candidates of the search x search
+ * window of proj_range [H][W] with the smallest |range - own range| * inv_gauss[k] (window
+ * padded with zeros, invalid pixels (< 0) at infinity, centre = the point itself) vote with their
+ * proj_argmax label; candidates beyond `cutoff` (> 0) do not vote; out[i] = most voted class in
+ * 1..nclasses-1 (first on ties).  inv_gauss = 1 - gaussian kernel, search*search floats.        */
+int c3d_knn_vote(const float* proj_range, const int64_t* proj_argmax, int H, int W,
+                 const float* unproj_range, const int64_t* px, const int64_t* py, int64_t n,
+                 const float* inv_gauss, int search, int knn, float cutoff, int nclasses,
+                 int64_t* out, c3d_stream stream);
+
 /* ------------------------------------------------------------------ scan -> range image
  * pc_processor/dataset/preprocess/projection.py:43-115, augmentor.py:150-230,
  * pc_processor/dataset/semantic_kitti/wss_sem_kitti_loader.py:113-170                          */

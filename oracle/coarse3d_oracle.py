@@ -649,6 +649,46 @@ def loader_tensors(proj, sem_label, weak_label):
     return dict(feature=feat, eval_label=ev, train_label=tr)
 
 
+# --------------------------------------------------------------------------------------
+# kNN label clean-up
+# --------------------------------------------------------------------------------------
+def knn_gaussian(kernel_size, sigma):
+    """knn.py:11-35: normalised 2-d gaussian, float32."""
+    import math
+    c = torch.arange(kernel_size)
+    xg = c.repeat(kernel_size).view(kernel_size, kernel_size)
+    grid = torch.stack([xg, xg.t()], dim=-1).float()
+    mean = (kernel_size - 1) / 2.
+    var = sigma ** 2.
+    g = (1. / (2. * math.pi * var)) * torch.exp(-torch.sum((grid - mean) ** 2., dim=-1) / (2 * var))
+    return g / torch.sum(g)
+
+
+def knn_vote(proj_range, unproj_range, proj_argmax, px, py, search, knn, sigma, cutoff, nclasses):
+    """knn.py:56-142 per point, without the unfolded images: window padded with zeros, invalid
+    ranges at infinity, centre replaced by the point's own range, weights 1 - gaussian, the
+    ``knn`` smallest weighted differences (earlier window position first on ties) vote."""
+    h, w = proj_range.shape
+    pad = (search - 1) // 2
+    ig = (1 - knn_gaussian(search, sigma)).reshape(-1)
+    rp = F.pad(proj_range, (pad, pad, pad, pad), value=0.0)
+    ap = F.pad(proj_argmax.long(), (pad, pad, pad, pad), value=0)
+    offs = [(k // search, k % search) for k in range(search * search)]
+    rng = torch.stack([rp[py + dy, px + dx] for dy, dx in offs], 1)           # [P, S*S]
+    lab = torch.stack([ap[py + dy, px + dx] for dy, dx in offs], 1)
+    rng = torch.where(rng < 0, torch.full_like(rng, float("inf")), rng)
+    rng[:, (search * search - 1) // 2] = unproj_range
+    dist = (rng - unproj_range[:, None]).abs() * ig[None, :]
+    order = torch.sort(dist, dim=1, stable=True)[1][:, :knn]
+    kd = torch.gather(dist, 1, order)
+    kl = torch.gather(lab, 1, order)
+    if cutoff > 0:
+        kl = torch.where(kd > cutoff, torch.full_like(kl, nclasses), kl)
+    votes = torch.zeros(px.numel(), nclasses + 1)
+    votes.scatter_add_(1, kl, torch.ones_like(kl, dtype=votes.dtype))
+    return votes[:, 1:-1].argmax(dim=1) + 1
+
+
 def normalise_input(x, eval_label, mean, std):
     m = (eval_label > 0).unsqueeze(1).to(x.dtype)
     return (x - mean[None, :, None, None]) / std[None, :, None, None] * m

@@ -352,6 +352,31 @@ def gold_projection():
     npz("projection.npz", **arrs)
 
 
+def gold_knn():
+    """The reference KNN module (pc_processor/postproc/knn.py, loaded by file) on a synthetic
+    scan: smooth range image with invalid pixels, points scattered around their pixels."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ref_knn", "/root/reference/pc_processor/postproc/knn.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.random.Generator(np.random.PCG64(23))
+    arrs = {}
+    for tag, h, w, npts, ncls, params in (("a", 16, 96, 1200, 20, dict(knn=5, search=5, sigma=1.0, cutoff=1.0)),
+                                          ("b", 12, 64, 700, 14, dict(knn=7, search=7, sigma=2.0, cutoff=0.0))):
+        yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        rng = (10 + 5 * np.sin(xx / 9.0) + 0.3 * yy + g.normal(0, 0.05, (h, w))).astype(np.float32)
+        rng[g.random((h, w)) < 0.1] = -1.0
+        lab = ((xx // 8 + yy // 4) % ncls).astype(np.int64)
+        py = g.integers(0, h, npts)
+        px = g.integers(0, w, npts)
+        ur = (np.abs(rng[py, px]) + g.normal(0, 0.2, npts)).astype(np.float32)
+        knn = mod.KNN(params, ncls)
+        out = knn(torch.from_numpy(rng), torch.from_numpy(ur), torch.from_numpy(lab), torch.from_numpy(px), torch.from_numpy(py))
+        arrs.update({f"{tag}/proj_range": rng, f"{tag}/proj_argmax": lab, f"{tag}/px": px, f"{tag}/py": py,
+                     f"{tag}/unproj_range": ur, f"{tag}/out": out})
+    npz("knn.npz", **arrs)
+
+
 # ----------------------------------------------------------------------------- full step
 def gold_step():
     """One optimisation step of the reference modules, trainer.py:621-704 order, with
@@ -434,4 +459,5 @@ if __name__ == "__main__":
     gold_losses()
     gold_metrics()
     gold_projection()
+    gold_knn()
     gold_step()

@@ -234,3 +234,17 @@ def test_projection_and_augmentation_vs_reference():
             assert np.array_equal(pr["proj_range"], d["raw/proj_range"])
             assert np.array_equal(pr["proj_pc"][same], d["raw/proj_pc"][same])
             assert np.array_equal(lt["feature"][:, same], d["raw/feature"][:, same])
+
+
+KNN_CASES = (("a", 20, dict(knn=5, search=5, sigma=1.0, cutoff=1.0)), ("b", 14, dict(knn=7, search=7, sigma=2.0, cutoff=0.0)))
+
+
+def test_knn_vote_vs_reference():
+    """N4: per-point restatement of KNN.forward vs the reference module (labels: exact, up to
+    torch.topk's unspecified choice among exactly tied distances -- none in this fixture)."""
+    d = np.load(os.path.join(GOLD, "knn.npz"))
+    for tag, ncls, p in KNN_CASES:
+        t = {k: torch.from_numpy(d[f"{tag}/{k}"]) for k in ("proj_range", "proj_argmax", "px", "py", "unproj_range", "out")}
+        out = oc.knn_vote(t["proj_range"], t["unproj_range"], t["proj_argmax"], t["px"], t["py"], p["search"], p["knn"],
+                          p["sigma"], p["cutoff"], ncls)
+        assert torch.equal(out, t["out"]), tag
