@@ -337,3 +337,24 @@ def test_eval_mode_forward_parity():
     assert torch.equal(out["pred_2d"], out2["pred_2d"]) and torch.equal(out["feat_2d"], out2["feat_2d"])
     assert torch.equal(m.prototypes.detach(), protos)
     assert "contrast_logits" not in out
+
+
+def test_eval_forward_is_graph_capturable():
+    """The C ABI never allocates or synchronises, so the eval forward can be recorded in a hipGraph
+    (coarse3d_amd/serving.py): the replay is bit-identical to the eager forward, also for a second
+    input fed through the same captured graph."""
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    from coarse3d_amd.serving import GraphedInference
+    torch.manual_seed(3)
+    m = SalsaNextProto(5, 20, 20, 0).to(DEV).eval()
+    gi = GraphedInference(m, return_feat=True)
+    for seed in (1, 2):
+        x = torch.randn(1, 5, 32, 256, generator=torch.Generator().manual_seed(seed)).to(DEV)
+        with torch.no_grad():
+            ref = m(x, return_feat=True)
+        out = gi(x)
+        assert torch.equal(out["pred_2d"], ref["pred_2d"]) and torch.equal(out["feat_2d"], ref["feat_2d"])
+    assert len(gi._graphs) == 1
+    m.train()
+    with pytest.raises(ValueError):
+        GraphedInference(m)
