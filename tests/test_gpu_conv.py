@@ -152,3 +152,78 @@ def test_split_bf16_mode_is_fp32_accurate(B, H, W, srcC, Cout, k, dil, pad):
         test_conv_forward_and_grads(B, H, W, srcC, Cout, k, dil, pad)
     finally:
         ops.set_matrix_precision("f32")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_conv_engine_random_shapes(mode):
+    """(fp32 MFMA engine, and the fp32-accurate split-bf16 engine of conv_bfp.hip at the same
+    tolerance.)  40 seeded random layer shapes: ragged H/W (partial 32-wide tiles, all tile-row variants),
+    1-3 concatenated sources with channel offsets inside wider tensors, output written at a channel
+    offset of a wider tensor, accumulate mode, all three tap patterns -- forward, input gradient
+    and weight gradient against F.conv2d on the CPU (1e-4 of max|ref|)."""
+    import random
+    from coarse3d_amd import ops
+    rnd = random.Random(1234)
+    dev = "cuda"
+    ops.set_matrix_precision(mode)
+    try:
+        _random_shape_cases(ops, rnd, dev)
+    finally:
+        ops.set_matrix_precision("f32")
+
+
+def _random_shape_cases(ops, rnd, dev):
+    for case in range(40):
+        k, dil, pad = rnd.choice([(1, 1, 0), (3, 1, 1), (3, 2, 2), (2, 2, 1)])
+        B, H, W = rnd.choice([1, 2, 3]), rnd.choice([1, 2, 3, 5, 6, 8, 12, 17]), rnd.choice([7, 32, 33, 64, 95])
+        nsrc = rnd.choice([1, 1, 2, 3])
+        srcC = [rnd.choice([16, 32, 48]) for _ in range(nsrc)]
+        Cout = rnd.choice([16, 20, 32, 48, 64, 96])
+        g = torch.Generator().manual_seed(case)
+        Cin = sum(srcC)
+        wide = [c + rnd.choice([0, 16]) for c in srcC]                 # sources live inside wider tensors
+        coffs = [rnd.choice([0, w_ - c]) // 4 * 4 for c, w_ in zip(srcC, wide)]
+        full = [torch.randn(B, w_, H, W, generator=g) for w_ in wide]
+        xs = [f[:, o:o + c] for f, o, c in zip(full, coffs, srcC)]
+        scs = [torch.rand(c, generator=g) + 0.5 for c in srcC]
+        shs = [torch.randn(c, generator=g) * 0.3 for c in srcC]
+        w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+        bias = torch.randn(Cout, generator=g) * 0.1
+        xin = torch.cat([x * s[None, :, None, None] + t[None, :, None, None] for x, s, t in zip(xs, scs, shs)], 1)
+        xin.requires_grad_(True)
+        w_ref = w.clone().requires_grad_(True)
+        z = F.conv2d(xin, w_ref, bias, padding=pad, dilation=dil)
+        dz = torch.randn(z.shape, generator=g)
+        z.backward(dz)
+        taps = ops.conv_taps(k, k, dil, pad)
+        srcs = []
+        for f, o, c, s, t in zip(full, coffs, srcC, scs, shs):
+            src = ops.Source(ops.to_nhwc(f).to(dev), s.to(dev), t.to(dev))
+            src.C, src.coff = c, o
+            srcs.append(src)
+        wp = ops.pack_weights(w.to(dev), mode=0)
+        ocoff = rnd.choice([0, 4])
+        prev = torch.randn(B, H, W, Cout + ocoff + 4, generator=g)
+        out = prev.clone().to(dev)
+        acc = rnd.choice([False, True])
+        ops.conv_forward(srcs, wp, bias.to(dev), Cout, taps, lrelu=False, stats=True, out=out, out_coff=ocoff, accumulate=acc)
+        got = out.cpu()
+        want = ops.to_nhwc(z.detach()) + (prev[..., ocoff:ocoff + Cout] if acc else 0)
+        tag = (case, k, dil, B, H, W, srcC, coffs, Cout, ocoff, acc)
+        assert rel_err(got[..., ocoff:ocoff + Cout], want) < 1e-4, tag
+        assert torch.equal(got[..., :ocoff], prev[..., :ocoff]) and torch.equal(got[..., ocoff + Cout:], prev[..., ocoff + Cout:]), tag
+        # input gradient of source 0, weight gradient
+        dzd = ops.to_nhwc(dz).to(dev)
+        if Cout % 16:
+            dzp = torch.zeros(B, H, W, (Cout + 15) // 16 * 16, device=dev)
+            dzp[..., :Cout] = dzd
+            dzd = dzp
+        wd = ops.pack_weights(w.to(dev), mode=1, c_off=0, c_cnt=srcC[0], kpad=dzd.shape[3])
+        dx, _ = ops.conv_forward([ops.Source(dzd)], wd, None, srcC[0], ops.negate_taps(taps))
+        assert rel_err(ops.from_nhwc(dx.cpu()), xin.grad[:, :srcC[0]]) < 1e-4, tag
+        dw = torch.zeros_like(w, device=dev)
+        off = 0
+        for src, c in zip(srcs, srcC):
+            ops.conv_wgrad(src, dzd, dw, taps, cin_off=off)
+            off += c
+        assert rel_err(dw.cpu(), w_ref.grad) < 1e-4, tag
