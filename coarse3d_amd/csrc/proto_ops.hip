@@ -217,7 +217,30 @@ struct LearnArgs {
   int32_t* assign;       // [N] scratch
   int N, M, C, D, ignore;
   float momentum;
+  float* fsum;           // NULL, or [C][M][D+1]: write the masked feature sums + counts, skip the EMA
 };
+
+// EMA of the class's prototypes with the l2-normalised feature sums, then the final l2
+// normalisation (salsanext_proto.py:376-395, :402); one wave per prototype row.  f [M][D] (LDS,
+// overwritten), cnt [M], tot = sum(cnt).
+__device__ __forceinline__ void proto_ema_rows(float* f, const float* cnt, float tot, bool any, const float* pin,
+                                               float* pout, int M, int D, float momentum, int lane, int wv) {
+  for (int m = wv; m < M; m += 4) {
+    float ss = 0.f;
+    for (int d = lane; d < D; d += 64) ss += f[m * D + d] * f[m * D + d];
+    const float inv = 1.f / fmaxf(sqrtf(c3d_wave_sum(ss)), 1e-12f);
+    const bool upd = any && tot > 0.f && cnt[m] != 0.f;
+    float nn = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      float v = pin[m * D + d];
+      if (upd) v = momentum * v + (1.f - momentum) * (f[m * D + d] * inv);
+      f[m * D + d] = v;
+      nn += v * v;
+    }
+    const float inv2 = 1.f / fmaxf(sqrtf(c3d_wave_sum(nn)), 1e-12f);
+    for (int d = lane; d < D; d += 64) pout[m * D + d] = f[m * D + d] * inv2;
+  }
+}
 
 // 32-lane group helpers (a wave holds two independent groups; xor offsets < 32 stay inside one)
 __device__ __forceinline__ float group32_sum(float v) {
@@ -360,24 +383,31 @@ __global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
         if (s_m[ii] >= 0) cnt[s_m[ii]] += 1.f;
     __syncthreads();
   }
+  if (a.fsum) {          // data parallel "prototype sums" mode: hand the sums to the exchange, EMA later
+    float* o = a.fsum + (size_t)c * M * (D + 1);
+    for (int j = tid; j < M * D; j += 256) o[(j / D) * (D + 1) + j % D] = f[j];
+    if (tid < M) o[tid * (D + 1) + D] = cnt[tid];
+    return;
+  }
   float tot = 0.f;
   for (int m = 0; m < M; ++m) tot += cnt[m];
-  // ---- EMA + final l2 normalisation, one wave per prototype
-  for (int m = wv; m < M; m += 4) {
-    float ss = 0.f;
-    for (int d = lane; d < D; d += 64) ss += f[m * D + d] * f[m * D + d];
-    const float inv = 1.f / fmaxf(sqrtf(c3d_wave_sum(ss)), 1e-12f);
-    const bool upd = nc > 0 && tot > 0.f && cnt[m] != 0.f;
-    float nn = 0.f;
-    for (int d = lane; d < D; d += 64) {
-      float v = pin[m * D + d];
-      if (upd) v = a.momentum * v + (1.f - a.momentum) * (f[m * D + d] * inv);
-      f[m * D + d] = v;
-      nn += v * v;
-    }
-    const float inv2 = 1.f / fmaxf(sqrtf(c3d_wave_sum(nn)), 1e-12f);
-    for (int d = lane; d < D; d += 64) pout[m * D + d] = f[m * D + d] * inv2;
-  }
+  proto_ema_rows(f, cnt, tot, nc > 0, pin, pout, M, D, a.momentum, lane, wv);
+}
+
+// EMA from (all-reduced) sums: fsum [C][M][D+1] -> protos_out; one workgroup per class
+__global__ __launch_bounds__(256) void proto_ema_kernel(const float* __restrict__ fsum, const float* __restrict__ protos,
+                                                        float* __restrict__ protos_out, int M, int D, int ignore, float momentum) {
+  extern __shared__ float sm[];
+  float* f = sm;              // [M][D]
+  float* cnt = sm + M * D;    // [M]
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* src = fsum + (size_t)c * M * (D + 1);
+  for (int j = tid; j < M * D; j += 256) f[j] = src[(j / D) * (D + 1) + j % D];
+  if (tid < M) cnt[tid] = src[tid * (D + 1) + D];
+  __syncthreads();
+  float tot = 0.f;
+  for (int m = 0; m < M; ++m) tot += cnt[m];
+  proto_ema_rows(f, cnt, tot, c != ignore, protos + (size_t)c * M * D, protos_out + (size_t)c * M * D, M, D, momentum, lane, wv);
 }
 
 }  // namespace
@@ -432,13 +462,22 @@ extern "C" int c3d_proto_learn(const float* sim, const float* feat, const int32_
                                const float* ln_b, float ln_eps, const int32_t* counts,
                                const int32_t* idx, int32_t* rows, const float* noise, const float* protos,
                                float* protos_out, float* target, int32_t* assign, int B, int n, int M, int C, int D,
-                               int ignore_label, float momentum, c3d_stream stream) {
+                               int ignore_label, float momentum, float* fsum, c3d_stream stream) {
   C3D_REQUIRE(M <= 32, "proto_learn: at most 32 sub-prototypes per class");
   const int N = B * n;
   LearnArgs a{sim, feat, pred, ln_w, ln_b, ln_eps, counts, idx, rows, B, n, noise, protos, protos_out, target, assign, N, M, C, D,
-              ignore_label, momentum};
+              ignore_label, momentum, fsum};
   const size_t lds = (512 + 32 + 512 + (size_t)M * D + M) * sizeof(float);
   hipLaunchKernelGGL(proto_learn_kernel, dim3(C), dim3(256), lds, ST, a);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_proto_ema(const float* fsum, const float* protos, float* protos_out, int M, int C, int D,
+                             int ignore_label, float momentum, c3d_stream stream) {
+  C3D_REQUIRE(M <= 32, "proto_ema: at most 32 sub-prototypes per class");
+  hipLaunchKernelGGL(proto_ema_kernel, dim3(C), dim3(256), ((size_t)M * D + M) * sizeof(float), ST, fsum, protos, protos_out,
+                     M, D, ignore_label, momentum);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -128,13 +128,20 @@ class DataParallel(torch.nn.Module):
     backward); ``finish_gradients()`` waits for them and re-binds ``param.grad`` to the
     reduced flat views."""
 
-    def __init__(self, module, sync_bn=True):
+    def __init__(self, module, sync_bn=True, proto_sync="bank_mean"):
+        """proto_sync: "bank_mean" = reference semantics (mean over ranks of each rank's updated,
+        l2-normalised bank, salsanext_proto.py:397-400); "sums" = all-reduce the per-class masked
+        feature sums and counts and apply ONE momentum update with the global statistics (what a
+        single process on the global batch would compute, up to the per-rank Sinkhorn)."""
         super().__init__()
+        if proto_sync not in ("bank_mean", "sums"):
+            raise ValueError(f"proto_sync must be 'bank_mean' or 'sums', got {proto_sync!r}")
         self.module = module
         world = dist.get_world_size() if is_dist() else 1
         module._world = world if sync_bn else 1
         module._bn_reduce = allreduce_sum_ if (sync_bn and is_dist()) else None
-        module._proto_mean = world_mean if is_dist() else None
+        module._proto_mean = world_mean if (is_dist() and proto_sync == "bank_mean") else None
+        module._proto_sums_reduce = allreduce_sum_ if (is_dist() and proto_sync == "sums") else None
         self.flat = FlatGradients(module._trainable())
         module._flat_grads = self.flat.views
         module._block_done = self.flat.block_done

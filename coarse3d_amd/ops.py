@@ -477,8 +477,10 @@ def label_hist(labels, ncls):
 
 
 def proto_learn(sim, feat, pred, counts, idx, noise, protos, m, c, ignore_label, momentum, ln_w=None, ln_b=None,
-                ln_eps=1e-5):
-    """counts [B, C], idx [B, C, n]: per-image ordered pixel lists of each class."""
+                ln_eps=1e-5, sums_reduce=None):
+    """counts [B, C], idx [B, C, n]: per-image ordered pixel lists of each class.
+    ``sums_reduce`` (data parallel, optional): in-place all-reduce applied to the per-class
+    feature sums + counts [C, M, D+1] before the EMA ("per-class prototype sums" exchange)."""
     ntot, d = feat.shape
     b, _, n = idx.shape
     protos_out = torch.empty_like(protos)
@@ -486,9 +488,14 @@ def proto_learn(sim, feat, pred, counts, idx, noise, protos, m, c, ignore_label,
     assign = torch.empty(ntot, device=feat.device, dtype=torch.int32)
     rows = torch.empty(c, ntot, device=feat.device, dtype=torch.int32)
     assert pred is not None or ln_w is not None
+    fsum = torch.empty(c, m, d + 1, device=feat.device, dtype=torch.float32) if sums_reduce is not None else None
     _call("c3d_proto_learn", _dp(sim), _dp(feat), _dp(pred), _dp(ln_w), _dp(ln_b), ln_eps, _dp(counts), _dp(idx),
           _dp(rows), _dp(noise),
-          _dp(protos), _dp(protos_out), _dp(target), _dp(assign), b, n, m, c, d, ignore_label, momentum, _stream())
+          _dp(protos), _dp(protos_out), _dp(target), _dp(assign), b, n, m, c, d, ignore_label, momentum, _dp(fsum),
+          _stream())
+    if fsum is not None:
+        sums_reduce(fsum)
+        _call("c3d_proto_ema", _dp(fsum), _dp(protos), _dp(protos_out), m, c, d, ignore_label, momentum, _stream())
     return protos_out, target
 
 

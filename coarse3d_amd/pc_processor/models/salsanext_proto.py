@@ -154,6 +154,7 @@ class SalsaNextProto(nn.Module):
         self._bn_reduce = None        # data parallel: in-place all-reduce of fp64 BN sums
         self._world = 1
         self._proto_mean = None       # data parallel: mean of the bank over ranks
+        self._proto_sums_reduce = None   # data parallel alternative: all-reduce of the per-class feature sums
         self._grad_ready = None       # data parallel: called when all gradients are written
         self._block_done = None       # data parallel: called per block in backward order
         self._flat_grads = None
@@ -210,7 +211,7 @@ class SalsaNextProto(nn.Module):
                 res = proto_ops.prototype_step(
                     feat_nhwc, P, label.reshape(-1).long() if proto_loss else None, proto_loss,
                     noise=self.gumbel_noise, momentum=self.proto_mom, ignore_label=self.ignore_label,
-                    world_mean=self._proto_mean, ema_base=proto_pl)
+                    world_mean=self._proto_mean, ema_base=proto_pl, sums_reduce=self._proto_sums_reduce)
                 self.prototypes.data.copy_(res["bank_l2"])          # in-place renormalisation (:502)
                 if proto_pl is not None:
                     self.prototypes = nn.Parameter(proto_pl.clone(), requires_grad=False)

@@ -34,7 +34,7 @@ def similarity(feat_nhwc, bank_l2, ln_w, ln_b):
 
 
 def prototype_step(feat_nhwc, P, label, proto_loss, noise=None, momentum=0.999, ignore_label=0,
-                   world_mean=None, want_nearest=False, ema_base=None):  # label: [B, H*W] int64
+                   world_mean=None, want_nearest=False, ema_base=None, sums_reduce=None):  # label: [B, H*W] int64
     """One pass of salsanext_proto.py:494-530.
 
     P: dict with ``prototypes`` [C,M,D], ``feat_norm.*``, ``mask_norm.*``.  label: [N] int64 or
@@ -65,8 +65,10 @@ def prototype_step(feat_nhwc, P, label, proto_loss, noise=None, momentum=0.999, 
         base = bank_l2 if ema_base is None else ema_base.contiguous()   # proto_pl replaces the bank (:515-518)
         new_bank, target = ops.proto_learn(sim, rows, pred, counts, idx, noise.contiguous(),
                                            base, m, c, ignore_label, momentum, P["mask_norm.weight"],
-                                           P["mask_norm.bias"])
-        if world_mean is not None:       # data parallel: mean over ranks (salsanext_proto.py:397-400)
+                                           P["mask_norm.bias"], sums_reduce=sums_reduce)
+        if world_mean is not None and sums_reduce is None:
+            # data parallel, reference semantics: mean over ranks of the per-rank updated banks
+            # (salsanext_proto.py:397-400); with ``sums_reduce`` the ranks already agree
             new_bank = world_mean(new_bank)
         out.update(contrast_logits=sim, contrast_target=target, new_bank=new_bank)
     return out

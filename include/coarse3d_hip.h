@@ -234,12 +234,19 @@ int c3d_label_hist(const int64_t* labels, int groups, int n, int ncls, int32_t* 
  * bank and final l2.  counts [B][C] / idx [B][C][n] from c3d_group_compact(groups=B) on the
  * labels of the B images; rows [C][B*n] and assign [B*n] are scratch; target must be zeroed.
  * pred = c3d_proto_nearest's argmax, or NULL to evaluate it (with the mask_norm LayerNorm
- * ln_w/ln_b/ln_eps) for the labelled pixels only.                                              */
+ * ln_w/ln_b/ln_eps) for the labelled pixels only.
+ * fsum = NULL: the bank is updated by the call (protos_out).  fsum = [C][M][D+1]: the masked
+ * feature sums (and, in column D, the assignment counts) are written there instead and the bank
+ * is left alone -- data-parallel ranks all-reduce fsum and finish with c3d_proto_ema (the
+ * "per-class prototype sums" exchange).                                                        */
 int c3d_proto_learn(const float* sim, const float* feat, const int32_t* pred, const float* ln_w,
                     const float* ln_b, float ln_eps, const int32_t* counts, const int32_t* idx, int32_t* rows, const float* noise,
                     const float* protos, float* protos_out, float* target, int32_t* assign,
                     int B, int n, int M, int C, int D, int ignore_label, float momentum,
-                    c3d_stream stream);
+                    float* fsum, c3d_stream stream);
+/* EMA with the l2-normalised sums + final l2 normalisation (salsanext_proto.py:376-395, :402)  */
+int c3d_proto_ema(const float* fsum, const float* protos, float* protos_out, int M, int C, int D,
+                  int ignore_label, float momentum, c3d_stream stream);
 
 /* ------------------------------------------------------------------ contrast loss + PL selection
  * contrast_pixel_loss.py:27-195, trainer.py:447-518                                          */

@@ -358,3 +358,31 @@ def test_eval_forward_is_graph_capturable():
     m.train()
     with pytest.raises(ValueError):
         GraphedInference(m)
+
+
+def test_prototype_sums_exchange_mode():
+    """'Per-class prototype sums' exchange (DataParallel(proto_sync="sums")): the prototype kernel
+    hands out the masked feature sums + counts, an (injected) reduction runs on them, and
+    c3d_proto_ema applies the momentum update.  With the identity as reduction the bank equals the
+    fused single-kernel update bit for bit; doubling the sums leaves it unchanged as well (the sums
+    are l2-normalised before the EMA), while zeroing them freezes the bank."""
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    b, h, w, ncls = 2, 32, 64, 20
+    x, tr, ev = W.synthetic_batch(b, h, w, ncls, 5, 0.05, gh=8, gw=16)
+    noise = torch.rand(b * h * w, 20, generator=torch.Generator().manual_seed(2)) + 0.05
+    banks = {}
+    for tag, red in (("fused", None), ("identity", lambda t: t), ("double", lambda t: t.mul_(2)), ("zero", lambda t: t.zero_())):
+        m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True)
+        m.load_state_dict(W.closed_form_state(nclasses=ncls))
+        m.to(DEV).train()
+        m.dropout_masks = {k: v.to(DEV) for k, v in W.dropout_masks_for(None, b, 3).items()}
+        m.gumbel_noise = noise.to(DEV)
+        m._proto_sums_reduce = red
+        before = m.prototypes.detach().clone()
+        m(x.to(DEV), label=tr.to(DEV), eval_mask=(tr > 0).to(DEV), return_feat=True, proto_loss=True)
+        banks[tag] = (before, m.prototypes.detach().clone())
+    assert torch.equal(banks["identity"][1], banks["fused"][1])
+    assert float((banks["double"][1] - banks["fused"][1]).abs().max()) < 1e-6
+    l2 = banks["zero"][0] / banks["zero"][0].norm(dim=-1, keepdim=True)
+    assert float((banks["zero"][1] - l2).abs().max()) < 1e-6
+    assert float((banks["fused"][1] - l2).abs().max()) > 1e-6
