@@ -81,6 +81,10 @@ def cpu_baseline(ncls, h, w, budget_s=150.0):
             "sec_per_image": round(sec, 3)}
 
 
+def default_shape_for_step(args):
+    return (args.height, args.width, args.classes, args.dataset) == (64, 2048, 20, "SemanticKitti")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +230,14 @@ def main():
                                          "measured_in": "last warm-up step" if all_steps == 1 else "timed steps"}}
     ops.KERNEL_EVENTS = None
     ops.KERNEL_EVENT_FILTER = None
+    if roofline is not None and default_shape_for_step(args):
+        # whole-step view with SURVEY 8d's normative algorithmic work per 64x2048 image and step
+        # (533.5 GFLOP, 10.96 GB fp32): fraction of the fp32 matrix peak / of the 8 TB/s HBM peak
+        sec_img = elapsed / (args.batch * args.steps)
+        roofline["whole_step"] = {"algorithmic_TFLOPs": round(533.5e9 / sec_img / 1e12, 2),
+                                  "frac_of_mfma_peak": round(533.5e9 / sec_img / 1e12 / peak_tf, 4),
+                                  "algorithmic_GBps": round(10.96e9 / sec_img / 1e9, 1),
+                                  "frac_of_hbm_peak": round(10.96e9 / sec_img / 8e12, 4)}
 
     if rank == 0:
         images = args.batch * world * args.steps
