@@ -27,6 +27,9 @@ typedef void* c3d_stream;
 
 const char* c3d_last_error(void);
 int c3d_version(void);
+/* out4 = sizeof(c3d_src), sizeof(c3d_conv_desc), sizeof(c3d_wgrad_desc), sizeof(c3d_pack_entry):
+ * lets a foreign-language binding check its mirror of the struct layouts (host call, no GPU) */
+int c3d_abi_sizes(int32_t* out4);
 /* number of workgroups conv kernels will use for an [B,H,W] image: size of stat partial bufs */
 int c3d_conv_num_mtiles(int B, int H, int W);
 

@@ -24,6 +24,22 @@ def test_library_exports_every_header_symbol():
     assert L.lib().c3d_conv_num_mtiles(8, 64, 2048) == 8 * 8 * 64
 
 
+def test_ctypes_struct_mirrors_match_the_c_layouts():
+    """The ctypes Structures of coarse3d_amd/_lib.py must have exactly the size the C compiler
+    gives the descriptor structs of include/coarse3d_hip.h (a silent mismatch would shift every
+    field after the first divergence)."""
+    from coarse3d_amd import _lib as L
+    out = (ctypes.c_int32 * 4)()
+    assert L.lib().c3d_abi_sizes(out) == 0
+    assert list(out) == [ctypes.sizeof(L.Src), ctypes.sizeof(L.ConvDesc), ctypes.sizeof(L.WgradDesc),
+                         ctypes.sizeof(L.PackEntry)]
+    # a refused call reports why, without touching the GPU
+    d = L.ConvDesc()
+    d.nsrc = 7
+    assert L.lib().c3d_conv_forward(ctypes.byref(d), None) != 0
+    assert b"nsrc" in L.lib().c3d_last_error()
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from coarse3d_amd import _lib as L
     monkeypatch.setattr(L, "_lib", None)
