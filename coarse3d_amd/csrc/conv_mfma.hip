@@ -253,11 +253,16 @@ extern "C" int c3d_conv_num_mtiles(int B, int H, int W) {
 }
 
 extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
+  C3D_REQUIRE(d != nullptr, "conv: null descriptor");
   C3D_REQUIRE(d->nsrc >= 1 && d->nsrc <= C3D_MAX_SRC, "conv: nsrc must be 1..3");
+  C3D_REQUIRE(d->wpack && d->out, "conv: wpack and out must not be null");
+  C3D_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "conv: empty problem");
   C3D_REQUIRE(d->ntaps == 1 || d->ntaps == 4 || d->ntaps == 9, "conv: ntaps must be 1, 4 or 9");
   ConvArgs a;
   int K = 0, halo = 0;
   for (int s = 0; s < d->nsrc; ++s) {
+    C3D_REQUIRE(d->src[s].ptr != nullptr, "conv: null source pointer");
+    C3D_REQUIRE((d->src[s].scale == nullptr) == (d->src[s].shift == nullptr), "conv: scale and shift come together");
     C3D_REQUIRE(d->src[s].C % 16 == 0 && d->src[s].C > 0, "conv: source channels must be a multiple of 16");
     C3D_REQUIRE(d->src[s].cstride % 4 == 0 && d->src[s].coff % 4 == 0, "conv: source stride/offset must be multiples of 4");
     a.src[s] = d->src[s];
@@ -339,6 +344,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 
 extern "C" int c3d_pack_weights(const float* w_oihw, float* dst, int Cout, int Cin, int T, int mode,
                                 int c_off, int c_cnt, int Kpad, c3d_stream stream) {
+  C3D_REQUIRE(w_oihw && dst, "pack: null pointer");
   C3D_REQUIRE(Kpad % 16 == 0, "pack: Kpad must be a multiple of 16");
   const int N = mode == 0 ? Cout : c_cnt;
   const size_t total = (size_t)T * (Kpad / 4) * N * 4;

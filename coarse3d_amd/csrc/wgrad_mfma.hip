@@ -403,6 +403,7 @@ extern "C" int64_t c3d_wgrad_partial_floats(const c3d_wgrad_desc* d) {
 }
 
 extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
+  C3D_REQUIRE(d != nullptr && d->x.ptr && d->dz && d->dw && d->partial, "wgrad: null pointer");
   C3D_REQUIRE(d->ntaps == 1 || d->ntaps == 4 || d->ntaps == 9, "wgrad: ntaps must be 1, 4 or 9");
   C3D_REQUIRE(d->x.C % 4 == 0, "wgrad: source channels must be a multiple of 4");
   C3D_REQUIRE(d->dz_cstride % 4 == 0 && d->x.cstride % 4 == 0 && d->x.coff % 4 == 0, "wgrad: strides must be multiples of 4");

@@ -38,6 +38,10 @@ def test_ctypes_struct_mirrors_match_the_c_layouts():
     d.nsrc = 7
     assert L.lib().c3d_conv_forward(ctypes.byref(d), None) != 0
     assert b"nsrc" in L.lib().c3d_last_error()
+    d.nsrc = 1                                  # null pointers are refused on the host, not faulted on the GPU
+    assert L.lib().c3d_conv_forward(ctypes.byref(d), None) != 0
+    assert b"null" in L.lib().c3d_last_error()
+    assert L.lib().c3d_conv_wgrad(ctypes.byref(L.WgradDesc()), None) != 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):
