@@ -377,6 +377,54 @@ def gold_knn():
     npz("knn.npz", **arrs)
 
 
+def gold_rangenet():
+    """Reference RangeNetProto(layers=21) forward + backward with closed-form weights and injected
+    Dropout2d masks.  Gradients of a 25 M-parameter model are stored as per-tensor
+    (sum, sum of squares) plus a few small tensors in full."""
+    import contextlib
+    import importlib
+    import io
+    m = importlib.import_module("pc_processor.models.rangenet_proto")
+    arrs = {}
+    for tag, b, h, w, ncls, dataset in (("kitti", 2, 8, 64, 20, "SemanticKitti"), ("poss", 1, 8, 40, 14, "SemanticPOSS")):
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = m.RangeNetProto(layers=21, nclasses=ncls, use_prototype=True, dataset=dataset)
+        net.load_state_dict(W.rangenet_state(nclasses=ncls))
+        net.train()
+        masks = W.rangenet_masks(b, 3)
+        seq = iter(["enc1", "enc2", "enc3", "enc4", "enc5"])
+        net.backbone.dropout.forward = lambda x, seq=seq, masks=masks: x * masks[next(seq)][:, :, None, None]
+        net.decoder.dropout.forward = lambda x, masks=masks: x * masks["decoder"][:, :, None, None]
+        net.head[0].forward = lambda x, masks=masks: x * masks["head"][:, :, None, None]
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(b, 5, h, w, generator=g)
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = net(x, return_feat=True)
+        dp = torch.randn(out["pred_2d"].shape, generator=g)
+        df = torch.randn(out["feat_2d"].shape, generator=g) * 0.05
+        loss = (out["pred_2d"] * dp).sum() + (out["feat_2d"] * df).sum()
+        loss.backward()
+        # x, dp, df are regenerated by the tests from the same seeded generator
+        arrs.update({f"{tag}/pred_2d": out["pred_2d"].detach(), f"{tag}/feat_2d_sub": out["feat_2d"].detach()[:, ::4, :, ::2]})
+        names = []
+        for k, p_ in net.named_parameters():
+            if p_.grad is None:
+                continue
+            names.append(k)
+            gd = p_.grad.double()
+            arrs[f"{tag}/gsum/{k}"] = gd.sum()
+            arrs[f"{tag}/gsq/{k}"] = (gd * gd).sum()
+        for k in ("backbone.conv1.weight", "head.1.weight", "head.1.bias", "decoder.dec1.upconv.weight",
+                  "backbone.enc1.residual_0.bn2.weight", "projector.proj.3.bias", "decoder.dec5.bn.bias"):
+            arrs[f"{tag}/grad/{k}"] = dict(net.named_parameters())[k].grad
+        arrs[f"{tag}/grad_names"] = np.array(names)
+        sd = net.state_dict()
+        for k in ("backbone.bn1.running_mean", "backbone.enc5.bn.running_var", "decoder.dec1.residual.bn2.running_mean",
+                  "projector.proj.1.running_var"):
+            arrs[f"{tag}/run/{k}"] = sd[k]
+    npz("rangenet.npz", **arrs)
+
+
 # ----------------------------------------------------------------------------- full step
 def gold_step():
     """One optimisation step of the reference modules, trainer.py:621-704 order, with
@@ -460,4 +508,5 @@ if __name__ == "__main__":
     gold_metrics()
     gold_projection()
     gold_knn()
+    gold_rangenet()
     gold_step()

@@ -97,3 +97,51 @@ def dropout_masks_for(state_or_channels, b, seed):
     g = np.random.Generator(np.random.PCG64(seed))
     return {k: torch.from_numpy((g.random((b, c)) >= 0.2).astype(np.float32) * 1.25)
             for k, c in chans.items()}
+
+
+def rangenet_state(layers=21, nclasses=20, sub_proto=20, proj_dim=256, salt=0):
+    """Closed-form RangeNetProto parameters (names / shapes from oracle/rangenet_oracle.py): 25 M
+    values regenerated bit-identically wherever the tests run, so the 100 MB state never ships."""
+    from oracle import rangenet_oracle as ro
+    st = OrderedDict()
+    st["prototypes"] = torch.from_numpy(_gen("rn.prototypes", salt).normal(0, 0.02, (nclasses, sub_proto, proj_dim)).astype(np.float32))
+    for name, (shape, has_bias) in ro.conv_specs(layers, nclasses, proj_dim).items():
+        fan_in = shape[1] * shape[2] * shape[3] if "upconv" not in name else shape[0] * shape[3] / 2.0
+        bound = 1.0 / math.sqrt(fan_in)
+        g = _gen("rn." + name, salt)
+        st[f"{name}.weight"] = torch.from_numpy(g.uniform(-bound, bound, shape).astype(np.float32) * 1.7)
+        if has_bias:
+            st[f"{name}.bias"] = torch.from_numpy(g.uniform(-bound, bound, shape[1] if "upconv" in name else shape[0]).astype(np.float32))
+    for name, c in ro.bn_specs(layers).items():
+        g = _gen("rn." + name, salt)
+        st[f"{name}.weight"] = torch.from_numpy(g.uniform(0.5, 1.5, c).astype(np.float32))
+        st[f"{name}.bias"] = torch.from_numpy(g.uniform(-0.2, 0.2, c).astype(np.float32))
+        st[f"{name}.running_mean"] = torch.from_numpy(g.uniform(-0.1, 0.1, c).astype(np.float32))
+        st[f"{name}.running_var"] = torch.from_numpy(g.uniform(0.5, 1.5, c).astype(np.float32))
+        st[f"{name}.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    for name, c in (("feat_norm", proj_dim), ("mask_norm", nclasses)):
+        g = _gen("rn." + name, salt)
+        st[f"{name}.weight"] = torch.from_numpy(g.uniform(0.5, 1.5, c).astype(np.float32))
+        st[f"{name}.bias"] = torch.from_numpy(g.uniform(-0.2, 0.2, c).astype(np.float32))
+    return st
+
+
+def rangenet_masks(b, seed, layers=21):
+    """Injected Dropout2d multipliers for the seven call sites (keep-probabilities as in the
+    reference: 0.99 backbone, 0.999 decoder, 0.99 head; drawn with a larger drop rate so that the
+    fixtures actually contain dropped planes)."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    out = {}
+    for site, c, p in (("enc1", 64, 0.2), ("enc2", 128, 0.2), ("enc3", 256, 0.2), ("enc4", 512, 0.2), ("enc5", 1024, 0.2),
+                       ("decoder", 32, 0.2), ("head", 32, 0.2)):
+        out[site] = torch.from_numpy(((g.random((b, c)) >= p) / (1 - p)).astype(np.float32))
+    return out
+
+
+def rangenet_inputs(b, h, w, ncls, w_feat=None):
+    """x, d(pred), d(feat) of the RangeNet fixtures (seeded CPU generator, fixed draw order)."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(b, 5, h, w, generator=g)
+    dp = torch.randn(b, ncls, h, w, generator=g)
+    df = torch.randn(b, 256, h, w if w_feat is None else w_feat, generator=g) * 0.05
+    return x, dp, df

@@ -248,3 +248,40 @@ def test_knn_vote_vs_reference():
         out = oc.knn_vote(t["proj_range"], t["unproj_range"], t["proj_argmax"], t["px"], t["py"], p["search"], p["knn"],
                           p["sigma"], p["cutoff"], ncls)
         assert torch.equal(out, t["out"]), tag
+
+
+@pytest.mark.parametrize("tag,b,h,w,ncls,dataset", [("kitti", 2, 8, 64, 20, "SemanticKitti"), ("poss", 1, 8, 40, 14, "SemanticPOSS")])
+def test_rangenet_oracle_vs_reference(tag, b, h, w, ncls, dataset):
+    """N3: oracle/rangenet_oracle.py vs the reference RangeNetProto(21): forward 1e-5 of max,
+    running statistics 1e-6, every parameter gradient through its (sum, sum of squares) checksum at
+    1e-3 and a few small tensors element-wise."""
+    from oracle import rangenet_oracle as ro
+    d = np.load(os.path.join(GOLD, "rangenet.npz"))
+    st = W.rangenet_state(nclasses=ncls)
+    for k in ro.trainable_names(st):
+        st[k].requires_grad_(True)
+    x, dp, df = W.rangenet_inputs(b, h, w, ncls, w + 24 if dataset == "SemanticPOSS" else None)
+    out = ro.rangenet_forward(st, x, True, W.rangenet_masks(b, 3), True, 21, dataset)
+    for k, got in (("pred_2d", out["pred_2d"]), ("feat_2d_sub", out["feat_2d"][:, ::4, :, ::2])):
+        ref = torch.from_numpy(d[f"{tag}/{k}"])
+        assert got.shape == ref.shape
+        assert float((got.detach() - ref).abs().max()) < 1e-5 * float(ref.abs().max()), k
+    loss = (out["pred_2d"] * dp).sum() + (out["feat_2d"] * df).sum()
+    names = [str(n) for n in d[f"{tag}/grad_names"]]
+    grads = dict(zip(names, torch.autograd.grad(loss, [st[n] for n in names])))
+    for n in names:
+        gd = grads[n].double()
+        sq = float(d[f"{tag}/gsq/{n}"])
+        if n.endswith(("upconv.bias", "proj.0.bias")):   # a bias in front of BatchNorm: gradient exactly 0 up to rounding noise
+            assert sq < 1e-9 and float((gd * gd).sum()) < 1e-9, n
+            continue
+        assert abs(float((gd * gd).sum()) - sq) <= 1e-3 * sq + 1e-20, n
+        assert abs(float(gd.sum()) - float(d[f"{tag}/gsum/{n}"])) <= 1e-3 * sq ** 0.5 * gd.numel() ** 0.5 + 1e-12, n
+    for k in d.files:
+        if k.startswith(f"{tag}/grad/"):
+            n = k.split("/", 2)[2]
+            ref = torch.from_numpy(d[k])
+            assert float((grads[n] - ref).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-12, n
+        if k.startswith(f"{tag}/run/"):
+            n = k.split("/", 2)[2]
+            assert float((st[n].detach() - torch.from_numpy(d[k])).abs().max()) < 1e-6, n
