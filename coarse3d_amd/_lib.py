@@ -23,7 +23,8 @@ class ConvDesc(C.Structure):
                 ("ntaps", C.c_int32), ("tap_dy", C.c_int32 * 9), ("tap_dx", C.c_int32 * 9),
                 ("wpack", C.c_void_p), ("bias", C.c_void_p), ("epi_lrelu", C.c_int32),
                 ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
-                ("accumulate", C.c_int32), ("stat_partial", C.c_void_p), ("mfma_bf16", C.c_int32)]
+                ("accumulate", C.c_int32), ("stat_partial", C.c_void_p), ("lrelu_slope", C.c_float),
+                ("mfma_bf16", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -31,7 +32,8 @@ class WgradDesc(C.Structure):
                 ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cout", C.c_int32),
                 ("ntaps", C.c_int32), ("tap_dy", C.c_int32 * 9), ("tap_dx", C.c_int32 * 9),
                 ("Cin_total", C.c_int32), ("cin_off", C.c_int32),
-                ("dw", C.c_void_p), ("accumulate", C.c_int32), ("partial", C.c_void_p), ("mfma_bf16", C.c_int32)]
+                ("dw", C.c_void_p), ("accumulate", C.c_int32), ("partial", C.c_void_p), ("mfma_bf16", C.c_int32),
+                ("lrelu_slope", C.c_float)]
 
 
 class PackEntry(C.Structure):

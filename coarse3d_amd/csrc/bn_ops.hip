@@ -154,6 +154,7 @@ struct BwdArgs {
   float* dz; int dz_cs;
   float* partial;            // [C][2][gridDim.x]
   int pix_per_block;
+  float slope;
 };
 
 // thread = (pixel lane, channel quad); block walks a contiguous pixel chunk
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
     auto body = [&](f32x4 dy, const f32x4 a, int i) {
       if (p.mode == 1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dy[q] *= (a[q] * ps[q] + psh[q] > 0.f) ? 1.f : C3D_LRELU_SLOPE;
+        for (int q = 0; q < 4; ++q) dy[q] *= (a[q] * ps[q] + psh[q] > 0.f) ? 1.f : p.slope;
       }
       if (!APPLY) {
         s1 += dy;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float da = k1[q] * dy[q] + k2[q] * a[q] + k3[q];
-          if (p.mode == 0 || p.mode == 2) da *= (a[q] > 0.f) ? 1.f : C3D_LRELU_SLOPE;
+          if (p.mode == 0 || p.mode == 2) da *= (a[q] > 0.f) ? 1.f : p.slope;
           dz[q] = da;
         }
         *reinterpret_cast<f32x4*>(p.dz + (size_t)i * p.dz_cs + c) = dz;
@@ -302,13 +303,14 @@ extern "C" int c3d_bn_bwd_num_blocks(int npix) {
 
 static int bn_bwd_launch(bool apply, const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C, int mode,
                          const float* pre_scale, const float* pre_shift, const float* k1, const float* k2,
-                         const float* k3, float* dz, int dz_cs, float* partial, hipStream_t st) {
+                         const float* k3, float* dz, int dz_cs, float* partial, float slope, hipStream_t st) {
   C3D_REQUIRE(C % 4 == 0 && C <= 1024, "bn_bwd: C must be a multiple of 4 and <= 1024");
   C3D_REQUIRE(dy_cs % 4 == 0 && a_cs % 4 == 0 && (!apply || dz_cs % 4 == 0), "bn_bwd: strides must be multiples of 4");
   BwdArgs p;
   p.dy = dy; p.dy_cs = dy_cs; p.a = a; p.a_cs = a_cs; p.npix = npix; p.C = C; p.mode = mode;
   p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.k1 = k1; p.k2 = k2; p.k3 = k3;
   p.dz = dz; p.dz_cs = dz_cs; p.partial = partial;
+  p.slope = c3d_slope_or_default(slope);
   const int nb = c3d_bn_bwd_num_blocks(npix);
   p.pix_per_block = (npix + nb - 1) / nb;
   const int Q = C / 4;
@@ -322,9 +324,9 @@ static int bn_bwd_launch(bool apply, const float* dy, int dy_cs, const float* a,
 
 extern "C" int c3d_bn_bwd_reduce(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C, int mode,
                                  const float* pre_scale, const float* pre_shift, float* partial,
-                                 c3d_stream stream) {
+                                 float lrelu_slope, c3d_stream stream) {
   return bn_bwd_launch(false, dy, dy_cs, a, a_cs, npix, C, mode, pre_scale, pre_shift, nullptr, nullptr, nullptr,
-                       nullptr, 0, partial, (hipStream_t)stream);
+                       nullptr, 0, partial, lrelu_slope, (hipStream_t)stream);
 }
 
 extern "C" int c3d_bn_bwd_coeffs(const double* sums, const double* sums_param, double count, const float* mean,
@@ -339,9 +341,10 @@ extern "C" int c3d_bn_bwd_coeffs(const double* sums, const double* sums_param, d
 
 extern "C" int c3d_bn_bwd_apply(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C, int mode,
                                 const float* pre_scale, const float* pre_shift, const float* k1, const float* k2,
-                                const float* k3, float* dz, int dz_cs, float* partial, c3d_stream stream) {
+                                const float* k3, float* dz, int dz_cs, float* partial, float lrelu_slope,
+                                c3d_stream stream) {
   return bn_bwd_launch(true, dy, dy_cs, a, a_cs, npix, C, mode, pre_scale, pre_shift, k1, k2, k3, dz, dz_cs, partial,
-                       (hipStream_t)stream);
+                       lrelu_slope, (hipStream_t)stream);
 }
 
 extern "C" int c3d_sums_to_f32(const double* sums, int C, int col, float* out, int accumulate, c3d_stream stream) {

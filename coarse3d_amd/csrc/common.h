@@ -12,6 +12,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define C3D_MAX_TAPS 9
 
 __device__ __forceinline__ float c3d_lrelu(float v) { return v > 0.f ? v : C3D_LRELU_SLOPE * v; }
+__device__ __forceinline__ float c3d_lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
+// descriptors carry the slope as a float where 0 means the SalsaNext default (0.01)
+inline float c3d_slope_or_default(float s) { return s > 0.f ? s : C3D_LRELU_SLOPE; }
 
 // 8 floats -> 8 bf16 (round to nearest even; v_cvt_pk_bf16_f32 on gfx950): one operand of
 // v_mfma_f32_32x32x16_bf16

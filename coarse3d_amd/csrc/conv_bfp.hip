@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
           if (aff) v = v * psc + psh;
           if (lr) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q]);
+            for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q], a.slope);
           }
         }
         u32x2 pl[NP];
@@ -252,7 +252,7 @@ int launch_bfp(ConvArgs& a, hipStream_t st) {
 template <int TR, int NT, int NP>
 int launch_bfp_taps(ConvArgs& a, int halo, hipStream_t st) {
   if (a.T == 1) return launch_bfp<TR, NT, 16, 0, 1, NP>(a, st);
-  if (a.T == 4) return launch_bfp<TR, NT, 16, 1, 4, NP>(a, st);
+  if (a.T == 4) return halo <= 1 ? launch_bfp<TR, NT, 16, 1, 4, NP>(a, st) : launch_bfp<TR, NT, 16, 2, 4, NP>(a, st);
   if (halo <= 1) return launch_bfp<TR, NT, 16, 1, 9, NP>(a, st);
   return launch_bfp<TR, NT, 16, 2, 9, NP>(a, st);
 }

@@ -19,6 +19,7 @@ struct ConvArgs {
   float* stat_partial;
   int tiles_x, tiles_y, Kq;  // Kq = padded K / 4 (rows of the packed weight per tap)
   int ntn;                   // number of cout tiles
+  float slope;               // LeakyReLU slope of the on-load and epilogue activations
 };
 
 // bf16-plane kernels (conv_bfp.hip): planes = 1 (bf16) or 3 (bf16x3)
@@ -60,7 +61,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = acc[i][j][r] + bias;
-          if (a.epi_lrelu) v = c3d_lrelu(v);
+          if (a.epi_lrelu) v = c3d_lrelu(v, a.slope);
           if constexpr (ACC) v += old[r];
           orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs] = v;
           s1[j] += v;
@@ -88,7 +89,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         for (int r = 0; r < 16; ++r) {
           const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
           float v = acc[i][j][r] + bias;
-          if (a.epi_lrelu) v = c3d_lrelu(v);
+          if (a.epi_lrelu) v = c3d_lrelu(v, a.slope);
           if (cok && gy < a.H && gx < a.W) {
             float* o = a.out + ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co;
             if (a.accumulate) v += *o;

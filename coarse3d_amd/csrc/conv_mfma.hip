@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ?
           if (aff) v = v * psc + psh;
           if (lr) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q]);
+            for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q], a.slope);
           }
         }
         *reinterpret_cast<f32x4*>(s_in + (u / CQ) * CS + c4 * 4) = v;
@@ -224,7 +224,7 @@ int launch_cfg(ConvArgs& a, hipStream_t st) {
 template <int TR, int NT>
 int launch_taps(ConvArgs& a, int halo, hipStream_t st) {
   if (a.T == 1) return launch_cfg<TR, NT, 16, 0, 1>(a, st);
-  if (a.T == 4) return launch_cfg<TR, NT, 16, 1, 4>(a, st);
+  if (a.T == 4) return halo <= 1 ? launch_cfg<TR, NT, 16, 1, 4>(a, st) : launch_cfg<TR, NT, 16, 2, 4>(a, st);
   if (halo <= 1) return launch_cfg<TR, NT, 16, 1, 9>(a, st);
   return launch_cfg<TR, NT, 16, 2, 9>(a, st);
 }
@@ -276,7 +276,6 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   }
   C3D_REQUIRE(halo <= 2, "conv: tap offsets beyond +-2 are not supported");
   C3D_REQUIRE(d->ntaps != 1 || halo == 0, "conv: a single tap must have zero offset");
-  C3D_REQUIRE(d->ntaps != 4 || halo <= 1, "conv: 4-tap kernels support offsets of +-1");
   a.nsrc = d->nsrc;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
   a.T = d->ntaps;
@@ -284,6 +283,7 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   a.out = d->out; a.out_cstride = d->out_cstride; a.out_coff = d->out_coff;
   a.accumulate = d->accumulate;
   a.stat_partial = d->stat_partial;
+  a.slope = c3d_slope_or_default(d->lrelu_slope);
   const int tr = c3d_tile_rows(d->H);
   a.tiles_x = (d->W + 31) / 32;
   a.tiles_y = (d->H + tr - 1) / tr;

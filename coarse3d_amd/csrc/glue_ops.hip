@@ -107,18 +107,60 @@ __global__ __launch_bounds__(256) void conv_in5_wgrad_reduce_kernel(const float*
   if (lane == 0) dw[i] = (float)s;
 }
 
-// ---------------------------------------------------------------- out = x + (a*scale + shift)
+// ---------------------------------------------------------------- out = x + act(a*scale + shift)
+// act = identity (slope 0) or LeakyReLU(slope): the residual add of SalsaNext's blocks
+// (salsanext_proto.py:64,133) and of RangeNet's BasicBlock (rangenet_proto.py:52-63)
 __global__ void affine_add_kernel(const float* __restrict__ x, const float* __restrict__ a,
                                   const float* __restrict__ scale, const float* __restrict__ shift, size_t npix, int C,
-                                  float* __restrict__ out) {
+                                  float slope, float* __restrict__ out) {
   const int Q = C >> 2;
   const size_t total = npix * Q;
   for (size_t i = gtid(); i < total; i += gstride()) {
     const int c = (i % Q) * 4;
     f32x4 v = *reinterpret_cast<const f32x4*>(a + i * 4);
     if (scale) v = v * *reinterpret_cast<const f32x4*>(scale + c) + *reinterpret_cast<const f32x4*>(shift + c);
+    if (slope > 0.f) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q], slope);
+    }
     if (x) v += *reinterpret_cast<const f32x4*>(x + i * 4);
     *reinterpret_cast<f32x4*>(out + i * 4) = v;
+  }
+}
+
+// ---------------------------------------------------------------- column resampling for strided / transposed convs
+// up = 0: out[b][y][xo][c] = in[b][y][2*xo][c]            (W -> W/2: the stride-(1,2) convs of
+//         rangenet_proto.py:194-203 are computed at stride 1 and keep the even columns)
+// up = 1: out[b][y][2*xi][c] = in[b][y][xi][c], odd columns 0   (W -> 2W: zero insertion in front of
+//         the 1x4 conv that realises ConvTranspose2d([1,4], stride [1,2], padding [0,1]), :328-336)
+// Each is the other's adjoint, so the same kernel serves the backward passes.
+__global__ void cols_resample_kernel(const float* __restrict__ in, size_t rows, int Win, int C, int up,
+                                     float* __restrict__ out) {
+  const int Q = C >> 2;
+  const int Wout = up ? Win * 2 : Win / 2;
+  const size_t total = rows * Wout * Q;
+  for (size_t i = gtid(); i < total; i += gstride()) {
+    const int q = i % Q;
+    const size_t p = i / Q;
+    const int xo = p % Wout;
+    const size_t r = p / Wout;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!up) v = *reinterpret_cast<const f32x4*>(in + ((r * Win + 2 * (size_t)xo) * Q + q) * 4);
+    else if ((xo & 1) == 0) v = *reinterpret_cast<const f32x4*>(in + ((r * Win + (xo >> 1)) * Q + q) * 4);
+    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+  }
+}
+
+// x [B][Cn][H*W] (NCHW) -> out [B][H*W][Cp] (NHWC), channels Cn..Cp-1 zero: the 5-channel range image as a
+// 16-channel MFMA operand (first 3x3 conv of rangenet_proto.py:141-143)
+__global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, int B, int Cn, size_t HW, int Cp,
+                                        float* __restrict__ out) {
+  const size_t total = (size_t)B * HW * Cp;
+  for (size_t i = gtid(); i < total; i += gstride()) {
+    const int c = i % Cp;
+    const size_t p = (i / Cp) % HW;
+    const size_t b = i / ((size_t)Cp * HW);
+    out[i] = c < Cn ? x[(b * Cn + c) * HW + p] : 0.f;
   }
 }
 
@@ -529,10 +571,28 @@ extern "C" int c3d_conv_in5_wgrad(const float* x_nchw, const float* dz, int B, i
 }
 
 extern "C" int c3d_affine_add(const float* x, const float* a, const float* scale, const float* shift, int64_t npix,
-                              int C, float* out, c3d_stream stream) {
+                              int C, float lrelu_slope, float* out, c3d_stream stream) {
   C3D_REQUIRE(C % 4 == 0, "affine_add: C must be a multiple of 4");
   hipLaunchKernelGGL(affine_add_kernel, dim3(nblocks((size_t)npix * C / 4)), dim3(256), 0, ST, x, a, scale, shift,
-                     (size_t)npix, C, out);
+                     (size_t)npix, C, lrelu_slope, out);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_cols_resample(const float* in, int64_t rows, int Win, int C, int up, float* out, c3d_stream stream) {
+  C3D_REQUIRE(C % 4 == 0, "cols_resample: C must be a multiple of 4");
+  C3D_REQUIRE(up || Win % 2 == 0, "cols_resample: an even width is needed to drop every other column");
+  const size_t total = (size_t)rows * (up ? Win * 2 : Win / 2) * (C / 4);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(cols_resample_kernel, dim3(nblocks(total)), dim3(256), 0, ST, in, (size_t)rows, Win, C, up, out);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_nchw_to_nhwc_pad(const float* x, int B, int Cn, int64_t HW, int Cp, float* out, c3d_stream stream) {
+  C3D_REQUIRE(Cp >= Cn, "nchw_to_nhwc_pad: Cp must not be smaller than Cn");
+  hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(nblocks((size_t)B * HW * Cp)), dim3(256), 0, ST, x, B, Cn, (size_t)HW, Cp,
+                     out);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -33,6 +33,7 @@ struct WgradArgs {
   float* partial;
   int tiles_x, tiles_y, ntiles, strips, tiles_per_strip;
   int ci_slices, co_slices;
+  float slope;
 };
 
 // BF = false: fp32 MFMA (default parity path).  BF = true: operands rounded to bf16 (RNE) when
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
           if (aff) v = v * psc + psh;
           if (lr) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q]);
+            for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q], a.slope);
           }
         }
         *reinterpret_cast<f32x4*>(s_x + (u / (CI / 4)) * CI + xc4 * 4) = v;
@@ -386,8 +387,8 @@ int launch_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
     case 1: return launch_wg<1, 2, 2, 2, 2, 1, 0, BF>(a, st);
     case 2: return launch_wg<1, 2, 2, 1, 1, 4, 0, BF>(a, st);
     case 3: return launch_wg<1, 1, 1, 1, 1, 4, 0, BF>(a, st);
-    case 4: return launch_wg<4, 1, 2, 1, 1, 4, 1, BF>(a, st);
-    case 5: return launch_wg<4, 1, 1, 1, 1, 4, 1, BF>(a, st);
+    case 4: return halo <= 1 ? launch_wg<4, 1, 2, 1, 1, 4, 1, BF>(a, st) : launch_wg<4, 1, 2, 1, 1, 4, 2, BF>(a, st);
+    case 5: return halo <= 1 ? launch_wg<4, 1, 1, 1, 1, 4, 1, BF>(a, st) : launch_wg<4, 1, 1, 1, 1, 4, 2, BF>(a, st);
     case 6: return halo <= 1 ? launch_wg<9, 1, 1, 1, 2, 2, 1, BF>(a, st) : launch_wg<9, 1, 1, 1, 2, 2, 2, BF>(a, st);
     default: return halo <= 1 ? launch_wg<9, 1, 1, 1, 1, 4, 1, BF>(a, st) : launch_wg<9, 1, 1, 1, 1, 4, 2, BF>(a, st);
   }
@@ -419,8 +420,8 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   }
   C3D_REQUIRE(halo <= 2, "wgrad: tap offsets beyond +-2 are not supported");
   C3D_REQUIRE(d->ntaps != 1 || halo == 0, "wgrad: a single tap must have zero offset");
-  C3D_REQUIRE(d->ntaps != 4 || halo <= 1, "wgrad: 4-tap kernels support offsets of +-1");
   a.partial = d->partial;
+  a.slope = c3d_slope_or_default(d->lrelu_slope);
   WgCfg c;
   plan(d, a, c);
   hipStream_t st = (hipStream_t)stream;

@@ -160,7 +160,7 @@ def num_mtiles(b, h, w):
 
 
 def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=None, out_coff=0,
-                 accumulate=False, stat_partial=None):
+                 accumulate=False, stat_partial=None, slope=0.0):
     """y = [LeakyReLU](conv(cat(transformed srcs)) + bias); optional per-tile channel stats."""
     d = L.ConvDesc()
     d.nsrc = len(srcs)
@@ -174,6 +174,7 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     d.wpack = wpack.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.epi_lrelu = int(lrelu)
+    d.lrelu_slope = slope            # 0 = the SalsaNext default 0.01
     if out is None:
         out = torch.empty(b, h, w, cout, device=wpack.device, dtype=torch.float32)
     d.out, d.out_cstride, d.out_coff, d.accumulate = out.data_ptr(), out.shape[3], out_coff, int(accumulate)
@@ -201,7 +202,7 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     return out, stat_partial
 
 
-def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False):
+def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0):
     """dw[:, cin_off:cin_off+src.C] (+)= sum_p dz[p] (x) transformed src[p + tap]."""
     d = L.WgradDesc()
     src.fill(d.x)
@@ -213,6 +214,7 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False):
         d.tap_dy[i], d.tap_dx[i] = dy, dx
     d.Cin_total, d.cin_off = dw.shape[1], cin_off
     d.dw, d.accumulate = dw.data_ptr(), int(accumulate)
+    d.lrelu_slope = slope
     n = L.lib().c3d_wgrad_partial_floats(C.byref(d))
     part = torch.empty(n, device=dz.device, dtype=torch.float32)
     d.partial = part.data_ptr()
@@ -292,11 +294,11 @@ def bn_bwd_blocks(npix):
     return L.lib().c3d_bn_bwd_num_blocks(npix)
 
 
-def bn_bwd_reduce(dy, a, c, mode=0, pre_scale=None, pre_shift=None):
+def bn_bwd_reduce(dy, a, c, mode=0, pre_scale=None, pre_shift=None, slope=0.0):
     npix = dy.numel() // dy.shape[-1]
     part = torch.empty(c, 2, bn_bwd_blocks(npix), device=dy.device, dtype=torch.float32)
     _call("c3d_bn_bwd_reduce", _dp(dy), dy.shape[-1], _dp(a), a.shape[-1], npix, c, mode, _dp(pre_scale),
-          _dp(pre_shift), _dp(part), _stream())
+          _dp(pre_shift), _dp(part), float(slope), _stream())
     return part
 
 
@@ -308,7 +310,7 @@ def bn_bwd_coeffs(sums, count, mean, invstd, gamma, dgamma, dbeta, sums_param=No
     return k
 
 
-def bn_bwd_apply(dy, a, c, mode, k=None, pre_scale=None, pre_shift=None, dz=None):
+def bn_bwd_apply(dy, a, c, mode, k=None, pre_scale=None, pre_shift=None, dz=None, slope=0.0):
     """dz = act'(.) * (k1*dy + k2*a + k3); returns (dz, partial [C,2,nblk] with sum(dz) in row 0)."""
     npix = dy.numel() // dy.shape[-1]
     if dz is None:
@@ -316,7 +318,7 @@ def bn_bwd_apply(dy, a, c, mode, k=None, pre_scale=None, pre_shift=None, dz=None
     part = torch.empty(c, 2, bn_bwd_blocks(npix), device=dy.device, dtype=torch.float32)
     k1, k2, k3 = (k[0], k[1], k[2]) if k is not None else (None, None, None)
     _call("c3d_bn_bwd_apply", _dp(dy), dy.shape[-1], _dp(a), a.shape[-1], npix, c, mode, _dp(pre_scale),
-          _dp(pre_shift), _dp(k1), _dp(k2), _dp(k3), _dp(dz), dz.shape[-1], _dp(part), _stream())
+          _dp(pre_shift), _dp(k1), _dp(k2), _dp(k3), _dp(dz), dz.shape[-1], _dp(part), float(slope), _stream())
     return dz, part
 
 
@@ -347,11 +349,27 @@ def conv_in5_wgrad(x_nchw, dz, dw):
     return dw
 
 
-def affine_add(x, a, scale=None, shift=None, out=None):
+def affine_add(x, a, scale=None, shift=None, out=None, slope=0.0):
+    """out = x + act(a*scale + shift); act = LeakyReLU(slope) or the identity (slope 0)."""
     c = a.shape[-1]
     if out is None:
         out = torch.empty_like(a)
-    _call("c3d_affine_add", _dp(x), _dp(a), _dp(scale), _dp(shift), a.numel() // c, c, _dp(out), _stream())
+    _call("c3d_affine_add", _dp(x), _dp(a), _dp(scale), _dp(shift), a.numel() // c, c, float(slope), _dp(out), _stream())
+    return out
+
+
+def cols_resample(x, up):
+    """NHWC [B,H,W,C]: up=False keeps the even columns (-> W/2), up=True inserts zero columns (-> 2W)."""
+    b, h, w, c = x.shape
+    out = torch.empty(b, h, w * 2 if up else w // 2, c, device=x.device, dtype=torch.float32)
+    _call("c3d_cols_resample", _dp(x), b * h, w, c, int(up), _dp(out), _stream())
+    return out
+
+
+def nchw_to_nhwc_pad(x, cp):
+    b, cn, h, w = x.shape
+    out = torch.empty(b, h, w, cp, device=x.device, dtype=torch.float32)
+    _call("c3d_nchw_to_nhwc_pad", _dp(x.contiguous()), b, cn, h * w, cp, _dp(out), _stream())
     return out
 
 

@@ -65,6 +65,8 @@ typedef struct {
   int32_t out_coff;
   int32_t accumulate;       /* out += result (gradient accumulation)                     */
   float* stat_partial;      /* NULL or [Cout][2][c3d_conv_num_mtiles]: per-tile sum,sumsq */
+  float lrelu_slope;        /* slope of the on-load (src.lrelu) and epilogue LeakyReLU; 0 = 0.01
+                               (SalsaNext), RangeNet uses 0.1 (rangenet_proto.py:45)           */
   int32_t mfma_bf16;        /* 0: fp32 MFMA (the parity path).  1: operands rounded to bf16
                                (RNE) in LDS->register reads, v_mfma_f32_32x32x16_bf16, fp32
                                accumulate/storage -- opt-in mixed precision (BASELINE config 2) */
@@ -109,6 +111,7 @@ typedef struct {
   int32_t accumulate;
   float* partial;
   int32_t mfma_bf16;        /* as in c3d_conv_desc                                         */
+  float lrelu_slope;        /* as in c3d_conv_desc                                         */
 } c3d_wgrad_desc;
 int64_t c3d_wgrad_partial_floats(const c3d_wgrad_desc* d);
 int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream);
@@ -138,7 +141,7 @@ int c3d_bn_eval_affine(const float* gamma, const float* beta, const float* runni
 int c3d_bn_bwd_num_blocks(int npix);
 int c3d_bn_bwd_reduce(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C,
                       int mode, const float* pre_scale, const float* pre_shift, float* partial,
-                      c3d_stream stream);
+                      float lrelu_slope /* 0 = 0.01 */, c3d_stream stream);
 /* sums = (all-reduced) statistics for k1..k3; sums_param = this rank's own statistics for
  * dgamma/dbeta (NULL = same as sums): SyncBatchNorm semantics under data parallelism          */
 int c3d_bn_bwd_coeffs(const double* sums, const double* sums_param, double count,
@@ -148,7 +151,7 @@ int c3d_bn_bwd_coeffs(const double* sums, const double* sums_param, double count
 int c3d_bn_bwd_apply(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C,
                      int mode, const float* pre_scale, const float* pre_shift, const float* k1,
                      const float* k2, const float* k3, float* dz, int dz_cs, float* partial,
-                     c3d_stream stream);
+                     float lrelu_slope /* 0 = 0.01 */, c3d_stream stream);
 /* Single-rank fast paths: fold the partials [C][2][n] and finish in one launch (no all-reduce
  * hook in between): = c3d_stat_reduce + c3d_bn_finalize / + c3d_bn_bwd_coeffs / + column 0.    */
 int c3d_bn_finalize_partials(const float* partial, int n, double count, const float* gamma,
@@ -176,9 +179,21 @@ int c3d_conv_in5(const float* x_nchw, const float* w, const float* bias, int B, 
 /* its weight gradient dw[32][Cn]; partial = scratch of 1024*32*8 floats                      */
 int c3d_conv_in5_wgrad(const float* x_nchw, const float* dz, int B, int Cn, int HW,
                        float* partial, float* dw, c3d_stream stream);
-/* out = x + (a*scale + shift)  (x, scale may be NULL)   residual adds :64, :133             */
+/* out = x + act(a*scale + shift)  (x, scale may be NULL; act = LeakyReLU(lrelu_slope), or the
+ * identity when lrelu_slope == 0): residual adds of salsanext_proto.py:64,133 and of RangeNet's
+ * BasicBlock (rangenet_proto.py:52-63)                                                       */
 int c3d_affine_add(const float* x, const float* a, const float* scale, const float* shift,
-                   int64_t npix, int C, float* out, c3d_stream stream);
+                   int64_t npix, int C, float lrelu_slope, float* out, c3d_stream stream);
+/* NHWC [rows][Win][C] column resampling: up = 0 keeps the even columns (W -> W/2: a stride-(1,2)
+ * conv = stride-1 conv + this, rangenet_proto.py:194-203); up = 1 inserts a zero column after
+ * every column (W -> 2W: ConvTranspose2d([1,4],[1,2],[0,1]) = this + a 4-tap conv, :328-336).
+ * The two are adjoint: each is the other's backward.                                         */
+int c3d_cols_resample(const float* in, int64_t rows, int Win, int C, int up, float* out,
+                      c3d_stream stream);
+/* x NCHW [B][Cn][HW] -> NHWC [B][HW][Cp] with zero channels Cn..Cp-1 (5-channel input as a
+ * 16-channel MFMA operand)                                                                   */
+int c3d_nchw_to_nhwc_pad(const float* x, int B, int Cn, int64_t HW, int Cp, float* out,
+                         c3d_stream stream);
 /* y (+)= alpha*x, flat                                                                      */
 int c3d_axpy(const float* x, float alpha, int64_t n, float* y, int accumulate, c3d_stream stream);
 /* Dropout2d multiplier mask[B,C] (NULL = none) then AvgPool2d(3,2,1) if pool (:108-109,135-142) */
