@@ -28,19 +28,21 @@ BN_MOMENTUM = 0.1
 
 class Act:
     """An activation tensor as consumers see it: raw NHWC tensor + optional affine of its BN."""
-    __slots__ = ("t", "scale", "shift", "grad", "mask")
+    __slots__ = ("t", "scale", "shift", "grad", "mask", "no_grad")
 
     def __init__(self, t, scale=None, shift=None, mask=None):
         self.t, self.scale, self.shift = t, scale, shift
         self.grad = None      # gradient w.r.t. the affine-transformed value (NHWC, same shape)
         self.mask = mask      # Dropout2d multiplier [B,C] applied by the consumer (UpBlock out)
+        self.no_grad = False  # True: nothing upstream needs d(loss)/d(this) (network input, detached skips)
 
     def src(self, lrelu=False):
         return ops.Source(self.t, self.scale, self.shift, lrelu=lrelu)
 
 
 class _ConvRec:
-    __slots__ = ("name", "srcs", "src_lrelu", "taps", "cout", "mode", "bn", "out", "stats")
+    __slots__ = ("name", "srcs", "src_lrelu", "taps", "cout", "mode", "bn", "out", "stats", "slope", "weight",
+                 "dweight")
 
 
 class _BNRec:
@@ -61,7 +63,7 @@ class Backbone:
                                       # block's parameter gradients are final (backward order)
 
     # ------------------------------------------------------------------ forward helpers
-    def _bn_forward(self, name, partial, c, count):
+    def _bn_forward(self, name, partial, c, count, momentum=BN_MOMENTUM):
         P = self.P
         rec = _BNRec()
         rec.name = name
@@ -70,13 +72,13 @@ class Backbone:
             rv = P[f"{name}.running_var"] if self.update_running else None
             if self.reduce_fn is None:      # single rank: fold + finalize in one launch
                 rec.scale, rec.shift, rec.mean, rec.invstd = ops.bn_finalize_partials(
-                    partial, count, P[f"{name}.weight"], P[f"{name}.bias"], rm, rv, BN_MOMENTUM, BN_EPS)
+                    partial, count, P[f"{name}.weight"], P[f"{name}.bias"], rm, rv, momentum, BN_EPS)
             else:                           # SyncBN: all-reduce the fp64 sums in between
                 sums = ops.stat_reduce(partial, c)
                 self.reduce_fn(sums)
                 count = count * self.world
                 rec.scale, rec.shift, rec.mean, rec.invstd = ops.bn_finalize(
-                    sums, count, P[f"{name}.weight"], P[f"{name}.bias"], rm, rv, BN_MOMENTUM, BN_EPS)
+                    sums, count, P[f"{name}.weight"], P[f"{name}.bias"], rm, rv, momentum, BN_EPS)
             rec.count = count
             self.bn_seen.append(name)
         else:
@@ -86,23 +88,28 @@ class Backbone:
             rec.count = count
         return rec
 
-    def _conv(self, name, srcs, k, dil, pad, lrelu=True, bn=None, src_lrelu=False, cout_pad=None):
-        """srcs: list[Act].  Returns Act of the conv output (pre-BN tensor + BN affine)."""
-        w = self.P[f"{name}.weight"]
+    def _conv(self, name, srcs, k, dil, pad, lrelu=True, bn=None, src_lrelu=False, cout_pad=None, taps=None,
+              slope=0.0, bn_momentum=BN_MOMENTUM, weight=None, dweight=None):
+        """srcs: list[Act].  Returns Act of the conv output (pre-BN tensor + BN affine).
+        ``taps`` overrides the k x k pattern; ``slope`` is the LeakyReLU slope of the on-load and
+        epilogue activations (0 = 0.01); ``weight`` (OIHW) overrides ``P[name.weight]`` for layers
+        whose parameter is stored in another layout, ``dweight`` then receives its gradient."""
+        w = self.P[f"{name}.weight"] if weight is None else weight
         cout = w.shape[0]
-        taps = ops.conv_taps(k, k, dil, pad)
-        wp = self.packs.get(w, 0)
+        taps = ops.conv_taps(k, k, dil, pad) if taps is None else taps
+        wp = self.packs.get(w, 0) if weight is None else ops.pack_weights(w, 0)
         b, h, wd = srcs[0].t.shape[:3]
         out = None
         if cout_pad is not None and cout_pad != cout:
             out = torch.zeros(b, h, wd, cout_pad, device=w.device, dtype=torch.float32)
         need_stats = bn is not None and self.train
-        y, partial = ops.conv_forward([s.src(src_lrelu) for s in srcs], wp, self.P[f"{name}.bias"], cout, taps,
-                                      lrelu=lrelu, stats=need_stats, out=out)
+        y, partial = ops.conv_forward([s.src(src_lrelu) for s in srcs], wp, self.P.get(f"{name}.bias"), cout, taps,
+                                      lrelu=lrelu, stats=need_stats, out=out, slope=slope)
         rec = _ConvRec()
         rec.name, rec.srcs, rec.src_lrelu, rec.taps, rec.cout = name, srcs, src_lrelu, taps, cout
+        rec.slope, rec.weight, rec.dweight = slope, weight, dweight
         rec.mode = 0 if (lrelu and bn) else (2 if lrelu else (1 if bn else 3))
-        rec.bn = self._bn_forward(bn, partial, cout, b * h * wd) if bn is not None else None
+        rec.bn = self._bn_forward(bn, partial, cout, b * h * wd, bn_momentum) if bn is not None else None
         rec.out = Act(y, rec.bn.scale if rec.bn else None, rec.bn.shift if rec.bn else None)
         self.tape[name] = rec
         return rec.out
@@ -215,6 +222,23 @@ class Backbone:
         else:
             ops.axpy(g, act.grad)
 
+    def _bn_backward(self, bn, dy, a, c, mode, slope=0.0):
+        """dy: gradient w.r.t. BN(a) [mode 0] or LeakyReLU(BN(a)) [mode 1] -> (dz = d/da, partial with
+        sum(dz)); writes the BatchNorm parameter gradients.  SyncBN: the fp64 sums are all-reduced."""
+        G = self.grads
+        pre_s, pre_h = (bn.scale, bn.shift) if mode == 1 else (None, None)
+        part = ops.bn_bwd_reduce(dy, a, c, mode, pre_s, pre_h, slope=slope)
+        if self.reduce_fn is None:
+            k = ops.bn_bwd_coeffs_partials(part, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
+                                           G[f"{bn.name}.weight"], G[f"{bn.name}.bias"])
+        else:
+            sums = ops.stat_reduce(part, c)
+            local = sums.clone()      # dgamma/dbeta stay rank-local (averaged with the other grads)
+            self.reduce_fn(sums)
+            k = ops.bn_bwd_coeffs(sums, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
+                                  G[f"{bn.name}.weight"], G[f"{bn.name}.bias"], local)
+        return ops.bn_bwd_apply(dy, a, c, mode, k, pre_s, pre_h, slope=slope)
+
     def _conv_backward(self, name, dy):
         """dy: gradient w.r.t. the layer's consumer-visible output (BN output if it has BN)."""
         rec = self.tape[name]
@@ -223,33 +247,24 @@ class Backbone:
         cpad = a.shape[3]
         G = self.grads
         if rec.mode == 0 or rec.mode == 1:
-            bn = rec.bn
-            pre_s, pre_h = (bn.scale, bn.shift) if rec.mode == 1 else (None, None)
-            part = ops.bn_bwd_reduce(dy, a, c, rec.mode, pre_s, pre_h)
-            if self.reduce_fn is None:
-                k = ops.bn_bwd_coeffs_partials(part, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
-                                               G[f"{bn.name}.weight"], G[f"{bn.name}.bias"])
-            else:
-                sums = ops.stat_reduce(part, c)
-                local = sums.clone()      # dgamma/dbeta stay rank-local (averaged with the other grads)
-                self.reduce_fn(sums)
-                k = ops.bn_bwd_coeffs(sums, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
-                                      G[f"{bn.name}.weight"], G[f"{bn.name}.bias"], local)
-            dz, pz = ops.bn_bwd_apply(dy, a, c, rec.mode, k, pre_s, pre_h)
+            dz, pz = self._bn_backward(rec.bn, dy, a, c, rec.mode, rec.slope)
         elif rec.mode == 2:
-            dz, pz = ops.bn_bwd_apply(dy, a, c, 2)
+            dz, pz = ops.bn_bwd_apply(dy, a, c, 2, slope=rec.slope)
         else:
             dz, pz = ops.bn_bwd_apply(dy, dy, cpad, 3, dz=dy)
-        ops.bias_from_partials(pz, G[f"{name}.bias"])
-        w = self.P[f"{name}.weight"]
-        dw = G[f"{name}.weight"]
+        if f"{name}.bias" in G:
+            ops.bias_from_partials(pz, G[f"{name}.bias"])
+        w = self.P[f"{name}.weight"] if rec.weight is None else rec.weight
+        dw = G[f"{name}.weight"] if rec.dweight is None else rec.dweight
         ntaps = ops.negate_taps(rec.taps)
         off = 0
         for s in rec.srcs:
             cs = s.t.shape[3]
-            ops.conv_wgrad(s.src(rec.src_lrelu), dz, dw, rec.taps, cin_off=off)
+            ops.conv_wgrad(s.src(rec.src_lrelu), dz, dw, rec.taps, cin_off=off, slope=rec.slope)
             if not getattr(s, "no_grad", False):
-                wd = self.packs.get(w, 1, c_off=off, c_cnt=cs, kpad=(dz.shape[3] + 15) // 16 * 16)
+                kp = (dz.shape[3] + 15) // 16 * 16
+                wd = (self.packs.get(w, 1, c_off=off, c_cnt=cs, kpad=kp) if rec.weight is None
+                      else ops.pack_weights(w, 1, c_off=off, c_cnt=cs, kpad=kp))
                 if s.grad is None:
                     s.grad = torch.empty_like(s.t)
                     acc = False

@@ -1,0 +1,246 @@
+"""RangeNet (Darknet-21/53) prototype backbone: explicit forward / backward over the HIP ops
+(SURVEY 8f, N3).
+
+Mirrors the arithmetic of the reference ``RangeNetProto.forward`` (pc_processor/models/
+rangenet_proto.py: BasicBlock :38-63, Backbone :76-259, Decoder :261-372, forward :573-676) on
+the engine built for SalsaNext (coarse3d_amd/backbone.py), with the three things this family
+adds:
+
+* conv -> BatchNorm -> LeakyReLU(0.1) order: the conv epilogue emits raw outputs + statistics,
+  consumers apply affine + activation while staging (``src_lrelu`` with slope 0.1) and the
+  BatchNorm backward runs in its "BN then activation" mode;
+* stride-(1,2) 3x3 convs = stride-1 conv + even-column subsampling, ConvTranspose2d([1,4],[1,2],
+  [0,1]) = zero-column insertion + 4-tap conv (``c3d_cols_resample`` is its own adjoint);
+* skip connections are DETACHED in the reference (``skips[os] = x.detach()`` :217, ``skips[os]
+  .detach()`` :353, and the 480-channel embedding input): no gradient flows through them.
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+from .backbone import Act, Backbone
+
+SLOPE = 0.1                      # nn.LeakyReLU(0.1)
+BN_MOM = 0.01                    # Backbone.bn_d / Decoder.bn_d
+MODEL_BLOCKS = {21: [1, 1, 2, 2, 1], 53: [1, 2, 8, 8, 4]}
+UP_TAPS = [(0, 1 - k) for k in range(4)]     # out[x] = sum_k u[x + 1 - k] * w[:, :, 0, k]
+DROP_SITES = ("enc1", "enc2", "enc3", "enc4", "enc5", "decoder", "head")
+
+
+class RangeNetBackbone(Backbone):
+    def __init__(self, params, nclasses=20, dataset="SemanticKitti", reduce_fn=None, world_size=1, packs=None, layers=21):
+        super().__init__(params, nclasses, dataset, reduce_fn, world_size, packs)
+        self.blocks = MODEL_BLOCKS[layers]
+
+    # ------------------------------------------------------------------ forward helpers
+    def _materialise(self, a):
+        """Act with a pending BatchNorm affine + LeakyReLU -> plain Act (one elementwise pass)."""
+        return Act(ops.affine_add(None, a.t, a.scale, a.shift, slope=SLOPE))
+
+    def _basic_block(self, name, r):
+        """r: plain Act.  1x1 -> BN -> LReLU -> 3x3 -> BN -> LReLU, + r (rangenet_proto.py:52-63)."""
+        a1 = self._conv(f"{name}.conv1", [r], 1, 1, 0, lrelu=False, bn=f"{name}.bn1", slope=SLOPE, bn_momentum=BN_MOM)
+        a2 = self._conv(f"{name}.conv2", [a1], 3, 1, 1, lrelu=False, bn=f"{name}.bn2", src_lrelu=True, slope=SLOPE,
+                        bn_momentum=BN_MOM)
+        out = Act(ops.affine_add(r.t, a2.t, a2.scale, a2.shift, slope=SLOPE))
+        self.tape[f"{name}.out"] = (r, a1, a2, out)
+        return out
+
+    def _basic_block_backward(self, name):
+        r, a1, a2, out = self.tape[f"{name}.out"]
+        g = out.grad
+        out.grad = None
+        self._conv_backward(f"{name}.conv2", g)             # g = d/d LReLU(BN2(.)); BN backward mode 1
+        r.grad = g                                          # residual path: reuse the buffer, conv1's dgrad accumulates
+        self._conv_backward(f"{name}.conv1", a1.grad)
+        a1.grad = None
+
+    def _down(self, name, src, src_pending):
+        """stride-(1,2) 3x3 conv (no bias) -> BN -> LReLU, materialised (rangenet_proto.py:194-206)."""
+        w = self.P[f"{name}.conv.weight"]
+        cout = w.shape[0]
+        taps = ops.conv_taps(3, 3, 1, 1)
+        full, _ = ops.conv_forward([src.src(src_pending)], self.packs.get(w, 0), None, cout, taps, slope=SLOPE)
+        y = ops.cols_resample(full, up=False)
+        b, h, wd, _ = y.shape
+        bn = None
+        if self.train:
+            part = ops.bn_bwd_reduce(y, y, cout, 0)          # (sum y, sum y*y) per channel
+            bn = self._bn_forward(f"{name}.bn", part, cout, b * h * wd, BN_MOM)
+        else:
+            bn = self._bn_forward(f"{name}.bn", None, cout, b * h * wd, BN_MOM)
+        out = Act(ops.affine_add(None, y, bn.scale, bn.shift, slope=SLOPE))
+        self.tape[f"{name}.down"] = (src, src_pending, y, bn, out, taps)
+        return out
+
+    def _down_backward(self, name):
+        src, src_pending, y, bn, out, taps = self.tape[f"{name}.down"]
+        cout = y.shape[3]
+        dz_sub, _ = self._bn_backward(bn, out.grad, y, cout, 1, SLOPE)
+        out.grad = None
+        dz = ops.cols_resample(dz_sub, up=True)
+        w = self.P[f"{name}.conv.weight"]
+        dw = self.grads[f"{name}.conv.weight"]
+        cin = src.t.shape[3]
+        ops.conv_wgrad(src.src(src_pending), dz, dw, taps, slope=SLOPE)
+        if not src.no_grad:
+            wd = self.packs.get(w, 1, c_off=0, c_cnt=cin, kpad=(cout + 15) // 16 * 16)
+            acc = src.grad is not None
+            if not acc:
+                src.grad = torch.empty_like(src.t)
+            ops.conv_forward([ops.Source(dz)], wd, None, cin, ops.negate_taps(taps), out=src.grad, accumulate=acc)
+
+    def _up(self, name, t):
+        """ConvTranspose2d([1,4], stride [1,2], padding [0,1]) + bias -> BN -> LReLU, materialised."""
+        u = Act(ops.cols_resample(t.t, up=True))
+        w_t = self.P[f"{name}.upconv.weight"]               # [Cin, Cout, 1, 4]
+        w_conv = w_t.permute(1, 0, 2, 3).contiguous()       # OIHW of the equivalent 4-tap conv
+        dw_conv = torch.empty_like(w_conv) if self.train else None
+        z = self._conv(f"{name}.upconv", [u], 1, 1, 0, lrelu=False, bn=f"{name}.bn", taps=UP_TAPS, slope=SLOPE,
+                       bn_momentum=BN_MOM, weight=w_conv, dweight=dw_conv)
+        out = self._materialise(z)
+        self.tape[f"{name}.up"] = (t, u, z, out, dw_conv)
+        return out
+
+    def _up_backward(self, name):
+        t, u, z, out, dw_conv = self.tape[f"{name}.up"]
+        self._conv_backward(f"{name}.upconv", out.grad)
+        out.grad = None
+        self.grads[f"{name}.upconv.weight"].copy_(dw_conv.permute(1, 0, 2, 3))
+        t.grad = ops.cols_resample(u.grad, up=False)
+        u.grad = None
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, train=True, dropout_masks=None, return_feat=True, update_running=True):
+        """x [B,5,H,W] fp32 NCHW.  Returns dict with NHWC tensors: prob [B,H,Wo,C], logits
+        [B,H,W,32], feat [B,H,W,256] (if return_feat)."""
+        self.train, self.masks, self.update_running = train, dropout_masks, update_running
+        self.packs.refresh()
+        self.tape = OrderedDict()
+        self.bn_seen = []
+        ho, wo = x.shape[2], x.shape[3]
+        if self.dataset == "SemanticPOSS":                   # rangenet_proto.py:586-590
+            x = torch.nn.functional.pad(x, (0, 24))
+        assert x.shape[3] % 32 == 0, "W must be a multiple of 32 (five stride-2 stages)"
+        xin = Act(ops.nchw_to_nhwc_pad(x.contiguous(), 16))  # 5 channels as a 16-channel MFMA operand
+        xin.no_grad = True
+        w1 = self.P["backbone.conv1.weight"]
+        dw1 = torch.empty(w1.shape[0], 16, 3, 3, device=w1.device) if train else None
+        t = self._conv("backbone.conv1", [xin], 3, 1, 1, lrelu=False, bn="backbone.bn1", slope=SLOPE, bn_momentum=BN_MOM,
+                       dweight=dw1)
+        self.tape["conv1.dw"] = dw1
+        t_pending = True
+        skips = {}
+        os_ = 1
+        for i in range(1, 6):
+            name = f"backbone.enc{i}"
+            cur = self._down(name, t, t_pending)
+            for bidx in range(self.blocks[i - 1]):
+                cur = self._basic_block(f"{name}.residual_{bidx}", cur)
+            skips[os_] = (t, t_pending)
+            os_ *= 2
+            m = self._mask(f"enc{i}")
+            nxt = Act(ops.maskpool(cur.t, m, False)) if m is not None else cur
+            self.tape[f"{name}.drop"] = (cur, nxt, m)
+            t, t_pending = nxt, False
+        for i in (5, 4, 3, 2, 1):
+            name = f"decoder.dec{i}"
+            y = self._up(name, t)
+            y = self._basic_block(f"{name}.residual", y)
+            os_ //= 2
+            sk, sk_pending = skips[os_]
+            nxt = Act(ops.affine_add(y.t, sk.t, sk.scale if sk_pending else None, sk.shift if sk_pending else None,
+                                     slope=SLOPE if sk_pending else 0.0))
+            self.tape[f"{name}.skip"] = (y, nxt)
+            t = nxt
+        md, mh = self._mask("decoder"), self._mask("head")
+        m = md * mh if (md is not None and mh is not None) else (md if md is not None else mh)
+        th = Act(ops.maskpool(t.t, m, False)) if m is not None else t
+        self.tape["head.drop"] = (t, th, m)
+        logits = self._conv("head.1", [th], 3, 1, 1, lrelu=False, cout_pad=32)
+        prob = ops.softmax(logits.t, self.ncls, ho, wo)
+        self._prob = prob
+        out = {"prob": prob, "logits": logits.t}
+        self.return_feat = return_feat
+        if return_feat:
+            b, hp, wp = x.shape[0], x.shape[2], x.shape[3]
+            hh, wh = ho // 2, wo // 2
+            srcs = []
+            for k in (1, 2, 4, 8):
+                sk, pend = skips[k]
+                srcs.append(self._materialise(sk).t if pend else sk.t)
+            feat = torch.empty(b, hh, wh, sum(s.shape[3] for s in srcs), device=x.device, dtype=torch.float32)
+            off = 0
+            for s in srcs:
+                ops.bilinear(s, hh, wh, dst=feat, dcoff=off, c=s.shape[3])
+                off += s.shape[3]
+            feat_a = Act(feat)
+            feat_a.no_grad = True                            # the skips are detached: nothing upstream
+            z0 = self._conv("projector.proj.0", [feat_a], 1, 1, 0, lrelu=False, bn="projector.proj.1")
+            emb = self._conv("projector.proj.3", [z0], 1, 1, 0, lrelu=False, src_lrelu=True)
+            embn, norm = ops.l2norm(emb.t, 1e-12)
+            out["feat"] = ops.bilinear(embn, hp, wp)
+            self.tape["embed"] = (feat_a, z0, emb, embn, norm)
+        if train and update_running:
+            torch._foreach_add_([self.P[f"{n}.num_batches_tracked"] for n in self.bn_seen], 1)
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, d_prob=None, d_feat=None, grads=None):
+        """d_prob [B,H,Wo,C], d_feat [B,H,W,256] (NHWC).  ``grads``: name -> preallocated gradient."""
+        if grads is None:
+            grads = {k: torch.zeros_like(v) for k, v in self.P.items()
+                     if v.is_floating_point() and v.dim() > 0 and not k.endswith(("running_mean", "running_var"))
+                     and k != "prototypes" and not k.startswith(("feat_norm", "mask_norm"))}
+        self.grads = grads
+        hook = self.on_block_done if self.on_block_done is not None else (lambda tag: None)
+        if d_feat is not None and self.return_feat:
+            feat_a, z0, emb, embn, norm = self.tape["embed"]
+            d_embn = torch.empty_like(embn)
+            ops.bilinear_bwd(d_embn, d_feat.contiguous())
+            d_emb = ops.l2norm_bwd(embn, norm, d_embn, 1e-12)
+            self._conv_backward("projector.proj.3", d_emb)
+            self._conv_backward("projector.proj.0", z0.grad)
+            z0.grad = None
+        else:
+            for n in ("projector.proj.0", "projector.proj.1", "projector.proj.3"):
+                for suffix in ("weight", "bias"):
+                    grads[f"{n}.{suffix}"].zero_()
+        hook("projector")
+        if d_prob is None:
+            raise ValueError("backward needs d_prob (the segmentation losses always produce it)")
+        logits = self.tape["head.1"].out
+        dl = ops.softmax_bwd(self._prob, d_prob.contiguous(), tuple(logits.t.shape))
+        self._conv_backward("head.1", dl)
+        t, th, m = self.tape["head.drop"]
+        if th is not t:
+            t.grad = ops.maskpool_bwd(th.grad, m, None, tuple(t.t.shape), False)
+            th.grad = None
+        hook("head")
+        for i in (1, 2, 3, 4, 5):
+            name = f"decoder.dec{i}"
+            y, nxt = self.tape[f"{name}.skip"]
+            y.grad = nxt.grad                                # the skip is detached: the sum passes its gradient on
+            nxt.grad = None
+            self._basic_block_backward(f"{name}.residual")
+            self._up_backward(name)
+            hook(f"decoder.dec{i}")
+        for i in (5, 4, 3, 2, 1):
+            name = f"backbone.enc{i}"
+            cur, nxt, m = self.tape[f"{name}.drop"]
+            if nxt is not cur:
+                cur.grad = ops.maskpool_bwd(nxt.grad, m, None, tuple(cur.t.shape), False)
+                nxt.grad = None
+            for bidx in reversed(range(self.blocks[i - 1])):
+                self._basic_block_backward(f"{name}.residual_{bidx}")
+            self._down_backward(name)
+            hook(f"backbone.enc{i}")
+        rec = self.tape["backbone.conv1"]
+        self._conv_backward("backbone.conv1", rec.out.grad)
+        rec.out.grad = None
+        dw1 = self.tape["conv1.dw"]
+        grads["backbone.conv1.weight"].copy_(dw1[:, :grads["backbone.conv1.weight"].shape[1]])
+        hook("backbone.conv1")
+        self.tape = None
+        return grads

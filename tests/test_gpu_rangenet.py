@@ -1,0 +1,57 @@
+"""the RangeNet (Darknet-21) prototype backbone on the HIP engine
+(coarse3d_amd/rangenet.py) against the golden vectors captured from the reference RangeNetProto
+(tests/golden/rangenet.npz) with closed-form weights and injected Dropout2d masks.
+Forward 1e-4 of max|ref|; every parameter gradient through its (sum, sum of squares) checksum and
+a few small tensors element-wise, at the noise-calibrated tolerance used for the SalsaNext
+backbone (whole-network fp32 gradients are ~1 % noisy)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import weights as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("tag,b,h,w,ncls,dataset", [("kitti", 2, 8, 64, 20, "SemanticKitti"), ("poss", 1, 8, 40, 14, "SemanticPOSS")])
+def test_rangenet_backbone_vs_reference_golden(tag, b, h, w, ncls, dataset):
+    from coarse3d_amd.rangenet import RangeNetBackbone
+    d = np.load(os.path.join(GOLD, "rangenet.npz"))
+    st = {k: v.to(DEV) for k, v in W.rangenet_state(nclasses=ncls).items()}
+    x, dp, df = W.rangenet_inputs(b, h, w, ncls, w + 24 if dataset == "SemanticPOSS" else None)
+    masks = {k: v.to(DEV) for k, v in W.rangenet_masks(b, 3).items()}
+    bb = RangeNetBackbone(st, ncls, dataset)
+    out = bb.forward(x.to(DEV), True, masks, True)
+    pred = out["prob"].permute(0, 3, 1, 2)
+    feat = out["feat"].permute(0, 3, 1, 2)
+    assert rel(pred, torch.from_numpy(d[f"{tag}/pred_2d"])) < 1e-4
+    assert rel(feat[:, ::4, :, ::2], torch.from_numpy(d[f"{tag}/feat_2d_sub"])) < 1e-4
+    for k in d.files:
+        if k.startswith(f"{tag}/run/"):
+            n = k.split("/", 2)[2]
+            assert float((st[n].cpu() - torch.from_numpy(d[k])).abs().max()) < 1e-5, n
+    grads = bb.backward(dp.permute(0, 2, 3, 1).contiguous().to(DEV), df.permute(0, 2, 3, 1).contiguous().to(DEV))
+    names = [str(n) for n in d[f"{tag}/grad_names"]]
+    bad = []
+    for n in names:
+        gd = grads[n].double().cpu()
+        sq = float(d[f"{tag}/gsq/{n}"])
+        if n.endswith(("upconv.bias", "proj.0.bias")):       # bias in front of BatchNorm: exactly 0 up to noise
+            assert float((gd * gd).sum()) < 1e-8, n
+            continue
+        if abs(float((gd * gd).sum()) - sq) > 5e-2 * sq + 1e-20:
+            bad.append((n, float((gd * gd).sum()), sq))
+    assert len(bad) <= 0.1 * len(names), bad[:5]
+    for k in d.files:
+        if k.startswith(f"{tag}/grad/"):
+            n = k.split("/", 2)[2]
+            assert rel(grads[n], torch.from_numpy(d[k])) < 3e-2, n
