@@ -81,8 +81,38 @@ def cpu_baseline(ncls, h, w, budget_s=150.0):
             "sec_per_image": round(sec, 3)}
 
 
+def cpu_baseline_rangenet(ncls, h, w, layers, budget_s=150.0):
+    """RangeNet oracle on the host cores, bounded sample: forward + backward of the backbone and
+    embedding branch at bs=1 (the losses and the prototype step are negligible beside it)."""
+    from oracle import rangenet_oracle as ro
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import weights as W
+    cores = torch.get_num_threads()
+    st = W.rangenet_state(layers=layers, nclasses=ncls)
+    names = ro.trainable_names(st)
+    for k in names:
+        st[k].requires_grad_(True)
+    times = []
+    t_all = time.time()
+    for s in range(3):
+        g = torch.Generator().manual_seed(s)
+        x = torch.randn(1, 5, h, w, generator=g)
+        t0 = time.time()
+        out = ro.rangenet_forward(st, x, True, None, True, layers)
+        loss = (out["pred_2d"] * torch.randn(out["pred_2d"].shape, generator=g)).sum() + out["feat_2d"].sum()
+        torch.autograd.grad(loss, [st[k] for k in names], allow_unused=True)
+        times.append(time.time() - t0)
+        if time.time() - t_all > budget_s:
+            break
+    timed = times[1:] if len(times) > 1 else times
+    sec = float(np.median(timed))
+    return {"value": round(1.0 / sec, 4), "unit": "range-images/sec", "cores": cores, "kind": "port",
+            "sample": f"RangeNet-{layers} oracle forward+backward, bs=1, {h}x{w}x5, C={ncls}, fp32, {len(timed)} timed "
+                      f"pass(es) after {len(times) - len(timed)} warm-up", "sec_per_image": round(sec, 3)}
+
+
 def default_shape_for_step(args):
-    return (args.height, args.width, args.classes, args.dataset) == (64, 2048, 20, "SemanticKitti")
+    return (args.net, args.height, args.width, args.classes, args.dataset) == ("salsanext", 64, 2048, 20, "SemanticKitti")
 
 
 def main():
@@ -95,6 +125,8 @@ def main():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--classes", type=int, default=20)
     ap.add_argument("--dataset", default="SemanticKitti")
+    ap.add_argument("--net", choices=("salsanext", "rangenet21", "rangenet53"), default="salsanext",
+                    help="backbone (default: SalsaNextProto, the BASELINE workload; rangenet*: SURVEY 8f N3)")
     ap.add_argument("--matrix-dtype", choices=("f32", "bf16", "bf16x3"), default="f32",
                     help="MFMA operand type: f32 = the parity path and the headline; bf16 = opt-in mixed "
                          "precision (bf16 operands, fp32 accumulate and storage; BASELINE configs[2]); "
@@ -123,14 +155,18 @@ def main():
 
     from coarse3d_amd import dist as D
     from coarse3d_amd import ops
-    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    from coarse3d_amd.pc_processor.models import RangeNetProto, SalsaNextProto
     from coarse3d_amd.trainer import TrainStep
 
     ops.set_matrix_precision(args.matrix_dtype)
     peak_tf = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS,
                "bf16x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[args.matrix_dtype]   # 6 bf16 MFMAs per fp32-equivalent one
     torch.manual_seed(1)
-    model = SalsaNextProto(5, args.classes, 20, 0, use_prototype=True, dataset=args.dataset).to(dev).train()
+    if args.net == "salsanext":
+        model = SalsaNextProto(5, args.classes, 20, 0, use_prototype=True, dataset=args.dataset)
+    else:
+        model = RangeNetProto(layers=int(args.net[-2:]), nclasses=args.classes, dataset=args.dataset, use_prototype=True)
+    model = model.to(dev).train()
     wrapped = D.DataParallel(model) if (world > 1 or single_rank_group or os.environ.get("C3D_FORCE_DP")) else model
     ts = TrainStep(wrapped, args.classes, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512,
                    loss_w_ce_2d=1.0, loss_w_lov_2d=1.0, loss_w_contrast=0.1, feature_mean=FEATURE_MEAN,
@@ -211,7 +247,7 @@ def main():
         # HBM traffic of the same kernel from the PMC passes kept under profiles/ (2*FETCH_SIZE +
         # WRITE_SIZE, separate rocprofv3 --pmc runs of this bench; tools/profile_round.sh, tools/hbm_report.py)
         traffic = None
-        default_shape = (args.batch, args.height, args.width, args.classes, args.dataset) == (8, 64, 2048, 20, "SemanticKitti")
+        default_shape = args.batch == 8 and default_shape_for_step(args)
         try:
             if not default_shape:          # the PMC passes were collected on the headline workload only
                 raise KeyError("no PMC capture for this shape")
@@ -251,13 +287,15 @@ def main():
                       "bf16x3": "f32 values as 3 bf16 planes on the bf16 MFMA pipe, f32 accumulate/storage"}[args.matrix_dtype],
             "data": "synthetic",
             "config": {"workload": f"{args.dataset} {args.height}x{args.width}x5 range image, C={args.classes}, "
-                                   f"bs={args.batch}/GPU, SalsaNextProto fwd+bwd + prototype bank + contrast "
-                                   f"loss + AdamW (BASELINE.json configs[{2 if args.matrix_dtype == 'bf16' else 1}])",
+                                   f"bs={args.batch}/GPU, {type(model).__name__}{'' if args.net == 'salsanext' else args.net[-2:]} fwd+bwd + prototype bank + contrast "
+                                   f"loss + AdamW" + (f" (BASELINE.json configs[{2 if args.matrix_dtype == 'bf16' else 1}])"
+                                                      if args.net == "salsanext" else " (SURVEY 8f N3 backbone)"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.classes, args.height, args.width)
+            out["cpu_baseline"] = (cpu_baseline(args.classes, args.height, args.width) if args.net == "salsanext"
+                                   else cpu_baseline_rangenet(args.classes, args.height, args.width, int(args.net[-2:])))
         else:
             out["cpu_baseline"] = None
         line = json.dumps(out)

@@ -81,8 +81,7 @@ class _BackboneFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x, masks, return_feat, names, *tensors):
-        P = model._tensor_dict()
-        bb = Backbone(P, model.nclasses, model.dataset, model._bn_reduce, model._world, model._packs)
+        bb = model._make_backbone(model._tensor_dict())
         bb.on_block_done = model._block_done
         out = bb.forward(x.detach().float(), model.training, masks, return_feat)
         ctx.bb, ctx.names, ctx.model = bb, names, model
@@ -161,6 +160,13 @@ class SalsaNextProto(nn.Module):
         self._packs = ops_mod.PackCache()   # batched weight repacking (one launch per step)
 
     # ------------------------------------------------------------------ plumbing
+    def _make_backbone(self, P):
+        return Backbone(P, self.nclasses, self.dataset, self._bn_reduce, self._world, self._packs)
+
+    def _check_input(self, h, w):
+        hp, wp = (h + 8, w + 8) if self.dataset == "SemanticPOSS" else (h, w)
+        assert hp % 16 == 0 and wp % 16 == 0, "input height and width must be multiples of 16"
+
     def _tensor_dict(self):
         d = {k: v.detach() for k, v in self.named_parameters()}
         d.update({k: v for k, v in self.named_buffers()})
@@ -173,8 +179,8 @@ class SalsaNextProto(nn.Module):
     def _grad_buffers(self, names):
         if self._flat_grads is not None:
             return self._flat_grads
-        dev = self.cls_head.weight.device
         P = dict(self.named_parameters())
+        dev = next(iter(P.values())).device
         return {n: torch.empty_like(P[n], device=dev) for n in names}
 
     def _draw_masks(self, b, device):
@@ -192,8 +198,7 @@ class SalsaNextProto(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, x, label=None, eval_mask=None, return_feat=True, proto_loss=False, proto_pl=None):
         b, c, h, w = x.shape
-        hp, wp = (h + 8, w + 8) if self.dataset == "SemanticPOSS" else (h, w)
-        assert hp % 16 == 0 and wp % 16 == 0, "input height and width must be multiples of 16"
+        self._check_input(h, w)
         masks = self._draw_masks(b, x.device) if self.training else None
         named = self._trainable()
         names = tuple(k for k, _ in named)
