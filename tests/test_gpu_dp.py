@@ -13,7 +13,7 @@ import weights as W
 pytestmark = pytest.mark.gpu
 
 
-def _run(rank, world, port, q, b, h, w, ncls):
+def _run(rank, world, port, q, b, h, w, ncls, proto_sync="bank_mean"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,7 +34,7 @@ def _run(rank, world, port, q, b, h, w, ncls):
     m.eval_dropout = True
     m.dropout_masks = {k: torch.full_like(v, 1.0)[sl].to(dev) for k, v in W.dropout_masks_for(None, b, 1).items()}
     m.gumbel_noise = noise.reshape(b, h * w, 20)[sl].reshape(-1, 20).to(dev)
-    model = D.DataParallel(m) if world > 1 else m
+    model = D.DataParallel(m, proto_sync=proto_sync) if world > 1 else m
     out = model(x[sl].to(dev), label=tr[sl].to(dev), eval_mask=(tr[sl] > 0).to(dev), return_feat=True, proto_loss=True)
     # sum-type loss scaled by world: the DP mean of rank gradients equals the full-batch gradient
     loss = world * ((out["pred_2d"] * dp[sl].to(dev)).sum() + (out["feat_2d"] * df[sl].to(dev)).sum())
@@ -91,6 +91,28 @@ def test_two_ranks_match_full_batch():
     assert (res[0]["protos"] == res[1]["protos"]).all()
     n = torch.from_numpy(res[0]["protos"]).norm(dim=-1)
     assert float(n.min()) > 0.9 and float(n.max()) < 1.0 + 1e-5
+
+
+def test_two_ranks_prototype_sums_exchange():
+    """DataParallel(proto_sync="sums"): the per-class feature sums + counts are all-reduced before ONE
+    momentum update -- both ranks end with the identical, unit-norm bank, which differs from the
+    bank-mean result (a mean of two unit vectors is shorter than 1)."""
+    b, h, w, ncls = 2, 32, 64, 20
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29801 + os.getpid() % 500
+    procs = [ctx.Process(target=_run, args=(r, 2, port, q, b, h, w, ncls, "sums")) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    assert (res[0]["protos"] == res[1]["protos"]).all()
+    n = torch.from_numpy(res[0]["protos"]).norm(dim=-1)
+    assert float((n - 1).abs().max()) < 1e-5
+    for k in res[0]["grads"]:
+        assert (res[0]["grads"][k] == res[1]["grads"][k]).all(), k
 
 
 def test_rccl_exchange_points_in_a_single_rank_group():
