@@ -46,12 +46,18 @@ def world_mean(t):
 
 # parameter-name prefixes in the order in which Backbone.backward finishes them
 BACKWARD_ORDER = ("projector", "cls_head", "upBlock4", "upBlock3", "upBlock2", "upBlock1", "resBlock5", "resBlock4",
-                  "resBlock3", "resBlock2", "resBlock1", "downCntx3", "downCntx2", "downCntx")
+                  "resBlock3", "resBlock2", "resBlock1", "downCntx3", "downCntx2", "downCntx",
+                  # RangeNetBackbone.backward (coarse3d_amd/rangenet.py)
+                  "head", "decoder.dec1", "decoder.dec2", "decoder.dec3", "decoder.dec4", "decoder.dec5",
+                  "backbone.enc5", "backbone.enc4", "backbone.enc3", "backbone.enc2", "backbone.enc1", "backbone.conv1")
 
 
 def _block_of(name):
-    head = name.split(".")[0]
-    return head
+    """Parameter name -> tag of the backward block that finishes it."""
+    parts = name.split(".")
+    if parts[0] in ("backbone", "decoder"):
+        return "backbone.conv1" if parts[1] == "bn1" else f"{parts[0]}.{parts[1]}"
+    return parts[0]
 
 
 class FlatGradients:
