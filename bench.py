@@ -32,6 +32,7 @@ FEATURE_MEAN = [12.12, 10.88, 0.23, -1.04, 0.21]     # config_semantic_kitti.yam
 FEATURE_STD = [12.32, 11.47, 6.91, 0.86, 0.16]       # config_semantic_kitti.yaml:148-153
 PEAK_FP32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md chip-level parameters
 PEAK_BF16_MFMA_TFLOPS = 2500.0                       # dense bf16 (no sparsity), same guide
+PMC_FILE = "round1_f{tag}_hbm.json"                  # committed per-kernel HBM-traffic capture (tools/profile_round.sh)
 
 
 def synth_batch(b, h, w, ncls, seed, device, label_rate=1e-3):
@@ -45,19 +46,48 @@ def synth_batch(b, h, w, ncls, seed, device, label_rate=1e-3):
     return x, (ev * keep).long(), ev.long()
 
 
-def cpu_baseline(ncls, h, w, budget_s=150.0):
-    """Oracle train step on the host cores, bounded sample: bs=1, one warm-up + timed steps."""
+def host_cpu():
+    """(model string, physical cores of socket 0, sockets) from /proc/cpuinfo."""
+    model, cores, sockets = "unknown", set(), set()
+    try:
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+                sockets.add(v)
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                if phys == min(sockets):
+                    cores.add(core)
+                phys = core = None
+    except OSError:
+        pass
+    return model, (len(cores) or (os.cpu_count() or 1)), max(len(sockets), 1)
+
+
+def cpu_baseline(ncls, h, w, budget_s=240.0, bs=2, timed_steps=3):
+    """the CPU oracle's train step on this host, bs=2, fp32, one process,
+    torch.set_num_threads(physical cores of one socket), one warm-up step (oneDNN primitive
+    creation) + ``timed_steps`` timed steps, median reported.  Bounded: stops early when the
+    budget is spent (the sample line says how many steps were timed)."""
     from oracle import coarse3d_oracle as oc
-    cores = torch.get_num_threads()
+    model, cores, sockets = host_cpu()
+    cores = min(cores, os.cpu_count() or cores)
+    torch.set_num_threads(cores)
     st = oc.init_state(nclasses=ncls, seed=1)
     for k in oc.trainable_names(st):
         st[k].requires_grad_(True)
     mean, std = torch.tensor(FEATURE_MEAN), torch.tensor(FEATURE_STD)
     times = []
     t_all = time.time()
-    for s in range(3):
-        x, tr, ev = synth_batch(1, h, w, ncls, 1000 + s, "cpu")
-        masks = {k: (torch.rand(1, c) >= 0.2).float() * 1.25 for k, c in (
+    for s in range(1 + timed_steps):
+        x, tr, ev = synth_batch(bs, h, w, ncls, 1000 + s, "cpu")
+        masks = {k: (torch.rand(bs, c) >= 0.2).float() * 1.25 for k, c in (
             ("resBlock2.dropout", 128), ("resBlock3.dropout", 256), ("resBlock4.dropout", 256),
             ("resBlock5.dropout", 256), ("upBlock1.dropout1", 64), ("upBlock1.dropout2", 320),
             ("upBlock1.dropout3", 128), ("upBlock2.dropout1", 32), ("upBlock2.dropout2", 288),
@@ -75,10 +105,12 @@ def cpu_baseline(ncls, h, w, budget_s=150.0):
             break
     timed = times[1:] if len(times) > 1 else times
     sec = float(np.median(timed))
-    return {"value": round(1.0 / sec, 4), "unit": "range-images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle train step, bs=1, {h}x{w}x5, C={ncls}, fp32, {len(timed)} timed step(s) after "
-                      f"{len(times) - len(timed)} warm-up (first step {times[0]:.1f} s incl. oneDNN warm-up)",
-            "sec_per_image": round(sec, 3)}
+    return {"value": round(bs / sec, 4), "unit": "range-images/sec", "cores": cores, "kind": "port",
+            "cpu": f"{model} ({sockets} socket(s), {cores} physical cores used = one socket)",
+            "sample": f"oracle train step, bs={bs}, {h}x{w}x5, C={ncls}, fp32, median of {len(timed)} timed step(s) "
+                      f"after {len(times) - len(timed)} warm-up (first step {times[0]:.1f} s incl. oneDNN warm-up), "
+                      f"torch.set_num_threads({cores})",
+            "sec_per_image": round(sec / bs, 3)}
 
 
 def cpu_baseline_rangenet(ncls, h, w, layers, budget_s=150.0):
@@ -111,6 +143,53 @@ def cpu_baseline_rangenet(ncls, h, w, layers, budget_s=150.0):
                       f"pass(es) after {len(times) - len(timed)} warm-up", "sec_per_image": round(sec, 3)}
 
 
+def launch_ranks(n):
+    """One process per GPU, as the reference's launcher does (tasks/weak_segmentation/run.sh:1:
+    `python -m torch.distributed.launch --nproc_per_node=N`): start N copies of this script with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's single JSON line, fail if any rank
+    fails.  Runs BEFORE anything initialises the GPU in this process (children are fresh
+    interpreters; this parent never calls into HIP)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):     # one rank died: the others would hang in a collective
+            time.sleep(2.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                                  # exactly the children started above
+        time.sleep(0.2)
+    reader.join(10)
+    out0 = buf[0] if buf else ""
+    rcs = [p.returncode for p in procs]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    for ln in lines[:-1]:
+        print(ln, file=sys.stderr)               # anything rank 0 printed before its JSON line
+    if any(rcs):
+        for ln in lines[-1:]:
+            print(ln, file=sys.stderr)
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+        return 1
+    if not lines:
+        print("bench.py: rank 0 printed nothing", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def default_shape_for_step(args):
     return (args.net, args.height, args.width, args.classes, args.dataset) == ("salsanext", 64, 2048, 20, "SemanticKitti")
 
@@ -136,9 +215,17 @@ def main():
     ap.add_argument("--kernel-table", default=None, help="write a per-(kernel, layer shape) timing table (JSON) here")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher.  Nothing above or in
+        # launch_ranks() touches the GPU (no torch.cuda call), so starting children is safe.
+        raise SystemExit(launch_ranks(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
+              f"measuring {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     local_rank = local_rank % torch.cuda.device_count()       # (2 ranks on a 1-GPU box: debug only)
@@ -217,6 +304,7 @@ def main():
         ops.KERNEL_EVENTS = []
         if survey is not None:
             ops.KERNEL_EVENT_FILTER = max(survey[0].items(), key=lambda kv: kv[1][1])[0]
+    counts0 = dict(D.COUNTS)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.warmup, total_steps):
@@ -252,13 +340,17 @@ def main():
             if not default_shape:          # the PMC passes were collected on the headline workload only
                 raise KeyError("no PMC capture for this shape")
             tag = {"f32": "", "bf16": "_bf16", "bf16x3": "_bf16x3"}[args.matrix_dtype]
-            pmc = json.load(open(os.path.join(ROOT, "profiles", f"round1_f{tag}_hbm.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE.format(tag=tag))))
             traffic = round(pmc[name]["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2),
                     "peak": peak_tf, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak_tf, 4),
-                    "traffic": traffic, "launches_per_step": n // args.steps,
+                    "traffic": traffic,
+                    "traffic_source": (f"committed PMC pass profiles/{PMC_FILE.format(tag=tag)} (2*FETCH_SIZE + WRITE_SIZE "
+                                       "per launch of this kernel, separate rocprofv3 --pmc runs of this bench); not "
+                                       "re-measured in this run") if traffic is not None else None,
+                    "launches_per_step": n // args.steps,
                     "avg_launch_us": round(sec / n * 1e6, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
                     "all_mfma_kernels": {"achieved": round(all_fl / all_sec / 1e12, 2),
                                          "frac": round(all_fl / all_sec / 1e12 / peak_tf, 4),
@@ -275,12 +367,20 @@ def main():
                                   "algorithmic_GBps": round(10.96e9 / sec_img / 1e9, 1),
                                   "frac_of_hbm_peak": round(10.96e9 / sec_img / 8e12, 4)}
 
+    # ranks as the process group reports them (RCCL / gloo), not as the command line claims
+    n_ranks = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    collectives = None
+    if n_ranks > 1 or single_rank_group:
+        collectives = {k: round((D.COUNTS[k] - counts0[k]) / args.steps, 2) for k in D.COUNTS}
+        collectives["total"] = round(sum(collectives.values()), 2)
+        collectives["note"] = ("syncbn: 43 forward + 43 backward BatchNorm layers, minus the exchanges batched with an "
+                               "independent layer's; the weight-gradient stream runs under them")
     if rank == 0:
-        images = args.batch * world * args.steps
+        images = args.batch * n_ranks * args.steps
         out = {
-            "metric": "range-images/sec training step, 64x2048x5, bs=8/GPU",
+            "metric": f"range-images/sec training step, {args.height}x{args.width}x5, bs={args.batch}/GPU",
             "value": round(images / elapsed, 3), "unit": "range-images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16": "bf16 MFMA operands, f32 accumulate/storage",
@@ -290,7 +390,8 @@ def main():
                                    f"bs={args.batch}/GPU, {type(model).__name__}{'' if args.net == 'salsanext' else args.net[-2:]} fwd+bwd + prototype bank + contrast "
                                    f"loss + AdamW" + (f" (BASELINE.json configs[{2 if args.matrix_dtype == 'bf16' else 1}])"
                                                       if args.net == "salsanext" else " (SURVEY 8f N3 backbone)"),
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
+                       "global_batch": args.batch * n_ranks, "parallelism": f"dp{n_ranks}", "final_loss": round(loss, 4),
+                       "collectives_per_step": collectives},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

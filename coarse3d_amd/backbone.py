@@ -16,6 +16,8 @@ projector.py:11-27) with an MI355X-first dataflow:
 Parameter tensors are taken by *reference-compatible names* (``downCntx.conv1.weight`` ...)
 in OIHW layout, gradients are produced in the same layout.
 """
+import contextlib
+import os
 from collections import OrderedDict
 
 import torch
@@ -50,9 +52,12 @@ class _BNRec:
 
 
 class Backbone:
-    def __init__(self, params, nclasses=20, dataset="SemanticKitti", reduce_fn=None, world_size=1, packs=None):
-        """params: mapping name -> CUDA tensor (the module's parameters and buffers)."""
+    def __init__(self, params, nclasses=20, dataset="SemanticKitti", reduce_fn=None, world_size=1, packs=None,
+                 side_stream=None):
+        """params: mapping name -> CUDA tensor (the module's parameters and buffers).
+        side_stream: second HIP stream for the weight-gradient chain of the backward pass."""
         self.P = params
+        self.side = side_stream if os.environ.get("C3D_WGRAD_STREAM", "1") != "0" else None
         self.ncls = nclasses
         self.dataset = dataset
         self.reduce_fn = reduce_fn
@@ -88,9 +93,40 @@ class Backbone:
             rec.count = count
         return rec
 
+    def _bn_forward_group(self, pending):
+        """SyncBN for several layers with no data dependence between them: their fp64 sums travel
+        in ONE all-reduce.  pending: list of (conv record, bn name, partial, count, momentum)."""
+        P = self.P
+        if not (self.train and self.reduce_fn is not None):
+            for rec, bn, partial, count, mom in pending:
+                rec.bn = self._bn_forward(bn, partial, rec.cout, count, mom)
+                rec.out.scale, rec.out.shift = rec.bn.scale, rec.bn.shift
+            return
+        dev = pending[0][2].device
+        buf = torch.empty(sum(p[0].cout for p in pending), 2, device=dev, dtype=torch.float64)
+        off = 0
+        for rec, bn, partial, count, mom in pending:
+            ops.stat_reduce(partial, rec.cout, sums=buf[off:off + rec.cout])
+            off += rec.cout
+        self.reduce_fn(buf)
+        off = 0
+        for rec, bn, partial, count, mom in pending:
+            r = _BNRec()
+            r.name, r.count = bn, count * self.world
+            rm = P[f"{bn}.running_mean"] if self.update_running else None
+            rv = P[f"{bn}.running_var"] if self.update_running else None
+            r.scale, r.shift, r.mean, r.invstd = ops.bn_finalize(
+                buf[off:off + rec.cout], r.count, P[f"{bn}.weight"], P[f"{bn}.bias"], rm, rv, mom, BN_EPS)
+            off += rec.cout
+            self.bn_seen.append(bn)
+            rec.bn = r
+            rec.out.scale, rec.out.shift = r.scale, r.shift
+
     def _conv(self, name, srcs, k, dil, pad, lrelu=True, bn=None, src_lrelu=False, cout_pad=None, taps=None,
-              slope=0.0, bn_momentum=BN_MOMENTUM, weight=None, dweight=None):
+              slope=0.0, bn_momentum=BN_MOMENTUM, weight=None, dweight=None, defer_bn=None):
         """srcs: list[Act].  Returns Act of the conv output (pre-BN tensor + BN affine).
+        ``defer_bn``: a list -- the BatchNorm finalisation is postponed and queued there for
+        ``_bn_forward_group`` (the returned Act gets its affine then).
         ``taps`` overrides the k x k pattern; ``slope`` is the LeakyReLU slope of the on-load and
         epilogue activations (0 = 0.01); ``weight`` (OIHW) overrides ``P[name.weight]`` for layers
         whose parameter is stored in another layout, ``dweight`` then receives its gradient."""
@@ -109,8 +145,13 @@ class Backbone:
         rec.name, rec.srcs, rec.src_lrelu, rec.taps, rec.cout = name, srcs, src_lrelu, taps, cout
         rec.slope, rec.weight, rec.dweight = slope, weight, dweight
         rec.mode = 0 if (lrelu and bn) else (2 if lrelu else (1 if bn else 3))
-        rec.bn = self._bn_forward(bn, partial, cout, b * h * wd, bn_momentum) if bn is not None else None
-        rec.out = Act(y, rec.bn.scale if rec.bn else None, rec.bn.shift if rec.bn else None)
+        if bn is not None and defer_bn is not None:
+            rec.bn = None
+            rec.out = Act(y)
+            defer_bn.append((rec, bn, partial, b * h * wd, bn_momentum))
+        else:
+            rec.bn = self._bn_forward(bn, partial, cout, b * h * wd, bn_momentum) if bn is not None else None
+            rec.out = Act(y, rec.bn.scale if rec.bn else None, rec.bn.shift if rec.bn else None)
         self.tape[name] = rec
         return rec.out
 
@@ -149,11 +190,17 @@ class Backbone:
         self.tape[f"{name}.tail"] = (short, a5, res_a, res_b, mask, pooling)
         return res_b, res_a
 
-    def _up_block(self, name, xin, skip, drop_out=True):
+    def _up_block(self, name, xin, skip, drop_out=True, bn_group=None):
+        """bn_group: already-queued BatchNorm finalisations (``_conv(defer_bn=...)``) of layers that
+        do not depend on this block; they share the statistics exchange of this block's bn1."""
         m1 = self._mask(f"{name}.dropout1") if drop_out else None
         m2 = self._mask(f"{name}.dropout2") if drop_out else None
         up_b = Act(ops.pixshuf_cat(xin.t, xin.scale, xin.shift, xin.mask, m1, m2, skip.t))
-        e1 = self._conv(f"{name}.conv1", [up_b], 3, 1, 1, bn=f"{name}.bn1")
+        if bn_group is not None:
+            e1 = self._conv(f"{name}.conv1", [up_b], 3, 1, 1, bn=f"{name}.bn1", defer_bn=bn_group)
+            self._bn_forward_group(bn_group)
+        else:
+            e1 = self._conv(f"{name}.conv1", [up_b], 3, 1, 1, bn=f"{name}.bn1")
         e2 = self._conv(f"{name}.conv2", [e1], 3, 2, 2, bn=f"{name}.bn2")
         e3 = self._conv(f"{name}.conv3", [e2], 2, 2, 1, bn=f"{name}.bn3")
         a4 = self._conv(f"{name}.conv4", [e1, e2, e3], 1, 1, 0, bn=f"{name}.bn4")
@@ -183,18 +230,14 @@ class Backbone:
         d2c, d2b = self._res_block("resBlock3", d1c)
         d3c, d3b = self._res_block("resBlock4", d2c)
         d5c, _ = self._res_block("resBlock5", d3c, pooling=False)
-        u4 = self._up_block("upBlock1", d5c, d3b)
-        u3 = self._up_block("upBlock2", u4, d2b)
-        u2 = self._up_block("upBlock3", u3, d1b)
-        u1 = self._up_block("upBlock4", u2, d0b, drop_out=False)
-        logits = self._conv("cls_head", [u1], 1, 1, 0, lrelu=False, cout_pad=32)
-        prob = ops.softmax(logits.t, self.ncls, ho, wo)
-        self._prob = prob
-        out = {"prob": prob, "logits": logits.t}
         self.skips = (d0b, d1b, d2b, d3b)
         self.out_hw = (ho, wo)
         self.return_feat = return_feat
+        group = None
         if return_feat:
+            # embedding branch, first half (salsanext_proto.py:466-483 + projector.proj.0): it only needs
+            # the encoder skips, so its 704-wide GEMM is issued here and its BatchNorm statistics
+            # share ONE exchange with upBlock1.bn1 (SyncBN: one all-reduce less per step)
             b = x.shape[0]
             hh, wh = ho // 2, wo // 2
             feat = torch.empty(b, hh, wh, sum(s.t.shape[3] for s in self.skips), device=x.device,
@@ -204,7 +247,17 @@ class Backbone:
                 ops.bilinear(s.t, hh, wh, dst=feat, dcoff=off, c=s.t.shape[3])
                 off += s.t.shape[3]
             feat_a = Act(feat)
-            z0 = self._conv("projector.proj.0", [feat_a], 1, 1, 0, lrelu=False, bn="projector.proj.1")
+            group = []
+            z0 = self._conv("projector.proj.0", [feat_a], 1, 1, 0, lrelu=False, bn="projector.proj.1", defer_bn=group)
+        u4 = self._up_block("upBlock1", d5c, d3b, bn_group=group)
+        u3 = self._up_block("upBlock2", u4, d2b)
+        u2 = self._up_block("upBlock3", u3, d1b)
+        u1 = self._up_block("upBlock4", u2, d0b, drop_out=False)
+        logits = self._conv("cls_head", [u1], 1, 1, 0, lrelu=False, cout_pad=32)
+        prob = ops.softmax(logits.t, self.ncls, ho, wo)
+        self._prob = prob
+        out = {"prob": prob, "logits": logits.t}
+        if return_feat:
             emb = self._conv("projector.proj.3", [z0], 1, 1, 0, lrelu=False, src_lrelu=True)
             embn, norm = ops.l2norm(emb.t, 1e-12)
             feat2d = ops.bilinear(embn, ho, wo)
@@ -222,45 +275,103 @@ class Backbone:
         else:
             ops.axpy(g, act.grad)
 
-    def _bn_backward(self, bn, dy, a, c, mode, slope=0.0):
+    def _bn_backward(self, bn, dy, a, c, mode, slope=0.0, k=None):
         """dy: gradient w.r.t. BN(a) [mode 0] or LeakyReLU(BN(a)) [mode 1] -> (dz = d/da, partial with
-        sum(dz)); writes the BatchNorm parameter gradients.  SyncBN: the fp64 sums are all-reduced."""
+        sum(dz)); writes the BatchNorm parameter gradients.  SyncBN: the fp64 sums are all-reduced
+        (``k``: coefficients already computed by ``_bn_backward_group``)."""
         G = self.grads
         pre_s, pre_h = (bn.scale, bn.shift) if mode == 1 else (None, None)
-        part = ops.bn_bwd_reduce(dy, a, c, mode, pre_s, pre_h, slope=slope)
-        if self.reduce_fn is None:
-            k = ops.bn_bwd_coeffs_partials(part, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
-                                           G[f"{bn.name}.weight"], G[f"{bn.name}.bias"])
-        else:
-            sums = ops.stat_reduce(part, c)
-            local = sums.clone()      # dgamma/dbeta stay rank-local (averaged with the other grads)
-            self.reduce_fn(sums)
-            k = ops.bn_bwd_coeffs(sums, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
-                                  G[f"{bn.name}.weight"], G[f"{bn.name}.bias"], local)
+        if k is None:
+            part = ops.bn_bwd_reduce(dy, a, c, mode, pre_s, pre_h, slope=slope)
+            if self.reduce_fn is None:
+                k = ops.bn_bwd_coeffs_partials(part, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
+                                               G[f"{bn.name}.weight"], G[f"{bn.name}.bias"])
+            else:
+                sums = ops.stat_reduce(part, c)
+                local = sums.clone()      # dgamma/dbeta stay rank-local (averaged with the other grads)
+                self.reduce_fn(sums)
+                k = ops.bn_bwd_coeffs(sums, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
+                                      G[f"{bn.name}.weight"], G[f"{bn.name}.bias"], local)
         return ops.bn_bwd_apply(dy, a, c, mode, k, pre_s, pre_h, slope=slope)
 
-    def _conv_backward(self, name, dy):
-        """dy: gradient w.r.t. the layer's consumer-visible output (BN output if it has BN)."""
+    def _bn_backward_group(self, items):
+        """SyncBN backward of layers whose output gradients are all available: the (sum dy, sum dy*a)
+        vectors of every layer travel in ONE all-reduce.  items: list of (conv name, dy).
+        Returns {conv name: coefficients} for ``_conv_backward(..., k=...)``; empty when there is
+        nothing to exchange (single rank: each layer folds its own partials in one launch)."""
+        if self.reduce_fn is None:
+            return {}
+        G = self.grads
+        recs = [self.tape[n] for n, _ in items]
+        assert all(r.mode in (0, 1) for r in recs)
+        buf = torch.empty(sum(r.cout for r in recs), 2, device=items[0][1].device, dtype=torch.float64)
+        off = 0
+        for r, (_, dy) in zip(recs, items):
+            pre_s, pre_h = (r.bn.scale, r.bn.shift) if r.mode == 1 else (None, None)
+            part = ops.bn_bwd_reduce(dy, r.out.t, r.cout, r.mode, pre_s, pre_h, slope=r.slope)
+            ops.stat_reduce(part, r.cout, sums=buf[off:off + r.cout])
+            off += r.cout
+        local = buf.clone()
+        self.reduce_fn(buf)
+        ks, off = {}, 0
+        for r in recs:
+            bn = r.bn
+            ks[r.name] = ops.bn_bwd_coeffs(buf[off:off + r.cout], bn.count, bn.mean, bn.invstd,
+                                           self.P[f"{bn.name}.weight"], G[f"{bn.name}.weight"],
+                                           G[f"{bn.name}.bias"], local[off:off + r.cout])
+            off += r.cout
+        return ks
+
+    def _fork(self, *tensors):
+        """Context under which launches go to the side stream, ordered after everything issued so
+        far on the current stream.  ``tensors`` were allocated on the current stream and are read
+        by the side stream: the caching allocator must not hand their memory out again before
+        the side stream is done with it."""
+        if self.side is None:
+            return contextlib.nullcontext()
+        self.side.wait_stream(torch.cuda.current_stream())
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.side)
+        return torch.cuda.stream(self.side)
+
+    def _join(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+    def _conv_backward(self, name, dy, k=None):
+        """dy: gradient w.r.t. the layer's consumer-visible output (BN output if it has BN).
+        k: BatchNorm-backward coefficients from ``_bn_backward_group`` (else computed here).
+
+        Two chains leave dz: the input gradients (dgrad -> the next layer's BatchNorm backward,
+        the critical path, stays on the current stream) and the weight gradients, which nothing in
+        the rest of backward reads -- they go to the side stream, so that the matrix-bound wgrad
+        kernels run under the HBM-bound BatchNorm-backward / glue kernels of the following layers
+        (and, data parallel, under the SyncBN exchanges the main stream waits for)."""
         rec = self.tape[name]
         a = rec.out.t
         c = rec.cout
         cpad = a.shape[3]
         G = self.grads
         if rec.mode == 0 or rec.mode == 1:
-            dz, pz = self._bn_backward(rec.bn, dy, a, c, rec.mode, rec.slope)
+            dz, pz = self._bn_backward(rec.bn, dy, a, c, rec.mode, rec.slope, k)
         elif rec.mode == 2:
             dz, pz = ops.bn_bwd_apply(dy, a, c, 2, slope=rec.slope)
         else:
             dz, pz = ops.bn_bwd_apply(dy, dy, cpad, 3, dz=dy)
-        if f"{name}.bias" in G:
-            ops.bias_from_partials(pz, G[f"{name}.bias"])
         w = self.P[f"{name}.weight"] if rec.weight is None else rec.weight
         dw = G[f"{name}.weight"] if rec.dweight is None else rec.dweight
+        with self._fork(dz, pz):
+            if f"{name}.bias" in G:
+                ops.bias_from_partials(pz, G[f"{name}.bias"])
+            off = 0
+            for s in rec.srcs:
+                ops.conv_wgrad(s.src(rec.src_lrelu), dz, dw, rec.taps, cin_off=off, slope=rec.slope)
+                off += s.t.shape[3]
         ntaps = ops.negate_taps(rec.taps)
         off = 0
         for s in rec.srcs:
             cs = s.t.shape[3]
-            ops.conv_wgrad(s.src(rec.src_lrelu), dz, dw, rec.taps, cin_off=off, slope=rec.slope)
             if not getattr(s, "no_grad", False):
                 kp = (dz.shape[3] + 15) // 16 * 16
                 wd = (self.packs.get(w, 1, c_off=off, c_cnt=cs, kpad=kp) if rec.weight is None
@@ -287,8 +398,9 @@ class Backbone:
         if first:
             _, x, s_act = self.tape[f"{name}.conv1"]
             dz, pz = ops.bn_bwd_apply(s.grad, s.t, 32, 2)
-            ops.bias_from_partials(pz, self.grads[f"{name}.conv1.bias"])
-            ops.conv_in5_wgrad(x, dz, self.grads[f"{name}.conv1.weight"])
+            with self._fork(dz, pz):
+                ops.bias_from_partials(pz, self.grads[f"{name}.conv1.bias"])
+                ops.conv_in5_wgrad(x, dz, self.grads[f"{name}.conv1.weight"])
         else:
             self._conv_backward(f"{name}.conv1", s.grad)
         s.grad = None
@@ -311,10 +423,10 @@ class Backbone:
         r1.grad = None
         self._conv_backward(f"{name}.conv1", d)
 
-    def _up_backward(self, name):
+    def _up_backward(self, name, k4=None):
         xin, skip, up_b, m1, m2 = self.tape[f"{name}.head"]
         a4 = self.tape[f"{name}.conv4"].out
-        self._conv_backward(f"{name}.conv4", a4.grad)
+        self._conv_backward(f"{name}.conv4", a4.grad, k4)
         e1, e2, e3 = self.tape[f"{name}.conv4"].srcs
         self._conv_backward(f"{name}.conv3", e3.grad)
         e3.grad = None
@@ -343,14 +455,33 @@ class Backbone:
                                    "mask_norm.bias")}
         self.grads = grads
         d0b, d1b, d2b, d3b = self.skips
-        # ---- embedding branch first: it initialises the skip gradients (gather-form transposes)
-        if d_feat is not None and self.return_feat:
+        def done(tag):
+            # data parallel: the block's gradients are final once the side stream (weight
+            # gradients) has caught up with the main stream (BatchNorm / bias gradients); the
+            # bucket all-reduce is issued from the side stream so the main stream never waits
+            if self.on_block_done is not None:
+                with self._fork():
+                    self.on_block_done(tag)
+
+        if d_prob is None:
+            raise ValueError("backward needs d_prob (the segmentation losses always produce it)")
+        embed = d_feat is not None and self.return_feat
+        # ---- both heads down to their first BatchNorm: projector.proj.3 and cls_head
+        if embed:
             feat_a, z0, emb, embn, norm = self.tape["embed"]
             d_embn = torch.empty_like(embn)
             ops.bilinear_bwd(d_embn, d_feat.contiguous())
             d_emb = ops.l2norm_bwd(embn, norm, d_embn, 1e-12)
             self._conv_backward("projector.proj.3", d_emb)
-            self._conv_backward("projector.proj.0", z0.grad)
+        logits = self.tape["cls_head"].out
+        dl = ops.softmax_bwd(self._prob, d_prob.contiguous(), tuple(logits.t.shape))
+        self._conv_backward("cls_head", dl)
+        a4 = self.tape["upBlock4.conv4"].out
+        # ---- the two BatchNorm backwards that are ready now share one statistics exchange
+        ks = self._bn_backward_group(([("projector.proj.0", z0.grad)] if embed else []) + [("upBlock4.conv4", a4.grad)])
+        # ---- rest of the embedding branch: it initialises the skip gradients (gather-form transposes)
+        if embed:
+            self._conv_backward("projector.proj.0", z0.grad, ks.get("projector.proj.0"))
             z0.grad = None
             off = 0
             for s in self.skips:
@@ -362,17 +493,10 @@ class Backbone:
             for n in ("projector.proj.0", "projector.proj.1", "projector.proj.3"):
                 for suffix in ("weight", "bias"):
                     grads[f"{n}.{suffix}"].zero_()
-        # ---- segmentation head
-        logits = self.tape["cls_head"].out
-        if d_prob is None:
-            raise ValueError("backward needs d_prob (the segmentation losses always produce it)")
-        dl = ops.softmax_bwd(self._prob, d_prob.contiguous(), tuple(logits.t.shape))
-        done = self.on_block_done if self.on_block_done is not None else (lambda tag: None)
         done("projector")
-        self._conv_backward("cls_head", dl)
         done("cls_head")
         for name in ("upBlock4", "upBlock3", "upBlock2", "upBlock1"):
-            self._up_backward(name)
+            self._up_backward(name, ks.get(f"{name}.conv4"))
             done(name)
         for name in ("resBlock5", "resBlock4", "resBlock3", "resBlock2", "resBlock1"):
             self._res_backward(name)
@@ -383,5 +507,6 @@ class Backbone:
         done("downCntx2")
         self._ctx_backward("downCntx", first=True)
         done("downCntx")
+        self._join()
         self.tape = None
         return grads

@@ -51,14 +51,19 @@ __global__ __launch_bounds__(256) void project_points_kernel(const float* __rest
     const float pitch = (float)asin((double)c3d_div_rn(z, depth));
     float fx = __fmul_rn(c3d_div_rn(__fadd_rn(yaw, fov_left_abs), fov_hori), (float)W);
     float fy = __fmul_rn(__fsub_rn(1.0f, c3d_div_rn(__fadd_rn(pitch, fov_down_abs), fov_vert)), (float)H);
-    fx = fmaxf(fminf((float)(W - 1), floorf(fx)), 0.f);   // NaN (a point at the origin) -> 0
-    fy = fmaxf(fminf((float)(H - 1), floorf(fy)), 0.f);
+    // A point at the origin (or with non-finite coordinates) has no direction: z/depth is NaN.
+    // numpy's minimum/maximum propagate the NaN and the int32 cast of it is undefined in the
+    // reference (projection.py:74-85); here such a point is reported at pixel (0, 0) and never
+    // enters the z-buffer, so it cannot shadow a real return.
+    const bool ok = isfinite(fx) && isfinite(fy) && depth >= 0.f;
+    fx = ok ? fmaxf(fminf((float)(W - 1), floorf(fx)), 0.f) : 0.f;
+    fy = ok ? fmaxf(fminf((float)(H - 1), floorf(fy)), 0.f) : 0.f;
     const int px = (int)fx, py = (int)fy;
     ux[i] = px;
     uy[i] = py;
     udepth[i] = depth;
     const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned)i;
-    if (depth >= 0.f) atomicMin(&zbuf[(size_t)py * W + px], key);
+    if (ok) atomicMin(&zbuf[(size_t)py * W + px], key);
   }
 }
 
@@ -120,7 +125,8 @@ extern "C" int c3d_range_project(const float* pc, int n, int stride, int cols, c
   C3D_REQUIRE(!feat5 || cols >= 4, "range_project: the 5-channel feature needs x, y, z, intensity");
   C3D_REQUIRE((!eval_label || sem) && (!train_label || weak), "range_project: labels missing");
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(zbuf, 0xff, sizeof(uint64_t) * (size_t)H * W, st);
+  C3D_REQUIRE(hipMemsetAsync(zbuf, 0xff, sizeof(uint64_t) * (size_t)H * W, st) == hipSuccess,
+              "range_project: clearing the z-buffer failed");
   if (n > 0) {
     hipLaunchKernelGGL(project_points_kernel, dim3(grid_for(n)), dim3(256), 0, st, pc, n, stride, depth, fov_left_abs, fov_hori,
                        fov_down_abs, fov_vert, W, H, ux, uy, udepth, reinterpret_cast<unsigned long long*>(zbuf));

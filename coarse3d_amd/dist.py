@@ -28,10 +28,24 @@ def is_dist():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() >= _min_world()
 
 
+# collectives issued by this process since start-up, by exchange point (bench.py reports the
+# per-step counts as config.collectives_per_step)
+COUNTS = {"syncbn": 0, "gradient_buckets": 0, "prototype_bank": 0}
+
+
 def allreduce_sum_(t):
     """In-place sum over ranks (used for the fp64 BatchNorm sums)."""
     if is_dist():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        COUNTS["syncbn"] += 1
+    return t
+
+
+def allreduce_proto_sums_(t):
+    """In-place sum over ranks of the per-class prototype feature sums + counts."""
+    if is_dist():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        COUNTS["prototype_bank"] += 1
     return t
 
 
@@ -41,6 +55,7 @@ def world_mean(t):
         return t
     t = t.clone().div_(dist.get_world_size())
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    COUNTS["prototype_bank"] += 1
     return t
 
 
@@ -80,17 +95,29 @@ class FlatGradients:
             self.block_end[_block_of(n)] = off
         self._sent = 0
         self._works = []
+        self._seen = []
+        self.collectives = 0
 
     # ---- bucketed, overlapped mean over ranks
     def begin(self):
         self._sent = 0
         self._works = []
+        self._seen = []
+        self.collectives = 0
 
     def block_done(self, tag, min_bytes=4 << 20):
         """Gradients of block ``tag`` are final: all-reduce the finished prefix once it is large
         enough (a few big messages: xGMI is latency-, not bandwidth-limited at 29.6 MB total)."""
         end = self.block_end.get(tag)
-        if end is None or not is_dist():
+        if end is None:
+            return
+        # the prefix [0, end) is sent as final: that only holds if blocks report in the order the
+        # buffer was laid out in (BACKWARD_ORDER must match the hook order of Backbone.backward)
+        if self._seen and end <= self.block_end[self._seen[-1]]:
+            raise RuntimeError(f"gradient block {tag!r} reported after {self._seen[-1]!r}: BACKWARD_ORDER in "
+                               "coarse3d_amd/dist.py no longer matches the backward pass")
+        self._seen.append(tag)
+        if not is_dist():
             return
         if (end - self._sent) * 4 >= min_bytes or end == self.flat.numel():
             self._launch(end)
@@ -101,9 +128,14 @@ class FlatGradients:
         seg = self.flat[self._sent:end]
         seg.div_(dist.get_world_size())
         self._works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+        self.collectives += 1
+        COUNTS["gradient_buckets"] += 1
         self._sent = end
 
     def finish(self):
+        missing = [t for t in self.block_end if t not in self._seen]
+        if self._seen and missing:
+            raise RuntimeError(f"backward finished without reporting gradient blocks {missing}")
         if is_dist():
             self._launch(self.flat.numel())
             for w in self._works:
@@ -147,7 +179,7 @@ class DataParallel(torch.nn.Module):
         module._world = world if sync_bn else 1
         module._bn_reduce = allreduce_sum_ if (sync_bn and is_dist()) else None
         module._proto_mean = world_mean if (is_dist() and proto_sync == "bank_mean") else None
-        module._proto_sums_reduce = allreduce_sum_ if (is_dist() and proto_sync == "sums") else None
+        module._proto_sums_reduce = allreduce_proto_sums_ if (is_dist() and proto_sync == "sums") else None
         self.flat = FlatGradients(module._trainable())
         module._flat_grads = self.flat.views
         module._block_done = self.flat.block_done

@@ -122,6 +122,8 @@ class PackCache:
         self.table = None
         self.ptrs = None
         self.fresh = False
+        self.generation = 0      # bumped whenever the device table is (re)built: a captured hipGraph that
+                                 # baked the old table's address must not be replayed any more
 
     def get(self, w, mode=0, c_off=0, c_cnt=None, kpad=None):
         key = (w.data_ptr(), tuple(w.shape), mode, c_off, c_cnt, kpad)   # parameter storage is stable across steps
@@ -151,6 +153,7 @@ class PackCache:
             dev = next(iter(self.entries.values()))[5].device
             self.table = raw.to(dev)
             self.ptrs = ptrs
+            self.generation += 1
         _call("c3d_pack_weights_batch", _dp(self.table), len(self.entries), _stream())
         self.fresh = True
 

@@ -89,10 +89,13 @@ class RangeNetProto(SalsaNextProto):
         self._grad_ready = None
         self._block_done = None
         self._flat_grads = None
+        self._side = None
         self._packs = ops_mod.PackCache()
 
     def _make_backbone(self, P):
-        return RangeNetBackbone(P, self.nclasses, self.dataset, self._bn_reduce, self._world, self._packs, self.layers)
+        reduce_fn, world = self._bn_exchange()
+        return RangeNetBackbone(P, self.nclasses, self.dataset, reduce_fn, world, self._packs, self.layers,
+                                self._side_stream_for(P))
 
     def _check_input(self, h, w):
         wp = w + 24 if self.dataset == "SemanticPOSS" else w

@@ -15,6 +15,7 @@ Deliberate fixes: the debug lines that overwrite the inpu
 not replicated (Q1); both H and W are validated (Q4).
 """
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 
 from ... import ops as ops_mod
@@ -103,6 +104,11 @@ class _BackboneFn(torch.autograd.Function):
         ctx.bb = None
         if model._grad_ready is not None:
             model._grad_ready()
+        if model._flat_grads is not None:
+            # coarse3d_amd.dist.DataParallel: the gradients live in its flat buffer (being all-reduced
+            # in place right now); finish_gradients() binds param.grad to those views.  Handing them
+            # to autograd would make AccumulateGrad clone ~200 tensors out of a buffer in flight.
+            return (None,) * (5 + len(ctx.names))
         return (None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
 
 
@@ -113,8 +119,8 @@ class SalsaNextProto(nn.Module):
         super().__init__()
         if classification:
             raise ValueError("classification=True (ImageNet pre-training head) is outside the accelerated path")
-        if not softmax:
-            raise ValueError("softmax=False is not supported: the head always returns probabilities")
+        # ``softmax`` is accepted and stored like the reference does (:261, :279) -- and, like the
+        # reference, never read again: forward applies F.softmax unconditionally (:460)
         self.nclasses = nclasses
         self.base_channels = 32
         self.proj_dim = proj_dim
@@ -157,11 +163,64 @@ class SalsaNextProto(nn.Module):
         self._grad_ready = None       # data parallel: called when all gradients are written
         self._block_done = None       # data parallel: called per block in backward order
         self._flat_grads = None
+        self._side = None             # second HIP stream (weight-gradient chain of the backward pass)
         self._packs = ops_mod.PackCache()   # batched weight repacking (one launch per step)
 
     # ------------------------------------------------------------------ plumbing
+    def _bn_exchange(self):
+        """(in-place fp64 all-reduce or None, number of ranks) for the BatchNorm statistics.
+
+        Wired explicitly by coarse3d_amd.dist.DataParallel, or -- the reference trainer's own wrap,
+        tasks/weak_segmentation/trainer.py:54-60 -- switched on by the module tree itself: after
+        ``torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)`` the BatchNorm children ARE
+        SyncBatchNorm modules, and like those (torch/nn/modules/batchnorm.py: need_sync = training
+        and world_size > 1) the statistics are exchanged over their process group whenever a
+        group is initialised.  Plain BatchNorm2d children keep rank-local statistics, exactly as
+        under stock DistributedDataParallel without the conversion."""
+        if self._bn_reduce is not None:
+            return self._bn_reduce, self._world
+        if not (self.training and dist.is_available() and dist.is_initialized()):
+            return None, 1
+        sync = [m for m in self.modules() if isinstance(m, nn.SyncBatchNorm)]
+        if not sync:
+            return None, 1
+        n_bn = sum(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in self.modules())
+        if len(sync) != n_bn:
+            raise RuntimeError(f"{len(sync)} of {n_bn} BatchNorm layers are SyncBatchNorm: convert the whole model "
+                               "(torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)) or none of it")
+        group = sync[0].process_group
+        if any(m.process_group is not group for m in sync):
+            raise RuntimeError("all SyncBatchNorm layers of the model must share one process group")
+        world = dist.get_world_size(group)
+        if world < 2:
+            return None, 1
+
+        def reduce_(t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return t
+        return reduce_, world
+
+    def _bank_exchange(self):
+        """Mean of the updated bank over ranks.  The reference does it whenever a process group is
+        initialised (salsanext_proto.py:397-400), i.e. also under its own stock-DDP wrap."""
+        if self._proto_mean is not None or self._proto_sums_reduce is not None:
+            return self._proto_mean
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from ... import dist as c3d_dist
+            return c3d_dist.world_mean
+        return None
+
+    def _side_stream_for(self, P):
+        dev = next(iter(P.values())).device
+        if dev.type != "cuda":
+            return None
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
+
     def _make_backbone(self, P):
-        return Backbone(P, self.nclasses, self.dataset, self._bn_reduce, self._world, self._packs)
+        reduce_fn, world = self._bn_exchange()
+        return Backbone(P, self.nclasses, self.dataset, reduce_fn, world, self._packs, self._side_stream_for(P))
 
     def _check_input(self, h, w):
         hp, wp = (h + 8, w + 8) if self.dataset == "SemanticPOSS" else (h, w)
@@ -216,7 +275,7 @@ class SalsaNextProto(nn.Module):
                 res = proto_ops.prototype_step(
                     feat_nhwc, P, label.reshape(-1).long() if proto_loss else None, proto_loss,
                     noise=self.gumbel_noise, momentum=self.proto_mom, ignore_label=self.ignore_label,
-                    world_mean=self._proto_mean, ema_base=proto_pl, sums_reduce=self._proto_sums_reduce)
+                    world_mean=self._bank_exchange(), ema_base=proto_pl, sums_reduce=self._proto_sums_reduce)
                 self.prototypes.data.copy_(res["bank_l2"])          # in-place renormalisation (:502)
                 if proto_pl is not None:
                     self.prototypes = nn.Parameter(proto_pl.clone(), requires_grad=False)

@@ -29,8 +29,9 @@ DROP_SITES = ("enc1", "enc2", "enc3", "enc4", "enc5", "decoder", "head")
 
 
 class RangeNetBackbone(Backbone):
-    def __init__(self, params, nclasses=20, dataset="SemanticKitti", reduce_fn=None, world_size=1, packs=None, layers=21):
-        super().__init__(params, nclasses, dataset, reduce_fn, world_size, packs)
+    def __init__(self, params, nclasses=20, dataset="SemanticKitti", reduce_fn=None, world_size=1, packs=None, layers=21,
+                 side_stream=None):
+        super().__init__(params, nclasses, dataset, reduce_fn, world_size, packs, side_stream)
         self.blocks = MODEL_BLOCKS[layers]
 
     # ------------------------------------------------------------------ forward helpers
@@ -83,7 +84,8 @@ class RangeNetBackbone(Backbone):
         w = self.P[f"{name}.conv.weight"]
         dw = self.grads[f"{name}.conv.weight"]
         cin = src.t.shape[3]
-        ops.conv_wgrad(src.src(src_pending), dz, dw, taps, slope=SLOPE)
+        with self._fork(dz):                                 # weight-gradient chain: side stream (Backbone._conv_backward)
+            ops.conv_wgrad(src.src(src_pending), dz, dw, taps, slope=SLOPE)
         if not src.no_grad:
             wd = self.packs.get(w, 1, c_off=0, c_cnt=cin, kpad=(cout + 15) // 16 * 16)
             acc = src.grad is not None
@@ -107,7 +109,8 @@ class RangeNetBackbone(Backbone):
         t, u, z, out, dw_conv = self.tape[f"{name}.up"]
         self._conv_backward(f"{name}.upconv", out.grad)
         out.grad = None
-        self.grads[f"{name}.upconv.weight"].copy_(dw_conv.permute(1, 0, 2, 3))
+        with self._fork():                                   # after the wgrad that fills dw_conv
+            self.grads[f"{name}.upconv.weight"].copy_(dw_conv.permute(1, 0, 2, 3))
         t.grad = ops.cols_resample(u.grad, up=False)
         u.grad = None
 
@@ -194,7 +197,10 @@ class RangeNetBackbone(Backbone):
                      if v.is_floating_point() and v.dim() > 0 and not k.endswith(("running_mean", "running_var"))
                      and k != "prototypes" and not k.startswith(("feat_norm", "mask_norm"))}
         self.grads = grads
-        hook = self.on_block_done if self.on_block_done is not None else (lambda tag: None)
+        def hook(tag):                                       # see Backbone.backward
+            if self.on_block_done is not None:
+                with self._fork():
+                    self.on_block_done(tag)
         if d_feat is not None and self.return_feat:
             feat_a, z0, emb, embn, norm = self.tape["embed"]
             d_embn = torch.empty_like(embn)
@@ -240,7 +246,9 @@ class RangeNetBackbone(Backbone):
         self._conv_backward("backbone.conv1", rec.out.grad)
         rec.out.grad = None
         dw1 = self.tape["conv1.dw"]
-        grads["backbone.conv1.weight"].copy_(dw1[:, :grads["backbone.conv1.weight"].shape[1]])
+        with self._fork():
+            grads["backbone.conv1.weight"].copy_(dw1[:, :grads["backbone.conv1.weight"].shape[1]])
         hook("backbone.conv1")
+        self._join()
         self.tape = None
         return grads

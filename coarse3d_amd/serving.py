@@ -5,7 +5,20 @@ forward is launch-bound (the host needs longer to enqueue the kernels than the G
 them).  Every kernel of the C ABI is launched on the caller's stream with caller-provided
 buffers and the library never allocates or synchronises, so the whole forward is capturable:
 ``GraphedInference`` records it once per input shape and replays it with one launch."""
+import contextlib
+
 import torch
+
+from . import ops
+
+
+@contextlib.contextmanager
+def _own_packs(model, packs):
+    saved, model._packs = model._packs, packs
+    try:
+        yield
+    finally:
+        model._packs = saved
 
 
 class GraphedInference:
@@ -16,27 +29,42 @@ class GraphedInference:
     def __init__(self, model, return_feat=False, warmup=2):
         if model.training:
             raise ValueError("GraphedInference captures the eval-mode forward: call model.eval() first")
+        if warmup < 2:
+            # the first eager pass records which weight repacks the plan needs, the second builds the
+            # batched-repack table (a pageable H2D copy): neither may happen inside the capture
+            raise ValueError("GraphedInference needs warmup >= 2")
         self.model, self.return_feat, self.warmup = model, return_feat, warmup
         self._graphs = {}
+        # The captured graph bakes in raw device addresses of the weight-pack table and buffers.
+        # They live in a PackCache owned by THIS object, which nothing else adds entries to: a
+        # training step or a second GraphedInference on the same model (different pack set) can then
+        # never free or move what a captured graph still points at.
+        self._packs = ops.PackCache()
 
     def _capture(self, x):
         static_x = x.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(self.warmup):                 # lazy initialisation (weight packs, ...) outside the graph
-                self.model(static_x, return_feat=self.return_feat)
-        torch.cuda.current_stream().wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g), torch.no_grad():
-            out = self.model(static_x, return_feat=self.return_feat)
-        return g, static_x, out
+        with _own_packs(self.model, self._packs):
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(self.warmup):             # lazy initialisation (weight packs, ...) outside the graph
+                    self.model(static_x, return_feat=self.return_feat)
+            torch.cuda.current_stream().wait_stream(side)
+            gen = self._packs.generation
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g), torch.no_grad():
+                out = self.model(static_x, return_feat=self.return_feat)
+            if self._packs.generation != gen:
+                raise RuntimeError("the weight-pack table was rebuilt during graph capture")
+        return g, static_x, out, gen
 
     def __call__(self, x):
         key = tuple(x.shape)
+        if key in self._graphs and self._graphs[key][3] != self._packs.generation:
+            del self._graphs[key]                        # parameters moved (e.g. load_state_dict to new storage): re-capture
         if key not in self._graphs:
             self._graphs[key] = self._capture(x)
-        g, static_x, out = self._graphs[key]
+        g, static_x, out, _ = self._graphs[key]
         static_x.copy_(x)
         g.replay()
         return out

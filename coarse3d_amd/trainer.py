@@ -5,6 +5,11 @@ prototype bank update, focal + Lovasz, entropy-based pseudo-label selection, pro
 contrastive loss, backward, AdamW, scheduler) with the per-iteration host synchronisations
 (``.item()`` logging :750-802, barrier + scalar all-reduces :740-743) removed from the step.
 Config keys follow tasks/weak_segmentation/option.py:43-49 / config_semantic_kitti.yaml:20-42.
+
+``proto_loss`` defaults to False like the reference trainer, which never passes it to the model
+(trainer.py:625-630): the bank is then only l2-renormalised each step.  ``proto_loss=True`` runs
+the prototype update (Sinkhorn + EMA + bank exchange, salsanext_proto.py:337-402) inside the
+step -- what BASELINE.json's north star measures; bench.py and the golden step test opt in.
 """
 import numpy as np
 import torch
@@ -23,7 +28,7 @@ class TrainStep:
     def __init__(self, model, n_classes, *, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512,
                  loss_w_ce_2d=1.0, loss_w_lov_2d=1.0, loss_w_contrast=0.1, contrast_warmup=0,
                  entropy_selection=True, ignore_cls=0, cls_weight=None, feature_mean=None, feature_std=None,
-                 proto_loss=True, optimizer=None, scheduler=None, inputs_resident=False):
+                 proto_loss=False, optimizer=None, scheduler=None, inputs_resident=False):
         self.model = model
         self.net = model.module if hasattr(model, "module") else model
         self.n_classes = n_classes

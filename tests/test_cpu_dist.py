@@ -60,3 +60,72 @@ def test_exchange_points_world2():
     for i, n in enumerate(["downCntx.conv1.weight", "upBlock4.conv1.bias", "projector.proj.0.weight"]):
         torch.testing.assert_close(g0[n], torch.full_like(g0[n], 1.5 * (i + 1)))
         torch.testing.assert_close(g0[n], g1[n])
+
+
+def _syncbn_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    from coarse3d_amd import dist as D
+    m = SalsaNextProto(5, 20, 20, 0, use_prototype=True).train()
+    plain = m._bn_exchange()                       # BatchNorm2d children: rank-local statistics (stock DDP semantics)
+    m.resBlock1.bn1 = torch.nn.SyncBatchNorm(64)   # partially converted model: refuse, do not silently de-sync
+    try:
+        m._bn_exchange()
+        partial = "accepted"
+    except RuntimeError as e:
+        partial = str(e)
+    m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(SalsaNextProto(5, 20, 20, 0, use_prototype=True)).train()
+    fn, w = m._bn_exchange()
+    sums = torch.full((4, 2), float(rank + 1), dtype=torch.float64)
+    fn(sums)
+    m.eval()
+    ev = m._bn_exchange()
+    bank = m._bank_exchange()
+    q.put((rank, plain == (None, 1), partial, w, sums.numpy(), ev == (None, 1), bank is D.world_mean,
+           sorted(k for k, _ in m.named_parameters())[:3]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reference_syncbn_wrap_switches_the_statistics_exchange_on():
+    """tasks/weak_segmentation/trainer.py:54-60 wraps the model with
+    SyncBatchNorm.convert_sync_batchnorm + DistributedDataParallel.  The converted children must
+    turn the fp64 statistics exchange on by themselves (world-2 gloo group, CPU)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, plain_local, partial, w, sums, eval_local, bank_ok, names in res:
+        assert plain_local
+        assert "SyncBatchNorm" in partial and partial != "accepted"
+        assert w == 2
+        assert (sums == 3.0).all()                 # 1 + 2 summed over the two ranks
+        assert eval_local                          # eval mode never exchanges (running statistics)
+        assert bank_ok                             # salsanext_proto.py:397-400: bank mean whenever a group exists
+        assert names == ["cls_head.bias", "cls_head.weight", "downCntx.bn1.bias"]   # state_dict names survive the conversion
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` without a launcher must start two ranks itself (run.sh:1 of the
+    reference does the same with torch.distributed.launch).  There is no GPU here, so both ranks
+    stop at the "needs an MI355X" check: the parent has to relay that as a non-zero exit code."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present: covered by tests/test_gpu_dp.py::test_bench_launches_two_ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("needs an MI355X") == 2, r.stderr[-2000:]
+    assert "rank exit codes" in r.stderr
+    assert r.stdout.strip() == ""

@@ -55,7 +55,7 @@ def test_full_step_properties_at_benchmark_size():
     b, h, w, ncls = 8, 64, 2048, 20
     torch.manual_seed(1)
     m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True).to(DEV).train()
-    ts = TrainStep(m, ncls, lr=1e-3, num_anchor=512, feature_mean=bench.FEATURE_MEAN, feature_std=bench.FEATURE_STD)
+    ts = TrainStep(m, ncls, proto_loss=True, lr=1e-3, num_anchor=512, feature_mean=bench.FEATURE_MEAN, feature_std=bench.FEATURE_STD)
     x, tr, ev = bench.synth_batch(b, h, w, ncls, 1000, DEV)
     res = ts.step(x, tr, ev, epoch=10)
     for k in ("ce", "lov", "contrast", "loss"):
@@ -105,7 +105,7 @@ def test_bf16_matrix_mode_tracks_fp32():
             torch.manual_seed(1)
             m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True).to(DEV).train()
             m.dropout_masks = {k: v.to(DEV) for k, v in W.dropout_masks_for(None, b, 11).items()}
-            ts = TrainStep(m, ncls, lr=1e-3, num_anchor=64, feature_mean=bench.FEATURE_MEAN,
+            ts = TrainStep(m, ncls, proto_loss=True, lr=1e-3, num_anchor=64, feature_mean=bench.FEATURE_MEAN,
                            feature_std=bench.FEATURE_STD, loss_w_contrast=0.1)
             x, tr, ev = bench.synth_batch(b, h, w, ncls, 1000, DEV, label_rate=2e-2)
             torch.manual_seed(7)

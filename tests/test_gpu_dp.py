@@ -13,7 +13,7 @@ import weights as W
 pytestmark = pytest.mark.gpu
 
 
-def _run(rank, world, port, q, b, h, w, ncls, proto_sync="bank_mean"):
+def _run(rank, world, port, q, b, h, w, ncls, proto_sync="bank_mean", wrap="c3d"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,12 +34,18 @@ def _run(rank, world, port, q, b, h, w, ncls, proto_sync="bank_mean"):
     m.eval_dropout = True
     m.dropout_masks = {k: torch.full_like(v, 1.0)[sl].to(dev) for k, v in W.dropout_masks_for(None, b, 1).items()}
     m.gumbel_noise = noise.reshape(b, h * w, 20)[sl].reshape(-1, 20).to(dev)
-    model = D.DataParallel(m, proto_sync=proto_sync) if world > 1 else m
+    if world > 1 and wrap == "reference":
+        # the reference trainer's own wrap (tasks/weak_segmentation/trainer.py:54-60)
+        m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m).cuda()
+        model = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], output_device=0,
+                                                          find_unused_parameters=True)
+    else:
+        model = D.DataParallel(m, proto_sync=proto_sync) if world > 1 else m
     out = model(x[sl].to(dev), label=tr[sl].to(dev), eval_mask=(tr[sl] > 0).to(dev), return_feat=True, proto_loss=True)
     # sum-type loss scaled by world: the DP mean of rank gradients equals the full-batch gradient
     loss = world * ((out["pred_2d"] * dp[sl].to(dev)).sum() + (out["feat_2d"] * df[sl].to(dev)).sum())
     loss.backward()
-    if world > 1:
+    if world > 1 and wrap == "c3d":
         model.finish_gradients()
     torch.cuda.synchronize()
     res = {"grads": {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None},
@@ -91,6 +97,66 @@ def test_two_ranks_match_full_batch():
     assert (res[0]["protos"] == res[1]["protos"]).all()
     n = torch.from_numpy(res[0]["protos"]).norm(dim=-1)
     assert float(n.min()) > 0.9 and float(n.max()) < 1.0 + 1e-5
+
+
+def test_reference_wrap_syncbn_and_stock_ddp_match_full_batch():
+    """SyncBatchNorm.convert_sync_batchnorm(model) + DistributedDataParallel(find_unused_parameters=
+    True), exactly as tasks/weak_segmentation/trainer.py:54-60 wraps the model: the converted
+    BatchNorm children switch the fp64 statistics exchange on, stock DDP averages the gradients
+    the explicit backward hands to autograd, and the bank mean runs because a group exists."""
+    b, h, w, ncls = 2, 32, 64, 20
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_run, args=(0, 1, 29900, q, b, h, w, ncls))
+    p.start()
+    _, full = q.get(timeout=300)
+    p.join(60)
+    port = 29901 + os.getpid() % 500
+    procs = [ctx.Process(target=_run, args=(r, 2, port, q, b, h, w, ncls, "bank_mean", "reference")) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+
+    def rel(a, ref):
+        a, ref = torch.from_numpy(a).double(), torch.from_numpy(ref).double()
+        return float((a - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+    for k in res[0]["grads"]:
+        assert (res[0]["grads"][k] == res[1]["grads"][k]).all(), k
+    assert set(res[0]["grads"]) == set(full["grads"])
+    for r in range(2):                    # synchronised statistics: each rank's image as in the full batch
+        assert rel(res[r]["pred"], full["pred"][r:r + 1]) < 1e-4
+    assert rel(res[0]["rm"], full["rm"]) < 1e-4
+    errs = sorted(rel(res[0]["grads"][k], full["grads"][k]) for k in full["grads"] if k != "projector.proj.0.bias")
+    assert errs[len(errs) // 2] < 2e-3, errs[len(errs) // 2]
+    assert errs[int(len(errs) * 0.9)] < 5e-2
+    assert (res[0]["protos"] == res[1]["protos"]).all()
+
+
+def test_bench_launches_two_ranks():
+    """`python bench.py --gpus 2` (no launcher, no WORLD_SIZE) starts two ranks before touching the
+    GPU and relays rank 0's JSON line; the two ranks share this box's one GPU over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--height", "32", "--width", "256", "--no-cpu-baseline", "--no-kernel-events"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(C3D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    coll = out["config"]["collectives_per_step"]
+    assert 0 < coll["syncbn"] < 86, coll           # 43 + 43 BatchNorm exchanges, two of them batched away
+    assert coll["gradient_buckets"] >= 1 and coll["prototype_bank"] == 1
+    assert out["value"] > 0
 
 
 def test_two_ranks_prototype_sums_exchange():

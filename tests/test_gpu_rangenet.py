@@ -86,7 +86,7 @@ def test_rangenet_module_api_and_training_step():
     import bench
     m.train()
     m.dropout_masks = None
-    ts = TrainStep(m, ncls, lr=2e-3, num_anchor=32, feature_mean=bench.FEATURE_MEAN, feature_std=bench.FEATURE_STD)
+    ts = TrainStep(m, ncls, proto_loss=True, lr=2e-3, num_anchor=32, feature_mean=bench.FEATURE_MEAN, feature_std=bench.FEATURE_STD)
     xb, tr, ev = bench.synth_batch(2, 16, 256, ncls, 5, DEV, label_rate=5e-2)
     losses = [float(ts.step(xb, tr, ev, epoch=10)["loss"]) for _ in range(8)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

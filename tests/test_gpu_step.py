@@ -169,7 +169,7 @@ def test_full_training_step_vs_golden():
     m.to(DEV).train()
     m.dropout_masks = {k: v.to(DEV) for k, v in W.dropout_masks_for(None, b, 78).items()}
     m.gumbel_noise = pixel_noise(tr, g, ncls).to(DEV)
-    ts = TrainStep(m, ncls, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=64)
+    ts = TrainStep(m, ncls, proto_loss=True, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=64)
     # pseudo-label noise: rows in (b, class) order of the pairs that reached the multinomial
     pred_g = g["pred_2d"]
     pseudo = pred_g.argmax(1)
@@ -234,7 +234,7 @@ def test_data_parallel_wrapper_single_rank_matches_plain():
         m.dropout_masks = masks
         m.gumbel_noise = torch.ones(b * h * w, 20, device=DEV)
         model = D.DataParallel(m) if wrap else m
-        ts = TrainStep(model, ncls, lr=1e-3, num_anchor=64, loss_w_contrast=0.0)
+        ts = TrainStep(model, ncls, proto_loss=True, lr=1e-3, num_anchor=64, loss_w_contrast=0.0)
         res = ts.step(x.to(DEV), tr.to(DEV), ev.to(DEV), epoch=10)
         if wrap:
             assert model.module is m
@@ -300,7 +300,7 @@ def test_edge_cases_no_labels_and_no_feat_branch():
     m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True)
     m.load_state_dict(W.closed_form_state(nclasses=ncls))
     m.to(DEV).train()
-    ts = TrainStep(m, ncls, lr=1e-3, num_anchor=64)
+    ts = TrainStep(m, ncls, proto_loss=True, lr=1e-3, num_anchor=64)
     res = ts.step(x.to(DEV), torch.zeros_like(tr).to(DEV), ev.to(DEV), epoch=10)
     assert float(res["ce"].detach()) == 0.0 and float(res["lov"].detach()) == 0.0 and float(res["contrast"].detach()) == 0.0
     assert int((res["labels_contra"] != 0).sum()) == 0
@@ -308,7 +308,7 @@ def test_edge_cases_no_labels_and_no_feat_branch():
         if p.grad is not None:
             assert torch.isfinite(p.grad).all(), k
     # (b) warm-up epoch: no embedding branch
-    ts2 = TrainStep(m, ncls, lr=1e-3, num_anchor=64, contrast_warmup=5)
+    ts2 = TrainStep(m, ncls, proto_loss=True, lr=1e-3, num_anchor=64, contrast_warmup=5)
     res = ts2.step(x.to(DEV), tr.to(DEV), ev.to(DEV), epoch=0)
     assert "contrast" not in res and torch.isfinite(res["loss"])
     assert float(m.projector.proj[0].weight.grad.abs().max()) == 0.0

@@ -8,6 +8,7 @@ TAG=$1; shift
 export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
+rm -rf /tmp/p_stats /tmp/p_fetch /tmp/p_write      # a stale CSV from an earlier call must not be picked up below
 mkdir -p $OUT /tmp/p_stats /tmp/p_fetch /tmp/p_write
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events $@"
 cd /tmp
