@@ -57,13 +57,20 @@ class Backbone:
         """params: mapping name -> CUDA tensor (the module's parameters and buffers).
         side_stream: second HIP stream for the weight-gradient chain of the backward pass."""
         self.P = params
-        self.side = side_stream if os.environ.get("C3D_WGRAD_STREAM", "1") != "0" else None
+        # The weight-gradient chain moves to the side stream when there is exchange latency to hide
+        # under it (data parallel: SyncBN statistics, gradient buckets).  On one GPU it measured
+        # 54.4 vs 55.5 ms/step (-1.8 %) while inflating every per-kernel duration (kernels of the two
+        # streams share the CUs), so there it is opt-in: C3D_WGRAD_STREAM=1 forces it, =0 forbids it.
+        mode = os.environ.get("C3D_WGRAD_STREAM", "auto")
+        use_side = mode == "1" or (mode != "0" and reduce_fn is not None)
+        self.side = side_stream if use_side else None
         self.ncls = nclasses
         self.dataset = dataset
         self.reduce_fn = reduce_fn
         self.world = world_size
         self.packs = packs if packs is not None else ops.PackCache()
         self.tape = None
+        self.capture = None           # test hook: dict -> per conv layer (record, dy, dz) of the backward pass
         self.on_block_done = None     # data parallel: called with a block tag as soon as that
                                       # block's parameter gradients are final (backward order)
 
@@ -359,6 +366,8 @@ class Backbone:
             dz, pz = ops.bn_bwd_apply(dy, a, c, 2, slope=rec.slope)
         else:
             dz, pz = ops.bn_bwd_apply(dy, dy, cpad, 3, dz=dy)
+        if self.capture is not None:
+            self.capture[name] = (rec, None if dy is dz else dy.clone(), dz.clone())
         w = self.P[f"{name}.weight"] if rec.weight is None else rec.weight
         dw = G[f"{name}.weight"] if rec.dweight is None else rec.dweight
         with self._fork(dz, pz):

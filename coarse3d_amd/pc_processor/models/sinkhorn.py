@@ -8,8 +8,10 @@ import torch
 from ... import ops
 
 
-def distributed_sinkhorn(out, sinkhorn_iterations=3, epsilon=0.05):
-    """out [n, K] similarity scores -> (Q one-hot [n, K] from a Gumbel-hard draw, argmax [n])."""
+def distributed_sinkhorn(out, sinkhorn_iterations=3, epsilon=0.05, noise=None):
+    """out [n, K] similarity scores -> (Q one-hot [n, K] from a Gumbel-hard draw, argmax [n]).
+    ``noise`` (not in the reference signature): the Exp(1) variates [n, K] that
+    F.gumbel_softmax would draw (sinkhorn.py:31), for replaying a recorded reference run."""
     if sinkhorn_iterations != 3 or abs(epsilon - 0.05) > 1e-12:
         raise ValueError("the HIP kernel implements the reference defaults (3 iterations, eps 0.05)")
     n, k = out.shape
@@ -19,7 +21,7 @@ def distributed_sinkhorn(out, sinkhorn_iterations=3, epsilon=0.05):
     pred = torch.zeros(n, device=dev, dtype=torch.int32)
     counts = torch.tensor([[n]], device=dev, dtype=torch.int32)
     idx = torch.arange(n, device=dev, dtype=torch.int32).view(1, 1, n)
-    noise = torch.empty(n, k, device=dev).exponential_()
+    noise = torch.empty(n, k, device=dev).exponential_() if noise is None else noise.to(dev).float().contiguous()
     bank = torch.zeros(1, k, 4, device=dev)
     _, target = ops.proto_learn(sim, rows, pred, counts, idx, noise, bank, k, 1, -1, 0.999)   # pred given
     index = target.long()

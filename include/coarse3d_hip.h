@@ -380,6 +380,25 @@ int c3d_range_project(const float* pc, int n, int stride, int cols, const float*
                       const int64_t* sem, const int64_t* weak, float* feat5, float* eval_label,
                       float* train_label, c3d_stream stream);
 
+/* ------------------------------------------------------------------ weak-label voxel sampler
+ * tasks/prepare_data/gen_sem_weak_label_rand_grid.py:190-246 (SemanticData.__getitem__): voxel
+ * grid of edge `voxel_size` over one scan (open3d 0.15.2 rule: origin = min_bound - voxel_size/2,
+ * voxel = floor((p - origin)/voxel_size) in double; :190-202), voxels in np.unique(axis=0) order
+ * with the label of their first point (:203-207), the `n_sample` voxels with label > 0 that
+ * have the smallest priority[first point] (a uniform sample without replacement when the
+ * priorities are i.i.d.; :218-225), and their label written to all points of the voxel
+ * (propagate != 0) or to its first point only (:233-241).
+ *   xyz [n][stride] float32 (x, y, z first), label int32 [n] (mapped classes, 0 = ignore),
+ *   priority float32 [n], workspace >= c3d_voxel_sampler_workspace_bytes(n) bytes,
+ *   point2voxel int32 [n][3] or NULL, weak int32 [n],
+ *   stats int32 [5] = {points with non-finite / out-of-range coordinates, voxels, voxels with
+ *   label > 0, voxels sampled (< n_sample: not enough valid voxels), labelled points}.          */
+int64_t c3d_voxel_sampler_workspace_bytes(int n);
+int c3d_voxel_weak_labels(const float* xyz, int n, int stride, const int32_t* label, double voxel_size,
+                          const float* priority, int n_sample, int propagate, void* workspace,
+                          int64_t workspace_bytes, int32_t* point2voxel, int32_t* weak, int32_t* stats,
+                          c3d_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

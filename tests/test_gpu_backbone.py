@@ -12,6 +12,7 @@ import pytest
 import torch
 
 import weights as W
+from _measure import record
 from oracle import coarse3d_oracle as oc
 
 pytestmark = pytest.mark.gpu
@@ -84,5 +85,11 @@ def test_backbone_forward_backward(b, h, w, ncls, dataset, seed):
             bad.append((k, eh, eo))
     print(f"median err vs f64: hip {np.median(e_hip):.2e} oracle-fp32 {np.median(e_ora):.2e}; "
           f"max hip {max(e_hip):.2e} oracle {max(e_ora):.2e}")
+    tag = f"backbone/{dataset}_{h}x{w}"
+    record(f"{tag}/grad_err_vs_f64_median_hip", float(np.median(e_hip)))
+    record(f"{tag}/grad_err_vs_f64_median_oracle_fp32", float(np.median(e_ora)))
+    record(f"{tag}/grad_err_vs_f64_max_hip", float(max(e_hip)))
+    record(f"{tag}/grad_err_vs_f64_max_oracle_fp32", float(max(e_ora)))
+    record(f"{tag}/tensors_beyond_3x_oracle_noise", len(bad) / len(g64))
     assert len(bad) <= 0.15 * len(g64), bad[:10]
     assert np.median(e_hip) < 3 * np.median(e_ora) + 1e-5

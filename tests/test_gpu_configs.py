@@ -87,6 +87,75 @@ def test_full_step_properties_at_benchmark_size():
     assert bool((picked == cls[:, None]).all())
 
 
+@pytest.mark.parametrize("b,h,w,ncls,dataset,rate", [
+    (16, 32, 1024, 17, "nuScenes", 1e-3),          # BASELINE configs[3]: bs=16/GPU, small-H path
+    (8, 40, 1800, 14, "SemanticPOSS", 1e-4),       # BASELINE configs[4]: 0.01 % weak labels, entropy selection on
+])
+def test_full_step_properties_at_config_batch_sizes(b, h, w, ncls, dataset, rate):
+    """Full training steps of configs[3] / configs[4] at their per-GPU batch sizes: the properties
+    that do not depend on the size (finite losses and gradients for every trainable tensor, unit
+    prototype bank, pseudo labels only where allowed, weak labels preserved, anchors of their own
+    class) + the forward of image 0 of the batch against the CPU oracle run on that batch's own
+    statistics is covered at these shapes by test_forward_parity_at_config_sizes."""
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    from coarse3d_amd.trainer import TrainStep
+    import bench
+    torch.manual_seed(1)
+    m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True, dataset=dataset).to(DEV).train()
+    ts = TrainStep(m, ncls, proto_loss=True, lr=1e-3, num_anchor=512, feature_mean=bench.FEATURE_MEAN,
+                   feature_std=bench.FEATURE_STD, entropy_selection=True)
+    losses = []
+    for s in range(2):
+        x, tr, ev = bench.synth_batch(b, h, w, ncls, 1000 + s, DEV, rate)
+        res = ts.step(x, tr, ev, epoch=10)
+        for k in ("ce", "lov", "contrast", "loss"):
+            assert torch.isfinite(res[k]).all(), (k, s)
+        losses.append(float(res["loss"]))
+        assert res["pred_2d"].shape == (b, ncls, h, w)
+        assert float((res["pred_2d"].sum(1) - 1).abs().max()) < 1e-5
+        lab = res["labels_contra"]
+        assert bool((lab[ev == 0] == 0).all()) and bool((lab[tr > 0] == tr[tr > 0]).all())
+        assert int((lab > 0).sum()) >= int((tr > 0).sum())
+    for k, p in m.named_parameters():
+        if p.requires_grad and not k.startswith(("feat_norm", "mask_norm")):
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    assert float((m.prototypes.norm(dim=-1) - 1).abs().max()) < 1e-4
+    assert int(m.state_dict()["resBlock1.bn1.num_batches_tracked"]) == 2
+
+
+def test_bf16_matrix_mode_at_config2_size():
+    """BASELINE configs[2] at its real per-GPU size (8 x 64x2048, bf16 matrix operands): the step
+    runs, stays finite and tracks the fp32 step of the same seed (probabilities, loss terms)."""
+    from coarse3d_amd import ops
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    from coarse3d_amd.trainer import TrainStep
+    import bench
+    b, h, w, ncls = 8, 64, 2048, 20
+    outs = {}
+    for kind in ("f32", "bf16"):
+        ops.set_matrix_precision(kind)
+        try:
+            torch.manual_seed(1)
+            m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True).to(DEV).train()
+            m.dropout_masks = {k: v.to(DEV) for k, v in W.dropout_masks_for(None, b, 11).items()}
+            ts = TrainStep(m, ncls, proto_loss=True, lr=1e-3, num_anchor=512, feature_mean=bench.FEATURE_MEAN,
+                           feature_std=bench.FEATURE_STD)
+            x, tr, ev = bench.synth_batch(b, h, w, ncls, 1000, DEV)
+            torch.manual_seed(7)
+            res = ts.step(x, tr, ev, epoch=10)
+            outs[kind] = {k: res[k].detach().clone() for k in ("pred_2d", "ce", "lov", "contrast", "loss")}
+            del m, ts, res
+            torch.cuda.empty_cache()
+        finally:
+            ops.set_matrix_precision("f32")
+    for k in ("ce", "lov", "contrast", "loss"):
+        assert torch.isfinite(outs["bf16"][k]).all()
+    dp = (outs["f32"]["pred_2d"] - outs["bf16"]["pred_2d"]).abs()
+    assert float(dp.mean()) < 1e-2 and float(dp.max()) < 0.3, (float(dp.mean()), float(dp.max()))
+    for k in ("ce", "lov"):
+        assert abs(float(outs["bf16"][k]) - float(outs["f32"][k])) < 3e-2 * abs(float(outs["f32"][k])), k
+
+
 def test_bf16_matrix_mode_tracks_fp32():
     """BASELINE configs[2] (bf16): opt-in mode with bf16 MFMA operands and fp32 accumulate /
     storage.  Not a parity path (the reference has no bf16 mode): the check is that one training

@@ -1,0 +1,81 @@
+"""Stand-alone module mirrors against golden vectors of the reference (tests/golden/heads.npz,
+tests/golden/make_golden_round2.py): ``distributed_sinkhorn`` (sinkhorn.py:5-33),
+``ProjectionV1.forward`` (projector.py:11-27) and the ``proto_pl`` branch of
+``SalsaNextProto.forward`` (salsanext_proto.py:515-518)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import weights as W
+from _measure import record
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "heads.npz"))
+
+
+def t(k):
+    return torch.from_numpy(G[k])
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def test_distributed_sinkhorn_vs_reference():
+    from coarse3d_amd.pc_processor.models import distributed_sinkhorn
+    q, idx = distributed_sinkhorn(t("sink/out").to(DEV), noise=t("sink/noise"))
+    assert q.shape == (300, 20) and idx.shape == (300,)
+    agree_idx = record("sinkhorn/argmax_agreement", (idx.cpu() == t("sink/indexs")).float().mean().item())
+    agree_q = record("sinkhorn/gumbel_onehot_agreement", (q.cpu().argmax(1) == t("sink/q").argmax(1)).float().mean().item())
+    assert agree_idx == 1.0 and agree_q == 1.0           # measured: every one of the 300 rows
+    assert torch.equal(q.sum(1).cpu(), torch.ones(300))
+    with pytest.raises(ValueError):
+        distributed_sinkhorn(t("sink/out").to(DEV), sinkhorn_iterations=5)
+
+
+def test_projection_v1_forward_vs_reference():
+    from coarse3d_amd.pc_processor.models import ProjectionV1
+    proj = ProjectionV1(32, 16)
+    proj.load_state_dict({k[len("proj/state/"):]: t(k) for k in G.files if k.startswith("proj/state/")})
+    proj.to(DEV).train()
+    y = proj(t("proj/x").to(DEV))
+    assert y.shape == (2, 16, 8, 32)
+    assert rel(y, t("proj/y_train")) < 1e-4
+    assert rel(proj.proj[1].running_mean, t("proj/run_mean")) < 1e-5
+    assert rel(proj.proj[1].running_var, t("proj/run_var")) < 1e-5
+    proj.eval()
+    assert rel(proj(t("proj/x").to(DEV)), t("proj/y_eval")) < 1e-4
+
+
+def test_proto_pl_replaces_the_bank_before_the_update():
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    b, h, w, ncls, seed = 2, 32, 64, 20, 101
+    x, tr, ev = W.synthetic_batch(b, h, w, ncls, seed, 0.02, gh=8, gw=16)
+    masks = {k: v.to(DEV) for k, v in W.dropout_masks_for(None, b, seed + 1).items()}
+    noise = torch.ones(b * h * w, 20)
+    flat = tr.reshape(-1)
+    for c in range(1, ncls):
+        if f"pl/gumbel_{c}" in G.files:
+            noise[flat == c] = t(f"pl/gumbel_{c}")
+    bank = t("pl/bank").to(DEV)
+    for proto_loss in (True, False):
+        m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True)
+        m.load_state_dict(W.closed_form_state(nclasses=ncls))
+        m.to(DEV).train()
+        m.dropout_masks, m.gumbel_noise = masks, noise.to(DEV)
+        out = m(x.to(DEV), label=tr.to(DEV), eval_mask=(tr > 0).to(DEV), return_feat=True, proto_loss=proto_loss,
+                proto_pl=bank)
+        if proto_loss:
+            assert rel(m.prototypes, t("pl/new_prototypes")) < 1e-4
+            assert rel(out["contrast_logits"][::16], t("pl/contrast_logits_sub")) < 1e-4
+            agree = record("proto_pl/contrast_target_agreement",
+                           (out["contrast_target"].cpu() == t("pl/contrast_target")).float().mean().item())
+            assert agree >= 0.999
+        else:
+            assert "contrast_logits" not in out
+            assert torch.equal(m.prototypes.detach().cpu(), t("pl/replaced_only"))
+        assert not m.prototypes.requires_grad and m.prototypes.data_ptr() != bank.data_ptr()

@@ -11,6 +11,7 @@ import pytest
 import torch
 
 import weights as W
+from _measure import record
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -50,6 +51,9 @@ def test_rangenet_backbone_vs_reference_golden(tag, b, h, w, ncls, dataset):
             continue
         if abs(float((gd * gd).sum()) - sq) > 2e-2 * sq + 1e-20:        # measured: median 8e-5, max 3.4e-3
             bad.append((n, float((gd * gd).sum()), sq))
+    worst = max((abs(float((grads[n].double().cpu() ** 2).sum()) - float(d[f"{tag}/gsq/{n}"])) / (float(d[f"{tag}/gsq/{n}"]) + 1e-30)
+                 for n in names if not n.endswith(("upconv.bias", "proj.0.bias"))), default=0.0)
+    record(f"rangenet/{tag}/grad_sumsq_rel_err_max", worst)
     assert not bad, bad[:5]
     for k in d.files:
         if k.startswith(f"{tag}/grad/"):

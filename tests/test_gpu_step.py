@@ -10,6 +10,7 @@ import pytest
 import torch
 
 import weights as W
+from _measure import record
 from oracle import coarse3d_oracle as oc
 
 pytestmark = pytest.mark.gpu
@@ -82,7 +83,7 @@ def test_contrast_loss_vs_golden():
     T = g["indices"].shape[0]
     assert int(dbg["T"]) == T
     got = dbg["idx"][:T].cpu().long()
-    same = (got == g["indices"]).float().mean().item()
+    same = record("contrast/anchor_index_agreement", (got == g["indices"]).float().mean().item())
     # weights come from expf/logf on the GPU (<= 1 ulp from the CPU's): a draw that falls within
     # 1 ulp of a bin edge may move to the neighbouring pixel
     assert same >= 0.995, same
@@ -118,9 +119,9 @@ def test_entropy_selection_vs_golden():
             noise[bi, cls] = next(it)
     lab, mask = contrast.entropy_selection(prob.permute(0, 2, 3, 1).contiguous().to(DEV), tr.to(DEV), ev.to(DEV),
                                            float(g["ratio"]), noise=noise.to(DEV))
-    agree = (lab.cpu() == g["labels"]).float().mean().item()
+    agree = record("pl_select/label_agreement", (lab.cpu() == g["labels"]).float().mean().item())
     assert agree >= 0.9995, agree          # expf/logf ulp differences can flip a borderline pixel
-    assert (mask.cpu() == g["mask"]).float().mean().item() >= 0.9995
+    assert record("pl_select/mask_agreement", (mask.cpu() == g["mask"]).float().mean().item()) >= 0.9995
 
 
 @pytest.mark.parametrize("tag,b,h,w,ncls,dataset,seed", [
@@ -192,7 +193,7 @@ def test_full_training_step_vs_golden():
     torch.cuda.synchronize()
     assert rel(res["ce"], g["ce"]) < 1e-4
     assert rel(res["lov"], g["lov"]) < 1e-4
-    assert (res["labels_contra"].cpu() == g["labels_contra"]).float().mean().item() >= 0.9995
+    assert record("step/labels_contra_agreement", (res["labels_contra"].cpu() == g["labels_contra"]).float().mean().item()) >= 0.9995
     assert rel(m.prototypes, g["new_prototypes"]) < 1e-4
     assert rel(res["contrast"], g["contrast"]) < 2e-3      # a few anchors may differ (ulp-level weights)
     assert rel(res["loss"], g["loss"]) < 1e-3
@@ -206,6 +207,10 @@ def test_full_training_step_vs_golden():
         sub = gr if gr.numel() <= 4096 else gr.reshape(-1)[:: max(gr.numel() // 2048, 1)]
         errs.append(float((sub - ref).abs().max()) / (float(ref.abs().max()) + 1e-12))
         assert abs(float(gr.norm()) - float(g[f"gnorm/{k}"])) <= 5e-2 * float(g[f"gnorm/{k}"]) + 1e-9, k
+    record("step/grad_rel_err_median", float(np.median(errs)))
+    record("step/grad_rel_err_max", float(max(errs)))
+    record("step/contrast_rel_err", rel(res["contrast"], g["contrast"]))
+    record("step/loss_rel_err", rel(res["loss"], g["loss"]))
     assert np.median(errs) < 3e-2 and max(errs) < 0.35, (np.median(errs), max(errs))
     # AdamW moved every trainable tensor; non-trainable ones untouched
     moved = sum(int(not torch.equal(before[k], p.detach())) for k, p in m.named_parameters() if p.requires_grad)

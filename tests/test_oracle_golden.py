@@ -285,3 +285,23 @@ def test_rangenet_oracle_vs_reference(tag, b, h, w, ncls, dataset):
         if k.startswith(f"{tag}/run/"):
             n = k.split("/", 2)[2]
             assert float((st[n].detach() - torch.from_numpy(d[k])).abs().max()) < 1e-6, n
+
+
+def test_weak_label_sampler_oracle_vs_reference_script():
+    """oracle/weak_label_oracle.py against the outputs of the reference's own
+    SemanticData.__getitem__ (tests/golden/make_golden_weak_label.py), the recorded draw injected."""
+    import numpy as np
+    from oracle import weak_label_oracle as wo
+    g = np.load(os.path.join(GOLD, "weak_label.npz"))
+    for tag in "abcd":
+        scan, lab = g[f"{tag}.scan"], g[f"{tag}.mapped_label"]
+        k = wo.sample_count(len(scan), float(g[f"{tag}.label_ratio"]))
+        assert k == int(g[f"{tag}.sample_voxel"])
+        weak, info = wo.voxel_weak_labels(scan[:, :3], lab, float(g[f"{tag}.voxel_size"]), k,
+                                          bool(g[f"{tag}.propagation"]), sample_idx=g[f"{tag}.sample_idx"])
+        assert (weak == g[f"{tag}.weak"]).all()
+        assert int((weak > 0).sum()) == int(g[f"{tag}.num_labelled"])
+        # and with the reference's seed instead of the recorded draw: same global-RNG consumption
+        rng = np.random.RandomState(int(g[f"{tag}.seed"]))
+        weak2, _ = wo.voxel_weak_labels(scan[:, :3], lab, float(g[f"{tag}.voxel_size"]), k, bool(g[f"{tag}.propagation"]), rng=rng)
+        assert (weak2 == g[f"{tag}.weak"]).all()
