@@ -91,5 +91,8 @@ def test_backbone_forward_backward(b, h, w, ncls, dataset, seed):
     record(f"{tag}/grad_err_vs_f64_max_hip", float(max(e_hip)))
     record(f"{tag}/grad_err_vs_f64_max_oracle_fp32", float(max(e_ora)))
     record(f"{tag}/tensors_beyond_3x_oracle_noise", len(bad) / len(g64))
-    assert len(bad) <= 0.15 * len(g64), bad[:10]
-    assert np.median(e_hip) < 3 * np.median(e_ora) + 1e-5
+    # measured (round 2, profiles/round2_parity_measured.json): at most 6.8 % of the tensors beyond
+    # 3x the fp32 oracle's own error, HIP median <= 1.25x and HIP max <= 1.0x the oracle's
+    assert len(bad) <= 0.14 * len(g64), bad[:10]
+    assert np.median(e_hip) < 2 * np.median(e_ora) + 1e-5
+    assert max(e_hip) < 2 * max(e_ora) + 1e-4

@@ -5,8 +5,8 @@ pass are recomputed in float64 from the HIP pass's OWN activations and output gr
 The whole-network gradient tests (test_gpu_backbone.py, test_gpu_step.py) compare against an
 oracle that ran its own forward: one LeakyReLU pre-activation landing on the other side of zero
 changes a derivative from 1 to 0.01 and shows up as percent-level differences that say nothing
-about the kernels.  Here both sides see identical activations, so each layer is held to 1e-4 of
-max|ref| end to end -- a wrong wgrad scaling or tap offset in ANY layer fails this test."""
+about the kernels.  Here both sides see identical activations, so each layer is held to 1e-5 of
+max|ref| end to end (measured: 7e-7) -- a wrong wgrad scaling or tap offset in ANY layer fails this test."""
 import numpy as np
 import pytest
 import torch
@@ -69,7 +69,7 @@ def test_every_layer_gradient_vs_float64_on_the_hip_activations(b, h, w, ncls, d
     def rel(a, ref, what, name):
         e = float((a.double().cpu() - ref).abs().max() / (ref.abs().max() + 1e-300))
         worst[what] = max(worst[what], e)
-        assert e < 1e-4, (name, what, e)
+        assert e < 1e-5, (name, what, e)
 
     for name, (rec, dy, dz) in cap.items():
         slope = rec.slope if rec.slope > 0 else 0.01
@@ -79,7 +79,13 @@ def test_every_layer_gradient_vs_float64_on_the_hip_activations(b, h, w, ncls, d
         wref = _wgrad64(xin, dz64, rec.taps, cout)
         rel(grads[f"{name}.weight"].reshape(cout, xin.shape[1], -1), wref, "wgrad", name)
         if f"{name}.bias" in grads:
-            rel(grads[f"{name}.bias"], dz64.sum(dim=(0, 2, 3)), "bias", name)
+            if rec.mode == 1:
+                # a bias directly in front of a BatchNorm is cancelled exactly: sum(dz) = 0 up to the
+                # rounding of its summands -- bound the error by their magnitude instead of by ~0
+                err = (grads[f"{name}.bias"].double().cpu() - dz64.sum(dim=(0, 2, 3))).abs().max()
+                assert float(err / dz64.abs().sum(dim=(0, 2, 3)).max()) < 1e-6, name
+            else:
+                rel(grads[f"{name}.bias"], dz64.sum(dim=(0, 2, 3)), "bias", name)
         if rec.mode in (0, 1):
             # mode 0: conv -> LeakyReLU -> BatchNorm (SalsaNext blocks): dz = lrelu'(a) * dBN
             # mode 1: conv -> BatchNorm -> LeakyReLU (projector): dy passes the activation first

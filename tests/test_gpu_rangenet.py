@@ -49,7 +49,7 @@ def test_rangenet_backbone_vs_reference_golden(tag, b, h, w, ncls, dataset):
         if n.endswith(("upconv.bias", "proj.0.bias")):       # bias in front of BatchNorm: exactly 0 up to noise
             assert float((gd * gd).sum()) < 1e-8, n
             continue
-        if abs(float((gd * gd).sum()) - sq) > 2e-2 * sq + 1e-20:        # measured: median 8e-5, max 3.4e-3
+        if abs(float((gd * gd).sum()) - sq) > 7e-3 * sq + 1e-20:        # measured: median 8e-5, max 3.4e-3 (bound 2x)
             bad.append((n, float((gd * gd).sum()), sq))
     worst = max((abs(float((grads[n].double().cpu() ** 2).sum()) - float(d[f"{tag}/gsq/{n}"])) / (float(d[f"{tag}/gsq/{n}"]) + 1e-30)
                  for n in names if not n.endswith(("upconv.bias", "proj.0.bias"))), default=0.0)

@@ -85,8 +85,9 @@ def test_contrast_loss_vs_golden():
     got = dbg["idx"][:T].cpu().long()
     same = record("contrast/anchor_index_agreement", (got == g["indices"]).float().mean().item())
     # weights come from expf/logf on the GPU (<= 1 ulp from the CPU's): a draw that falls within
-    # 1 ulp of a bin edge may move to the neighbouring pixel
-    assert same >= 0.995, same
+    # 1 ulp of a bin edge could move to the neighbouring pixel -- measured on MI355X (round 2,
+    # profiles/round2_parity_measured.json): every one of the indices agrees, so that is the bar
+    assert same == 1.0, same
     assert rel(loss, g["loss"]) < 1e-4
     loss.backward()
     if same == 1.0:
@@ -120,8 +121,8 @@ def test_entropy_selection_vs_golden():
     lab, mask = contrast.entropy_selection(prob.permute(0, 2, 3, 1).contiguous().to(DEV), tr.to(DEV), ev.to(DEV),
                                            float(g["ratio"]), noise=noise.to(DEV))
     agree = record("pl_select/label_agreement", (lab.cpu() == g["labels"]).float().mean().item())
-    assert agree >= 0.9995, agree          # expf/logf ulp differences can flip a borderline pixel
-    assert record("pl_select/mask_agreement", (mask.cpu() == g["mask"]).float().mean().item()) >= 0.9995
+    assert agree == 1.0, agree             # measured: exact (profiles/round2_parity_measured.json)
+    assert record("pl_select/mask_agreement", (mask.cpu() == g["mask"]).float().mean().item()) == 1.0
 
 
 @pytest.mark.parametrize("tag,b,h,w,ncls,dataset,seed", [
@@ -193,10 +194,10 @@ def test_full_training_step_vs_golden():
     torch.cuda.synchronize()
     assert rel(res["ce"], g["ce"]) < 1e-4
     assert rel(res["lov"], g["lov"]) < 1e-4
-    assert record("step/labels_contra_agreement", (res["labels_contra"].cpu() == g["labels_contra"]).float().mean().item()) >= 0.9995
+    assert record("step/labels_contra_agreement", (res["labels_contra"].cpu() == g["labels_contra"]).float().mean().item()) == 1.0
     assert rel(m.prototypes, g["new_prototypes"]) < 1e-4
-    assert rel(res["contrast"], g["contrast"]) < 2e-3      # a few anchors may differ (ulp-level weights)
-    assert rel(res["loss"], g["loss"]) < 1e-3
+    assert rel(res["contrast"], g["contrast"]) < 1e-5      # measured 1.5e-7: every anchor index agrees
+    assert rel(res["loss"], g["loss"]) < 1e-5              # measured 4.0e-7
     # gradients: same noise-calibrated criterion as tests/test_oracle_golden.py
     errs = []
     for k, p in m.named_parameters():
@@ -211,7 +212,10 @@ def test_full_training_step_vs_golden():
     record("step/grad_rel_err_max", float(max(errs)))
     record("step/contrast_rel_err", rel(res["contrast"], g["contrast"]))
     record("step/loss_rel_err", rel(res["loss"], g["loss"]))
-    assert np.median(errs) < 3e-2 and max(errs) < 0.35, (np.median(errs), max(errs))
+    # measured (round 2): median 6.1e-3, max 3.9e-2 -- the oracle's own fp32-vs-fp64 noise on this
+    # network (tests/test_gpu_backbone.py); bounds at 2x.  Layer-exact gradient parity (1e-5) is
+    # tests/test_gpu_layer_grads.py, which removes the LeakyReLU sign-flip noise.
+    assert np.median(errs) < 1.2e-2 and max(errs) < 8e-2, (np.median(errs), max(errs))
     # AdamW moved every trainable tensor; non-trainable ones untouched
     moved = sum(int(not torch.equal(before[k], p.detach())) for k, p in m.named_parameters() if p.requires_grad)
     assert moved >= 190
