@@ -5,11 +5,13 @@
 //   NP = 1  "bf16":   every operand is rounded once to bf16 (RNE) while it is staged in LDS.
 //   NP = 3  "bf16x3": every fp32 operand is split EXACTLY into three bf16 planes
 //                     x = h + m + l  (h = RNE8(x), m = RNE8(x-h), l = RNE8(x-h-m); both
-//                     residuals are exact in fp32, 3 x 8 significand bits cover all 24) and six
+//                     residuals are exact in fp32, 3 x 8 significand bits cover all 24) and eight
 //                     of the nine plane products are accumulated, smallest first:
-//                     l*h + h*l + m*m + m*h + h*m + h*h.  The dropped terms are < 2^-23 |a||b|,
-//                     i.e. the result is in the accuracy class of an fp32 FMA chain, at 6/16 of
-//                     the fp32-MFMA issue time.
+//                     l*m + m*l + l*h + h*l + m*m + m*h + h*m + h*h.  Only l*l (< 2^-32 |a||b|) is
+//                     dropped, so each product a*b is exact far below fp32 resolution and the
+//                     result carries fp32 accumulation rounding only -- at 8/16 of the fp32-MFMA
+//                     issue time.  (Six products -- without l*m, m*l -- measured ~4x the gradient
+//                     noise of the fp32 engine on the whole network: tests/test_gpu_backbone.py.)
 //
 // Same GEMM view, tile shapes, on-load BatchNorm affine and epilogue as conv_mfma.hip.  The split
 // happens ONCE per staged element (not per fragment read): LDS holds NP bf16 images of the
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
   constexpr int RPW = TR / WM;
   constexpr int NPW = NT / WN;
   static_assert(NT % WN == 0, "NT must split across waves");
+  static_assert(NT / WN <= 2, "the ragged-tile path assumes at most two cout sub-tiles per wave");
   static_assert(CK % 16 == 0, "K chunk must be a multiple of the MFMA K (16)");
   constexpr int CQ = CK / 4;
   constexpr int IN_ROWS = THh * TWh;
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
     }
   };
 
+  const int nj = min(NPW, (a.Cout - n0 - wn * NPW * 32 + 31) / 32);   // live 32-wide cout sub-tiles (conv_mfma.hip)
   int s = 0, c0 = 0, kbase = 0;
   load_chunk(s, c0, kbase);
   while (true) {
@@ -192,35 +196,45 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
     const bool more = s2 < a.nsrc;
     if (more) load_chunk(s2, c2, kb2);
     __builtin_amdgcn_s_setprio(1);
+    // NJ = live 32-wide cout sub-tiles of this wave, a compile-time constant per code path: a
+    // per-MFMA predicate (as the fp32 kernel uses) broke the bf16 MFMA schedule (68 vs 53 ms/step)
+    auto mfma_phase = [&](auto nj_tag) {
+      constexpr int NJ = decltype(nj_tag)::value;
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
-      const int tap_off = ((HALO + a.dy[t]) * TWh + (HALO + a.dx[t]) + l31) * CSB + half * 8;
-      const unsigned short* wb = s_w + (t * TN + wn * NPW * 32 + l31) * CSB + half * 8;
+      for (int t = 0; t < TT; ++t) {
+        const int tap_off = ((HALO + a.dy[t]) * TWh + (HALO + a.dx[t]) + l31) * CSB + half * 8;
+        const unsigned short* wb = s_w + (t * TN + wn * NPW * 32 + l31) * CSB + half * 8;
 #pragma unroll
-      for (int kk = 0; kk < CK / 16; ++kk) {
-        bf16x8 bp[NP][NPW];
+        for (int kk = 0; kk < CK / 16; ++kk) {
+          bf16x8 bp[NP][NJ];
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
+          for (int p = 0; p < NP; ++p)
 #pragma unroll
-          for (int j = 0; j < NPW; ++j)
-            bp[p][j] = *reinterpret_cast<const bf16x8*>(wb + (p * W_ROWS + j * 32) * CSB + kk * 16);
-        bf16x8 ap[NP][RPW];
+            for (int j = 0; j < NJ; ++j)
+              bp[p][j] = *reinterpret_cast<const bf16x8*>(wb + (p * W_ROWS + j * 32) * CSB + kk * 16);
+          bf16x8 ap[NP][RPW];
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
+          for (int p = 0; p < NP; ++p)
 #pragma unroll
-          for (int i = 0; i < RPW; ++i)
-            ap[p][i] = *reinterpret_cast<const bf16x8*>(s_in + (p * IN_ROWS + (wm + i * WM) * TWh) * CSB + tap_off + kk * 16);
-#define C3D_PLANE(PA, PB)                                                                           \
-  _Pragma("unroll") for (int i = 0; i < RPW; ++i) _Pragma("unroll") for (int j = 0; j < NPW; ++j)  \
+            for (int i = 0; i < RPW; ++i)
+              ap[p][i] = *reinterpret_cast<const bf16x8*>(s_in + (p * IN_ROWS + (wm + i * WM) * TWh) * CSB + tap_off + kk * 16);
+#define C3D_PLANE(PA, PB)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < RPW; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)  \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA][i], bp[PB][j], acc[i][j], 0, 0, 0);
-        if constexpr (NP == 3) {
-          C3D_PLANE(2, 0) C3D_PLANE(0, 2) C3D_PLANE(1, 1) C3D_PLANE(1, 0) C3D_PLANE(0, 1) C3D_PLANE(0, 0)
-        } else {
-          C3D_PLANE(0, 0)
-        }
+          if constexpr (NP == 3) {
+            // eight of the nine plane products, smallest first; only l*l (< 2^-32 |a||b|) is dropped:
+            // every a*b is then exact to 2^-32, i.e. the result carries fp32 ACCUMULATION rounding only
+            C3D_PLANE(2, 1) C3D_PLANE(1, 2) C3D_PLANE(2, 0) C3D_PLANE(0, 2) C3D_PLANE(1, 1) C3D_PLANE(1, 0) C3D_PLANE(0, 1)
+            C3D_PLANE(0, 0)
+          } else {
+            C3D_PLANE(0, 0)
+          }
 #undef C3D_PLANE
+        }
       }
-    }
+    };
+    if (NPW == 1 || nj >= NPW) mfma_phase(std::integral_constant<int, NPW>{});
+    else mfma_phase(std::integral_constant<int, 1>{});
     __builtin_amdgcn_s_setprio(0);
     if (!more) break;
     s = s2;

@@ -153,6 +153,9 @@ __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ?
     }
   };
 
+  // 32-wide cout sub-tiles of this wave that exist: a ragged last tile (Cout = 400 = 12.5 x 32,
+  // 80, 160, 288) skips the MFMAs of its dead sub-tiles instead of multiplying zero columns
+  const int nj = min(NPW, (a.Cout - n0 - wn * NPW * 32 + 31) / 32);
   int s = 0, c0 = 0, kbase = 0;
   load_chunk(s, c0, kbase);
   while (true) {
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ?
           for (int i = 0; i < RPW; ++i)
 #pragma unroll
             for (int j = 0; j < NPW; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
+              if (j < nj) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -318,27 +321,32 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
 
 // ------------------------------------------------------------------ weight repack
 namespace {
+// value of packed element i = (t, kq, n, j) -- shared by the single and the batched kernel
+__device__ __forceinline__ float pack_value(const float* __restrict__ w, size_t i, int N, int K, int Cin, int T, int mode,
+                                            int c_off, int Kpad) {
+  const int j = i & 3;
+  size_t r = i >> 2;
+  const int n = r % N;
+  r /= N;
+  const int kq = r % (Kpad / 4);
+  const int t = r / (Kpad / 4);
+  const int k = kq * 4 + j;
+  float v = 0.f;
+  if (k < K) {
+    if ((mode & 1) == 0) v = w[((size_t)n * Cin + c_off + k) * T + t];
+    else v = w[((size_t)k * Cin + c_off + n) * T + t];
+  }
+  return v;
+}
+
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin,
                                     int T, int mode, int c_off, int c_cnt, int Kpad) {
   // dst[t][kq][n][j]
-  const int N = mode == 0 ? Cout : c_cnt;
-  const int K = mode == 0 ? c_cnt : Cout;
+  const int N = (mode & 1) == 0 ? Cout : c_cnt;
+  const int K = (mode & 1) == 0 ? c_cnt : Cout;
   const size_t total = (size_t)T * (Kpad / 4) * N * 4;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int j = i & 3;
-    size_t r = i >> 2;
-    const int n = r % N;
-    r /= N;
-    const int kq = r % (Kpad / 4);
-    const int t = r / (Kpad / 4);
-    const int k = kq * 4 + j;
-    float v = 0.f;
-    if (k < K) {
-      if (mode == 0) v = w[((size_t)n * Cin + c_off + k) * T + t];
-      else v = w[((size_t)k * Cin + c_off + n) * T + t];
-    }
-    dst[i] = v;
-  }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = pack_value(w, i, N, K, Cin, T, mode, c_off, Kpad);
 }
 }  // namespace
 
@@ -346,7 +354,8 @@ extern "C" int c3d_pack_weights(const float* w_oihw, float* dst, int Cout, int C
                                 int c_off, int c_cnt, int Kpad, c3d_stream stream) {
   C3D_REQUIRE(w_oihw && dst, "pack: null pointer");
   C3D_REQUIRE(Kpad % 16 == 0, "pack: Kpad must be a multiple of 16");
-  const int N = mode == 0 ? Cout : c_cnt;
+  C3D_REQUIRE(mode == 0 || mode == 1, "pack: mode must be 0 or 1");
+  const int N = (mode & 1) == 0 ? Cout : c_cnt;
   const size_t total = (size_t)T * (Kpad / 4) * N * 4;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
@@ -361,24 +370,11 @@ extern "C" int c3d_pack_weights(const float* w_oihw, float* dst, int Cout, int C
 namespace {
 __global__ void pack_weights_batch_kernel(const c3d_pack_entry* __restrict__ table) {
   const c3d_pack_entry e = table[blockIdx.y];
-  const int N = e.mode == 0 ? e.Cout : e.c_cnt;
-  const int K = e.mode == 0 ? e.c_cnt : e.Cout;
+  const int N = (e.mode & 1) == 0 ? e.Cout : e.c_cnt;
+  const int K = (e.mode & 1) == 0 ? e.c_cnt : e.Cout;
   const size_t total = (size_t)e.T * (e.Kpad / 4) * N * 4;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int j = i & 3;
-    size_t r = i >> 2;
-    const int n = r % N;
-    r /= N;
-    const int kq = r % (e.Kpad / 4);
-    const int t = r / (e.Kpad / 4);
-    const int k = kq * 4 + j;
-    float v = 0.f;
-    if (k < K) {
-      if (e.mode == 0) v = e.src[((size_t)n * e.Cin + e.c_off + k) * e.T + t];
-      else v = e.src[((size_t)k * e.Cin + e.c_off + n) * e.T + t];
-    }
-    e.dst[i] = v;
-  }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    e.dst[i] = pack_value(e.src, i, N, K, e.Cin, e.T, e.mode, e.c_off, e.Kpad);
 }
 }  // namespace
 

@@ -20,8 +20,9 @@ KERNEL_EVENT_FILTER = None       # None = every MFMA launch; else only launches 
 #              mixed precision, BASELINE configs[2])
 #   2 "bf16x3" fp32 operands split exactly into three bf16 planes, six plane products per step on
 #              the bf16 matrix pipe: fp32-accurate results (opt-in; see csrc/common.h)
-MFMA_MODE = 0
 _MODES = {"f32": 0, "bf16": 1, "bf16x3": 2}
+# C3D_MATRIX=bf16x3 python -m pytest tests -m gpu   runs the WHOLE parity suite on the exact-split engine
+MFMA_MODE = _MODES[__import__("os").environ.get("C3D_MATRIX", "f32")]
 
 
 def set_matrix_precision(kind):
