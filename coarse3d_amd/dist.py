@@ -62,8 +62,8 @@ def world_mean(t):
 # parameter-name prefixes in the order in which Backbone.backward finishes them
 BACKWARD_ORDER = ("projector", "cls_head", "upBlock4", "upBlock3", "upBlock2", "upBlock1", "resBlock5", "resBlock4",
                   "resBlock3", "resBlock2", "resBlock1", "downCntx3", "downCntx2", "downCntx",
-                  # RangeNetBackbone.backward (coarse3d_amd/rangenet.py)
-                  "head", "decoder.dec1", "decoder.dec2", "decoder.dec3", "decoder.dec4", "decoder.dec5",
+                  # RangeNetBackbone / SqueezeSegBackbone.backward (coarse3d_amd/rangenet.py, squeezeseg.py)
+                  "head", "head5", "decoder.dec1", "decoder.dec2", "decoder.dec3", "decoder.dec4", "decoder.dec5",
                   "backbone.enc5", "backbone.enc4", "backbone.enc3", "backbone.enc2", "backbone.enc1", "backbone.conv1")
 
 

@@ -298,11 +298,20 @@ def bn_bwd_blocks(npix):
     return L.lib().c3d_bn_bwd_num_blocks(npix)
 
 
+_BN_BWD_MAX_C = 1024      # channels one c3d_bn_bwd_* launch handles; wider layers (SqueezeSegV3's 9C attention maps) go in slices
+
+
+def _off(t, c0):
+    return None if t is None else t.data_ptr() + 4 * c0
+
+
 def bn_bwd_reduce(dy, a, c, mode=0, pre_scale=None, pre_shift=None, slope=0.0):
     npix = dy.numel() // dy.shape[-1]
     part = torch.empty(c, 2, bn_bwd_blocks(npix), device=dy.device, dtype=torch.float32)
-    _call("c3d_bn_bwd_reduce", _dp(dy), dy.shape[-1], _dp(a), a.shape[-1], npix, c, mode, _dp(pre_scale),
-          _dp(pre_shift), _dp(part), float(slope), _stream())
+    for c0 in range(0, c, _BN_BWD_MAX_C):
+        cc = min(_BN_BWD_MAX_C, c - c0)
+        _call("c3d_bn_bwd_reduce", _off(dy, c0), dy.shape[-1], _off(a, c0), a.shape[-1], npix, cc, mode, _off(pre_scale, c0),
+              _off(pre_shift, c0), _dp(part[c0:c0 + cc]), float(slope), _stream())
     return part
 
 
@@ -321,8 +330,11 @@ def bn_bwd_apply(dy, a, c, mode, k=None, pre_scale=None, pre_shift=None, dz=None
         dz = torch.empty(dy.shape[:-1] + (c,), device=dy.device, dtype=torch.float32)
     part = torch.empty(c, 2, bn_bwd_blocks(npix), device=dy.device, dtype=torch.float32)
     k1, k2, k3 = (k[0], k[1], k[2]) if k is not None else (None, None, None)
-    _call("c3d_bn_bwd_apply", _dp(dy), dy.shape[-1], _dp(a), a.shape[-1], npix, c, mode, _dp(pre_scale),
-          _dp(pre_shift), _dp(k1), _dp(k2), _dp(k3), _dp(dz), dz.shape[-1], _dp(part), float(slope), _stream())
+    for c0 in range(0, c, _BN_BWD_MAX_C):
+        cc = min(_BN_BWD_MAX_C, c - c0)
+        _call("c3d_bn_bwd_apply", _off(dy, c0), dy.shape[-1], _off(a, c0), a.shape[-1], npix, cc, mode, _off(pre_scale, c0),
+              _off(pre_shift, c0), _off(k1, c0), _off(k2, c0), _off(k3, c0), _off(dz, c0), dz.shape[-1],
+              _dp(part[c0:c0 + cc]), float(slope), _stream())
     return dz, part
 
 
@@ -722,6 +734,36 @@ def range_project(pc, depth, fov, w, h, want_image=True, sem=None, weak=None):
           _dp(out["proj_idx"]), _dp(out["proj_mask"]), _dp(sem), _dp(weak), _dp(out.get("feat5")),
           _dp(out.get("eval_label")), _dp(out.get("train_label")), _stream())
     return out
+
+
+# ---------------------------------------------------------------------------- SqueezeSegV3 SAC block (N3)
+def sac_im2col7(xyz4):
+    """xyz [B,H,W,>=3] -> the 7x7 neighbourhood columns [B,H,W,160] (147 used)."""
+    b, h, w, cs = xyz4.shape
+    out = torch.empty(b, h, w, 160, device=xyz4.device, dtype=torch.float32)
+    _call("c3d_sac_im2col7", _dp(xyz4), b, h, w, cs, _dp(out), _stream())
+    return out
+
+
+def sac_modulate(feat, att, scale, shift):
+    b, h, w, c = feat.shape
+    m = torch.empty(b, h, w, 9 * c, device=feat.device, dtype=torch.float32)
+    _call("c3d_sac_modulate", _dp(feat), _dp(att), _dp(scale), _dp(shift), b, h, w, c, _dp(m), _stream())
+    return m
+
+
+def sac_modulate_bwd(dm, feat, att, scale, shift):
+    """Returns d(att BatchNorm output); ``dm`` is overwritten with dm * sigmoid (input of sac_fold)."""
+    b, h, w, c = feat.shape
+    datt = torch.empty_like(dm)
+    _call("c3d_sac_modulate_bwd", _dp(dm), _dp(feat), _dp(att), _dp(scale), _dp(shift), b, h, w, c, _dp(datt), _stream())
+    return datt
+
+
+def sac_fold(t, dfeat, accumulate):
+    b, h, w, c = dfeat.shape
+    _call("c3d_sac_fold", _dp(t), b, h, w, c, int(accumulate), _dp(dfeat), _stream())
+    return dfeat
 
 
 # ---------------------------------------------------------------------------- kNN clean-up (N4)

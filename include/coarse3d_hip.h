@@ -399,6 +399,22 @@ int c3d_voxel_weak_labels(const float* xyz, int n, int stride, const int32_t* la
                           int64_t workspace_bytes, int32_t* point2voxel, int32_t* weak, int32_t* stats,
                           c3d_stream stream);
 
+/* ------------------------------------------------------------------ SqueezeSegV3 SAC block
+ * pc_processor/models/squeezesegv3_Proto.py:468-503 (SACBlock).  NHWC fp32.
+ * c3d_sac_im2col7:  xcol[B,H,W,160], column c*49 + ky*7 + kx = xyz[p + (ky-3, kx-3)][c] (c < 3; zero
+ *   outside the image, columns 147..159 zero): conv7x7(xyz) (:474-477) becomes a 160 -> 9C GEMM.
+ * c3d_sac_modulate: m[p][j] = feat[p + tap(j % 9)][j / 9] * sigmoid(att[p][j]*scale[j] + shift[j]),
+ *   j = c*9 + tap in F.unfold order (:495-497); att = raw conv output, (scale, shift) its BatchNorm.
+ * c3d_sac_modulate_bwd: datt = dm * feat_tap * s * (1-s) (gradient at the BatchNorm output), and
+ *   dm <- dm * s in place; c3d_sac_fold: dfeat[q][c] (+)= sum_k dm[q - tap(k)][c*9 + k].               */
+int c3d_sac_im2col7(const float* xyz, int B, int H, int W, int xcs, float* xcol, c3d_stream stream);
+int c3d_sac_modulate(const float* feat, const float* att, const float* scale, const float* shift,
+                     int B, int H, int W, int C, float* m, c3d_stream stream);
+int c3d_sac_modulate_bwd(float* dm, const float* feat, const float* att, const float* scale,
+                         const float* shift, int B, int H, int W, int C, float* datt, c3d_stream stream);
+int c3d_sac_fold(const float* t, int B, int H, int W, int C, int accumulate, float* dfeat,
+                 c3d_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

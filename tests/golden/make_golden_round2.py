@@ -78,5 +78,57 @@ def gold_heads():
     MG.npz("heads.npz", **arrs)
 
 
+def gold_squeezeseg():
+    """Reference SqueezeSegV3Proto(layers=21) forward + backward with closed-form weights and
+    injected Dropout2d masks (second backbone): outputs, running statistics,
+    per-tensor gradient checksums and a few small gradients in full."""
+    import contextlib
+    import importlib
+    import io
+    m = importlib.import_module("pc_processor.models.squeezesegv3_Proto")
+    arrs = {}
+    for tag, b, h, w, ncls in (("kitti", 2, 8, 64, 20), ("poss", 1, 8, 40, 14)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = m.SqueezeSegV3Proto(nclasses=ncls, use_prototype=True, layers=21)
+        missing = net.load_state_dict(W.squeezeseg_state(nclasses=ncls))
+        assert not missing.missing_keys and not missing.unexpected_keys
+        net.train()
+        masks = W.squeezeseg_masks(b, 3)
+        seq = iter(["enc1", "enc2", "enc3", "enc4", "enc5"])
+        net.backbone.dropout.forward = lambda x, seq=seq, masks=masks: x * masks[next(seq)][:, :, None, None]
+        net.decoder.dropout.forward = lambda x, masks=masks: x * masks["decoder"][:, :, None, None]
+        net.head5[0].forward = lambda x, masks=masks: x * masks["head"][:, :, None, None]
+        x, dp, df = W.rangenet_inputs(b, h, w, ncls)
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = net(x, return_feat=True)
+        loss = (out["pred_2d"] * dp).sum() + (out["feat_2d"] * df).sum()
+        loss.backward()
+        arrs.update({f"{tag}/pred_2d": out["pred_2d"].detach(), f"{tag}/feat_2d_sub": out["feat_2d"].detach()[:, ::4, :, ::2]})
+        names = []
+        for k, p_ in net.named_parameters():
+            if p_.grad is None:
+                continue
+            names.append(k)
+            gd = p_.grad.double()
+            arrs[f"{tag}/gsum/{k}"] = gd.sum()
+            arrs[f"{tag}/gsq/{k}"] = (gd * gd).sum()
+        for k in ("backbone.conv1.weight", "head5.1.weight", "head5.1.bias", "decoder.dec1.upconv.weight",
+                  "backbone.enc1.residual_0.attention_x.0.weight", "backbone.enc1.residual_0.position_mlp_2.0.weight",
+                  "backbone.enc3.residual_1.position_mlp_2.4.weight", "backbone.enc2.conv.weight",
+                  "projector.proj.3.bias", "decoder.dec4.conv.bias", "decoder.dec1.residual.conv2.weight"):
+            arrs[f"{tag}/grad/{k}"] = dict(net.named_parameters())[k].grad
+        arrs[f"{tag}/grad_names"] = np.array(names)
+        sd = net.state_dict()
+        for k in ("backbone.bn1.running_mean", "backbone.enc3.bn.running_var", "backbone.enc2.residual_0.attention_x.1.running_mean",
+                  "backbone.enc5.residual_0.position_mlp_2.4.running_var", "decoder.dec1.residual.bn2.running_mean",
+                  "projector.proj.1.running_var"):
+            arrs[f"{tag}/run/{k}"] = sd[k]
+    MG.npz("squeezeseg.npz", **arrs)
+
+
 if __name__ == "__main__":
-    gold_heads()
+    which = sys.argv[1:] or ["heads", "squeezeseg"]
+    if "heads" in which:
+        gold_heads()
+    if "squeezeseg" in which:
+        gold_squeezeseg()

@@ -145,3 +145,38 @@ def rangenet_inputs(b, h, w, ncls, w_feat=None):
     dp = torch.randn(b, ncls, h, w, generator=g)
     df = torch.randn(b, 256, h, w if w_feat is None else w_feat, generator=g) * 0.05
     return x, dp, df
+
+
+def squeezeseg_state(layers=21, nclasses=20, sub_proto=20, proj_dim=256, salt=0):
+    """Closed-form SqueezeSegV3Proto parameters (names / shapes from oracle/squeezeseg_oracle.py)."""
+    from oracle import squeezeseg_oracle as so
+    st = OrderedDict()
+    st["prototypes"] = torch.from_numpy(_gen("ss.prototypes", salt).normal(0, 0.02, (nclasses, sub_proto, proj_dim)).astype(np.float32))
+    for name, (shape, has_bias) in so.conv_specs(layers, nclasses, proj_dim).items():
+        fan_in = shape[1] * shape[2] * shape[3] if "upconv" not in name else shape[0] * shape[3] / 2.0
+        bound = 1.0 / math.sqrt(fan_in)
+        g = _gen("ss." + name, salt)
+        st[f"{name}.weight"] = torch.from_numpy(g.uniform(-bound, bound, shape).astype(np.float32) * 1.7)
+        if has_bias:
+            st[f"{name}.bias"] = torch.from_numpy(g.uniform(-bound, bound, shape[1] if "upconv" in name else shape[0]).astype(np.float32))
+    for name, c in so.bn_specs(layers).items():
+        g = _gen("ss." + name, salt)
+        st[f"{name}.weight"] = torch.from_numpy(g.uniform(0.5, 1.5, c).astype(np.float32))
+        st[f"{name}.bias"] = torch.from_numpy(g.uniform(-0.2, 0.2, c).astype(np.float32))
+        st[f"{name}.running_mean"] = torch.from_numpy(g.uniform(-0.1, 0.1, c).astype(np.float32))
+        st[f"{name}.running_var"] = torch.from_numpy(g.uniform(0.5, 1.5, c).astype(np.float32))
+        st[f"{name}.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    for name, c in (("feat_norm", proj_dim), ("mask_norm", nclasses)):
+        g = _gen("ss." + name, salt)
+        st[f"{name}.weight"] = torch.from_numpy(g.uniform(0.5, 1.5, c).astype(np.float32))
+        st[f"{name}.bias"] = torch.from_numpy(g.uniform(-0.2, 0.2, c).astype(np.float32))
+    return st
+
+
+def squeezeseg_masks(b, seed):
+    """Injected Dropout2d multipliers for the seven call sites of SqueezeSegV3Proto (drawn with a
+    larger drop rate than the reference's 0.01 so that the fixtures contain dropped planes)."""
+    from oracle import squeezeseg_oracle as so
+    g = np.random.Generator(np.random.PCG64(seed))
+    return {site: torch.from_numpy(((g.random((b, c)) >= 0.2) / 0.8).astype(np.float32))
+            for site, c in zip(so.DROP_SITES, so.DROP_CHANNELS)}

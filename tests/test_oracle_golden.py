@@ -305,3 +305,45 @@ def test_weak_label_sampler_oracle_vs_reference_script():
         rng = np.random.RandomState(int(g[f"{tag}.seed"]))
         weak2, _ = wo.voxel_weak_labels(scan[:, :3], lab, float(g[f"{tag}.voxel_size"]), k, bool(g[f"{tag}.propagation"]), rng=rng)
         assert (weak2 == g[f"{tag}.weak"]).all()
+
+
+SS_CANCELLED = ("attention_x.0.bias", "position_mlp_2.0.bias", "position_mlp_2.3.bias", "upconv.bias", ".conv.bias",
+                "proj.0.bias")
+
+
+@pytest.mark.parametrize("tag,b,h,w,ncls", [("kitti", 2, 8, 64, 20), ("poss", 1, 8, 40, 14)])
+def test_squeezeseg_oracle_vs_reference_golden(tag, b, h, w, ncls):
+    """oracle/squeezeseg_oracle.py against the reference SqueezeSegV3Proto (tests/golden/
+    make_golden_round2.py::gold_squeezeseg): forward, running statistics, every parameter gradient."""
+    from oracle import squeezeseg_oracle as so
+    d = np.load(os.path.join(GOLD, "squeezeseg.npz"))
+    st = W.squeezeseg_state(nclasses=ncls)
+    names = [n for n in so.trainable_names(st) if not n.startswith(("head1", "head2", "head3", "head4"))]
+    for k in names:
+        st[k].requires_grad_(True)
+    x, dp, df = W.rangenet_inputs(b, h, w, ncls)
+    out = so.squeezeseg_forward(st, x, True, W.squeezeseg_masks(b, 3), True)
+
+    def rel(a, ref):
+        a, ref = a.detach().double(), torch.from_numpy(np.asarray(ref)).double()
+        return float((a - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+    assert rel(out["pred_2d"], d[f"{tag}/pred_2d"]) < 1e-5
+    assert rel(out["feat_2d"][:, ::4, :, ::2], d[f"{tag}/feat_2d_sub"]) < 1e-5
+    for k in d.files:
+        if k.startswith(f"{tag}/run/"):
+            assert rel(st[k.split("/", 2)[2]], d[k]) < 1e-5, k
+    grads = torch.autograd.grad((out["pred_2d"] * dp).sum() + (out["feat_2d"] * df).sum(), [st[k] for k in names],
+                                allow_unused=True)
+    got = {k: g for k, g in zip(names, grads) if g is not None}
+    assert sorted(got) == sorted(str(n) for n in d[f"{tag}/grad_names"])
+    for n, g in got.items():
+        sq = float(d[f"{tag}/gsq/{n}"])
+        if n.endswith(SS_CANCELLED):                      # biases in front of a BatchNorm: exactly cancelled, pure noise
+            continue
+        assert abs(float((g.double() ** 2).sum()) - sq) <= 2e-2 * sq, n
+    for k in d.files:
+        if k.startswith(f"{tag}/grad/"):
+            n = k.split("/", 2)[2]
+            if not n.endswith(SS_CANCELLED):
+                assert rel(got[n], d[k]) < 2e-2, n
