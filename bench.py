@@ -113,15 +113,23 @@ def cpu_baseline(ncls, h, w, budget_s=240.0, bs=2, timed_steps=3):
             "sec_per_image": round(sec / bs, 3)}
 
 
-def cpu_baseline_rangenet(ncls, h, w, layers, budget_s=150.0):
-    """RangeNet oracle on the host cores, bounded sample: forward + backward of the backbone and
-    embedding branch at bs=1 (the losses and the prototype step are negligible beside it)."""
-    from oracle import rangenet_oracle as ro
+def cpu_baseline_rangenet(ncls, h, w, layers, budget_s=150.0, family="rangenet"):
+    """RangeNet / SqueezeSegV3 oracle on the host cores, bounded sample: forward + backward of the
+    backbone and embedding branch at bs=1 (the losses and the prototype step are negligible beside it)."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import weights as W
-    cores = torch.get_num_threads()
-    st = W.rangenet_state(layers=layers, nclasses=ncls)
-    names = ro.trainable_names(st)
+    if family == "rangenet":
+        from oracle import rangenet_oracle as ro
+        st = W.rangenet_state(layers=layers, nclasses=ncls)
+        fwd = ro.rangenet_forward
+    else:
+        from oracle import squeezeseg_oracle as ro
+        st = W.squeezeseg_state(layers=layers, nclasses=ncls)
+        fwd = lambda st_, x_, tr_, m_, rf_, layers_: ro.squeezeseg_forward(st_, x_, tr_, m_, rf_, layers_)   # noqa: E731
+    model_cpu, cores, _ = host_cpu()
+    cores = min(cores, os.cpu_count() or cores)
+    torch.set_num_threads(cores)
+    names = [k for k in ro.trainable_names(st) if not k.startswith(("head1.", "head2.", "head3.", "head4."))]
     for k in names:
         st[k].requires_grad_(True)
     times = []
@@ -130,7 +138,7 @@ def cpu_baseline_rangenet(ncls, h, w, layers, budget_s=150.0):
         g = torch.Generator().manual_seed(s)
         x = torch.randn(1, 5, h, w, generator=g)
         t0 = time.time()
-        out = ro.rangenet_forward(st, x, True, None, True, layers)
+        out = fwd(st, x, True, None, True, layers)
         loss = (out["pred_2d"] * torch.randn(out["pred_2d"].shape, generator=g)).sum() + out["feat_2d"].sum()
         torch.autograd.grad(loss, [st[k] for k in names], allow_unused=True)
         times.append(time.time() - t0)
@@ -139,8 +147,10 @@ def cpu_baseline_rangenet(ncls, h, w, layers, budget_s=150.0):
     timed = times[1:] if len(times) > 1 else times
     sec = float(np.median(timed))
     return {"value": round(1.0 / sec, 4), "unit": "range-images/sec", "cores": cores, "kind": "port",
-            "sample": f"RangeNet-{layers} oracle forward+backward, bs=1, {h}x{w}x5, C={ncls}, fp32, {len(timed)} timed "
-                      f"pass(es) after {len(times) - len(timed)} warm-up", "sec_per_image": round(sec, 3)}
+            "cpu": model_cpu,
+            "sample": f"{family}-{layers} oracle forward+backward, bs=1, {h}x{w}x5, C={ncls}, fp32, {len(timed)} timed "
+                      f"pass(es) after {len(times) - len(timed)} warm-up, torch.set_num_threads({cores})",
+            "sec_per_image": round(sec, 3)}
 
 
 def launch_ranks(n):
@@ -204,8 +214,8 @@ def main():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--classes", type=int, default=20)
     ap.add_argument("--dataset", default="SemanticKitti")
-    ap.add_argument("--net", choices=("salsanext", "rangenet21", "rangenet53"), default="salsanext",
-                    help="backbone (default: SalsaNextProto, the BASELINE workload; rangenet*: SURVEY 8f N3)")
+    ap.add_argument("--net", choices=("salsanext", "rangenet21", "rangenet53", "squeezeseg21", "squeezeseg53"), default="salsanext",
+                    help="backbone (default: SalsaNextProto, the BASELINE workload; rangenet* / squeezeseg*: SURVEY 8f N3)")
     ap.add_argument("--matrix-dtype", choices=("f32", "bf16", "bf16x3"), default="f32",
                     help="MFMA operand type: f32 = the parity path and the headline; bf16 = opt-in mixed "
                          "precision (bf16 operands, fp32 accumulate and storage; BASELINE configs[2]); "
@@ -242,7 +252,7 @@ def main():
 
     from coarse3d_amd import dist as D
     from coarse3d_amd import ops
-    from coarse3d_amd.pc_processor.models import RangeNetProto, SalsaNextProto
+    from coarse3d_amd.pc_processor.models import RangeNetProto, SalsaNextProto, SqueezeSegV3Proto
     from coarse3d_amd.trainer import TrainStep
 
     ops.set_matrix_precision(args.matrix_dtype)
@@ -251,8 +261,10 @@ def main():
     torch.manual_seed(1)
     if args.net == "salsanext":
         model = SalsaNextProto(5, args.classes, 20, 0, use_prototype=True, dataset=args.dataset)
-    else:
+    elif args.net.startswith("rangenet"):
         model = RangeNetProto(layers=int(args.net[-2:]), nclasses=args.classes, dataset=args.dataset, use_prototype=True)
+    else:
+        model = SqueezeSegV3Proto(nclasses=args.classes, layers=int(args.net[-2:]), dataset=args.dataset, use_prototype=True)
     model = model.to(dev).train()
     wrapped = D.DataParallel(model) if (world > 1 or single_rank_group or os.environ.get("C3D_FORCE_DP")) else model
     ts = TrainStep(wrapped, args.classes, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512,
@@ -396,7 +408,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = (cpu_baseline(args.classes, args.height, args.width) if args.net == "salsanext"
-                                   else cpu_baseline_rangenet(args.classes, args.height, args.width, int(args.net[-2:])))
+                                   else cpu_baseline_rangenet(args.classes, args.height, args.width, int(args.net[-2:]),
+                                                              family=args.net[:-2]))
         else:
             out["cpu_baseline"] = None
         line = json.dumps(out)
