@@ -32,7 +32,7 @@ FEATURE_MEAN = [12.12, 10.88, 0.23, -1.04, 0.21]     # config_semantic_kitti.yam
 FEATURE_STD = [12.32, 11.47, 6.91, 0.86, 0.16]       # config_semantic_kitti.yaml:148-153
 PEAK_FP32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md chip-level parameters
 PEAK_BF16_MFMA_TFLOPS = 2500.0                       # dense bf16 (no sparsity), same guide
-PMC_FILE = "round1_f{tag}_hbm.json"                  # committed per-kernel HBM-traffic capture (tools/profile_round.sh)
+PMC_FILE = "round2{tag}_hbm.json"                    # committed per-kernel HBM-traffic capture (tools/profile_round.sh)
 
 
 def synth_batch(b, h, w, ncls, seed, device, label_rate=1e-3):
@@ -370,6 +370,23 @@ def main():
                                          "measured_in": "last warm-up step" if all_steps == 1 else "timed steps"}}
     ops.KERNEL_EVENTS = None
     ops.KERNEL_EVENT_FILTER = None
+    if roofline is not None and default_shape_for_step(args) and args.batch == 8 and args.matrix_dtype == "f32":
+        # the HBM-bound kernels of the conv blocks (north star: "achieved HBM GB/s for the conv blocks"):
+        # bytes = 2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes over this same bench command,
+        # time = that capture's kernel-trace average
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE.format(tag=""))))
+            rows = {}
+            for k in ("bn_bwd_kernel<true>", "bn_bwd_kernel<false>", "bilinear_kernel", "bilinear_bwd_kernel",
+                      "affine_add_kernel", "maskpool_kernel", "maskpool_bwd_kernel", "catskip_kernel", "catskip_bwd_kernel",
+                      "l2norm_bwd_kernel", "rownorm_kernel"):
+                if k in pmc:
+                    rows[k] = {"GBps": round(pmc[k]["gbps"]), "frac_of_8TBps": round(pmc[k]["gbps"] / 8000.0, 3),
+                               "ms_per_step": round(pmc[k]["ms_per_step"], 3)}
+            roofline["hbm_kernels"] = {"source": f"profiles/{PMC_FILE.format(tag='')} (committed rocprofv3 PMC passes, not re-measured here)",
+                                       "peak_GBps": 8000, "kernels": rows}
+        except (OSError, KeyError, ValueError):
+            pass
     if roofline is not None and default_shape_for_step(args):
         # whole-step view with SURVEY 8d's normative algorithmic work per 64x2048 image and step
         # (533.5 GFLOP, 10.96 GB fp32): fraction of the fp32 matrix peak / of the 8 TB/s HBM peak

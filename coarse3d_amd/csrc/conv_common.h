@@ -24,6 +24,8 @@ struct ConvArgs {
 
 // bf16-plane kernels (conv_bfp.hip): planes = 1 (bf16) or 3 (bf16x3)
 int c3d_conv_forward_bfp(ConvArgs& a, int planes, int tr, int halo, bool k32, hipStream_t st);
+// second-generation bf16x3 engine for 8-row tiles with 4 or 9 taps (conv_x3.hip); needs a mode | 2 pack
+int c3d_conv_forward_x3(ConvArgs& a, int halo, hipStream_t st);
 
 namespace {
 

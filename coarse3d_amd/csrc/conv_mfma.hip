@@ -297,6 +297,7 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
     C3D_REQUIRE(d->mfma_bf16 == 1 || d->mfma_bf16 == 2, "conv: mfma_bf16 must be 0, 1 or 2");
     bool k32 = true;
     for (int s = 0; s < d->nsrc; ++s) k32 = k32 && (d->src[s].C % 32 == 0);
+    if (d->mfma_bf16 == 2 && tr == 8 && d->ntaps > 1) return c3d_conv_forward_x3(a, halo, st);
     return c3d_conv_forward_bfp(a, d->mfma_bf16 == 2 ? 3 : 1, tr, halo, k32, st);
   }
   if (tr == 8 && d->ntaps == 1) {
@@ -339,6 +340,23 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, size_t 
   return v;
 }
 
+// mode & 2: behind the fp32 image, the exact 3-way bf16 split of every value (h = RNE8(v), m = RNE8(v - h),
+// l = RNE8(v - h - m)) as three bf16 images of the same [t][kq][n][4] shape -- the weights are split ONCE
+// per step here instead of by every workgroup that stages them (conv_x3.hip)
+__device__ __forceinline__ void pack_store(float* __restrict__ dst, size_t i, size_t total, int mode, float v) {
+  dst[i] = v;
+  if (mode & 2) {
+    __bf16* d = reinterpret_cast<__bf16*>(dst + total);
+    float r = v;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const __bf16 h = (__bf16)r;
+      d[(size_t)p * total + i] = h;
+      r -= (float)h;
+    }
+  }
+}
+
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin,
                                     int T, int mode, int c_off, int c_cnt, int Kpad) {
   // dst[t][kq][n][j]
@@ -346,7 +364,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   const int K = (mode & 1) == 0 ? c_cnt : Cout;
   const size_t total = (size_t)T * (Kpad / 4) * N * 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-    dst[i] = pack_value(w, i, N, K, Cin, T, mode, c_off, Kpad);
+    pack_store(dst, i, total, mode, pack_value(w, i, N, K, Cin, T, mode, c_off, Kpad));
 }
 }  // namespace
 
@@ -354,7 +372,7 @@ extern "C" int c3d_pack_weights(const float* w_oihw, float* dst, int Cout, int C
                                 int c_off, int c_cnt, int Kpad, c3d_stream stream) {
   C3D_REQUIRE(w_oihw && dst, "pack: null pointer");
   C3D_REQUIRE(Kpad % 16 == 0, "pack: Kpad must be a multiple of 16");
-  C3D_REQUIRE(mode == 0 || mode == 1, "pack: mode must be 0 or 1");
+  C3D_REQUIRE(mode >= 0 && mode <= 3, "pack: mode must be 0..3");
   const int N = (mode & 1) == 0 ? Cout : c_cnt;
   const size_t total = (size_t)T * (Kpad / 4) * N * 4;
   int blocks = (int)((total + 255) / 256);
@@ -374,7 +392,7 @@ __global__ void pack_weights_batch_kernel(const c3d_pack_entry* __restrict__ tab
   const int K = (e.mode & 1) == 0 ? e.c_cnt : e.Cout;
   const size_t total = (size_t)e.T * (e.Kpad / 4) * N * 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-    e.dst[i] = pack_value(e.src, i, N, K, e.Cin, e.T, e.mode, e.c_off, e.Kpad);
+    pack_store(e.dst, i, total, e.mode, pack_value(e.src, i, N, K, e.Cin, e.T, e.mode, e.c_off, e.Kpad));
 }
 }  // namespace
 

@@ -104,9 +104,12 @@ def pack_weights(w, mode=0, c_off=0, c_cnt=None, kpad=None):
     n = cout if mode == 0 else c_cnt
     if kpad is None:
         kpad = (k + 15) // 16 * 16
-    dst = torch.empty(t * (kpad // 4) * n * 4, device=w.device, dtype=torch.float32)
-    L.check(L.lib().c3d_pack_weights(_p(w), _p(dst), cout, cin, t, mode, c_off, c_cnt, kpad, _stream()),
-            "c3d_pack_weights")
+    numel = t * (kpad // 4) * n * 4
+    planes = MFMA_MODE == 2 and t > 1      # bf16x3 engine for multi-tap convs: the pre-split bf16 planes follow the fp32 image
+    dst = torch.empty(numel * 5 // 2 if planes else numel, device=w.device, dtype=torch.float32)
+    L.check(L.lib().c3d_pack_weights(_p(w), _p(dst), cout, cin, t, mode | (2 if planes else 0), c_off, c_cnt, kpad,
+                                     _stream()), "c3d_pack_weights")
+    dst.c3d_planes = planes
     return dst
 
 
@@ -127,7 +130,7 @@ class PackCache:
                                  # baked the old table's address must not be replayed any more
 
     def get(self, w, mode=0, c_off=0, c_cnt=None, kpad=None):
-        key = (w.data_ptr(), tuple(w.shape), mode, c_off, c_cnt, kpad)   # parameter storage is stable across steps
+        key = (w.data_ptr(), tuple(w.shape), mode, c_off, c_cnt, kpad, MFMA_MODE == 2)   # parameter storage is stable across steps
         ent = self.entries.get(key)
         if ent is not None and self.fresh:
             return ent[5]
@@ -149,7 +152,7 @@ class PackCache:
             for i, (w, mode, c_off, cc, kpad, dst) in enumerate(self.entries.values()):
                 arr[i].src, arr[i].dst = w.data_ptr(), dst.data_ptr()
                 arr[i].Cout, arr[i].Cin, arr[i].T = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
-                arr[i].mode, arr[i].c_off, arr[i].c_cnt, arr[i].Kpad = mode, c_off, cc, kpad
+                arr[i].mode, arr[i].c_off, arr[i].c_cnt, arr[i].Kpad = mode | (2 if getattr(dst, "c3d_planes", False) else 0), c_off, cc, kpad
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             dev = next(iter(self.entries.values()))[5].device
             self.table = raw.to(dev)
@@ -175,6 +178,8 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     d.ntaps = len(taps)
     for i, (dy, dx) in enumerate(taps):
         d.tap_dy[i], d.tap_dx[i] = dy, dx
+    if MFMA_MODE == 2 and len(taps) > 1 and not getattr(wpack, "c3d_planes", False):
+        raise RuntimeError("bf16x3 mode needs weight packs made after ops.set_matrix_precision('bf16x3')")
     d.wpack = wpack.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.epi_lrelu = int(lrelu)
@@ -190,7 +195,9 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     nt_ = len(taps)
     hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
     k32 = tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs)
-    if MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
+    if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
+        name = f"conv_x3_kernel<{2 if cout > 32 else 1}, {hh}, {nt_}>"
+    elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
         np_ = 3 if MFMA_MODE == 2 else 1
         name = (f"conv_bfp_kernel<8, {2 if cout > 32 else 1}, 32, 0, 1, {np_}>" if k32 else
                 f"conv_bfp_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}, {np_}>")

@@ -69,7 +69,10 @@ typedef struct {
                                (SalsaNext), RangeNet uses 0.1 (rangenet_proto.py:45)           */
   int32_t mfma_bf16;        /* 0: fp32 MFMA (the parity path).  1: operands rounded to bf16
                                (RNE) in LDS->register reads, v_mfma_f32_32x32x16_bf16, fp32
-                               accumulate/storage -- opt-in mixed precision (BASELINE config 2) */
+                               accumulate/storage -- opt-in mixed precision (BASELINE config 2).
+                               2: every fp32 operand split exactly into three bf16 planes, eight of
+                               the nine plane products accumulated in fp32 (fp32-class result on the
+                               bf16 pipe); multi-tap convs then need a c3d_pack_weights(mode | 2) pack */
 } c3d_conv_desc;
 
 /* y = epilogue(conv(transform(cat(src)))) as an implicit GEMM on fp32 MFMA.
@@ -82,7 +85,10 @@ int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream);
 /* Weight repack from the reference's OIHW layout [Cout][Cin][T] (T = kh*kw):
  *   mode 0 (forward):  dst[t][k/4][n][k%4] = W[n][k0 + k][t],  k < K=Cin_cnt,  n < Cout
  *   mode 1 (dgrad):    dst[t][k/4][n][k%4] = W[k][n0 + n][t],  k < Cout,       n < N=Cin_cnt
- * K is zero-padded to Kpad (multiple of 16).                                                */
+ * K is zero-padded to Kpad (multiple of 16).
+ *   mode | 2: dst (2.5x the floats) additionally receives, behind the fp32 image, three bf16
+ *   images of the same shape holding the exact split w = h + m + l (h = RNE8(w), m = RNE8(w - h),
+ *   l = RNE8(w - h - m)): what c3d_conv_forward reads with mfma_bf16 == 2 for multi-tap convs.   */
 int c3d_pack_weights(const float* w_oihw, float* dst, int Cout, int Cin, int T, int mode,
                      int c_off, int c_cnt, int Kpad, c3d_stream stream);
 /* The same for a whole model in ONE launch: `table_dev` is a device array of n entries.       */
