@@ -144,7 +144,7 @@ def test_bench_launches_two_ranks():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
-           "--height", "32", "--width", "256", "--no-cpu-baseline", "--no-kernel-events"]
+           "--height", "32", "--width", "256", "--no-cpu-baseline", "--no-kernel-events", "--no-second-engine"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(C3D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -192,7 +192,7 @@ def test_rccl_exchange_points_in_a_single_rank_group():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--height", "32",
-           "--width", "256", "--no-cpu-baseline", "--no-kernel-events"]
+           "--width", "256", "--no-cpu-baseline", "--no-kernel-events", "--no-second-engine"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", HSA_ENABLE_IPC_MODE_LEGACY="0")
     plain = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert plain.returncode == 0, plain.stderr[-2000:]
