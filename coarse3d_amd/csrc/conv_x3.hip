@@ -14,7 +14,10 @@
 //   * the weight slab is staged ONE TAP ROW (3 taps) at a time: LDS = 3 planes x (input tile +
 //     3 taps x TN couts) x 32 B = 51-60 KB -> two workgroups per CU;
 //     (tried and slower, 0.66 vs 0.62 ms on 64->64 3x3 d2 at 8x64x2048: B fragments straight
-//     from the L2-resident planes into registers, one tap ahead, no weight LDS at all)
+//     from the L2-resident planes into registers, one tap ahead, no weight LDS at all.  Also
+//     tried: a pointwise twin of this kernel -- 32-channel chunks, rotated 64-byte rows, 64 or
+//     128 couts per workgroup: 117 TF on the 704x704 GEMM against conv_bfp's 124, the 128-wide
+//     one spills -- so 1x1 layers stay on conv_bfp.hip's NP = 3 kernel)
 //   * LDS rows are 32 B (16 channels) with NO padding; the two 16-B halves of row R are swapped
 //     when bit 3 of R is set, which makes every ds_read_b128 fragment read conflict-free.
 // GEMM view, tile shape (8 x 32 pixels x 32*NT couts), on-load BatchNorm affine and epilogue as
