@@ -224,6 +224,9 @@ def main():
                          "f32: the fp32-MFMA engine (also timed, reported under `engines`); bf16: opt-in mixed "
                          "precision (operands rounded to bf16, fp32 accumulate and storage; BASELINE configs[2])")
     ap.add_argument("--no-second-engine", action="store_true", help="skip the fp32-MFMA engine's comparison run")
+    ap.add_argument("--storage", choices=("bf16", "f32"), default="bf16",
+                    help="activation storage of --matrix-dtype bf16 (BASELINE configs[2]): bf16 tensors in HBM "
+                         "(default) or fp32 tensors with bf16 MFMA operands only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--kernel-table", default=None, help="write a per-(kernel, layer shape) timing table (JSON) here")
@@ -259,7 +262,7 @@ def main():
     from coarse3d_amd.pc_processor.models import RangeNetProto, SalsaNextProto, SqueezeSegV3Proto
     from coarse3d_amd.trainer import TrainStep
 
-    ops.set_matrix_precision(args.matrix_dtype)
+    ops.set_matrix_precision(args.matrix_dtype, storage=args.storage if args.matrix_dtype == "bf16" else None)
     # bf16x3: EIGHT bf16 MFMAs (32x32x16) do the work of eight fp32 MFMAs' worth of K... i.e. per fp32 product
     # eight plane products: the fp32-equivalent ceiling of that engine is the dense bf16 peak / 8
     peak_tf = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS,
@@ -435,7 +438,8 @@ def main():
             "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16": "bf16 MFMA operands, f32 accumulate/storage",
+            "dtype": {"f32": "f32", "bf16": ("bf16 activations in HBM + bf16 MFMA operands, f32 accumulate / statistics / master weights"
+                               if args.storage == "bf16" else "bf16 MFMA operands, f32 accumulate/storage"),
                       "bf16x3": "f32 via 3xbf16 exact split (conv + input-gradient kernels: 8 of 9 plane products, f32 "
                                 "accumulate; weight gradients on f32 MFMA; f32 storage everywhere)"}[args.matrix_dtype],
             "data": "synthetic",

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libcoarse3d_hip.so")
 class Src(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
                 ("C", C.c_int32), ("cstride", C.c_int32), ("coff", C.c_int32),
-                ("lrelu", C.c_int32)]
+                ("lrelu", C.c_int32), ("bf16", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -24,7 +24,7 @@ class ConvDesc(C.Structure):
                 ("wpack", C.c_void_p), ("bias", C.c_void_p), ("epi_lrelu", C.c_int32),
                 ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
                 ("accumulate", C.c_int32), ("stat_partial", C.c_void_p), ("lrelu_slope", C.c_float),
-                ("mfma_bf16", C.c_int32)]
+                ("mfma_bf16", C.c_int32), ("out_bf16", C.c_int32), ("reserved", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -33,7 +33,7 @@ class WgradDesc(C.Structure):
                 ("ntaps", C.c_int32), ("tap_dy", C.c_int32 * 9), ("tap_dx", C.c_int32 * 9),
                 ("Cin_total", C.c_int32), ("cin_off", C.c_int32),
                 ("dw", C.c_void_p), ("accumulate", C.c_int32), ("partial", C.c_void_p), ("mfma_bf16", C.c_int32),
-                ("lrelu_slope", C.c_float)]
+                ("lrelu_slope", C.c_float), ("dz_bf16", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PackEntry(C.Structure):

@@ -248,7 +248,7 @@ class Backbone:
             b = x.shape[0]
             hh, wh = ho // 2, wo // 2
             feat = torch.empty(b, hh, wh, sum(s.t.shape[3] for s in self.skips), device=x.device,
-                               dtype=torch.float32)
+                               dtype=self.skips[0].t.dtype)
             off = 0
             for s in self.skips:
                 ops.bilinear(s.t, hh, wh, dst=feat, dcoff=off, c=s.t.shape[3])
@@ -267,7 +267,7 @@ class Backbone:
         if return_feat:
             emb = self._conv("projector.proj.3", [z0], 1, 1, 0, lrelu=False, src_lrelu=True)
             embn, norm = ops.l2norm(emb.t, 1e-12)
-            feat2d = ops.bilinear(embn, ho, wo)
+            feat2d = ops.bilinear(embn, ho, wo, out_dtype=torch.float32)   # the embedding leaves the backbone in fp32
             self.tape["embed"] = (feat_a, z0, emb, embn, norm)
             out["feat"] = feat2d
         if train and update_running:

@@ -155,6 +155,7 @@ struct BwdArgs {
   float* partial;            // [C][2][gridDim.x]
   int pix_per_block;
   float slope;
+  int bf;                    // bit 0: dy, bit 1: a, bit 2: dz are bf16
 };
 
 // thread = (pixel lane, channel quad); block walks a contiguous pixel chunk
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
           if (p.mode == 0 || p.mode == 2) da *= (a[q] > 0.f) ? 1.f : p.slope;
           dz[q] = da;
         }
-        *reinterpret_cast<f32x4*>(p.dz + (size_t)i * p.dz_cs + c) = dz;
+        c3d_st4(p.dz, (size_t)i * p.dz_cs + c, p.bf & 4, dz);
         s1 += dz;
       }
     };
@@ -208,15 +209,14 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
       f32x4 dyv[UN], av[UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
-        dyv[u] = *reinterpret_cast<const f32x4*>(p.dy + (size_t)(i + u * PL) * p.dy_cs + c);
-        av[u] = *reinterpret_cast<const f32x4*>(p.a + (size_t)(i + u * PL) * p.a_cs + c);
+        dyv[u] = c3d_ld4(p.dy, (size_t)(i + u * PL) * p.dy_cs + c, p.bf & 1);
+        av[u] = c3d_ld4(p.a, (size_t)(i + u * PL) * p.a_cs + c, p.bf & 2);
       }
 #pragma unroll
       for (int u = 0; u < UN; ++u) body(dyv[u], av[u], i + u * PL);
     }
     for (; i < p1; i += PL)
-      body(*reinterpret_cast<const f32x4*>(p.dy + (size_t)i * p.dy_cs + c),
-           *reinterpret_cast<const f32x4*>(p.a + (size_t)i * p.a_cs + c), i);
+      body(c3d_ld4(p.dy, (size_t)i * p.dy_cs + c, p.bf & 1), c3d_ld4(p.a, (size_t)i * p.a_cs + c, p.bf & 2), i);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       red[(pl * p.C + c + q) * 2 + 0] = s1[q];
@@ -303,7 +303,7 @@ extern "C" int c3d_bn_bwd_num_blocks(int npix) {
 
 static int bn_bwd_launch(bool apply, const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C, int mode,
                          const float* pre_scale, const float* pre_shift, const float* k1, const float* k2,
-                         const float* k3, float* dz, int dz_cs, float* partial, float slope, hipStream_t st) {
+                         const float* k3, float* dz, int dz_cs, float* partial, float slope, int bf, hipStream_t st) {
   C3D_REQUIRE(C % 4 == 0 && C <= 1024, "bn_bwd: C must be a multiple of 4 and <= 1024");
   C3D_REQUIRE(dy_cs % 4 == 0 && a_cs % 4 == 0 && (!apply || dz_cs % 4 == 0), "bn_bwd: strides must be multiples of 4");
   BwdArgs p;
@@ -311,6 +311,7 @@ static int bn_bwd_launch(bool apply, const float* dy, int dy_cs, const float* a,
   p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.k1 = k1; p.k2 = k2; p.k3 = k3;
   p.dz = dz; p.dz_cs = dz_cs; p.partial = partial;
   p.slope = c3d_slope_or_default(slope);
+  p.bf = bf;
   const int nb = c3d_bn_bwd_num_blocks(npix);
   p.pix_per_block = (npix + nb - 1) / nb;
   const int Q = C / 4;
@@ -324,9 +325,9 @@ static int bn_bwd_launch(bool apply, const float* dy, int dy_cs, const float* a,
 
 extern "C" int c3d_bn_bwd_reduce(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C, int mode,
                                  const float* pre_scale, const float* pre_shift, float* partial,
-                                 float lrelu_slope, c3d_stream stream) {
+                                 float lrelu_slope, int bf16_mask, c3d_stream stream) {
   return bn_bwd_launch(false, dy, dy_cs, a, a_cs, npix, C, mode, pre_scale, pre_shift, nullptr, nullptr, nullptr,
-                       nullptr, 0, partial, lrelu_slope, (hipStream_t)stream);
+                       nullptr, 0, partial, lrelu_slope, bf16_mask, (hipStream_t)stream);
 }
 
 extern "C" int c3d_bn_bwd_coeffs(const double* sums, const double* sums_param, double count, const float* mean,
@@ -341,10 +342,10 @@ extern "C" int c3d_bn_bwd_coeffs(const double* sums, const double* sums_param, d
 
 extern "C" int c3d_bn_bwd_apply(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C, int mode,
                                 const float* pre_scale, const float* pre_shift, const float* k1, const float* k2,
-                                const float* k3, float* dz, int dz_cs, float* partial, float lrelu_slope,
+                                const float* k3, float* dz, int dz_cs, float* partial, float lrelu_slope, int bf16_mask,
                                 c3d_stream stream) {
   return bn_bwd_launch(true, dy, dy_cs, a, a_cs, npix, C, mode, pre_scale, pre_shift, k1, k2, k3, dz, dz_cs, partial,
-                       lrelu_slope, (hipStream_t)stream);
+                       lrelu_slope, bf16_mask, (hipStream_t)stream);
 }
 
 extern "C" int c3d_sums_to_f32(const double* sums, int C, int col, float* out, int accumulate, c3d_stream stream) {

@@ -25,6 +25,41 @@ __device__ __forceinline__ bf16x8 c3d_pack_bf16x8(f32x4 a, f32x4 b) {
   return r;
 }
 
+// ---- activation storage: fp32 or bf16 behind the same (float*) signatures; `i` counts ELEMENTS.
+// The flag is uniform over a launch, so the branch costs nothing.
+typedef unsigned int c3d_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 c3d_ld4(const float* p, size_t i, bool bf) {
+  if (bf) {
+    const c3d_u32x2 r = *reinterpret_cast<const c3d_u32x2*>(reinterpret_cast<const unsigned short*>(p) + i);
+    f32x4 v;
+    v[0] = __uint_as_float(r[0] << 16);
+    v[1] = __uint_as_float(r[0] & 0xffff0000u);
+    v[2] = __uint_as_float(r[1] << 16);
+    v[3] = __uint_as_float(r[1] & 0xffff0000u);
+    return v;
+  }
+  return *reinterpret_cast<const f32x4*>(p + i);
+}
+__device__ __forceinline__ void c3d_st4(float* p, size_t i, bool bf, f32x4 v) {
+  if (bf) {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    bf16x4_t h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h[q] = (__bf16)v[q];
+    *reinterpret_cast<c3d_u32x2*>(reinterpret_cast<unsigned short*>(p) + i) = __builtin_bit_cast(c3d_u32x2, h);
+  } else {
+    *reinterpret_cast<f32x4*>(p + i) = v;
+  }
+}
+__device__ __forceinline__ float c3d_ld1(const float* p, size_t i, bool bf) {
+  if (bf) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p)[i] << 16);
+  return p[i];
+}
+__device__ __forceinline__ void c3d_st1(float* p, size_t i, bool bf, float v) {
+  if (bf) reinterpret_cast<__bf16*>(p)[i] = (__bf16)v;
+  else p[i] = v;
+}
+
 // Bijective XCD-aware remap: consecutive logical tiles land on the same XCD (block b runs on
 // XCD b % 8 on MI355X), so neighbouring tiles that share halos / weights hit one L2.
 __device__ __forceinline__ int c3d_xcd_remap(int bid, int n) {

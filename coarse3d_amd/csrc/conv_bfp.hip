@@ -123,11 +123,24 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
 
   auto load_chunk = [&](int s, int c0, int kbase) {
     const c3d_src& sr = a.src[s];
-    const float* base = sr.ptr + tile_pix * sr.cstride + sr.coff + c0 + c4 * 4;
+    if (NP == 1 && sr.bf16) {        // bf16 activation storage: 8-byte loads, widened in registers
+      const unsigned short* base = reinterpret_cast<const unsigned short*>(sr.ptr) + tile_pix * sr.cstride + sr.coff + c0 + c4 * 4;
 #pragma unroll
-    for (int i = 0; i < IN_PT; ++i) {
-      pin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if ((inb >> i) & 1u) pin[i] = *reinterpret_cast<const f32x4*>(base + (ptrdiff_t)pixrel[i] * sr.cstride);
+      for (int i = 0; i < IN_PT; ++i) {
+        pin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if ((inb >> i) & 1u) {
+          const c3d_u32x2 r = *reinterpret_cast<const c3d_u32x2*>(base + (ptrdiff_t)pixrel[i] * sr.cstride);
+          pin[i] = f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+                         __uint_as_float(r[1] & 0xffff0000u)};
+        }
+      }
+    } else {
+      const float* base = sr.ptr + tile_pix * sr.cstride + sr.coff + c0 + c4 * 4;
+#pragma unroll
+      for (int i = 0; i < IN_PT; ++i) {
+        pin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if ((inb >> i) & 1u) pin[i] = *reinterpret_cast<const f32x4*>(base + (ptrdiff_t)pixrel[i] * sr.cstride);
+      }
     }
     if (sr.scale) {
       psc = *reinterpret_cast<const f32x4*>(sr.scale + c0 + c4 * 4);
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
     c0 = c2;
     kbase = kb2;
   }
-  conv_epilogue<TR, NT, WM, WN>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
+  conv_epilogue<TR, NT, WM, WN, NP == 1>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
 }
 
 template <int TR, int NT, int CK, int HALO, int TT, int NP>

@@ -20,6 +20,7 @@ struct ConvArgs {
   int tiles_x, tiles_y, Kq;  // Kq = padded K / 4 (rows of the packed weight per tap)
   int ntn;                   // number of cout tiles
   float slope;               // LeakyReLU slope of the on-load and epilogue activations
+  int out_bf16;              // out is bf16 (conv_bfp NP = 1 only)
 };
 
 // bf16-plane kernels (conv_bfp.hip): planes = 1 (bf16) or 3 (bf16x3)
@@ -29,10 +30,15 @@ int c3d_conv_forward_x3(ConvArgs& a, int halo, hipStream_t st);
 
 namespace {
 
+template <typename T>
+struct c3d_type_tag {
+  using type = T;
+};
+
 // Epilogue of one workgroup tile: bias, LeakyReLU, (accumulating) store, per-tile channel
 // statistics [C][2][ntile].  acc[i][j] is the 32x32 MFMA accumulator of tile row wm + i*WM and
 // cout tile wn*NPW + j (lane l: cout l&31, pixels (r&3) + 8*(r>>2) + 4*(l>>5)).
-template <int TR, int NT, int WM, int WN>
+template <int TR, int NT, int WM, int WN, bool BF16_OUT = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TR / WM][NT / WN], float* smem, int tid,
                                               int lane, int half, int l31, int wm, int wn, int b, int x0, int y0,
                                               int n0, int mt, int ntile, size_t tile_pix) {
@@ -41,11 +47,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
   constexpr int TN = 32 * NT;
   float s1[NPW], s2v[NPW];
   const bool full_tile = (x0 + 32 <= a.W) && (y0 + TR <= a.H) && (n0 + TN <= a.Cout);
-  float* obase = a.out + tile_pix * a.out_cstride + a.out_coff + n0 + l31;   // + per-lane cout
   const int ocs = a.out_cstride;
-  // fast path (interior tiles): straight-line, no per-element predicates
-  auto fast_epilogue = [&](auto accumulate_tag) {
+  const size_t obase_i = tile_pix * a.out_cstride + a.out_coff + n0 + l31;   // element index, + per-lane cout
+  // fast path (interior tiles): straight-line, no per-element predicates.  OT = float or __bf16 (bf16
+  // activation storage, values rounded RNE on store; the statistics below use the fp32 values)
+  auto fast_epilogue = [&](auto accumulate_tag, auto type_tag) {
     constexpr bool ACC = decltype(accumulate_tag)::value;
+    using OT = typename decltype(type_tag)::type;
+    OT* obase = reinterpret_cast<OT*>(a.out) + obase_i;
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
       const int cl = (wn * NPW + j) * 32;
@@ -54,28 +63,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
       s2v[j] = 0.f;
 #pragma unroll
       for (int i = 0; i < RPW; ++i) {
-        float* orow = obase + (ptrdiff_t)((wm + i * WM) * a.W + 4 * half) * ocs + cl;
+        OT* orow = obase + (ptrdiff_t)((wm + i * WM) * a.W + 4 * half) * ocs + cl;
         float old[16];
         if constexpr (ACC) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) old[r] = orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs];
+          for (int r = 0; r < 16; ++r) old[r] = (float)orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = acc[i][j][r] + bias;
           if (a.epi_lrelu) v = c3d_lrelu(v, a.slope);
           if constexpr (ACC) v += old[r];
-          orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs] = v;
+          orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs] = (OT)v;
           s1[j] += v;
           s2v[j] += v * v;
         }
       }
     }
   };
-  if (full_tile && !a.accumulate) {
-    fast_epilogue(std::false_type{});
+  const bool obf = BF16_OUT && a.out_bf16 != 0;      // engines that never store bf16 compile that path out
+  if (full_tile && !obf) {
+    if (!a.accumulate) fast_epilogue(std::false_type{}, c3d_type_tag<float>{});
+    else fast_epilogue(std::true_type{}, c3d_type_tag<float>{});
   } else if (full_tile) {
-    fast_epilogue(std::true_type{});
+    if constexpr (BF16_OUT) {
+      if (!a.accumulate) fast_epilogue(std::false_type{}, c3d_type_tag<__bf16>{});
+      else fast_epilogue(std::true_type{}, c3d_type_tag<__bf16>{});
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
@@ -93,9 +107,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
           float v = acc[i][j][r] + bias;
           if (a.epi_lrelu) v = c3d_lrelu(v, a.slope);
           if (cok && gy < a.H && gx < a.W) {
-            float* o = a.out + ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co;
-            if (a.accumulate) v += *o;
-            *o = v;
+            const size_t o = ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co;
+            if (a.accumulate) v += c3d_ld1(a.out, o, obf);
+            c3d_st1(a.out, o, obf, v);
             s1[j] += v;
             s2v[j] += v * v;
           }

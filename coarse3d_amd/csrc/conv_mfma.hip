@@ -287,6 +287,13 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   a.accumulate = d->accumulate;
   a.stat_partial = d->stat_partial;
   a.slope = c3d_slope_or_default(d->lrelu_slope);
+  a.out_bf16 = d->out_bf16;
+  {
+    bool any_bf = d->out_bf16 != 0;
+    for (int s = 0; s < d->nsrc; ++s) any_bf = any_bf || d->src[s].bf16 != 0;
+    C3D_REQUIRE(!any_bf || d->mfma_bf16 == 1, "conv: bf16 activation storage needs mfma_bf16 == 1");
+    C3D_REQUIRE(!d->out_bf16 || (d->out_cstride % 4 == 0 && d->out_coff % 4 == 0), "conv: bf16 out stride/offset must be multiples of 4");
+  }
   const int tr = c3d_tile_rows(d->H);
   a.tiles_x = (d->W + 31) / 32;
   a.tiles_y = (d->H + tr - 1) / tr;

@@ -1,5 +1,6 @@
 // HBM-bound glue of the SalsaNext blocks (gfx950): everything between the convolutions.
-// All tensors NHWC fp32; kernels are float4-vectorised along channels and grid-strided.
+// All tensors NHWC, fp32 or -- per activation pointer, bit i of the trailing `bf16_mask` argument -- bf16
+// (BASELINE configs[2] storage); kernels are 4-channel-vectorised and grid-strided, arithmetic is fp32.
 // Reference (pc_processor/models/salsanext_proto.py unless noted):
 //   input_norm            tasks/weak_segmentation/trainer.py:599-609
 //   conv_in5              downCntx.conv1 (5 -> 32, 1x1) + LeakyReLU, :41-42,53-54
@@ -42,7 +43,7 @@ __global__ void input_norm_kernel(const float* __restrict__ x, const int64_t* __
 // x NCHW [B,Cn,H,W] (Cn <= 8), w [32][Cn], out NHWC [B,HW,32]
 __global__ __launch_bounds__(256) void conv_in5_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, int Cn, int HW, int total_pix,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, int bf) {
   __shared__ float tile[256][33];
   __shared__ float sw[32 * 8 + 32];
   const int tid = threadIdx.x;
@@ -65,14 +66,14 @@ __global__ __launch_bounds__(256) void conv_in5_kernel(const float* __restrict__
   __syncthreads();
   for (int i = tid; i < 256 * 32; i += 256) {
     const int pp = i >> 5, co = i & 31;
-    if (p0 + pp < (size_t)total_pix) out[(p0 + pp) * 32 + co] = tile[pp][co];
+    if (p0 + pp < (size_t)total_pix) c3d_st1(out, (p0 + pp) * 32 + co, bf & 1, tile[pp][co]);
   }
 }
 
 // dW partial: [nblk][32][8]
 __global__ __launch_bounds__(256) void conv_in5_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                              int Cn, int HW, int total_pix, int pix_per_block,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, int bf) {
   __shared__ float red[8][32][8];
   const int tid = threadIdx.x, co = tid & 31, pl = tid >> 5;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_in5_wgrad_kernel(const float* __rest
   const int p1 = min(p0 + pix_per_block, total_pix);
   for (int p = p0 + pl; p < p1; p += 8) {
     const int b = p / HW, hw = p % HW;
-    const float g = dz[(size_t)p * 32 + co];
+    const float g = c3d_ld1(dz, (size_t)p * 32 + co, bf & 1);
     for (int c = 0; c < Cn; ++c) acc[c] = fmaf(g, x[((size_t)b * Cn + c) * HW + hw], acc[c]);
   }
   for (int c = 0; c < 8; ++c) red[pl][co][c] = acc[c];
@@ -112,19 +113,19 @@ __global__ __launch_bounds__(256) void conv_in5_wgrad_reduce_kernel(const float*
 // (salsanext_proto.py:64,133) and of RangeNet's BasicBlock (rangenet_proto.py:52-63)
 __global__ void affine_add_kernel(const float* __restrict__ x, const float* __restrict__ a,
                                   const float* __restrict__ scale, const float* __restrict__ shift, size_t npix, int C,
-                                  float slope, float* __restrict__ out) {
+                                  float slope, float* __restrict__ out, int bf) {
   const int Q = C >> 2;
   const size_t total = npix * Q;
   for (size_t i = gtid(); i < total; i += gstride()) {
     const int c = (i % Q) * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(a + i * 4);
+    f32x4 v = c3d_ld4(a, i * 4, bf & 2);
     if (scale) v = v * *reinterpret_cast<const f32x4*>(scale + c) + *reinterpret_cast<const f32x4*>(shift + c);
     if (slope > 0.f) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q], slope);
     }
-    if (x) v += *reinterpret_cast<const f32x4*>(x + i * 4);
-    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    if (x) v += c3d_ld4(x, i * 4, bf & 1);
+    c3d_st4(out, i * 4, bf & 4, v);
   }
 }
 
@@ -165,18 +166,19 @@ __global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, int B, int 
 }
 
 // y (+)= alpha * x  (flat)
-__global__ void axpy_kernel(const float* __restrict__ x, float alpha, size_t n4, float* __restrict__ y, int accumulate) {
+__global__ void axpy_kernel(const float* __restrict__ x, float alpha, size_t n4, float* __restrict__ y, int accumulate,
+                            int bf) {
   for (size_t i = gtid(); i < n4; i += gstride()) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4) * alpha;
-    if (accumulate) v += *reinterpret_cast<const f32x4*>(y + i * 4);
-    *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    f32x4 v = c3d_ld4(x, i * 4, bf & 1) * alpha;
+    if (accumulate) v += c3d_ld4(y, i * 4, bf & 2);
+    c3d_st4(y, i * 4, bf & 2, v);
   }
 }
 
 // ---------------------------------------------------------------- mask (+ 3x3 stride-2 average pool)
 // in [B,H,W,C], mask [B,C] or null; pool: out [B,Ho,Wo,C]; no pool: out = in*mask
 __global__ void maskpool_kernel(const float* __restrict__ in, const float* __restrict__ mask, int B, int H, int W, int C,
-                                int pool, int Ho, int Wo, float* __restrict__ out) {
+                                int pool, int Ho, int Wo, float* __restrict__ out, int bf) {
   const int Q = C >> 2;
   const size_t total = (size_t)B * Ho * Wo * Q;
   for (size_t i = gtid(); i < total; i += gstride()) {
@@ -194,21 +196,21 @@ __global__ void maskpool_kernel(const float* __restrict__ in, const float* __res
         for (int dx = -1; dx <= 1; ++dx) {
           const int y = 2 * yo + dy, x = 2 * xo + dx;
           if (y >= 0 && y < H && x >= 0 && x < W)
-            acc += *reinterpret_cast<const f32x4*>(in + ((size_t)(b * H + y) * W + x) * C + c);
+            acc += c3d_ld4(in, ((size_t)(b * H + y) * W + x) * C + c, bf & 1);
         }
       acc *= (1.f / 9.f);
     } else {
-      acc = *reinterpret_cast<const f32x4*>(in + ((size_t)(b * H + yo) * W + xo) * C + c);
+      acc = c3d_ld4(in, ((size_t)(b * H + yo) * W + xo) * C + c, bf & 1);
     }
     if (mask) acc *= *reinterpret_cast<const f32x4*>(mask + (size_t)b * C + c);
-    *reinterpret_cast<f32x4*>(out + i * 4) = acc;
+    c3d_st4(out, i * 4, bf & 2, acc);
   }
 }
 
 // d_in = (extra ? extra : 0) + mask * poolT(d_out)
 __global__ void maskpool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ mask,
                                     const float* __restrict__ extra, int B, int H, int W, int C, int pool, int Ho,
-                                    int Wo, float* __restrict__ din) {
+                                    int Wo, float* __restrict__ din, int bf) {
   const int Q = C >> 2;
   const size_t total = (size_t)B * H * W * Q;
   for (size_t i = gtid(); i < total; i += gstride()) {
@@ -229,15 +231,15 @@ __global__ void maskpool_bwd_kernel(const float* __restrict__ dout, const float*
         for (int v = 0; v < 2; ++v) {
           const int yo = ys[u], xo = xs[v];
           if (yo >= 0 && yo < Ho && xo >= 0 && xo < Wo)
-            acc += *reinterpret_cast<const f32x4*>(dout + ((size_t)(b * Ho + yo) * Wo + xo) * C + c);
+            acc += c3d_ld4(dout, ((size_t)(b * Ho + yo) * Wo + xo) * C + c, bf & 1);
         }
       acc *= (1.f / 9.f);
     } else {
-      acc = *reinterpret_cast<const f32x4*>(dout + i * 4);
+      acc = c3d_ld4(dout, i * 4, bf & 1);
     }
     if (mask) acc *= *reinterpret_cast<const f32x4*>(mask + (size_t)b * C + c);
-    if (extra) acc += *reinterpret_cast<const f32x4*>(extra + i * 4);
-    *reinterpret_cast<f32x4*>(din + i * 4) = acc;
+    if (extra) acc += c3d_ld4(extra, i * 4, bf & 2);
+    c3d_st4(din, i * 4, bf & 4, acc);
   }
 }
 
@@ -250,6 +252,7 @@ struct PsArgs {
   const float* skip;  // [B,H,W,Cs]
   int B, Hs, Ws, Cx, Cs;
   float* out;  // [B,2Hs,2Ws,Cu+Cs]
+  int bf;      // bit 0: xa, bit 1: skip, bit 2: out are bf16
 };
 
 __global__ void pixshuf_kernel(PsArgs p) {
@@ -262,7 +265,7 @@ __global__ void pixshuf_kernel(PsArgs p) {
     r /= p.Ws;
     const int ys = r % p.Hs;
     const int b = r / p.Hs;
-    f32x4 v = *reinterpret_cast<const f32x4*>(p.xa + ((size_t)(b * p.Hs + ys) * p.Ws + xs) * p.Cx + c * 4);
+    f32x4 v = c3d_ld4(p.xa, ((size_t)(b * p.Hs + ys) * p.Ws + xs) * p.Cx + c * 4, p.bf & 1);
     if (p.sc) v = v * *reinterpret_cast<const f32x4*>(p.sc + c * 4) + *reinterpret_cast<const f32x4*>(p.sh + c * 4);
     if (p.m3) v *= *reinterpret_cast<const f32x4*>(p.m3 + (size_t)b * p.Cx + c * 4);
     float m = 1.f;
@@ -271,7 +274,7 @@ __global__ void pixshuf_kernel(PsArgs p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int y = 2 * ys + (k >> 1), x = 2 * xs + (k & 1);
-      p.out[((size_t)(b * H + y) * W + x) * Ct + c] = v[k] * m;
+      c3d_st1(p.out, ((size_t)(b * H + y) * W + x) * Ct + c, p.bf & 4, v[k] * m);
     }
   }
 }
@@ -284,9 +287,9 @@ __global__ void catskip_kernel(PsArgs p) {
     const int c = (i % Q) * 4;
     const size_t pix = i / Q;
     const int b = pix / ((size_t)H * W);
-    f32x4 v = *reinterpret_cast<const f32x4*>(p.skip + pix * p.Cs + c);
+    f32x4 v = c3d_ld4(p.skip, pix * p.Cs + c, p.bf & 2);
     if (p.m2) v *= *reinterpret_cast<const f32x4*>(p.m2 + (size_t)b * Ct + Cu + c);
-    *reinterpret_cast<f32x4*>(p.out + pix * Ct + Cu + c) = v;
+    c3d_st4(p.out, pix * Ct + Cu + c, p.bf & 4, v);
   }
 }
 
@@ -297,6 +300,7 @@ struct PsBwdArgs {
   float* dxa;    // [B,Hs,Ws,Cx]  gradient w.r.t. the (affine-transformed) producer output
   float* dskip;  // [B,H,W,Cs]
   int skip_accumulate;
+  int bf;        // bit 0: dout, bit 1: dxa, bit 2: dskip are bf16
 };
 
 __global__ void pixshuf_bwd_kernel(PsBwdArgs p) {
@@ -316,10 +320,10 @@ __global__ void pixshuf_bwd_kernel(PsBwdArgs p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int y = 2 * ys + (k >> 1), x = 2 * xs + (k & 1);
-      v[k] = p.dout[((size_t)(b * H + y) * W + x) * Ct + c] * m;
+      v[k] = c3d_ld1(p.dout, ((size_t)(b * H + y) * W + x) * Ct + c, p.bf & 1) * m;
     }
     if (p.m3) v *= *reinterpret_cast<const f32x4*>(p.m3 + (size_t)b * p.Cx + c * 4);
-    *reinterpret_cast<f32x4*>(p.dxa + ((size_t)(b * p.Hs + ys) * p.Ws + xs) * p.Cx + c * 4) = v;
+    c3d_st4(p.dxa, ((size_t)(b * p.Hs + ys) * p.Ws + xs) * p.Cx + c * 4, p.bf & 2, v);
   }
 }
 
@@ -331,10 +335,10 @@ __global__ void catskip_bwd_kernel(PsBwdArgs p) {
     const int c = (i % Q) * 4;
     const size_t pix = i / Q;
     const int b = pix / ((size_t)H * W);
-    f32x4 v = *reinterpret_cast<const f32x4*>(p.dout + pix * Ct + Cu + c);
+    f32x4 v = c3d_ld4(p.dout, pix * Ct + Cu + c, p.bf & 1);
     if (p.m2) v *= *reinterpret_cast<const f32x4*>(p.m2 + (size_t)b * Ct + Cu + c);
-    f32x4* d = reinterpret_cast<f32x4*>(p.dskip + pix * p.Cs + c);
-    *d = p.skip_accumulate ? (*d + v) : v;
+    if (p.skip_accumulate) v += c3d_ld4(p.dskip, pix * p.Cs + c, p.bf & 4);
+    c3d_st4(p.dskip, pix * p.Cs + c, p.bf & 4, v);
   }
 }
 
@@ -397,6 +401,7 @@ struct BlArgs {
   float* dst; int Hd, Wd, dcs, dcoff;
   int B, C;
   float ry, rx;
+  int bf;        // bit 0: src, bit 1: dst are bf16
 };
 
 __device__ __forceinline__ void bl_coords(int d, float ratio, int n, int& i0, int& i1, float& l1) {
@@ -421,15 +426,14 @@ __global__ void bilinear_kernel(BlArgs p) {
     float ly, lx;
     bl_coords(yd, p.ry, p.Hs, y0, y1, ly);
     bl_coords(xd, p.rx, p.Ws, x0, x1, lx);
-    const float* s = p.src + (size_t)b * p.Hs * p.Ws * p.scs + p.scoff + c;
-    const f32x4 v00 = *reinterpret_cast<const f32x4*>(s + ((size_t)y0 * p.Ws + x0) * p.scs);
-    const f32x4 v01 = *reinterpret_cast<const f32x4*>(s + ((size_t)y0 * p.Ws + x1) * p.scs);
-    const f32x4 v10 = *reinterpret_cast<const f32x4*>(s + ((size_t)y1 * p.Ws + x0) * p.scs);
-    const f32x4 v11 = *reinterpret_cast<const f32x4*>(s + ((size_t)y1 * p.Ws + x1) * p.scs);
+    const size_t s = (size_t)b * p.Hs * p.Ws * p.scs + p.scoff + c;
+    const f32x4 v00 = c3d_ld4(p.src, s + ((size_t)y0 * p.Ws + x0) * p.scs, p.bf & 1);
+    const f32x4 v01 = c3d_ld4(p.src, s + ((size_t)y0 * p.Ws + x1) * p.scs, p.bf & 1);
+    const f32x4 v10 = c3d_ld4(p.src, s + ((size_t)y1 * p.Ws + x0) * p.scs, p.bf & 1);
+    const f32x4 v11 = c3d_ld4(p.src, s + ((size_t)y1 * p.Ws + x1) * p.scs, p.bf & 1);
     const f32x4 top = v00 * (1.f - lx) + v01 * lx;
     const f32x4 bot = v10 * (1.f - lx) + v11 * lx;
-    *reinterpret_cast<f32x4*>(p.dst + ((size_t)(b * p.Hd + yd) * p.Wd + xd) * p.dcs + p.dcoff + c) =
-        top * (1.f - ly) + bot * ly;
+    c3d_st4(p.dst, ((size_t)(b * p.Hd + yd) * p.Wd + xd) * p.dcs + p.dcoff + c, p.bf & 2, top * (1.f - ly) + bot * ly);
   }
 }
 
@@ -481,32 +485,32 @@ __global__ void bilinear_bwd_kernel(BlArgs p, int accumulate) {
       for (int xd = xlo; xd <= xhi; ++xd) {
         const float wx = bl_weight(xd, xs, p.rx, p.Ws);
         if (wx == 0.f) continue;
-        acc += *reinterpret_cast<const f32x4*>(p.dst + ((size_t)(b * p.Hd + yd) * p.Wd + xd) * p.dcs + p.dcoff + c) *
-               (wy * wx);
+        acc += c3d_ld4(p.dst, ((size_t)(b * p.Hd + yd) * p.Wd + xd) * p.dcs + p.dcoff + c, p.bf & 2) * (wy * wx);
       }
     }
-    f32x4* o = reinterpret_cast<f32x4*>(dsrc + ((size_t)(b * p.Hs + ys) * p.Ws + xs) * p.scs + p.scoff + c);
-    *o = accumulate ? (*o + acc) : acc;
+    const size_t o = ((size_t)(b * p.Hs + ys) * p.Ws + xs) * p.scs + p.scoff + c;
+    if (accumulate) acc += c3d_ld4(dsrc, o, p.bf & 1);
+    c3d_st4(dsrc, o, p.bf & 1, acc);
   }
 }
 
 // ---------------------------------------------------------------- row-wise L2 normalise (one wave per row)
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, size_t n, int C, float eps,
-                                                     float* __restrict__ y, float* __restrict__ norm) {
+                                                     float* __restrict__ y, float* __restrict__ norm, int bf) {
   const int lane = threadIdx.x & 63;
   const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
   for (size_t r = wave; r < n; r += nw) {
     float s = 0.f;
     for (int c = lane * 4; c < C; c += 256) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + c);
+      const f32x4 v = c3d_ld4(x, r * C + c, bf & 1);
       s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
     s = c3d_wave_sum(s);
     const float nr = sqrtf(s);
     const float inv = 1.f / fmaxf(nr, eps);
     for (int c = lane * 4; c < C; c += 256)
-      *reinterpret_cast<f32x4*>(y + r * C + c) = *reinterpret_cast<const f32x4*>(x + r * C + c) * inv;
+      c3d_st4(y, r * C + c, bf & 2, c3d_ld4(x, r * C + c, bf & 1) * inv);
     if (norm && lane == 0) norm[r] = nr;
   }
 }
@@ -514,23 +518,23 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x
 // dx = (dy - y * sum(y*dy)) / max(norm, eps)
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ norm,
                                                          const float* __restrict__ dy, size_t n, int C, float eps,
-                                                         float* __restrict__ dx) {
+                                                         float* __restrict__ dx, int bf) {
   const int lane = threadIdx.x & 63;
   const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
   for (size_t r = wave; r < n; r += nw) {
     float s = 0.f;
     for (int c = lane * 4; c < C; c += 256) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(y + r * C + c);
-      const f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + c);
+      const f32x4 a = c3d_ld4(y, r * C + c, bf & 1);
+      const f32x4 g = c3d_ld4(dy, r * C + c, bf & 2);
       s += a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3];
     }
     s = c3d_wave_sum(s);
     const float inv = 1.f / fmaxf(norm[r], eps);
     for (int c = lane * 4; c < C; c += 256) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(y + r * C + c);
-      const f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + c);
-      *reinterpret_cast<f32x4*>(dx + r * C + c) = (g - a * s) * inv;
+      const f32x4 a = c3d_ld4(y, r * C + c, bf & 1);
+      const f32x4 g = c3d_ld4(dy, r * C + c, bf & 2);
+      c3d_st4(dx, r * C + c, bf & 4, (g - a * s) * inv);
     }
   }
 }
@@ -547,23 +551,23 @@ extern "C" int c3d_input_norm(const float* x, const int64_t* eval_label, const f
   return 0;
 }
 
-extern "C" int c3d_conv_in5(const float* x_nchw, const float* w, const float* bias, int B, int Cn, int HW, float* out,
+extern "C" int c3d_conv_in5(const float* x_nchw, const float* w, const float* bias, int B, int Cn, int HW, float* out, int bf16_mask,
                             c3d_stream stream) {
   C3D_REQUIRE(Cn <= 8, "conv_in5: at most 8 input channels");
   const int total = B * HW;
-  hipLaunchKernelGGL(conv_in5_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, x_nchw, w, bias, Cn, HW, total, out);
+  hipLaunchKernelGGL(conv_in5_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, x_nchw, w, bias, Cn, HW, total, out, bf16_mask);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int c3d_conv_in5_wgrad(const float* x_nchw, const float* dz, int B, int Cn, int HW, float* partial,
-                                  float* dw, c3d_stream stream) {
+                                  float* dw, int bf16_mask, c3d_stream stream) {
   C3D_REQUIRE(Cn <= 8, "conv_in5: at most 8 input channels");
   const int total = B * HW;
   int nb = (total + 511) / 512;
   if (nb > 1024) nb = 1024;
   const int ppb = (total + nb - 1) / nb;
-  hipLaunchKernelGGL(conv_in5_wgrad_kernel, dim3(nb), dim3(256), 0, ST, x_nchw, dz, Cn, HW, total, ppb, partial);
+  hipLaunchKernelGGL(conv_in5_wgrad_kernel, dim3(nb), dim3(256), 0, ST, x_nchw, dz, Cn, HW, total, ppb, partial, bf16_mask);
   C3D_CHECK_LAUNCH();
   hipLaunchKernelGGL(conv_in5_wgrad_reduce_kernel, dim3((32 * Cn * 64 + 255) / 256), dim3(256), 0, ST, partial, nb, Cn, dw);
   C3D_CHECK_LAUNCH();
@@ -571,10 +575,10 @@ extern "C" int c3d_conv_in5_wgrad(const float* x_nchw, const float* dz, int B, i
 }
 
 extern "C" int c3d_affine_add(const float* x, const float* a, const float* scale, const float* shift, int64_t npix,
-                              int C, float lrelu_slope, float* out, c3d_stream stream) {
+                              int C, float lrelu_slope, float* out, int bf16_mask, c3d_stream stream) {
   C3D_REQUIRE(C % 4 == 0, "affine_add: C must be a multiple of 4");
   hipLaunchKernelGGL(affine_add_kernel, dim3(nblocks((size_t)npix * C / 4)), dim3(256), 0, ST, x, a, scale, shift,
-                     (size_t)npix, C, lrelu_slope, out);
+                     (size_t)npix, C, lrelu_slope, out, bf16_mask);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -597,38 +601,38 @@ extern "C" int c3d_nchw_to_nhwc_pad(const float* x, int B, int Cn, int64_t HW, i
   return 0;
 }
 
-extern "C" int c3d_axpy(const float* x, float alpha, int64_t n, float* y, int accumulate, c3d_stream stream) {
+extern "C" int c3d_axpy(const float* x, float alpha, int64_t n, float* y, int accumulate, int bf16_mask, c3d_stream stream) {
   C3D_REQUIRE(n % 4 == 0, "axpy: n must be a multiple of 4");
-  hipLaunchKernelGGL(axpy_kernel, dim3(nblocks((size_t)n / 4)), dim3(256), 0, ST, x, alpha, (size_t)n / 4, y, accumulate);
+  hipLaunchKernelGGL(axpy_kernel, dim3(nblocks((size_t)n / 4)), dim3(256), 0, ST, x, alpha, (size_t)n / 4, y, accumulate, bf16_mask);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int c3d_maskpool(const float* in, const float* mask, int B, int H, int W, int C, int pool, float* out,
+extern "C" int c3d_maskpool(const float* in, const float* mask, int B, int H, int W, int C, int pool, float* out, int bf16_mask,
                             c3d_stream stream) {
   C3D_REQUIRE(C % 4 == 0, "maskpool: C must be a multiple of 4");
   const int Ho = pool ? (H + 1) / 2 : H, Wo = pool ? (W + 1) / 2 : W;
   hipLaunchKernelGGL(maskpool_kernel, dim3(nblocks((size_t)B * Ho * Wo * C / 4)), dim3(256), 0, ST, in, mask, B, H, W, C,
-                     pool, Ho, Wo, out);
+                     pool, Ho, Wo, out, bf16_mask);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int c3d_maskpool_bwd(const float* dout, const float* mask, const float* extra, int B, int H, int W, int C,
-                                int pool, float* din, c3d_stream stream) {
+                                int pool, float* din, int bf16_mask, c3d_stream stream) {
   C3D_REQUIRE(C % 4 == 0, "maskpool: C must be a multiple of 4");
   const int Ho = pool ? (H + 1) / 2 : H, Wo = pool ? (W + 1) / 2 : W;
   hipLaunchKernelGGL(maskpool_bwd_kernel, dim3(nblocks((size_t)B * H * W * C / 4)), dim3(256), 0, ST, dout, mask, extra,
-                     B, H, W, C, pool, Ho, Wo, din);
+                     B, H, W, C, pool, Ho, Wo, din, bf16_mask);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int c3d_pixshuf_cat(const float* xa, const float* sc, const float* sh, const float* m3, const float* m1,
-                               const float* m2, const float* skip, int B, int Hs, int Ws, int Cx, int Cs, float* out,
+                               const float* m2, const float* skip, int B, int Hs, int Ws, int Cx, int Cs, float* out, int bf16_mask,
                                c3d_stream stream) {
   C3D_REQUIRE(Cx % 16 == 0 && Cs % 4 == 0, "pixshuf_cat: Cx %% 16 and Cs %% 4 required");
-  PsArgs p{xa, sc, sh, m3, m1, m2, skip, B, Hs, Ws, Cx, Cs, out};
+  PsArgs p{xa, sc, sh, m3, m1, m2, skip, B, Hs, Ws, Cx, Cs, out, bf16_mask};
   hipLaunchKernelGGL(pixshuf_kernel, dim3(nblocks((size_t)B * Hs * Ws * (Cx / 4))), dim3(256), 0, ST, p);
   C3D_CHECK_LAUNCH();
   hipLaunchKernelGGL(catskip_kernel, dim3(nblocks((size_t)B * Hs * Ws * 4 * (Cs / 4))), dim3(256), 0, ST, p);
@@ -637,9 +641,9 @@ extern "C" int c3d_pixshuf_cat(const float* xa, const float* sc, const float* sh
 }
 
 extern "C" int c3d_pixshuf_cat_bwd(const float* dout, const float* m3, const float* m1, const float* m2, int B, int Hs,
-                                   int Ws, int Cx, int Cs, float* dxa, float* dskip, int skip_accumulate,
+                                   int Ws, int Cx, int Cs, float* dxa, float* dskip, int skip_accumulate, int bf16_mask,
                                    c3d_stream stream) {
-  PsBwdArgs p{dout, m3, m1, m2, B, Hs, Ws, Cx, Cs, dxa, dskip, skip_accumulate};
+  PsBwdArgs p{dout, m3, m1, m2, B, Hs, Ws, Cx, Cs, dxa, dskip, skip_accumulate, bf16_mask};
   hipLaunchKernelGGL(pixshuf_bwd_kernel, dim3(nblocks((size_t)B * Hs * Ws * (Cx / 4))), dim3(256), 0, ST, p);
   C3D_CHECK_LAUNCH();
   hipLaunchKernelGGL(catskip_bwd_kernel, dim3(nblocks((size_t)B * Hs * Ws * 4 * (Cs / 4))), dim3(256), 0, ST, p);
@@ -670,43 +674,45 @@ static BlArgs bl_args(const float* src, int Hs, int Ws, int scs, int scoff, floa
   BlArgs p;
   p.src = src; p.Hs = Hs; p.Ws = Ws; p.scs = scs; p.scoff = scoff;
   p.dst = dst; p.Hd = Hd; p.Wd = Wd; p.dcs = dcs; p.dcoff = dcoff;
-  p.B = B; p.C = C;
+  p.B = B; p.C = C; p.bf = 0;
   p.ry = Hd > 1 ? (float)(Hs - 1) / (float)(Hd - 1) : 0.f;
   p.rx = Wd > 1 ? (float)(Ws - 1) / (float)(Wd - 1) : 0.f;
   return p;
 }
 
 extern "C" int c3d_bilinear(const float* src, int Hs, int Ws, int scs, int scoff, float* dst, int Hd, int Wd, int dcs,
-                            int dcoff, int B, int C, c3d_stream stream) {
+                            int dcoff, int B, int C, int bf16_mask, c3d_stream stream) {
   C3D_REQUIRE(C % 4 == 0 && scs % 4 == 0 && dcs % 4 == 0 && scoff % 4 == 0 && dcoff % 4 == 0,
               "bilinear: channel counts/strides must be multiples of 4");
   BlArgs p = bl_args(src, Hs, Ws, scs, scoff, dst, Hd, Wd, dcs, dcoff, B, C);
+  p.bf = bf16_mask;
   hipLaunchKernelGGL(bilinear_kernel, dim3(nblocks((size_t)B * Hd * Wd * C / 4)), dim3(256), 0, ST, p);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int c3d_bilinear_bwd(float* dsrc, int Hs, int Ws, int scs, int scoff, const float* ddst, int Hd, int Wd,
-                                int dcs, int dcoff, int B, int C, int accumulate, c3d_stream stream) {
+                                int dcs, int dcoff, int B, int C, int accumulate, int bf16_mask, c3d_stream stream) {
   C3D_REQUIRE(C % 4 == 0 && scs % 4 == 0 && dcs % 4 == 0 && scoff % 4 == 0 && dcoff % 4 == 0,
               "bilinear_bwd: channel counts/strides must be multiples of 4");
   BlArgs p = bl_args(dsrc, Hs, Ws, scs, scoff, const_cast<float*>(ddst), Hd, Wd, dcs, dcoff, B, C);
+  p.bf = bf16_mask;
   hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(nblocks((size_t)B * Hs * Ws * C / 4)), dim3(256), 0, ST, p, accumulate);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int c3d_l2norm(const float* x, int64_t n, int C, float eps, float* y, float* norm, c3d_stream stream) {
+extern "C" int c3d_l2norm(const float* x, int64_t n, int C, float eps, float* y, float* norm, int bf16_mask, c3d_stream stream) {
   C3D_REQUIRE(C % 4 == 0, "l2norm: C must be a multiple of 4");
-  hipLaunchKernelGGL(l2norm_kernel, dim3(nblocks((size_t)n, 4)), dim3(256), 0, ST, x, (size_t)n, C, eps, y, norm);
+  hipLaunchKernelGGL(l2norm_kernel, dim3(nblocks((size_t)n, 4)), dim3(256), 0, ST, x, (size_t)n, C, eps, y, norm, bf16_mask);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int c3d_l2norm_bwd(const float* y, const float* norm, const float* dy, int64_t n, int C, float eps,
-                              float* dx, c3d_stream stream) {
+                              float* dx, int bf16_mask, c3d_stream stream) {
   C3D_REQUIRE(C % 4 == 0, "l2norm: C must be a multiple of 4");
-  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(nblocks((size_t)n, 4)), dim3(256), 0, ST, y, norm, dy, (size_t)n, C, eps, dx);
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(nblocks((size_t)n, 4)), dim3(256), 0, ST, y, norm, dy, (size_t)n, C, eps, dx, bf16_mask);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -17,6 +17,7 @@
 //
 // LDS images are [pixel][channel]; lane l reads channel (l&31) of pixel k + (l>>5): every
 // ds_read_b32 is conflict-free and feeds one MFMA operand (A = x, B = dz).
+#include <type_traits>
 #include "common.h"
 #include "../../include/coarse3d_hip.h"
 
@@ -26,6 +27,7 @@ struct WgradArgs {
   c3d_src x;
   const float* dz;
   int dz_cstride;
+  int dz_bf16;
   int B, H, W, Cout;
   int T;
   int dy[C3D_MAX_TAPS];
@@ -97,34 +99,45 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     const int b = mt / (a.tiles_x * a.tiles_y);
     const int x0 = tx * 32, y0 = ty * TRW;
     inb = 0;
+    // (one branch per tile on the storage type, not one per element: the per-element form cost
+    //  spills and ~70 % of the 704x704 weight gradient's time)
+    auto load_x = [&](auto bf_tag) {
+      constexpr bool XBF = decltype(bf_tag)::value;
 #pragma unroll
-    for (int i = 0; i < X_PT; ++i) {
-      const int u = tid + i * 256;
-      px_[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (u < X_UNITS) {
-        const int p = u / (CI / 4);
-        const int px = p % TWh, py = p / TWh;
-        const int gx = x0 + px - HALO, gy = y0 + py - HALO;
-        if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && xc_ok) {
-          px_[i] = *reinterpret_cast<const f32x4*>(a.x.ptr + ((size_t)(b * a.H + gy) * a.W + gx) * a.x.cstride +
-                                                   a.x.coff + xc);
-          inb |= 1u << i;
+      for (int i = 0; i < X_PT; ++i) {
+        const int u = tid + i * 256;
+        px_[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (u < X_UNITS) {
+          const int p = u / (CI / 4);
+          const int px = p % TWh, py = p / TWh;
+          const int gx = x0 + px - HALO, gy = y0 + py - HALO;
+          if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H && xc_ok) {
+            px_[i] = c3d_ld4(a.x.ptr, ((size_t)(b * a.H + gy) * a.W + gx) * a.x.cstride + a.x.coff + xc, XBF);
+            inb |= 1u << i;
+          }
         }
       }
-    }
+    };
+    auto load_dz = [&](auto bf_tag) {
+      constexpr bool DBF = decltype(bf_tag)::value;
 #pragma unroll
-    for (int i = 0; i < D_PT; ++i) {
-      const int u = tid + i * 256;
-      pd_[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (u < D_UNITS) {
-        const int c4 = u % (CO / 4);
-        const int p = u / (CO / 4);
-        const int gx = x0 + (p & 31), gy = y0 + (p >> 5);
-        const int c = co0 + c4 * 4;
-        if (gx < a.W && gy < a.H && c + 3 < a.dz_cstride)
-          pd_[i] = *reinterpret_cast<const f32x4*>(a.dz + ((size_t)(b * a.H + gy) * a.W + gx) * a.dz_cstride + c);
+      for (int i = 0; i < D_PT; ++i) {
+        const int u = tid + i * 256;
+        pd_[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (u < D_UNITS) {
+          const int c4 = u % (CO / 4);
+          const int p = u / (CO / 4);
+          const int gx = x0 + (p & 31), gy = y0 + (p >> 5);
+          const int c = co0 + c4 * 4;
+          if (gx < a.W && gy < a.H && c + 3 < a.dz_cstride)
+            pd_[i] = c3d_ld4(a.dz, ((size_t)(b * a.H + gy) * a.W + gx) * a.dz_cstride + c, DBF);
+        }
       }
-    }
+    };
+    if (BF && a.x.bf16) load_x(std::true_type{});
+    else load_x(std::false_type{});
+    if (BF && a.dz_bf16) load_dz(std::true_type{});
+    else load_dz(std::false_type{});
   };
   auto store_tile = [&]() {
 #pragma unroll
@@ -409,7 +422,8 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   C3D_REQUIRE(d->x.C % 4 == 0, "wgrad: source channels must be a multiple of 4");
   C3D_REQUIRE(d->dz_cstride % 4 == 0 && d->x.cstride % 4 == 0 && d->x.coff % 4 == 0, "wgrad: strides must be multiples of 4");
   WgradArgs a;
-  a.x = d->x; a.dz = d->dz; a.dz_cstride = d->dz_cstride;
+  a.x = d->x; a.dz = d->dz; a.dz_cstride = d->dz_cstride; a.dz_bf16 = d->dz_bf16;
+  C3D_REQUIRE((!d->dz_bf16 && !d->x.bf16) || d->mfma_bf16 == 1, "wgrad: bf16 activation storage needs mfma_bf16 == 1");
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.T = d->ntaps;
   int halo = 0;
   for (int t = 0; t < d->ntaps; ++t) {

@@ -25,11 +25,37 @@ _MODES = {"f32": 0, "bf16": 1, "bf16x3": 2}
 MFMA_MODE = _MODES[__import__("os").environ.get("C3D_MATRIX", "f32")]
 
 
-def set_matrix_precision(kind):
-    global MFMA_MODE
+# Activation storage of the "bf16" mode (BASELINE configs[2]): True = the backbone's activations and their
+# gradients live in HBM as bf16 (fp32 arithmetic, statistics, master weights, probabilities and embeddings);
+# False = fp32 tensors, bf16 MFMA operands only (round 1).  Tensors carry their own dtype: every wrapper below
+# derives the library's bf16 flags from them, so the two layouts can meet (e.g. fp32 loss gradients entering a
+# bf16 backbone).
+STORAGE_BF16 = MFMA_MODE == 1 and __import__("os").environ.get("C3D_BF16_STORAGE", "1") != "0"
+
+
+def set_matrix_precision(kind, storage=None):
+    """kind: "f32" | "bf16" | "bf16x3".  storage ("bf16" | "f32", "bf16" mode only; default "bf16")."""
+    global MFMA_MODE, STORAGE_BF16
     if kind not in _MODES:
         raise ValueError(f"matrix precision must be one of {sorted(_MODES)}, got {kind!r}")
+    if storage not in (None, "f32", "bf16") or (storage == "bf16" and kind != "bf16"):
+        raise ValueError("bf16 activation storage exists in the 'bf16' matrix mode only")
     MFMA_MODE = _MODES[kind]
+    STORAGE_BF16 = kind == "bf16" and storage != "f32"
+
+
+def act_dtype():
+    """dtype of the activations a fresh backbone pass should produce."""
+    return torch.bfloat16 if STORAGE_BF16 else torch.float32
+
+
+def _bf(*tensors):
+    """bf16_mask of the C ABI: bit i set <=> the i-th activation tensor is bf16 (None counts as fp32)."""
+    m = 0
+    for i, t in enumerate(tensors):
+        if t is not None and t.dtype == torch.bfloat16:
+            m |= 1 << i
+    return m
 
 
 def _stream():
@@ -72,7 +98,7 @@ class Source:
     __slots__ = ("t", "scale", "shift", "C", "coff", "lrelu")
 
     def __init__(self, t, scale=None, shift=None, C=None, coff=0, lrelu=False):
-        assert t.dim() == 4 and t.is_contiguous() and t.dtype == torch.float32
+        assert t.dim() == 4 and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)
         self.t, self.scale, self.shift = t, scale, shift
         self.C = t.shape[3] - coff if C is None else C
         self.coff, self.lrelu = coff, lrelu
@@ -82,6 +108,7 @@ class Source:
         s.scale = self.scale.data_ptr() if self.scale is not None else None
         s.shift = self.shift.data_ptr() if self.shift is not None else None
         s.C, s.cstride, s.coff, s.lrelu = self.C, self.t.shape[3], self.coff, int(self.lrelu)
+        s.bf16 = int(self.t.dtype == torch.bfloat16)
 
 
 def conv_taps(kh, kw, dil, pad):
@@ -184,9 +211,10 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     d.bias = bias.data_ptr() if bias is not None else None
     d.epi_lrelu = int(lrelu)
     d.lrelu_slope = slope            # 0 = the SalsaNext default 0.01
-    if out is None:
-        out = torch.empty(b, h, w, cout, device=wpack.device, dtype=torch.float32)
+    if out is None:      # the output lives in the layout of its (first) input: a bf16 chain stays bf16
+        out = torch.empty(b, h, w, cout, device=wpack.device, dtype=srcs[0].t.dtype)
     d.out, d.out_cstride, d.out_coff, d.accumulate = out.data_ptr(), out.shape[3], out_coff, int(accumulate)
+    d.out_bf16 = int(out.dtype == torch.bfloat16)
     if stats and stat_partial is None:
         stat_partial = torch.empty(cout, 2, num_mtiles(b, h, w), device=wpack.device, dtype=torch.float32)
     d.stat_partial = stat_partial.data_ptr() if stat_partial is not None else None
@@ -219,6 +247,7 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0):
     src.fill(d.x)
     b, h, w = src.t.shape[:3]
     d.dz, d.dz_cstride = dz.data_ptr(), dz.shape[3]
+    d.dz_bf16 = int(dz.dtype == torch.bfloat16)
     d.B, d.H, d.W, d.Cout = b, h, w, dw.shape[0]
     d.ntaps = len(taps)
     for i, (dy, dx) in enumerate(taps):
@@ -309,7 +338,7 @@ _BN_BWD_MAX_C = 1024      # channels one c3d_bn_bwd_* launch handles; wider laye
 
 
 def _off(t, c0):
-    return None if t is None else t.data_ptr() + 4 * c0
+    return None if t is None else t.data_ptr() + t.element_size() * c0
 
 
 def bn_bwd_reduce(dy, a, c, mode=0, pre_scale=None, pre_shift=None, slope=0.0):
@@ -318,7 +347,7 @@ def bn_bwd_reduce(dy, a, c, mode=0, pre_scale=None, pre_shift=None, slope=0.0):
     for c0 in range(0, c, _BN_BWD_MAX_C):
         cc = min(_BN_BWD_MAX_C, c - c0)
         _call("c3d_bn_bwd_reduce", _off(dy, c0), dy.shape[-1], _off(a, c0), a.shape[-1], npix, cc, mode, _off(pre_scale, c0),
-              _off(pre_shift, c0), _dp(part[c0:c0 + cc]), float(slope), _stream())
+              _off(pre_shift, c0), _dp(part[c0:c0 + cc]), float(slope), _bf(dy, a), _stream())
     return part
 
 
@@ -334,14 +363,14 @@ def bn_bwd_apply(dy, a, c, mode, k=None, pre_scale=None, pre_shift=None, dz=None
     """dz = act'(.) * (k1*dy + k2*a + k3); returns (dz, partial [C,2,nblk] with sum(dz) in row 0)."""
     npix = dy.numel() // dy.shape[-1]
     if dz is None:
-        dz = torch.empty(dy.shape[:-1] + (c,), device=dy.device, dtype=torch.float32)
+        dz = torch.empty(dy.shape[:-1] + (c,), device=dy.device, dtype=a.dtype)
     part = torch.empty(c, 2, bn_bwd_blocks(npix), device=dy.device, dtype=torch.float32)
     k1, k2, k3 = (k[0], k[1], k[2]) if k is not None else (None, None, None)
     for c0 in range(0, c, _BN_BWD_MAX_C):
         cc = min(_BN_BWD_MAX_C, c - c0)
         _call("c3d_bn_bwd_apply", _off(dy, c0), dy.shape[-1], _off(a, c0), a.shape[-1], npix, cc, mode, _off(pre_scale, c0),
               _off(pre_shift, c0), _off(k1, c0), _off(k2, c0), _off(k3, c0), _off(dz, c0), dz.shape[-1],
-              _dp(part[c0:c0 + cc]), float(slope), _stream())
+              _dp(part[c0:c0 + cc]), float(slope), _bf(dy, a, dz), _stream())
     return dz, part
 
 
@@ -360,15 +389,15 @@ def input_norm(x, eval_label, mean, std):
 
 def conv_in5(x_nchw, w, bias):
     b, cn, h, wd = x_nchw.shape
-    out = torch.empty(b, h, wd, 32, device=x_nchw.device, dtype=torch.float32)
-    _call("c3d_conv_in5", _dp(x_nchw), _dp(w), _dp(bias), b, cn, h * wd, _dp(out), _stream())
+    out = torch.empty(b, h, wd, 32, device=x_nchw.device, dtype=act_dtype())
+    _call("c3d_conv_in5", _dp(x_nchw), _dp(w), _dp(bias), b, cn, h * wd, _dp(out), _bf(out), _stream())
     return out
 
 
 def conv_in5_wgrad(x_nchw, dz, dw):
     b, cn, h, wd = x_nchw.shape
     part = torch.empty(1024 * 32 * 8, device=dz.device, dtype=torch.float32)
-    _call("c3d_conv_in5_wgrad", _dp(x_nchw), _dp(dz), b, cn, h * wd, _dp(part), _dp(dw), _stream())
+    _call("c3d_conv_in5_wgrad", _dp(x_nchw), _dp(dz), b, cn, h * wd, _dp(part), _dp(dw), _bf(dz), _stream())
     return dw
 
 
@@ -377,7 +406,8 @@ def affine_add(x, a, scale=None, shift=None, out=None, slope=0.0):
     c = a.shape[-1]
     if out is None:
         out = torch.empty_like(a)
-    _call("c3d_affine_add", _dp(x), _dp(a), _dp(scale), _dp(shift), a.numel() // c, c, float(slope), _dp(out), _stream())
+    _call("c3d_affine_add", _dp(x), _dp(a), _dp(scale), _dp(shift), a.numel() // c, c, float(slope), _dp(out),
+          _bf(x, a, out), _stream())
     return out
 
 
@@ -397,39 +427,40 @@ def nchw_to_nhwc_pad(x, cp):
 
 
 def axpy(x, y, alpha=1.0, accumulate=True):
-    _call("c3d_axpy", _dp(x), alpha, x.numel(), _dp(y), int(accumulate), _stream())
+    _call("c3d_axpy", _dp(x), alpha, x.numel(), _dp(y), int(accumulate), _bf(x, y), _stream())
     return y
 
 
 def maskpool(x, mask, pool):
     b, h, w, c = x.shape
     ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
-    out = torch.empty(b, ho, wo, c, device=x.device, dtype=torch.float32)
-    _call("c3d_maskpool", _dp(x), _dp(mask), b, h, w, c, int(pool), _dp(out), _stream())
+    out = torch.empty(b, ho, wo, c, device=x.device, dtype=x.dtype)
+    _call("c3d_maskpool", _dp(x), _dp(mask), b, h, w, c, int(pool), _dp(out), _bf(x, out), _stream())
     return out
 
 
 def maskpool_bwd(dout, mask, extra, shape, pool):
     b, h, w, c = shape
-    din = torch.empty(b, h, w, c, device=dout.device, dtype=torch.float32)
-    _call("c3d_maskpool_bwd", _dp(dout), _dp(mask), _dp(extra), b, h, w, c, int(pool), _dp(din), _stream())
+    din = torch.empty(b, h, w, c, device=dout.device, dtype=dout.dtype)
+    _call("c3d_maskpool_bwd", _dp(dout), _dp(mask), _dp(extra), b, h, w, c, int(pool), _dp(din), _bf(dout, extra, din),
+          _stream())
     return din
 
 
 def pixshuf_cat(xa, sc, sh, m3, m1, m2, skip):
     b, hs, ws, cx = xa.shape
     cs = skip.shape[-1]
-    out = torch.empty(b, 2 * hs, 2 * ws, cx // 4 + cs, device=xa.device, dtype=torch.float32)
+    out = torch.empty(b, 2 * hs, 2 * ws, cx // 4 + cs, device=xa.device, dtype=xa.dtype)
     _call("c3d_pixshuf_cat", _dp(xa), _dp(sc), _dp(sh), _dp(m3), _dp(m1), _dp(m2), _dp(skip), b, hs, ws, cx, cs,
-          _dp(out), _stream())
+          _dp(out), _bf(xa, skip, out), _stream())
     return out
 
 
 def pixshuf_cat_bwd(dout, m3, m1, m2, xa_shape, cs, dskip, skip_accumulate):
     b, hs, ws, cx = xa_shape
-    dxa = torch.empty(b, hs, ws, cx, device=dout.device, dtype=torch.float32)
+    dxa = torch.empty(b, hs, ws, cx, device=dout.device, dtype=dout.dtype)
     _call("c3d_pixshuf_cat_bwd", _dp(dout), _dp(m3), _dp(m1), _dp(m2), b, hs, ws, cx, cs, _dp(dxa), _dp(dskip),
-          int(skip_accumulate), _stream())
+          int(skip_accumulate), _bf(dout, dxa, dskip), _stream())
     return dxa
 
 
@@ -449,12 +480,13 @@ def softmax_bwd(prob, dprob, shape):
     return dl
 
 
-def bilinear(src, hd, wd, dst=None, dcoff=0, c=None, scoff=0):
+def bilinear(src, hd, wd, dst=None, dcoff=0, c=None, scoff=0, out_dtype=None):
     b, hs, ws, scs = src.shape
     c = c or scs
     if dst is None:
-        dst = torch.empty(b, hd, wd, c, device=src.device, dtype=torch.float32)
-    _call("c3d_bilinear", _dp(src), hs, ws, scs, scoff, _dp(dst), hd, wd, dst.shape[-1], dcoff, b, c, _stream())
+        dst = torch.empty(b, hd, wd, c, device=src.device, dtype=out_dtype or src.dtype)
+    _call("c3d_bilinear", _dp(src), hs, ws, scs, scoff, _dp(dst), hd, wd, dst.shape[-1], dcoff, b, c, _bf(src, dst),
+          _stream())
     return dst
 
 
@@ -463,7 +495,7 @@ def bilinear_bwd(dsrc, ddst, dcoff=0, c=None, scoff=0, accumulate=False):
     _, hd, wd, dcs = ddst.shape
     c = c or scs
     _call("c3d_bilinear_bwd", _dp(dsrc), hs, ws, scs, scoff, _dp(ddst), hd, wd, dcs, dcoff, b, c, int(accumulate),
-          _stream())
+          _bf(dsrc, ddst), _stream())
     return dsrc
 
 
@@ -472,14 +504,14 @@ def l2norm(x, eps=1e-12, want_norm=True):
     n = x.numel() // c
     y = torch.empty_like(x)
     norm = torch.empty(n, device=x.device, dtype=torch.float32) if want_norm else None
-    _call("c3d_l2norm", _dp(x), n, c, eps, _dp(y), _dp(norm), _stream())
+    _call("c3d_l2norm", _dp(x), n, c, eps, _dp(y), _dp(norm), _bf(x, y), _stream())
     return y, norm
 
 
 def l2norm_bwd(y, norm, dy, eps=1e-12):
     c = y.shape[-1]
     dx = torch.empty_like(y)
-    _call("c3d_l2norm_bwd", _dp(y), _dp(norm), _dp(dy), y.numel() // c, c, eps, _dp(dx), _stream())
+    _call("c3d_l2norm_bwd", _dp(y), _dp(norm), _dp(dy), y.numel() // c, c, eps, _dp(dx), _bf(y, dy, dx), _stream())
     return dx
 
 

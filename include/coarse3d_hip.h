@@ -33,6 +33,16 @@ int c3d_abi_sizes(int32_t* out4);
 /* number of workgroups conv kernels will use for an [B,H,W] image: size of stat partial bufs */
 int c3d_conv_num_mtiles(int B, int H, int W);
 
+/* bf16 activation storage (BASELINE configs[2], with mfma_bf16 == 1): the entry points below that
+ * take a trailing `bf16_mask` read / write the activation pointers whose bit is set as bf16 instead
+ * of fp32 (same NHWC indexing; arithmetic, statistics, masks, affines stay fp32).  Bit i = the i-th
+ * ACTIVATION pointer of the signature in declaration order:
+ *   c3d_conv_in5: out | c3d_conv_in5_wgrad: dz | c3d_affine_add: x, a, out | c3d_axpy: x, y |
+ *   c3d_maskpool: in, out | c3d_maskpool_bwd: dout, extra, din | c3d_pixshuf_cat: xa, skip, out |
+ *   c3d_pixshuf_cat_bwd: dout, dxa, dskip | c3d_bilinear: src, dst | c3d_bilinear_bwd: dsrc, ddst |
+ *   c3d_l2norm: x, y | c3d_l2norm_bwd: y, dy, dx | c3d_bn_bwd_reduce: dy, a | c3d_bn_bwd_apply: dy, a, dz
+ * (the convolution / weight-gradient descriptors carry per-tensor flags: c3d_src.bf16, out_bf16, dz_bf16). */
+
 /* ------------------------------------------------------------------ convolution engine */
 
 /* One channel-concatenated input of a convolution, transformed on load:
@@ -47,6 +57,9 @@ typedef struct {
   int32_t cstride;  /* channel stride of the underlying tensor           */
   int32_t coff;     /* first channel                                     */
   int32_t lrelu;
+  int32_t bf16;     /* 0: ptr is fp32; 1: ptr is bf16 (same NHWC indexing, 2-byte elements) -- bf16
+                       activation storage, only with mfma_bf16 == 1 (BASELINE configs[2])         */
+  int32_t reserved;
 } c3d_src;
 
 typedef struct {
@@ -73,6 +86,9 @@ typedef struct {
                                2: every fp32 operand split exactly into three bf16 planes, eight of
                                the nine plane products accumulated in fp32 (fp32-class result on the
                                bf16 pipe); multi-tap convs then need a c3d_pack_weights(mode | 2) pack */
+  int32_t out_bf16;         /* 1: `out` is bf16 (values rounded RNE on store, accumulate reads bf16);
+                               the statistics partials are taken from the fp32 values; mfma_bf16 == 1 only */
+  int32_t reserved;
 } c3d_conv_desc;
 
 /* y = epilogue(conv(transform(cat(src)))) as an implicit GEMM on fp32 MFMA.
@@ -118,6 +134,8 @@ typedef struct {
   float* partial;
   int32_t mfma_bf16;        /* as in c3d_conv_desc                                         */
   float lrelu_slope;        /* as in c3d_conv_desc                                         */
+  int32_t dz_bf16;          /* 1: dz is bf16 (x.bf16 says the same for x); mfma_bf16 == 1 only */
+  int32_t reserved;
 } c3d_wgrad_desc;
 int64_t c3d_wgrad_partial_floats(const c3d_wgrad_desc* d);
 int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream);
@@ -147,7 +165,7 @@ int c3d_bn_eval_affine(const float* gamma, const float* beta, const float* runni
 int c3d_bn_bwd_num_blocks(int npix);
 int c3d_bn_bwd_reduce(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C,
                       int mode, const float* pre_scale, const float* pre_shift, float* partial,
-                      float lrelu_slope /* 0 = 0.01 */, c3d_stream stream);
+                      float lrelu_slope /* 0 = 0.01 */, int bf16_mask, c3d_stream stream);
 /* sums = (all-reduced) statistics for k1..k3; sums_param = this rank's own statistics for
  * dgamma/dbeta (NULL = same as sums): SyncBatchNorm semantics under data parallelism          */
 int c3d_bn_bwd_coeffs(const double* sums, const double* sums_param, double count,
@@ -157,7 +175,7 @@ int c3d_bn_bwd_coeffs(const double* sums, const double* sums_param, double count
 int c3d_bn_bwd_apply(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C,
                      int mode, const float* pre_scale, const float* pre_shift, const float* k1,
                      const float* k2, const float* k3, float* dz, int dz_cs, float* partial,
-                     float lrelu_slope /* 0 = 0.01 */, c3d_stream stream);
+                     float lrelu_slope /* 0 = 0.01 */, int bf16_mask, c3d_stream stream);
 /* Single-rank fast paths: fold the partials [C][2][n] and finish in one launch (no all-reduce
  * hook in between): = c3d_stat_reduce + c3d_bn_finalize / + c3d_bn_bwd_coeffs / + column 0.    */
 int c3d_bn_finalize_partials(const float* partial, int n, double count, const float* gamma,
@@ -181,15 +199,15 @@ int c3d_input_norm(const float* x, const int64_t* eval_label, const float* mean,
                    const float* stdv, int B, int Cn, int HW, float* out, c3d_stream stream);
 /* downCntx.conv1: 1x1 conv Cn(<=8) -> 32 + LeakyReLU, NCHW in, NHWC out (salsanext_proto.py:41,53-54) */
 int c3d_conv_in5(const float* x_nchw, const float* w, const float* bias, int B, int Cn, int HW,
-                 float* out, c3d_stream stream);
+                 float* out, int bf16_mask, c3d_stream stream);
 /* its weight gradient dw[32][Cn]; partial = scratch of 1024*32*8 floats                      */
 int c3d_conv_in5_wgrad(const float* x_nchw, const float* dz, int B, int Cn, int HW,
-                       float* partial, float* dw, c3d_stream stream);
+                       float* partial, float* dw, int bf16_mask, c3d_stream stream);
 /* out = x + act(a*scale + shift)  (x, scale may be NULL; act = LeakyReLU(lrelu_slope), or the
  * identity when lrelu_slope == 0): residual adds of salsanext_proto.py:64,133 and of RangeNet's
  * BasicBlock (rangenet_proto.py:52-63)                                                       */
 int c3d_affine_add(const float* x, const float* a, const float* scale, const float* shift,
-                   int64_t npix, int C, float lrelu_slope, float* out, c3d_stream stream);
+                   int64_t npix, int C, float lrelu_slope, float* out, int bf16_mask, c3d_stream stream);
 /* NHWC [rows][Win][C] column resampling: up = 0 keeps the even columns (W -> W/2: a stride-(1,2)
  * conv = stride-1 conv + this, rangenet_proto.py:194-203); up = 1 inserts a zero column after
  * every column (W -> 2W: ConvTranspose2d([1,4],[1,2],[0,1]) = this + a 4-tap conv, :328-336).
@@ -201,20 +219,20 @@ int c3d_cols_resample(const float* in, int64_t rows, int Win, int C, int up, flo
 int c3d_nchw_to_nhwc_pad(const float* x, int B, int Cn, int64_t HW, int Cp, float* out,
                          c3d_stream stream);
 /* y (+)= alpha*x, flat                                                                      */
-int c3d_axpy(const float* x, float alpha, int64_t n, float* y, int accumulate, c3d_stream stream);
+int c3d_axpy(const float* x, float alpha, int64_t n, float* y, int accumulate, int bf16_mask, c3d_stream stream);
 /* Dropout2d multiplier mask[B,C] (NULL = none) then AvgPool2d(3,2,1) if pool (:108-109,135-142) */
 int c3d_maskpool(const float* in, const float* mask, int B, int H, int W, int C, int pool,
-                 float* out, c3d_stream stream);
+                 float* out, int bf16_mask, c3d_stream stream);
 /* din = extra + mask * pool^T(dout)   (extra may be NULL)                                   */
 int c3d_maskpool_bwd(const float* dout, const float* mask, const float* extra, int B, int H,
-                     int W, int C, int pool, float* din, c3d_stream stream);
+                     int W, int C, int pool, float* din, int bf16_mask, c3d_stream stream);
 /* out = cat(PixelShuffle2((xa*sc+sh)*m3)*m1, skip) * m2   (:185-191; masks may be NULL)     */
 int c3d_pixshuf_cat(const float* xa, const float* sc, const float* sh, const float* m3,
                     const float* m1, const float* m2, const float* skip, int B, int Hs, int Ws,
-                    int Cx, int Cs, float* out, c3d_stream stream);
+                    int Cx, int Cs, float* out, int bf16_mask, c3d_stream stream);
 int c3d_pixshuf_cat_bwd(const float* dout, const float* m3, const float* m1, const float* m2,
                         int B, int Hs, int Ws, int Cx, int Cs, float* dxa, float* dskip,
-                        int skip_accumulate, c3d_stream stream);
+                        int skip_accumulate, int bf16_mask, c3d_stream stream);
 /* softmax over the first C of cs channels, cropped to [Ho,Wo] (:456-460)                    */
 int c3d_softmax(const float* logits, int B, int H, int W, int cs, int C, int Ho, int Wo,
                 float* prob, c3d_stream stream);
@@ -222,16 +240,16 @@ int c3d_softmax_bwd(const float* prob, const float* dprob, int B, int H, int W, 
                     int Ho, int Wo, float* dlogits, c3d_stream stream);
 /* F.interpolate(bilinear, align_corners=True) between channel slices of NHWC tensors (:470-490) */
 int c3d_bilinear(const float* src, int Hs, int Ws, int scs, int scoff, float* dst, int Hd,
-                 int Wd, int dcs, int dcoff, int B, int C, c3d_stream stream);
+                 int Wd, int dcs, int dcoff, int B, int C, int bf16_mask, c3d_stream stream);
 /* dsrc (+)= bilinear^T(ddst): deterministic gather over the destination pixels that read each
  * source pixel (no atomics); accumulate != 0 adds to the existing dsrc                        */
 int c3d_bilinear_bwd(float* dsrc, int Hs, int Ws, int scs, int scoff, const float* ddst, int Hd,
-                     int Wd, int dcs, int dcoff, int B, int C, int accumulate, c3d_stream stream);
+                     int Wd, int dcs, int dcoff, int B, int C, int accumulate, int bf16_mask, c3d_stream stream);
 /* F.normalize(p=2) over rows of [n][C] (:485; eps 1e-12); norm may be NULL                  */
-int c3d_l2norm(const float* x, int64_t n, int C, float eps, float* y, float* norm,
+int c3d_l2norm(const float* x, int64_t n, int C, float eps, float* y, float* norm, int bf16_mask,
                c3d_stream stream);
 int c3d_l2norm_bwd(const float* y, const float* norm, const float* dy, int64_t n, int C,
-                   float eps, float* dx, c3d_stream stream);
+                   float eps, float* dx, int bf16_mask, c3d_stream stream);
 
 /* ------------------------------------------------------------------ prototype memory bank
  * salsanext_proto.py:494-510 (similarity) and :337-402 (prototype_learning), sinkhorn.py:5-33.

@@ -1,0 +1,161 @@
+"""bf16 ACTIVATION STORAGE (BASELINE configs[2]): every kernel that reads or writes backbone
+activations with the bf16 flag of the C ABI set, against the same kernel on fp32 tensors holding
+the same (bf16-representable) values.  Arithmetic is fp32 in both, so the only difference allowed
+is the final rounding of the stored result: |diff| <= 2^-8 |ref| (one bf16 ulp) + a tiny absolute
+term.  Statistics, norms and parameter gradients are fp32 outputs and must agree to fp32 accuracy."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def r16(t):
+    """fp32 tensor with bf16-representable values."""
+    return t.to(torch.bfloat16).float()
+
+
+def close16(got, ref, what):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs()
+    bound = ref.abs() * 2.0 ** -8 + 1e-6 * float(ref.abs().max())
+    assert bool((err <= bound).all()), (what, float((err - bound).max()))
+
+
+def close32(got, ref, what, tol=1e-5):
+    e = float((got.double() - ref.double()).abs().max() / (ref.double().abs().max() + 1e-30))
+    assert e < tol, (what, e)
+
+
+@pytest.fixture(autouse=True)
+def bf16_mode():
+    from coarse3d_amd import ops
+    ops.set_matrix_precision("bf16")
+    yield
+    ops.set_matrix_precision("f32")
+
+
+def test_glue_kernels_bf16_vs_fp32_storage():
+    from coarse3d_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(1)
+    b, h, w, c = 2, 8, 64, 32
+    x = r16(torch.randn(b, h, w, c, device=DEV, generator=g))
+    a = r16(torch.randn(b, h, w, c, device=DEV, generator=g))
+    sc, sh = torch.rand(c, device=DEV, generator=g) + 0.5, torch.randn(c, device=DEV, generator=g) * 0.2
+    xb, ab = x.bfloat16(), a.bfloat16()
+    # affine_add (incl. mixed layouts)
+    ref = ops.affine_add(x, a, sc, sh)
+    got = ops.affine_add(xb, ab, sc, sh)
+    assert got.dtype == torch.bfloat16
+    close16(got, ref, "affine_add")
+    close16(ops.affine_add(x, ab, sc, sh, out=torch.empty_like(ab)), ref, "affine_add mixed")
+    # axpy
+    y32, y16 = a.clone(), ab.clone()
+    ops.axpy(x, y32)
+    ops.axpy(xb, y16)
+    close16(y16, y32, "axpy")
+    # maskpool / backward
+    mask = (torch.rand(b, c, device=DEV, generator=g) > 0.2).float() * 1.25
+    for pool in (True, False):
+        close16(ops.maskpool(xb, mask, pool), ops.maskpool(x, mask, pool), f"maskpool {pool}")
+        ho, wo = ((h + 1) // 2, (w + 1) // 2) if pool else (h, w)
+        d = r16(torch.randn(b, ho, wo, c, device=DEV, generator=g))
+        close16(ops.maskpool_bwd(d.bfloat16(), mask, ab, (b, h, w, c), pool), ops.maskpool_bwd(d, mask, a, (b, h, w, c), pool),
+                f"maskpool_bwd {pool}")
+    # pixshuf_cat / backward
+    xa = r16(torch.randn(b, h // 2, w // 2, 64, device=DEV, generator=g))
+    skip = r16(torch.randn(b, h, w, 16, device=DEV, generator=g))
+    sc2, sh2 = torch.rand(64, device=DEV, generator=g) + 0.5, torch.randn(64, device=DEV, generator=g) * 0.2
+    m3 = (torch.rand(b, 64, device=DEV, generator=g) > 0.2).float() * 1.25
+    m1 = (torch.rand(b, 16, device=DEV, generator=g) > 0.2).float() * 1.25
+    m2 = (torch.rand(b, 32, device=DEV, generator=g) > 0.2).float() * 1.25
+    ref = ops.pixshuf_cat(xa, sc2, sh2, m3, m1, m2, skip)
+    close16(ops.pixshuf_cat(xa.bfloat16(), sc2, sh2, m3, m1, m2, skip.bfloat16()), ref, "pixshuf_cat")
+    dout = r16(torch.randn(b, h, w, 32, device=DEV, generator=g))
+    ds32, ds16 = torch.zeros_like(skip), torch.zeros(skip.shape, device=DEV, dtype=torch.bfloat16)
+    dx32 = ops.pixshuf_cat_bwd(dout, m3, m1, m2, tuple(xa.shape), 16, ds32, False)
+    dx16 = ops.pixshuf_cat_bwd(dout.bfloat16(), m3, m1, m2, tuple(xa.shape), 16, ds16, False)
+    close16(dx16, dx32, "pixshuf_cat_bwd dxa")
+    close16(ds16, ds32, "pixshuf_cat_bwd dskip")
+    # bilinear: bf16 -> bf16 into a wider tensor, bf16 -> fp32 (the embedding's exit), backward from fp32
+    dst32 = torch.zeros(b, 2 * h, 2 * w, 48, device=DEV)
+    dst16 = torch.zeros(b, 2 * h, 2 * w, 48, device=DEV, dtype=torch.bfloat16)
+    ops.bilinear(x, 2 * h, 2 * w, dst=dst32, dcoff=16, c=c)
+    ops.bilinear(xb, 2 * h, 2 * w, dst=dst16, dcoff=16, c=c)
+    close16(dst16, dst32, "bilinear")
+    close32(ops.bilinear(xb, 2 * h, 2 * w, out_dtype=torch.float32), ops.bilinear(x, 2 * h, 2 * w), "bilinear bf16->fp32")
+    dd = torch.randn(b, 2 * h, 2 * w, c, device=DEV, generator=g)
+    close16(ops.bilinear_bwd(torch.empty_like(xb), dd), ops.bilinear_bwd(torch.empty_like(x), dd), "bilinear_bwd fp32->bf16")
+    # l2norm / backward
+    y32, n32 = ops.l2norm(x)
+    y16, n16 = ops.l2norm(xb)
+    close16(y16, y32, "l2norm")
+    close32(n16, n32, "l2norm norm")
+    dy = r16(torch.randn(b, h, w, c, device=DEV, generator=g))
+    close16(ops.l2norm_bwd(r16(y32).bfloat16(), n32, dy.bfloat16()), ops.l2norm_bwd(r16(y32), n32, dy), "l2norm_bwd")
+    # first conv 5 -> 32 and its weight gradient
+    xin = torch.randn(b, 5, h, w, device=DEV, generator=g)
+    w5, b5 = torch.randn(32, 5, device=DEV, generator=g) * 0.3, torch.randn(32, device=DEV, generator=g) * 0.1
+    o16 = ops.conv_in5(xin, w5, b5)
+    assert o16.dtype == torch.bfloat16
+    ops.set_matrix_precision("bf16", storage="f32")
+    o32 = ops.conv_in5(xin, w5, b5)
+    assert o32.dtype == torch.float32
+    close16(o16, o32, "conv_in5")
+    dz = r16(torch.randn(b, h, w, 32, device=DEV, generator=g))
+    close32(ops.conv_in5_wgrad(xin, dz.bfloat16(), torch.empty(32, 5, device=DEV)),
+            ops.conv_in5_wgrad(xin, dz, torch.empty(32, 5, device=DEV)), "conv_in5_wgrad")
+
+
+def test_batchnorm_backward_bf16_vs_fp32_storage():
+    from coarse3d_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(2)
+    b, h, w, c = 2, 16, 64, 64
+    dy = r16(torch.randn(b, h, w, c, device=DEV, generator=g))
+    a = r16(torch.randn(b, h, w, c, device=DEV, generator=g))
+    sc, sh = torch.rand(c, device=DEV, generator=g) + 0.5, torch.randn(c, device=DEV, generator=g) * 0.2
+    k = torch.randn(3, c, device=DEV, generator=g) * 0.3
+    for mode in (0, 1, 2):
+        pre = (sc, sh) if mode == 1 else (None, None)
+        close32(ops.bn_bwd_reduce(dy.bfloat16(), a.bfloat16(), c, mode, *pre), ops.bn_bwd_reduce(dy, a, c, mode, *pre),
+                f"bn_bwd_reduce mode {mode}", 1e-5)
+        dz32, p32 = ops.bn_bwd_apply(dy, a, c, mode, k if mode < 2 else None, *pre)
+        dz16, p16 = ops.bn_bwd_apply(dy.bfloat16(), a.bfloat16(), c, mode, k if mode < 2 else None, *pre)
+        assert dz16.dtype == torch.bfloat16
+        close16(dz16, dz32, f"bn_bwd_apply mode {mode}")
+        close32(p16[:, 0], p32[:, 0], f"bn_bwd_apply sum(dz) mode {mode}", 1e-5)     # statistics come from the fp32 values
+
+
+@pytest.mark.parametrize("k,dil,pad,cin,cout", [(1, 1, 0, 64, 48), (3, 1, 1, 32, 64), (3, 2, 2, 32, 32), (2, 2, 1, 64, 64)])
+def test_conv_engine_bf16_vs_fp32_storage(k, dil, pad, cin, cout):
+    """conv_bfp NP = 1 with bf16 sources / bf16 output / accumulate, and the weight gradient with bf16 x
+    and dz, against the same kernels on fp32 tensors holding the same values."""
+    from coarse3d_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(3)
+    b, h, w = 2, 16, 95
+    x = r16(torch.randn(b, h, w, cin, device=DEV, generator=g))
+    sc, sh = torch.rand(cin, device=DEV, generator=g) + 0.5, torch.randn(cin, device=DEV, generator=g) * 0.2
+    wt = torch.randn(cout, cin, k, k, device=DEV, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, device=DEV, generator=g) * 0.1
+    taps = ops.conv_taps(k, k, dil, pad)
+    wp = ops.pack_weights(wt, 0)
+    y32, p32 = ops.conv_forward([ops.Source(x, sc, sh)], wp, bias, cout, taps, lrelu=True, stats=True)
+    y16, p16 = ops.conv_forward([ops.Source(x.bfloat16(), sc, sh)], wp, bias, cout, taps, lrelu=True, stats=True)
+    assert y16.dtype == torch.bfloat16 and y32.dtype == torch.float32
+    close16(y16, y32, "conv out")
+    close32(p16, p32, "conv statistics partials", 1e-6)                              # taken before the rounding
+    # input gradient (transposed weights), accumulating into an existing bf16 gradient
+    cp = (cout + 15) // 16 * 16
+    dz = torch.zeros(b, h, w, cp, device=DEV)
+    dz[..., :cout] = r16(torch.randn(b, h, w, cout, device=DEV, generator=g))
+    wd = ops.pack_weights(wt, 1, c_off=0, c_cnt=cin, kpad=cp)
+    g0 = r16(torch.randn(b, h, w, cin, device=DEV, generator=g))
+    g32, g16 = g0.clone(), g0.bfloat16()
+    ops.conv_forward([ops.Source(dz)], wd, None, cin, ops.negate_taps(taps), out=g32, accumulate=True)
+    ops.conv_forward([ops.Source(dz.bfloat16())], wd, None, cin, ops.negate_taps(taps), out=g16, accumulate=True)
+    close16(g16, g32, "dgrad accumulate")
+    # weight gradient: an fp32 result
+    dw32, dw16 = torch.zeros_like(wt), torch.zeros_like(wt)
+    ops.conv_wgrad(ops.Source(x, sc, sh), dz, dw32, taps)
+    ops.conv_wgrad(ops.Source(x.bfloat16(), sc, sh), dz.bfloat16(), dw16, taps)
+    close32(dw16, dw32, "wgrad", 1e-5)
