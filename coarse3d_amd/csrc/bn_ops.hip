@@ -159,68 +159,78 @@ struct BwdArgs {
 };
 
 // thread = (pixel lane, channel quad); block walks a contiguous pixel chunk
-template <bool APPLY>
+template <bool APPLY, int V>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
   extern __shared__ float red[];  // [PL][C][2]
-  const int Q = p.C >> 2;
+  const int Q = p.C / V;
   const int PL = max(256 / Q, 1);
   const int tid = threadIdx.x;
-  const int pl = tid / Q, c = (tid % Q) * 4;
+  const int pl = tid / Q, c = (tid % Q) * V;
   const bool active = tid < PL * Q;
   const int p0 = blockIdx.x * p.pix_per_block;
   const int p1 = min(p0 + p.pix_per_block, p.npix);
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  c3d_vec<V> s1 = c3d_vzero<V>(), s2 = c3d_vzero<V>();
   if (active) {
-    f32x4 ps = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
-    f32x4 k1 = {1.f, 1.f, 1.f, 1.f}, k2 = {0.f, 0.f, 0.f, 0.f}, k3 = {0.f, 0.f, 0.f, 0.f};
+    c3d_vec<V> ps, psh, k1, k2, k3;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      ps.v[q] = 1.f;
+      psh.v[q] = 0.f;
+      k1.v[q] = 1.f;
+      k2.v[q] = 0.f;
+      k3.v[q] = 0.f;
+    }
     if (p.mode == 1) {
-      ps = *reinterpret_cast<const f32x4*>(p.pre_scale + c);
-      psh = *reinterpret_cast<const f32x4*>(p.pre_shift + c);
+      ps = c3d_vldf<V>(p.pre_scale, c);
+      psh = c3d_vldf<V>(p.pre_shift, c);
     }
     if (APPLY && p.mode < 2) {
-      k1 = *reinterpret_cast<const f32x4*>(p.k1 + c);
-      k2 = *reinterpret_cast<const f32x4*>(p.k2 + c);
-      k3 = *reinterpret_cast<const f32x4*>(p.k3 + c);
+      k1 = c3d_vldf<V>(p.k1, c);
+      k2 = c3d_vldf<V>(p.k2, c);
+      k3 = c3d_vldf<V>(p.k3, c);
     }
     // UN pixels per trip: all 2*UN loads are issued before the first use (memory-level parallelism)
-    constexpr int UN = 4;
-    auto body = [&](f32x4 dy, const f32x4 a, int i) {
+    constexpr int UN = V == 8 ? 2 : 4;
+    auto body = [&](c3d_vec<V> dy, const c3d_vec<V>& a, int i) {
       if (p.mode == 1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dy[q] *= (a[q] * ps[q] + psh[q] > 0.f) ? 1.f : p.slope;
+        for (int q = 0; q < V; ++q) dy.v[q] *= (a.v[q] * ps.v[q] + psh.v[q] > 0.f) ? 1.f : p.slope;
       }
       if (!APPLY) {
-        s1 += dy;
-        s2 += dy * a;
-      } else {
-        f32x4 dz;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float da = k1[q] * dy[q] + k2[q] * a[q] + k3[q];
-          if (p.mode == 0 || p.mode == 2) da *= (a[q] > 0.f) ? 1.f : p.slope;
-          dz[q] = da;
+        for (int q = 0; q < V; ++q) {
+          s1.v[q] += dy.v[q];
+          s2.v[q] += dy.v[q] * a.v[q];
         }
-        c3d_st4(p.dz, (size_t)i * p.dz_cs + c, p.bf & 4, dz);
+      } else {
+        c3d_vec<V> dz;
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+          float da = k1.v[q] * dy.v[q] + k2.v[q] * a.v[q] + k3.v[q];
+          if (p.mode == 0 || p.mode == 2) da *= (a.v[q] > 0.f) ? 1.f : p.slope;
+          dz.v[q] = da;
+        }
+        c3d_vst<V>(p.dz, (size_t)i * p.dz_cs + c, p.bf & 4, dz);
         s1 += dz;
       }
     };
     int i = p0 + pl;
     for (; i + (UN - 1) * PL < p1; i += UN * PL) {
-      f32x4 dyv[UN], av[UN];
+      c3d_vec<V> dyv[UN], av[UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
-        dyv[u] = c3d_ld4(p.dy, (size_t)(i + u * PL) * p.dy_cs + c, p.bf & 1);
-        av[u] = c3d_ld4(p.a, (size_t)(i + u * PL) * p.a_cs + c, p.bf & 2);
+        dyv[u] = c3d_vld<V>(p.dy, (size_t)(i + u * PL) * p.dy_cs + c, p.bf & 1);
+        av[u] = c3d_vld<V>(p.a, (size_t)(i + u * PL) * p.a_cs + c, p.bf & 2);
       }
 #pragma unroll
       for (int u = 0; u < UN; ++u) body(dyv[u], av[u], i + u * PL);
     }
     for (; i < p1; i += PL)
-      body(c3d_ld4(p.dy, (size_t)i * p.dy_cs + c, p.bf & 1), c3d_ld4(p.a, (size_t)i * p.a_cs + c, p.bf & 2), i);
+      body(c3d_vld<V>(p.dy, (size_t)i * p.dy_cs + c, p.bf & 1), c3d_vld<V>(p.a, (size_t)i * p.a_cs + c, p.bf & 2), i);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      red[(pl * p.C + c + q) * 2 + 0] = s1[q];
-      red[(pl * p.C + c + q) * 2 + 1] = s2[q];
+    for (int q = 0; q < V; ++q) {
+      red[(pl * p.C + c + q) * 2 + 0] = s1.v[q];
+      red[(pl * p.C + c + q) * 2 + 1] = s2.v[q];
     }
   }
   __syncthreads();
@@ -314,11 +324,18 @@ static int bn_bwd_launch(bool apply, const float* dy, int dy_cs, const float* a,
   p.bf = bf;
   const int nb = c3d_bn_bwd_num_blocks(npix);
   p.pix_per_block = (npix + nb - 1) / nb;
-  const int Q = C / 4;
+  // 8 channels per lane when any tensor is bf16 (16-byte accesses), 4 otherwise (the fp32 path as before)
+  const bool wide = bf != 0 && C % 8 == 0 && dy_cs % 8 == 0 && a_cs % 8 == 0 && (!apply || dz_cs % 8 == 0);
+  const int Q = C / (wide ? 8 : 4);
   const int PL = 256 / Q > 0 ? 256 / Q : 1;
   const size_t lds = (size_t)PL * C * 2 * sizeof(float);
-  if (apply) hipLaunchKernelGGL(bn_bwd_kernel<true>, dim3(nb), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL(bn_bwd_kernel<false>, dim3(nb), dim3(256), lds, st, p);
+  if (wide) {
+    if (apply) hipLaunchKernelGGL((bn_bwd_kernel<true, 8>), dim3(nb), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((bn_bwd_kernel<false, 8>), dim3(nb), dim3(256), lds, st, p);
+  } else {
+    if (apply) hipLaunchKernelGGL((bn_bwd_kernel<true, 4>), dim3(nb), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((bn_bwd_kernel<false, 4>), dim3(nb), dim3(256), lds, st, p);
+  }
   C3D_CHECK_LAUNCH();
   return 0;
 }

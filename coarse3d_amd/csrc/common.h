@@ -60,6 +60,76 @@ __device__ __forceinline__ void c3d_st1(float* p, size_t i, bool bf, float v) {
   else p[i] = v;
 }
 
+// V = 4 or 8 channels per lane.  With bf16 storage only the 8-wide form keeps every lane on a 16-byte access
+// (8-byte accesses run at roughly half the instruction rate: the HBM-bound kernels measured SLOWER with bf16
+// tensors and 4-wide lanes than with fp32 tensors).
+template <int V>
+struct c3d_vec {
+  float v[V];
+  __device__ __forceinline__ c3d_vec& operator+=(const c3d_vec& o) {
+#pragma unroll
+    for (int q = 0; q < V; ++q) v[q] += o.v[q];
+    return *this;
+  }
+  __device__ __forceinline__ c3d_vec& operator*=(const c3d_vec& o) {
+#pragma unroll
+    for (int q = 0; q < V; ++q) v[q] *= o.v[q];
+    return *this;
+  }
+  __device__ __forceinline__ c3d_vec& operator*=(float s) {
+#pragma unroll
+    for (int q = 0; q < V; ++q) v[q] *= s;
+    return *this;
+  }
+};
+template <int V>
+__device__ __forceinline__ c3d_vec<V> c3d_vzero() {
+  c3d_vec<V> r;
+#pragma unroll
+  for (int q = 0; q < V; ++q) r.v[q] = 0.f;
+  return r;
+}
+template <int V>
+__device__ __forceinline__ c3d_vec<V> c3d_vld(const float* p, size_t i, bool bf) {
+  c3d_vec<V> r;
+  if (V == 8 && bf) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t w = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const unsigned short*>(p) + i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      r.v[2 * q] = __uint_as_float(w[q] << 16);
+      r.v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
+    }
+    return r;
+  }
+#pragma unroll
+  for (int h = 0; h < V / 4; ++h) {
+    const f32x4 t = c3d_ld4(p, i + 4 * h, bf);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r.v[4 * h + q] = t[q];
+  }
+  return r;
+}
+// fp32 per-channel vectors (scale, shift, masks)
+template <int V>
+__device__ __forceinline__ c3d_vec<V> c3d_vldf(const float* p, size_t i) {
+  return c3d_vld<V>(p, i, false);
+}
+template <int V>
+__device__ __forceinline__ void c3d_vst(float* p, size_t i, bool bf, const c3d_vec<V>& x) {
+  if (V == 8 && bf) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    bf16x8_t h;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) h[q] = (__bf16)x.v[q];
+    *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(p) + i) = __builtin_bit_cast(u32x4_t, h);
+    return;
+  }
+#pragma unroll
+  for (int h = 0; h < V / 4; ++h) c3d_st4(p, i + 4 * h, bf, f32x4{x.v[4 * h], x.v[4 * h + 1], x.v[4 * h + 2], x.v[4 * h + 3]});
+}
+
 // Bijective XCD-aware remap: consecutive logical tiles land on the same XCD (block b runs on
 // XCD b % 8 on MI355X), so neighbouring tiles that share halos / weights hit one L2.
 __device__ __forceinline__ int c3d_xcd_remap(int bid, int n) {

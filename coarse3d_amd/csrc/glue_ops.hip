@@ -111,21 +111,26 @@ __global__ __launch_bounds__(256) void conv_in5_wgrad_reduce_kernel(const float*
 // ---------------------------------------------------------------- out = x + act(a*scale + shift)
 // act = identity (slope 0) or LeakyReLU(slope): the residual add of SalsaNext's blocks
 // (salsanext_proto.py:64,133) and of RangeNet's BasicBlock (rangenet_proto.py:52-63)
+template <int V>
 __global__ void affine_add_kernel(const float* __restrict__ x, const float* __restrict__ a,
                                   const float* __restrict__ scale, const float* __restrict__ shift, size_t npix, int C,
                                   float slope, float* __restrict__ out, int bf) {
-  const int Q = C >> 2;
+  const int Q = C / V;
   const size_t total = npix * Q;
   for (size_t i = gtid(); i < total; i += gstride()) {
-    const int c = (i % Q) * 4;
-    f32x4 v = c3d_ld4(a, i * 4, bf & 2);
-    if (scale) v = v * *reinterpret_cast<const f32x4*>(scale + c) + *reinterpret_cast<const f32x4*>(shift + c);
+    const int c = (i % Q) * V;
+    c3d_vec<V> v = c3d_vld<V>(a, i * V, bf & 2);
+    if (scale) {
+      const c3d_vec<V> sc = c3d_vldf<V>(scale, c), sh = c3d_vldf<V>(shift, c);
+#pragma unroll
+      for (int q = 0; q < V; ++q) v.v[q] = v.v[q] * sc.v[q] + sh.v[q];
+    }
     if (slope > 0.f) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q], slope);
+      for (int q = 0; q < V; ++q) v.v[q] = c3d_lrelu(v.v[q], slope);
     }
-    if (x) v += c3d_ld4(x, i * 4, bf & 1);
-    c3d_st4(out, i * 4, bf & 4, v);
+    if (x) v += c3d_vld<V>(x, i * V, bf & 1);
+    c3d_vst<V>(out, i * V, bf & 4, v);
   }
 }
 
@@ -166,61 +171,64 @@ __global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, int B, int 
 }
 
 // y (+)= alpha * x  (flat)
-__global__ void axpy_kernel(const float* __restrict__ x, float alpha, size_t n4, float* __restrict__ y, int accumulate,
+template <int V>
+__global__ void axpy_kernel(const float* __restrict__ x, float alpha, size_t nv, float* __restrict__ y, int accumulate,
                             int bf) {
-  for (size_t i = gtid(); i < n4; i += gstride()) {
-    f32x4 v = c3d_ld4(x, i * 4, bf & 1) * alpha;
-    if (accumulate) v += c3d_ld4(y, i * 4, bf & 2);
-    c3d_st4(y, i * 4, bf & 2, v);
+  for (size_t i = gtid(); i < nv; i += gstride()) {
+    c3d_vec<V> v = c3d_vld<V>(x, i * V, bf & 1);
+    v *= alpha;
+    if (accumulate) v += c3d_vld<V>(y, i * V, bf & 2);
+    c3d_vst<V>(y, i * V, bf & 2, v);
   }
 }
 
 // ---------------------------------------------------------------- mask (+ 3x3 stride-2 average pool)
 // in [B,H,W,C], mask [B,C] or null; pool: out [B,Ho,Wo,C]; no pool: out = in*mask
+template <int V>
 __global__ void maskpool_kernel(const float* __restrict__ in, const float* __restrict__ mask, int B, int H, int W, int C,
                                 int pool, int Ho, int Wo, float* __restrict__ out, int bf) {
-  const int Q = C >> 2;
+  const int Q = C / V;
   const size_t total = (size_t)B * Ho * Wo * Q;
   for (size_t i = gtid(); i < total; i += gstride()) {
-    const int c = (i % Q) * 4;
+    const int c = (i % Q) * V;
     size_t r = i / Q;
     const int xo = r % Wo;
     r /= Wo;
     const int yo = r % Ho;
     const int b = r / Ho;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    c3d_vec<V> acc = c3d_vzero<V>();
     if (pool) {
 #pragma unroll
       for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
           const int y = 2 * yo + dy, x = 2 * xo + dx;
-          if (y >= 0 && y < H && x >= 0 && x < W)
-            acc += c3d_ld4(in, ((size_t)(b * H + y) * W + x) * C + c, bf & 1);
+          if (y >= 0 && y < H && x >= 0 && x < W) acc += c3d_vld<V>(in, ((size_t)(b * H + y) * W + x) * C + c, bf & 1);
         }
       acc *= (1.f / 9.f);
     } else {
-      acc = c3d_ld4(in, ((size_t)(b * H + yo) * W + xo) * C + c, bf & 1);
+      acc = c3d_vld<V>(in, ((size_t)(b * H + yo) * W + xo) * C + c, bf & 1);
     }
-    if (mask) acc *= *reinterpret_cast<const f32x4*>(mask + (size_t)b * C + c);
-    c3d_st4(out, i * 4, bf & 2, acc);
+    if (mask) acc *= c3d_vldf<V>(mask, (size_t)b * C + c);
+    c3d_vst<V>(out, i * V, bf & 2, acc);
   }
 }
 
 // d_in = (extra ? extra : 0) + mask * poolT(d_out)
+template <int V>
 __global__ void maskpool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ mask,
                                     const float* __restrict__ extra, int B, int H, int W, int C, int pool, int Ho,
                                     int Wo, float* __restrict__ din, int bf) {
-  const int Q = C >> 2;
+  const int Q = C / V;
   const size_t total = (size_t)B * H * W * Q;
   for (size_t i = gtid(); i < total; i += gstride()) {
-    const int c = (i % Q) * 4;
+    const int c = (i % Q) * V;
     size_t r = i / Q;
     const int x = r % W;
     r /= W;
     const int y = r % H;
     const int b = r / H;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    c3d_vec<V> acc = c3d_vzero<V>();
     if (pool) {
       const int ya = (y & 1) ? (y - 1) / 2 : y / 2, yb = (y & 1) ? (y + 1) / 2 : -1;
       const int xa = (x & 1) ? (x - 1) / 2 : x / 2, xb = (x & 1) ? (x + 1) / 2 : -1;
@@ -231,15 +239,15 @@ __global__ void maskpool_bwd_kernel(const float* __restrict__ dout, const float*
         for (int v = 0; v < 2; ++v) {
           const int yo = ys[u], xo = xs[v];
           if (yo >= 0 && yo < Ho && xo >= 0 && xo < Wo)
-            acc += c3d_ld4(dout, ((size_t)(b * Ho + yo) * Wo + xo) * C + c, bf & 1);
+            acc += c3d_vld<V>(dout, ((size_t)(b * Ho + yo) * Wo + xo) * C + c, bf & 1);
         }
       acc *= (1.f / 9.f);
     } else {
-      acc = c3d_ld4(dout, i * 4, bf & 1);
+      acc = c3d_vld<V>(dout, i * V, bf & 1);
     }
-    if (mask) acc *= *reinterpret_cast<const f32x4*>(mask + (size_t)b * C + c);
-    if (extra) acc += c3d_ld4(extra, i * 4, bf & 2);
-    c3d_st4(din, i * 4, bf & 4, acc);
+    if (mask) acc *= c3d_vldf<V>(mask, (size_t)b * C + c);
+    if (extra) acc += c3d_vld<V>(extra, i * V, bf & 2);
+    c3d_vst<V>(din, i * V, bf & 4, acc);
   }
 }
 
@@ -279,17 +287,18 @@ __global__ void pixshuf_kernel(PsArgs p) {
   }
 }
 
+template <int V>
 __global__ void catskip_kernel(PsArgs p) {
   const int Cu = p.Cx >> 2, Ct = Cu + p.Cs, H = 2 * p.Hs, W = 2 * p.Ws;
-  const int Q = p.Cs >> 2;
+  const int Q = p.Cs / V;
   const size_t total = (size_t)p.B * H * W * Q;
   for (size_t i = gtid(); i < total; i += gstride()) {
-    const int c = (i % Q) * 4;
+    const int c = (i % Q) * V;
     const size_t pix = i / Q;
     const int b = pix / ((size_t)H * W);
-    f32x4 v = c3d_ld4(p.skip, pix * p.Cs + c, p.bf & 2);
-    if (p.m2) v *= *reinterpret_cast<const f32x4*>(p.m2 + (size_t)b * Ct + Cu + c);
-    c3d_st4(p.out, pix * Ct + Cu + c, p.bf & 4, v);
+    c3d_vec<V> v = c3d_vld<V>(p.skip, pix * p.Cs + c, p.bf & 2);
+    if (p.m2) v *= c3d_vldf<V>(p.m2, (size_t)b * Ct + Cu + c);
+    c3d_vst<V>(p.out, pix * Ct + Cu + c, p.bf & 4, v);
   }
 }
 
@@ -327,18 +336,19 @@ __global__ void pixshuf_bwd_kernel(PsBwdArgs p) {
   }
 }
 
+template <int V>
 __global__ void catskip_bwd_kernel(PsBwdArgs p) {
   const int Cu = p.Cx >> 2, Ct = Cu + p.Cs, H = 2 * p.Hs, W = 2 * p.Ws;
-  const int Q = p.Cs >> 2;
+  const int Q = p.Cs / V;
   const size_t total = (size_t)p.B * H * W * Q;
   for (size_t i = gtid(); i < total; i += gstride()) {
-    const int c = (i % Q) * 4;
+    const int c = (i % Q) * V;
     const size_t pix = i / Q;
     const int b = pix / ((size_t)H * W);
-    f32x4 v = c3d_ld4(p.dout, pix * Ct + Cu + c, p.bf & 1);
-    if (p.m2) v *= *reinterpret_cast<const f32x4*>(p.m2 + (size_t)b * Ct + Cu + c);
-    if (p.skip_accumulate) v += c3d_ld4(p.dskip, pix * p.Cs + c, p.bf & 4);
-    c3d_st4(p.dskip, pix * p.Cs + c, p.bf & 4, v);
+    c3d_vec<V> v = c3d_vld<V>(p.dout, pix * Ct + Cu + c, p.bf & 1);
+    if (p.m2) v *= c3d_vldf<V>(p.m2, (size_t)b * Ct + Cu + c);
+    if (p.skip_accumulate) v += c3d_vld<V>(p.dskip, pix * p.Cs + c, p.bf & 4);
+    c3d_vst<V>(p.dskip, pix * p.Cs + c, p.bf & 4, v);
   }
 }
 
@@ -412,11 +422,12 @@ __device__ __forceinline__ void bl_coords(int d, float ratio, int n, int& i0, in
   l1 = fminf(fmaxf(r - (float)i0, 0.f), 1.f);
 }
 
+template <int V>
 __global__ void bilinear_kernel(BlArgs p) {
-  const int Q = p.C >> 2;
+  const int Q = p.C / V;
   const size_t total = (size_t)p.B * p.Hd * p.Wd * Q;
   for (size_t i = gtid(); i < total; i += gstride()) {
-    const int c = (i % Q) * 4;
+    const int c = (i % Q) * V;
     size_t r = i / Q;
     const int xd = r % p.Wd;
     r /= p.Wd;
@@ -427,13 +438,18 @@ __global__ void bilinear_kernel(BlArgs p) {
     bl_coords(yd, p.ry, p.Hs, y0, y1, ly);
     bl_coords(xd, p.rx, p.Ws, x0, x1, lx);
     const size_t s = (size_t)b * p.Hs * p.Ws * p.scs + p.scoff + c;
-    const f32x4 v00 = c3d_ld4(p.src, s + ((size_t)y0 * p.Ws + x0) * p.scs, p.bf & 1);
-    const f32x4 v01 = c3d_ld4(p.src, s + ((size_t)y0 * p.Ws + x1) * p.scs, p.bf & 1);
-    const f32x4 v10 = c3d_ld4(p.src, s + ((size_t)y1 * p.Ws + x0) * p.scs, p.bf & 1);
-    const f32x4 v11 = c3d_ld4(p.src, s + ((size_t)y1 * p.Ws + x1) * p.scs, p.bf & 1);
-    const f32x4 top = v00 * (1.f - lx) + v01 * lx;
-    const f32x4 bot = v10 * (1.f - lx) + v11 * lx;
-    c3d_st4(p.dst, ((size_t)(b * p.Hd + yd) * p.Wd + xd) * p.dcs + p.dcoff + c, p.bf & 2, top * (1.f - ly) + bot * ly);
+    const c3d_vec<V> v00 = c3d_vld<V>(p.src, s + ((size_t)y0 * p.Ws + x0) * p.scs, p.bf & 1);
+    const c3d_vec<V> v01 = c3d_vld<V>(p.src, s + ((size_t)y0 * p.Ws + x1) * p.scs, p.bf & 1);
+    const c3d_vec<V> v10 = c3d_vld<V>(p.src, s + ((size_t)y1 * p.Ws + x0) * p.scs, p.bf & 1);
+    const c3d_vec<V> v11 = c3d_vld<V>(p.src, s + ((size_t)y1 * p.Ws + x1) * p.scs, p.bf & 1);
+    c3d_vec<V> o;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const float top = v00.v[q] * (1.f - lx) + v01.v[q] * lx;
+      const float bot = v10.v[q] * (1.f - lx) + v11.v[q] * lx;
+      o.v[q] = top * (1.f - ly) + bot * ly;
+    }
+    c3d_vst<V>(p.dst, ((size_t)(b * p.Hd + yd) * p.Wd + xd) * p.dcs + p.dcoff + c, p.bf & 2, o);
   }
 }
 
@@ -464,12 +480,13 @@ __device__ __forceinline__ float bl_weight(int d, int s, float ratio, int n) {
 
 // d_src (+)= bilinear^T(d_dst) as a GATHER over the destination pixels that read each source
 // pixel: deterministic, no atomics.  src = d_src (written), dst = d_dst (read).
+template <int V>
 __global__ void bilinear_bwd_kernel(BlArgs p, int accumulate) {
-  const int Q = p.C >> 2;
+  const int Q = p.C / V;
   const size_t total = (size_t)p.B * p.Hs * p.Ws * Q;
   float* dsrc = const_cast<float*>(p.src);
   for (size_t i = gtid(); i < total; i += gstride()) {
-    const int c = (i % Q) * 4;
+    const int c = (i % Q) * V;
     size_t r = i / Q;
     const int xs = r % p.Ws;
     r /= p.Ws;
@@ -478,23 +495,26 @@ __global__ void bilinear_bwd_kernel(BlArgs p, int accumulate) {
     int ylo, yhi, xlo, xhi;
     bl_dst_range(ys, p.ry, p.Hd, ylo, yhi);
     bl_dst_range(xs, p.rx, p.Wd, xlo, xhi);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    c3d_vec<V> acc = c3d_vzero<V>();
     for (int yd = ylo; yd <= yhi; ++yd) {
       const float wy = bl_weight(yd, ys, p.ry, p.Hs);
       if (wy == 0.f) continue;
       for (int xd = xlo; xd <= xhi; ++xd) {
         const float wx = bl_weight(xd, xs, p.rx, p.Ws);
         if (wx == 0.f) continue;
-        acc += c3d_ld4(p.dst, ((size_t)(b * p.Hd + yd) * p.Wd + xd) * p.dcs + p.dcoff + c, p.bf & 2) * (wy * wx);
+        c3d_vec<V> g = c3d_vld<V>(p.dst, ((size_t)(b * p.Hd + yd) * p.Wd + xd) * p.dcs + p.dcoff + c, p.bf & 2);
+        g *= (wy * wx);
+        acc += g;
       }
     }
     const size_t o = ((size_t)(b * p.Hs + ys) * p.Ws + xs) * p.scs + p.scoff + c;
-    if (accumulate) acc += c3d_ld4(dsrc, o, p.bf & 1);
-    c3d_st4(dsrc, o, p.bf & 1, acc);
+    if (accumulate) acc += c3d_vld<V>(dsrc, o, p.bf & 1);
+    c3d_vst<V>(dsrc, o, p.bf & 1, acc);
   }
 }
 
 // ---------------------------------------------------------------- row-wise L2 normalise (one wave per row)
+template <int V>
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, size_t n, int C, float eps,
                                                      float* __restrict__ y, float* __restrict__ norm, int bf) {
   const int lane = threadIdx.x & 63;
@@ -502,20 +522,25 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x
   const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
   for (size_t r = wave; r < n; r += nw) {
     float s = 0.f;
-    for (int c = lane * 4; c < C; c += 256) {
-      const f32x4 v = c3d_ld4(x, r * C + c, bf & 1);
-      s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    for (int c = lane * V; c < C; c += 64 * V) {
+      const c3d_vec<V> v = c3d_vld<V>(x, r * C + c, bf & 1);
+#pragma unroll
+      for (int q = 0; q < V; ++q) s += v.v[q] * v.v[q];
     }
     s = c3d_wave_sum(s);
     const float nr = sqrtf(s);
     const float inv = 1.f / fmaxf(nr, eps);
-    for (int c = lane * 4; c < C; c += 256)
-      c3d_st4(y, r * C + c, bf & 2, c3d_ld4(x, r * C + c, bf & 1) * inv);
+    for (int c = lane * V; c < C; c += 64 * V) {
+      c3d_vec<V> v = c3d_vld<V>(x, r * C + c, bf & 1);
+      v *= inv;
+      c3d_vst<V>(y, r * C + c, bf & 2, v);
+    }
     if (norm && lane == 0) norm[r] = nr;
   }
 }
 
 // dx = (dy - y * sum(y*dy)) / max(norm, eps)
+template <int V>
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ norm,
                                                          const float* __restrict__ dy, size_t n, int C, float eps,
                                                          float* __restrict__ dx, int bf) {
@@ -524,17 +549,19 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
   const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
   for (size_t r = wave; r < n; r += nw) {
     float s = 0.f;
-    for (int c = lane * 4; c < C; c += 256) {
-      const f32x4 a = c3d_ld4(y, r * C + c, bf & 1);
-      const f32x4 g = c3d_ld4(dy, r * C + c, bf & 2);
-      s += a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3];
+    for (int c = lane * V; c < C; c += 64 * V) {
+      const c3d_vec<V> a = c3d_vld<V>(y, r * C + c, bf & 1), g = c3d_vld<V>(dy, r * C + c, bf & 2);
+#pragma unroll
+      for (int q = 0; q < V; ++q) s += a.v[q] * g.v[q];
     }
     s = c3d_wave_sum(s);
     const float inv = 1.f / fmaxf(norm[r], eps);
-    for (int c = lane * 4; c < C; c += 256) {
-      const f32x4 a = c3d_ld4(y, r * C + c, bf & 1);
-      const f32x4 g = c3d_ld4(dy, r * C + c, bf & 2);
-      c3d_st4(dx, r * C + c, bf & 4, (g - a * s) * inv);
+    for (int c = lane * V; c < C; c += 64 * V) {
+      const c3d_vec<V> a = c3d_vld<V>(y, r * C + c, bf & 1), g = c3d_vld<V>(dy, r * C + c, bf & 2);
+      c3d_vec<V> o;
+#pragma unroll
+      for (int q = 0; q < V; ++q) o.v[q] = (g.v[q] - a.v[q] * s) * inv;
+      c3d_vst<V>(dx, r * C + c, bf & 4, o);
     }
   }
 }
@@ -577,8 +604,12 @@ extern "C" int c3d_conv_in5_wgrad(const float* x_nchw, const float* dz, int B, i
 extern "C" int c3d_affine_add(const float* x, const float* a, const float* scale, const float* shift, int64_t npix,
                               int C, float lrelu_slope, float* out, int bf16_mask, c3d_stream stream) {
   C3D_REQUIRE(C % 4 == 0, "affine_add: C must be a multiple of 4");
-  hipLaunchKernelGGL(affine_add_kernel, dim3(nblocks((size_t)npix * C / 4)), dim3(256), 0, ST, x, a, scale, shift,
-                     (size_t)npix, C, lrelu_slope, out, bf16_mask);
+  if (bf16_mask && C % 8 == 0)
+    hipLaunchKernelGGL(affine_add_kernel<8>, dim3(nblocks((size_t)npix * C / 8)), dim3(256), 0, ST, x, a, scale, shift,
+                       (size_t)npix, C, lrelu_slope, out, bf16_mask);
+  else
+    hipLaunchKernelGGL(affine_add_kernel<4>, dim3(nblocks((size_t)npix * C / 4)), dim3(256), 0, ST, x, a, scale, shift,
+                       (size_t)npix, C, lrelu_slope, out, bf16_mask);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -603,7 +634,10 @@ extern "C" int c3d_nchw_to_nhwc_pad(const float* x, int B, int Cn, int64_t HW, i
 
 extern "C" int c3d_axpy(const float* x, float alpha, int64_t n, float* y, int accumulate, int bf16_mask, c3d_stream stream) {
   C3D_REQUIRE(n % 4 == 0, "axpy: n must be a multiple of 4");
-  hipLaunchKernelGGL(axpy_kernel, dim3(nblocks((size_t)n / 4)), dim3(256), 0, ST, x, alpha, (size_t)n / 4, y, accumulate, bf16_mask);
+  if (bf16_mask && n % 8 == 0)
+    hipLaunchKernelGGL(axpy_kernel<8>, dim3(nblocks((size_t)n / 8)), dim3(256), 0, ST, x, alpha, (size_t)n / 8, y, accumulate, bf16_mask);
+  else
+    hipLaunchKernelGGL(axpy_kernel<4>, dim3(nblocks((size_t)n / 4)), dim3(256), 0, ST, x, alpha, (size_t)n / 4, y, accumulate, bf16_mask);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -612,8 +646,12 @@ extern "C" int c3d_maskpool(const float* in, const float* mask, int B, int H, in
                             c3d_stream stream) {
   C3D_REQUIRE(C % 4 == 0, "maskpool: C must be a multiple of 4");
   const int Ho = pool ? (H + 1) / 2 : H, Wo = pool ? (W + 1) / 2 : W;
-  hipLaunchKernelGGL(maskpool_kernel, dim3(nblocks((size_t)B * Ho * Wo * C / 4)), dim3(256), 0, ST, in, mask, B, H, W, C,
-                     pool, Ho, Wo, out, bf16_mask);
+  if (bf16_mask && C % 8 == 0)
+    hipLaunchKernelGGL(maskpool_kernel<8>, dim3(nblocks((size_t)B * Ho * Wo * C / 8)), dim3(256), 0, ST, in, mask, B, H, W, C,
+                       pool, Ho, Wo, out, bf16_mask);
+  else
+    hipLaunchKernelGGL(maskpool_kernel<4>, dim3(nblocks((size_t)B * Ho * Wo * C / 4)), dim3(256), 0, ST, in, mask, B, H, W, C,
+                       pool, Ho, Wo, out, bf16_mask);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -622,8 +660,12 @@ extern "C" int c3d_maskpool_bwd(const float* dout, const float* mask, const floa
                                 int pool, float* din, int bf16_mask, c3d_stream stream) {
   C3D_REQUIRE(C % 4 == 0, "maskpool: C must be a multiple of 4");
   const int Ho = pool ? (H + 1) / 2 : H, Wo = pool ? (W + 1) / 2 : W;
-  hipLaunchKernelGGL(maskpool_bwd_kernel, dim3(nblocks((size_t)B * H * W * C / 4)), dim3(256), 0, ST, dout, mask, extra,
-                     B, H, W, C, pool, Ho, Wo, din, bf16_mask);
+  if (bf16_mask && C % 8 == 0)
+    hipLaunchKernelGGL(maskpool_bwd_kernel<8>, dim3(nblocks((size_t)B * H * W * C / 8)), dim3(256), 0, ST, dout, mask, extra,
+                       B, H, W, C, pool, Ho, Wo, din, bf16_mask);
+  else
+    hipLaunchKernelGGL(maskpool_bwd_kernel<4>, dim3(nblocks((size_t)B * H * W * C / 4)), dim3(256), 0, ST, dout, mask, extra,
+                       B, H, W, C, pool, Ho, Wo, din, bf16_mask);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -635,7 +677,10 @@ extern "C" int c3d_pixshuf_cat(const float* xa, const float* sc, const float* sh
   PsArgs p{xa, sc, sh, m3, m1, m2, skip, B, Hs, Ws, Cx, Cs, out, bf16_mask};
   hipLaunchKernelGGL(pixshuf_kernel, dim3(nblocks((size_t)B * Hs * Ws * (Cx / 4))), dim3(256), 0, ST, p);
   C3D_CHECK_LAUNCH();
-  hipLaunchKernelGGL(catskip_kernel, dim3(nblocks((size_t)B * Hs * Ws * 4 * (Cs / 4))), dim3(256), 0, ST, p);
+  if (bf16_mask && Cs % 8 == 0 && (Cx / 4) % 8 == 0)
+    hipLaunchKernelGGL(catskip_kernel<8>, dim3(nblocks((size_t)B * Hs * Ws * 4 * (Cs / 8))), dim3(256), 0, ST, p);
+  else
+    hipLaunchKernelGGL(catskip_kernel<4>, dim3(nblocks((size_t)B * Hs * Ws * 4 * (Cs / 4))), dim3(256), 0, ST, p);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -646,7 +691,10 @@ extern "C" int c3d_pixshuf_cat_bwd(const float* dout, const float* m3, const flo
   PsBwdArgs p{dout, m3, m1, m2, B, Hs, Ws, Cx, Cs, dxa, dskip, skip_accumulate, bf16_mask};
   hipLaunchKernelGGL(pixshuf_bwd_kernel, dim3(nblocks((size_t)B * Hs * Ws * (Cx / 4))), dim3(256), 0, ST, p);
   C3D_CHECK_LAUNCH();
-  hipLaunchKernelGGL(catskip_bwd_kernel, dim3(nblocks((size_t)B * Hs * Ws * 4 * (Cs / 4))), dim3(256), 0, ST, p);
+  if (bf16_mask && Cs % 8 == 0 && (Cx / 4) % 8 == 0)
+    hipLaunchKernelGGL(catskip_bwd_kernel<8>, dim3(nblocks((size_t)B * Hs * Ws * 4 * (Cs / 8))), dim3(256), 0, ST, p);
+  else
+    hipLaunchKernelGGL(catskip_bwd_kernel<4>, dim3(nblocks((size_t)B * Hs * Ws * 4 * (Cs / 4))), dim3(256), 0, ST, p);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -686,7 +734,10 @@ extern "C" int c3d_bilinear(const float* src, int Hs, int Ws, int scs, int scoff
               "bilinear: channel counts/strides must be multiples of 4");
   BlArgs p = bl_args(src, Hs, Ws, scs, scoff, dst, Hd, Wd, dcs, dcoff, B, C);
   p.bf = bf16_mask;
-  hipLaunchKernelGGL(bilinear_kernel, dim3(nblocks((size_t)B * Hd * Wd * C / 4)), dim3(256), 0, ST, p);
+  if (bf16_mask && C % 8 == 0 && scs % 8 == 0 && dcs % 8 == 0 && scoff % 8 == 0 && dcoff % 8 == 0)
+    hipLaunchKernelGGL(bilinear_kernel<8>, dim3(nblocks((size_t)B * Hd * Wd * C / 8)), dim3(256), 0, ST, p);
+  else
+    hipLaunchKernelGGL(bilinear_kernel<4>, dim3(nblocks((size_t)B * Hd * Wd * C / 4)), dim3(256), 0, ST, p);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -697,14 +748,20 @@ extern "C" int c3d_bilinear_bwd(float* dsrc, int Hs, int Ws, int scs, int scoff,
               "bilinear_bwd: channel counts/strides must be multiples of 4");
   BlArgs p = bl_args(dsrc, Hs, Ws, scs, scoff, const_cast<float*>(ddst), Hd, Wd, dcs, dcoff, B, C);
   p.bf = bf16_mask;
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(nblocks((size_t)B * Hs * Ws * C / 4)), dim3(256), 0, ST, p, accumulate);
+  if (bf16_mask && C % 8 == 0 && scs % 8 == 0 && dcs % 8 == 0 && scoff % 8 == 0 && dcoff % 8 == 0)
+    hipLaunchKernelGGL(bilinear_bwd_kernel<8>, dim3(nblocks((size_t)B * Hs * Ws * C / 8)), dim3(256), 0, ST, p, accumulate);
+  else
+    hipLaunchKernelGGL(bilinear_bwd_kernel<4>, dim3(nblocks((size_t)B * Hs * Ws * C / 4)), dim3(256), 0, ST, p, accumulate);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int c3d_l2norm(const float* x, int64_t n, int C, float eps, float* y, float* norm, int bf16_mask, c3d_stream stream) {
   C3D_REQUIRE(C % 4 == 0, "l2norm: C must be a multiple of 4");
-  hipLaunchKernelGGL(l2norm_kernel, dim3(nblocks((size_t)n, 4)), dim3(256), 0, ST, x, (size_t)n, C, eps, y, norm, bf16_mask);
+  if (bf16_mask && C % 8 == 0)
+    hipLaunchKernelGGL(l2norm_kernel<8>, dim3(nblocks((size_t)n, 4)), dim3(256), 0, ST, x, (size_t)n, C, eps, y, norm, bf16_mask);
+  else
+    hipLaunchKernelGGL(l2norm_kernel<4>, dim3(nblocks((size_t)n, 4)), dim3(256), 0, ST, x, (size_t)n, C, eps, y, norm, bf16_mask);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -712,7 +769,10 @@ extern "C" int c3d_l2norm(const float* x, int64_t n, int C, float eps, float* y,
 extern "C" int c3d_l2norm_bwd(const float* y, const float* norm, const float* dy, int64_t n, int C, float eps,
                               float* dx, int bf16_mask, c3d_stream stream) {
   C3D_REQUIRE(C % 4 == 0, "l2norm: C must be a multiple of 4");
-  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(nblocks((size_t)n, 4)), dim3(256), 0, ST, y, norm, dy, (size_t)n, C, eps, dx, bf16_mask);
+  if (bf16_mask && C % 8 == 0)
+    hipLaunchKernelGGL(l2norm_bwd_kernel<8>, dim3(nblocks((size_t)n, 4)), dim3(256), 0, ST, y, norm, dy, (size_t)n, C, eps, dx, bf16_mask);
+  else
+    hipLaunchKernelGGL(l2norm_bwd_kernel<4>, dim3(nblocks((size_t)n, 4)), dim3(256), 0, ST, y, norm, dy, (size_t)n, C, eps, dx, bf16_mask);
   C3D_CHECK_LAUNCH();
   return 0;
 }
