@@ -16,10 +16,10 @@ KERNEL_EVENTS = None
 KERNEL_EVENT_FILTER = None       # None = every MFMA launch; else only launches of this kernel instance
 # Matrix-pipe mode of the MFMA engines (c3d_conv_desc.mfma_bf16):
 #   0 "f32"    fp32 MFMA -- the parity path and the default
-#   1 "bf16"   operands rounded to bf16 inside the kernels, fp32 accumulate/storage (opt-in
-#              mixed precision, BASELINE configs[2])
-#   2 "bf16x3" fp32 operands split exactly into three bf16 planes, six plane products per step on
-#              the bf16 matrix pipe: fp32-accurate results (opt-in; see csrc/common.h)
+#   1 "bf16"   operands rounded to bf16 inside the kernels, fp32 accumulate; activations stored as bf16
+#              (STORAGE_BF16) or fp32 -- opt-in mixed precision, BASELINE configs[2]
+#   2 "bf16x3" fp32 operands split exactly into three bf16 planes, eight of nine plane products per step on
+#              the bf16 matrix pipe: fp32-class results (csrc/conv_x3.hip, csrc/conv_bfp.hip); what bench.py runs
 _MODES = {"f32": 0, "bf16": 1, "bf16x3": 2}
 # C3D_MATRIX=bf16x3 python -m pytest tests -m gpu   runs the WHOLE parity suite on the exact-split engine
 MFMA_MODE = _MODES[__import__("os").environ.get("C3D_MATRIX", "f32")]
