@@ -269,12 +269,14 @@ def main():
                "bf16x3": PEAK_BF16_MFMA_TFLOPS / 8.0}[args.matrix_dtype]
 
     def peak_for(kernel_name):
-        """Matrix-pipe ceiling of one kernel instance: the weight gradients stay on fp32 MFMA in every
-        mode but "bf16"; conv_bfp / conv_x3 instances run on the bf16 pipe."""
+        """Matrix-pipe ceiling of one kernel instance: conv_bfp / conv_x3 / wgrad_tr instances run on the bf16
+        pipe (eight plane products per fp32 product in the "<3" instances); the rest on fp32 MFMA."""
         if kernel_name.startswith(("conv_x3_kernel", "conv_bfp_kernel")):
             return PEAK_BF16_MFMA_TFLOPS / 8.0 if kernel_name.rstrip(">").endswith("3") or "x3" in kernel_name else PEAK_BF16_MFMA_TFLOPS
         if kernel_name.startswith("wgrad_mfma_kernel") and kernel_name.endswith("true>"):
             return PEAK_BF16_MFMA_TFLOPS
+        if kernel_name.startswith("wgrad_tr_kernel"):
+            return PEAK_BF16_MFMA_TFLOPS / 8.0 if kernel_name.startswith("wgrad_tr_kernel<3") else PEAK_BF16_MFMA_TFLOPS
         return PEAK_FP32_MFMA_TFLOPS
     torch.manual_seed(1)
     if args.net == "salsanext":

@@ -1,0 +1,43 @@
+// Shared by the weight-gradient kernels (wgrad_mfma.hip: fp32 MFMA; wgrad_tr.hip: bf16 planes read
+// through ds_read_b64_tr_b16): launch arguments, tile configurations and the partial-sum layout.
+#pragma once
+#include "common.h"
+#include "../../include/coarse3d_hip.h"
+
+struct WgradArgs {
+  c3d_src x;
+  const float* dz;
+  int dz_cstride;
+  int dz_bf16;
+  int B, H, W, Cout;
+  int T;
+  int dy[C3D_MAX_TAPS];
+  int dx[C3D_MAX_TAPS];
+  float* partial;
+  int tiles_x, tiles_y, ntiles, strips, tiles_per_strip;
+  int ci_slices, co_slices;
+  float slope;
+};
+
+// A workgroup owns a (CI cin, CO cout) slice and TRW x 32 pixel tiles.
+// id: 0..3 = 1x1 {128x256, 128x128, 64x64, 32x32}; 4,5 = 2x2 {CO64, CO32}; 6,7 = 3x3 {CO64, CO32}
+struct WgCfg {
+  int id, CI, CO, TRW;
+};
+
+// planes = 0: fp32 MFMA kernels; 1 / 3: bf16-plane kernels (smaller pixel tiles: three planes of a
+// tile must leave room for two workgroups per CU)
+inline WgCfg c3d_wgrad_cfg(int T, int Cin, int Cout, int planes) {
+  const bool tr = planes != 0;
+  if (T == 1) {
+    if (Cin >= 96 && Cout >= 192) return {0, 128, 256, 1};
+    if (Cin >= 96 && Cout >= 96) return {1, 128, 128, 1};
+    if (Cout > 32) return {2, 64, 64, tr ? 2 : 4};
+    return {3, 32, 32, 4};
+  }
+  if (T <= 4) return Cout > 32 ? WgCfg{4, 32, 64, tr ? 2 : 4} : WgCfg{5, 32, 32, 4};
+  return Cout > 32 ? WgCfg{6, 32, 64, 2} : WgCfg{7, 32, 32, tr ? 2 : 4};
+}
+
+// wgrad_tr.hip
+int c3d_wgrad_launch_tr(int planes, int id, int halo, const WgradArgs& a, hipStream_t st);

@@ -17,26 +17,11 @@
 //
 // LDS images are [pixel][channel]; lane l reads channel (l&31) of pixel k + (l>>5): every
 // ds_read_b32 is conflict-free and feeds one MFMA operand (A = x, B = dz).
+#include <stdlib.h>
 #include <type_traits>
-#include "common.h"
-#include "../../include/coarse3d_hip.h"
+#include "wgrad_common.h"
 
 namespace {
-
-struct WgradArgs {
-  c3d_src x;
-  const float* dz;
-  int dz_cstride;
-  int dz_bf16;
-  int B, H, W, Cout;
-  int T;
-  int dy[C3D_MAX_TAPS];
-  int dx[C3D_MAX_TAPS];
-  float* partial;
-  int tiles_x, tiles_y, ntiles, strips, tiles_per_strip;
-  int ci_slices, co_slices;
-  float slope;
-};
 
 // BF = false: fp32 MFMA (default parity path).  BF = true: operands rounded to bf16 (RNE) when
 // read from LDS, v_mfma_f32_32x32x16_bf16 with k = 16 consecutive pixels per step (lane l:
@@ -341,32 +326,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-struct WgCfg {
-  int id, CI, CO, TRW;
-};
-// id: 0..3 = 1x1 {A,A2,B,C}; 4,5 = 2x2 {CO64,CO32}; 6,7 = 3x3 {CO64,CO32}
-WgCfg cfg_for(int T, int Cin, int Cout) {
-  if (T == 1) {
-    if (Cin >= 96 && Cout >= 192) return {0, 128, 256, 1};
-    if (Cin >= 96 && Cout >= 96) return {1, 128, 128, 1};
-    if (Cout > 32) return {2, 64, 64, 4};
-    return {3, 32, 32, 4};
-  }
-  if (T <= 4) return Cout > 32 ? WgCfg{4, 32, 64, 4} : WgCfg{5, 32, 32, 4};
-  return Cout > 32 ? WgCfg{6, 32, 64, 2} : WgCfg{7, 32, 32, 4};
+// bf16 planes of the operands (wgrad_tr.hip) or 0 = the fp32-MFMA kernel of this file.
+// C3D_WGRAD_TR=0 keeps the kernels of this file for the bf16 modes too (A/B measurements).
+int planes_for(const c3d_wgrad_desc* d) {
+  static const int tr_on = [] {
+    const char* e = getenv("C3D_WGRAD_TR");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  if (!tr_on || d->mfma_bf16 == 0) return 0;
+  return d->mfma_bf16 == 2 ? 3 : 1;
 }
 
 void plan(const c3d_wgrad_desc* d, WgradArgs& a, WgCfg& c) {
-  c = cfg_for(d->ntaps, d->x.C, d->Cout);
+  c = c3d_wgrad_cfg(d->ntaps, d->x.C, d->Cout, planes_for(d));
   a.tiles_x = (d->W + 31) / 32;
   a.tiles_y = (d->H + c.TRW - 1) / c.TRW;
   a.ntiles = d->B * a.tiles_x * a.tiles_y;
   a.ci_slices = (d->x.C + c.CI - 1) / c.CI;
   a.co_slices = (d->Cout + c.CO - 1) / c.CO;
   const int nsl = a.ci_slices * a.co_slices;
-  // one resident round: 256 CUs x 2 workgroups; never exceed it (a 2nd, nearly empty round
-  // would double the kernel time)
-  int strips = 512 / nsl;
+  // one resident round: 256 CUs x 2 workgroups (x 1 eight-wave workgroup for the bf16-plane
+  // kernels); never exceed it (a 2nd, nearly empty round would double the kernel time)
+  int strips = (planes_for(d) ? 256 : 512) / nsl;
   if (strips > a.ntiles) strips = a.ntiles;
   if (strips < 1) strips = 1;
   a.tiles_per_strip = (a.ntiles + strips - 1) / strips;
@@ -439,9 +420,9 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   WgCfg c;
   plan(d, a, c);
   hipStream_t st = (hipStream_t)stream;
-  // bf16x3 (mode 2) keeps the fp32-MFMA weight gradient: splitting K = pixel fragments at read
-  // time costs more VALU time than the fp32 matrix pipe saves
-  const int rc = d->mfma_bf16 == 1 ? launch_id<true>(c.id, halo, a, st) : launch_id<false>(c.id, halo, a, st);
+  const int planes = planes_for(d);
+  const int rc = planes ? c3d_wgrad_launch_tr(planes, c.id, halo, a, st)
+                        : (d->mfma_bf16 == 1 ? launch_id<true>(c.id, halo, a, st) : launch_id<false>(c.id, halo, a, st));
   if (rc) return rc;
   const size_t total = (size_t)d->ntaps * c.CI * c.CO * a.ci_slices * a.co_slices;
   int blocks = (int)((total + 31) / 32);

@@ -1,0 +1,497 @@
+// Convolution weight gradient on the bf16 matrix pipe for gfx950, operands read through the LDS
+// transpose read (ds_read_b64_tr_b16).
+//
+//   dW[cout][cin][t] = sum_pixels x[p + tap_t][cin] * dz[p][cout]        (GEMM: M = cin, N = cout, K = pixels)
+// (autograd of the nn.Conv2d layers of pc_processor/models/salsanext_proto.py:41-62, 82-132,
+// 164-208, 318 and projector.py:18-23; same workgroup decomposition, partial layout and fold as
+// wgrad_mfma.hip.)
+//
+// v_mfma_f32_32x32x16_bf16 wants 8 CONSECUTIVE K values (pixels) per lane, but the activations
+// are stored [pixel][channel]: a plain LDS read would gather 8 rows.  ds_read_b64_tr_b16 does the
+// 4x4 transpose in the LDS pipe: a 16-lane group reads 4 pixel rows x 16 channels (lane s points
+// at 4 channels of pixel s/4) and lane i receives channel i of those 4 pixels -- two such reads
+// make one MFMA operand.  The LDS image therefore stays [pixel][channel] (bf16), tap shifts are
+// whole-row offsets (no alignment problem), and staging writes are plain 8-byte stores.
+//
+// NP = 3 ("bf16x3"): every fp32 operand is split exactly into three bf16 planes when the tile is
+// staged (once per element per workgroup) and eight of the nine plane products are accumulated in
+// fp32 -- only l*l (< 2^-32 |a||b|) is dropped, results are fp32-class; eight bf16 MFMAs cost
+// half the issue time of the 8 fp32 MFMAs (32x32x2) they replace.  NP = 1 ("bf16"): operands
+// rounded to bf16 (RNE) at staging, one product.
+//
+// Bank conflicts: one tr read touches 4 pixel rows x 64 B per 32-lane pass.  Rows are unpadded
+// (32*NS channels, NS = 1, 2, 4 or 8 segments of 64 B); segment s of pixel row R is stored at
+// segment s ^ f(R) with f = 0 / (R>>1)&1 / R&3 for NS = 1 / 2 / >= 4, which puts any 4 consecutive
+// rows in 4 different 16-bank groups (SQ_LDS_BANK_CONFLICT = 0 on every instance).
+//
+// Workgroup = 8 waves, one per CU: waves 0-3 (one per SIMD) only issue transposed reads + MFMAs on
+// the current tile buffer, waves 4-7 stage the next tile into the other LDS buffer and keep the
+// loads of TWO further tiles in flight in registers (one tile per CU in flight left the kernel
+// bound by memory latency).  One barrier per tile.  Measured on the 704x704 1x1 layer at
+// 8x32x1024 (bf16x3): fp32-MFMA kernel 2.77 ms, this kernel 2.26 ms; consumer waves alone 1.57 ms,
+// producer waves alone 1.06 ms.  The two do NOT overlap beyond ~15 %: a probe (tools/probes/
+// coissue_probe.hip) shows that on gfx950 VALU instructions of one wave and MFMAs of another wave
+// on the same SIMD simply add up (t(both) = t(MFMA) + t(VALU) to 1 %), so the plane split is a tax
+// of ~0.6 ms on top of ~1.2 ms of matrix time here and cannot be hidden by scheduling -- only
+// removed (fewer re-splits per element: wider slices or planes kept in HBM).
+#include <type_traits>
+#include "wgrad_common.h"
+
+namespace {
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <int NP>
+__device__ __forceinline__ void split_planes(f32x4 v, u32x2 (&out)[NP]) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  f32x4 r = v;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    bf16x4 h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h[q] = (__bf16)r[q];
+    out[p] = __builtin_bit_cast(u32x2, h);
+    if (p + 1 < NP) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[q] -= (float)h[q];
+    }
+  }
+}
+
+// element offset (bf16 units) of channel c of pixel row R in a [rows][32*NS] image
+template <int NS>
+__device__ __forceinline__ int tr_swz(int R, int c) {
+  const int f = NS == 1 ? 0 : (NS == 2 ? ((R >> 1) & 1) : (R & 3));
+  return R * (32 * NS) + (((c >> 5) ^ f) << 5) + (c & 31);
+}
+
+__device__ __forceinline__ s16x4 tr_read(const unsigned short* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+
+// one MFMA operand: channel (lane) x 8 pixels = two transposed reads 4 pixel rows apart
+template <int NS>
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned short* plane, int R, int c) {
+  const s16x4 lo = tr_read(plane + tr_swz<NS>(R, c));
+  const s16x4 hi = tr_read(plane + tr_swz<NS>(R + 4, c));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// 4 channels at (uniform element offset ubase) + (per-lane element offset off): the split keeps the
+// address a scalar base plus a 32-bit lane offset (global_load ... v, s[base]) -- no 64-bit lane math.
+// (readfirstlane pins the uniform part in SGPRs: without it the optimiser re-associates the sum
+//  and hoists one loop-invariant 64-bit lane address per staged unit out of the tile loop -- 24
+//  VGPRs, which spill.)
+__device__ __forceinline__ const char* c3d_uniform_ptr(const void* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+template <bool BF>
+__device__ __forceinline__ f32x4 c3d_ld4u(const float* p, size_t ubase, unsigned off) {
+  if constexpr (BF) {
+    const char* b = c3d_uniform_ptr(reinterpret_cast<const unsigned short*>(p) + ubase);
+    // (explicit global address space: the integer round trip above would otherwise leave a generic
+    //  pointer and a flat_load, which counts on lgkmcnt and stalls every LDS wait behind the prefetch)
+    const c3d_u32x2 r = *(const __attribute__((address_space(1))) c3d_u32x2*)(b + (size_t)(off * 2u));
+    f32x4 v;
+    v[0] = __uint_as_float(r[0] << 16);
+    v[1] = __uint_as_float(r[0] & 0xffff0000u);
+    v[2] = __uint_as_float(r[1] << 16);
+    v[3] = __uint_as_float(r[1] & 0xffff0000u);
+    return v;
+  } else {
+    const char* b = c3d_uniform_ptr(p + ubase);
+    return *(const __attribute__((address_space(1))) f32x4*)(b + (size_t)(off * 4u));
+  }
+}
+
+template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO>
+__global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
+  constexpr int WK = 4 / (WCI * WCO);
+  constexpr int CI = 32 * CI_T * WCI;  // cin slice of the workgroup
+  constexpr int CO = 32 * CO_T * WCO;  // cout slice of the workgroup
+  constexpr int NSX = CI / 32, NSD = CO / 32;
+  constexpr int TWh = 32 + 2 * HALO;
+  constexpr int THh = TRW + 2 * HALO;
+  constexpr int XROWS = THh * TWh, DROWS = TRW * 32;
+  constexpr int KS = TRW * 2;          // 16-pixel K steps per tile
+  constexpr int KPW = KS / WK;         // per wave
+  static_assert(KS % WK == 0 && KPW >= 1, "K steps must split across the K waves");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // two tile buffers, each [NP][XROWS][CI] x planes followed by [NP][DROWS][CO] dz planes
+  constexpr int BUF = NP * (XROWS * CI + DROWS * CO);
+  unsigned short* s_base = reinterpret_cast<unsigned short*>(smem);
+
+  // Eight waves, two roles: waves 0-3 (one per SIMD) only issue transposed reads and MFMAs on
+  // the current tile buffer; waves 4-7 stage the NEXT tile meanwhile (global loads -> on-load
+  // transform -> plane split -> LDS) into the other buffer.  One barrier per tile.  With all
+  // waves doing both jobs in turn (the first version of this kernel) the staging and matrix
+  // phases of the two resident workgroups fell into lock-step and simply added up
+  // (704x704 layer: 0.96 ms staging + 1.50 ms matrix phase -> 2.16 ms).
+  const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 256;   // wave-uniform, in an SGPR
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wci = wave % WCI, wco = (wave / WCI) % WCO, wk = wave / (WCI * WCO);
+  // transposed-read source of this lane: group g = lane>>4 covers channels 16*(g&1).. of pixels 8*(g>>1)..
+  const int lp = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const int lc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  const int nsl = a.ci_slices * a.co_slices;
+  const int logical = c3d_xcd_remap(blockIdx.x, a.strips * nsl);
+  const int strip = logical / nsl;
+  const int sl = logical % nsl;
+  const int ci0 = (sl % a.ci_slices) * CI;
+  const int co0 = (sl / a.ci_slices) * CO;
+
+  // ---- register staging (prefetch) of the next pixel tile while the current one is consumed
+  constexpr int X_UNITS = XROWS * (CI / 4);
+  constexpr int X_PT = (X_UNITS + 255) / 256;
+  constexpr int D_UNITS = DROWS * (CO / 4);
+  constexpr int D_PT = (D_UNITS + 255) / 256;
+  // one register set per tile in flight; the producers keep TWO tiles of loads outstanding (one
+  // tile per CU in flight left the kernel bound by memory latency)
+  struct Stage {
+    f32x4 px[X_PT], pd[D_PT];
+    unsigned inb;   // units of px that came from inside the image (the others are zero padding)
+    unsigned dmask; // same for pd
+  };
+  const int xc4 = tid % (CI / 4);          // 256 % (CI/4) == 0: fixed channel quad per thread
+  const int xc = ci0 + xc4 * 4;
+  const bool xc_ok = xc < a.x.C;
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  if (a.x.scale && xc_ok) {
+    psc = *reinterpret_cast<const f32x4*>(a.x.scale + xc);
+    psh = *reinterpret_cast<const f32x4*>(a.x.shift + xc);
+  }
+  const bool aff = a.x.scale != nullptr, lr = a.x.lrelu != 0;
+
+  // Per-thread constant element offsets of every staged unit relative to the tile's first (halo)
+  // pixel: interior tiles (the vast majority) load with a uniform base + these offsets, no
+  // per-unit index arithmetic or bounds tests.  Without a halo a pass of 256 threads advances by
+  // a uniform pixel offset, so one offset per thread is enough.
+  const int xp0 = tid / (CI / 4);
+  constexpr int XSTEP = 256 / (CI / 4);    // pixels per pass of the workgroup
+  const int dc4 = tid % (CO / 4), dp0 = tid / (CO / 4);
+  constexpr int DSTEP = 256 / (CO / 4);
+  static_assert(XSTEP % 32 == 0 || 32 % XSTEP == 0, "pass size must tile the 32-pixel rows");
+  static_assert(DSTEP % 32 == 0 || 32 % DSTEP == 0, "pass size must tile the 32-pixel rows");
+  const int dc = co0 + dc4 * 4;
+  const bool dc_ok = dc + 3 < a.dz_cstride;
+  unsigned xoff[HALO > 0 ? X_PT : 1];
+  if constexpr (HALO > 0) {
+#pragma unroll
+    for (int i = 0; i < X_PT; ++i) {
+      const int pp = xp0 + i * XSTEP;
+      xoff[i] = (unsigned)(((pp / TWh) * a.W + pp % TWh) * a.x.cstride + a.x.coff + xc);
+    }
+  } else {
+    xoff[0] = (unsigned)(((xp0 / 32) * a.W + xp0 % 32) * a.x.cstride + a.x.coff + xc);
+  }
+  const unsigned doff0 = (unsigned)(((dp0 / 32) * a.W + dp0 % 32) * a.dz_cstride + dc);
+  const unsigned x_all = xc_ok ? ((X_UNITS % 256 == 0 || tid < X_UNITS % 256) ? ((1u << X_PT) - 1u) : ((1u << (X_PT - 1)) - 1u)) : 0u;
+
+  // coordinates of the next tile to load (producer state, advanced by load_tile)
+  int ltx = 0, lty = 0, lb = 0;
+  auto seek_tile = [&](int mt) {
+    ltx = mt % a.tiles_x;
+    lty = (mt / a.tiles_x) % a.tiles_y;
+    lb = mt / (a.tiles_x * a.tiles_y);
+  };
+  auto load_tile = [&](Stage& sg) {
+    const int x0 = ltx * 32, y0 = lty * TRW, b = lb;
+    if (++ltx == a.tiles_x) {
+      ltx = 0;
+      if (++lty == a.tiles_y) {
+        lty = 0;
+        ++lb;
+      }
+    }
+    const bool interior = x0 >= HALO && x0 + 32 + HALO <= a.W && y0 >= HALO && y0 + TRW + HALO <= a.H;   // uniform
+    // validity of this thread's units: interior tiles (the vast majority) need no pixel tests
+    unsigned xmask = x_all, dmask = dc_ok ? ((1u << D_PT) - 1u) : 0u;
+    if (!interior) {
+      xmask = 0;
+#pragma unroll
+      for (int i = 0; i < X_PT; ++i) {
+        const int pp = xp0 + i * XSTEP;
+        const int gx = x0 + pp % TWh - HALO, gy = y0 + pp / TWh - HALO;
+        if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H) xmask |= 1u << i;
+      }
+      xmask &= x_all;
+      unsigned dm = 0;
+#pragma unroll
+      for (int i = 0; i < D_PT; ++i) {
+        const int pp = dp0 + i * DSTEP;
+        if (x0 + (pp & 31) < a.W && y0 + (pp >> 5) < a.H) dm |= 1u << i;
+      }
+      dmask &= dm;
+    }
+    sg.inb = xmask;
+    sg.dmask = dmask;
+    // EVERY unit issues its load (invalid ones read element 0 of the image and are zeroed in
+    // store_tile): with a fixed number of loads per tile the compiler can wait for the older of
+    // the two tiles in flight with s_waitcnt vmcnt(N); loads under per-unit branches made it
+    // fall back to vmcnt(0), which serialised the two tiles.
+    const size_t ximg = (size_t)b * a.H * a.W * a.x.cstride, dimg = (size_t)b * a.H * a.W * a.dz_cstride;   // uniform
+    const int xt = ((y0 - HALO) * a.W + (x0 - HALO)) * a.x.cstride;     // uniform; < 0 only where masked
+    const int dt = (y0 * a.W + x0) * a.dz_cstride;
+    auto load_x = [&](auto bf_tag) {
+      constexpr bool XBF = decltype(bf_tag)::value;
+#pragma unroll
+      for (int i = 0; i < X_PT; ++i) {
+        int off;
+        if constexpr (HALO > 0) off = xt + (int)xoff[i];
+        else off = xt + (((i * XSTEP) / 32) * a.W + (i * XSTEP) % 32) * a.x.cstride + (int)xoff[0];
+        sg.px[i] = c3d_ld4u<XBF>(a.x.ptr, ximg, ((xmask >> i) & 1u) ? (unsigned)off : 0u);
+      }
+    };
+    auto load_dz = [&](auto bf_tag) {
+      constexpr bool DBF = decltype(bf_tag)::value;
+#pragma unroll
+      for (int i = 0; i < D_PT; ++i) {
+        const int off = dt + (((i * DSTEP) / 32) * a.W + (i * DSTEP) % 32) * a.dz_cstride + (int)doff0;
+        sg.pd[i] = c3d_ld4u<DBF>(a.dz, dimg, ((dmask >> i) & 1u) ? (unsigned)off : 0u);
+      }
+    };
+    if (NP == 1 && a.x.bf16) load_x(std::true_type{});
+    else load_x(std::false_type{});
+    if (NP == 1 && a.dz_bf16) load_dz(std::true_type{});
+    else load_dz(std::false_type{});
+  };
+  auto store_tile = [&](int buf, const Stage& sg) {
+    unsigned short* s_x = s_base + buf * BUF;
+    unsigned short* s_dz = s_x + NP * XROWS * CI;
+#pragma unroll
+    for (int i = 0; i < X_PT; ++i) {
+      const int u = tid + i * 256;
+      if (u < X_UNITS) {
+        f32x4 v = sg.px[i];
+        if (aff) v = v * psc + psh;
+        if (lr) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q], a.slope);
+        }
+        if (!((sg.inb >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x2 pl[NP];
+        split_planes<NP>(v, pl);
+        const int o = tr_swz<NSX>(u / (CI / 4), xc4 * 4);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_x + p * XROWS * CI + o) = pl[p];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < D_PT; ++i) {
+      const int u = tid + i * 256;
+      if (u < D_UNITS) {
+        u32x2 pl[NP];
+        split_planes<NP>(((sg.dmask >> i) & 1u) ? sg.pd[i] : f32x4{0.f, 0.f, 0.f, 0.f}, pl);
+        const int o = tr_swz<NSD>(u / (CO / 4), (u % (CO / 4)) * 4);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_dz + p * DROWS * CO + o) = pl[p];
+      }
+    }
+  };
+
+  int tapoff[TMAX];                        // pixel-row offset of each tap (a.T == TMAX by construction)
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) tapoff[t] = a.dy[t] * TWh + a.dx[t];
+
+  const int t_begin = strip * a.tiles_per_strip;
+  const int t_end = min(t_begin + a.tiles_per_strip, a.ntiles);
+  // ---- producer waves: stage tile mt+1 while the consumers work on tile mt; they take part in
+  //      every barrier of the consumer path below (tile loop + K-split fold) and nothing else
+  if (producer) {
+    Stage sa, sb;      // tile n of the strip travels through set / LDS buffer (n - t_begin) & 1
+    int mt = t_begin;
+    if (t_end - t_begin >= 5) {
+      // long strips: prologue and steady state carry no condition around a load, so the waits in
+      // front of store_tile are s_waitcnt vmcnt(<loads of the younger tile>), not vmcnt(0)
+      seek_tile(t_begin);
+      load_tile(sa);
+      load_tile(sb);
+      store_tile(0, sa);
+      load_tile(sa);
+      __syncthreads();
+      while (mt + 4 < t_end) {      // two tiles per trip
+        store_tile(1, sb);
+        load_tile(sb);
+        __syncthreads();
+        store_tile(0, sa);
+        load_tile(sa);
+        __syncthreads();
+        mt += 2;
+      }
+    } else {
+      if (t_begin < t_end) {
+        seek_tile(t_begin);
+        load_tile(sa);
+        if (t_begin + 1 < t_end) load_tile(sb);
+        store_tile(0, sa);
+        if (t_begin + 2 < t_end) load_tile(sa);
+      }
+      __syncthreads();
+    }
+    for (; mt < t_end;) {
+      // consumers on buffer 0: tile mt+1 -> buffer 1, then tile mt+3 takes its registers
+      if (mt + 1 < t_end) {
+        store_tile(1, sb);
+        if (mt + 3 < t_end) load_tile(sb);
+      }
+      __syncthreads();
+      if (++mt >= t_end) break;
+      if (mt + 1 < t_end) {
+        store_tile(0, sa);
+        if (mt + 3 < t_end) load_tile(sa);
+      }
+      __syncthreads();
+      ++mt;
+    }
+    if (WK > 1) {
+      for (int t = 0; t < a.T; ++t) {
+        __syncthreads();
+        __syncthreads();
+      }
+    }
+    return;
+  }
+
+  // ---- consumer waves
+  f32x16 acc[TMAX][CI_T][CO_T];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+    for (int i = 0; i < CI_T; ++i)
+#pragma unroll
+      for (int j = 0; j < CO_T; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+  __syncthreads();
+  for (int mt = t_begin; mt < t_end; ++mt) {
+    const int cur = (mt - t_begin) & 1;
+    {
+    const unsigned short* s_x = s_base + cur * BUF;
+    const unsigned short* s_dz = s_x + NP * XROWS * CI;
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) {
+      // (tried: issuing the transposed reads of step s+1 ahead of the MFMAs of step s -- the
+      //  matrix phase alone did not get faster (1.50 -> 1.53 ms on the 704x704 layer) and the extra
+      //  fragment registers spill in the staging phases: 2.15 -> 2.78 ms)
+      const int ks = wk * KPW + kk;
+      const int row = ks >> 1, px0 = (ks & 1) * 16;
+      const int Rd = row * 32 + px0 + lp;
+      const int Rx0 = (row + HALO) * TWh + HALO + px0 + lp;
+#pragma unroll
+      for (int j = 0; j < CO_T; ++j) {
+        bf16x8 bp[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bp[p] = tr_frag<NSD>(s_dz + p * DROWS * CO, Rd, (wco * CO_T + j) * 32 + lc);
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+          for (int i = 0; i < CI_T; ++i) {
+            bf16x8 ap[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+              ap[p] = tr_frag<NSX>(s_x + p * XROWS * CI, Rx0 + tapoff[t], (wci * CI_T + i) * 32 + lc);
+            if constexpr (NP == 3) {
+              // eight of the nine plane products, smallest first
+#define C3D_PLANE(PA, PB) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA], bp[PB], acc[t][i][j], 0, 0, 0);
+              C3D_PLANE(2, 1) C3D_PLANE(1, 2) C3D_PLANE(2, 0) C3D_PLANE(0, 2) C3D_PLANE(1, 1) C3D_PLANE(1, 0)
+              C3D_PLANE(0, 1) C3D_PLANE(0, 0)
+#undef C3D_PLANE
+            } else {
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[0], acc[t][i][j], 0, 0, 0);
+            }
+          }
+      }
+    }
+    }
+    __syncthreads();   // next buffer written, this one no longer read
+  }
+  // ---- fold the WK pixel groups through LDS, write the workgroup partial
+  //      partial layout per (slice, strip): [t][cin (slice-local CI)][cout (slice-local CO)]
+  const size_t slice_floats = (size_t)a.T * CI * CO;
+  float* pout = a.partial + ((size_t)(sl * a.strips + strip)) * slice_floats;
+  float* red = smem;  // [WK-1][WCI*WCO][CI_T*CO_T][16][64], one tap at a time (the tile loop ended on a barrier)
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    if (t < a.T) {
+      if (WK > 1) {
+        __syncthreads();
+        if (wk > 0) {
+#pragma unroll
+          for (int i = 0; i < CI_T; ++i)
+#pragma unroll
+            for (int j = 0; j < CO_T; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                red[(((((wk - 1) * WCO + wco) * WCI + wci) * CI_T + i) * CO_T + j) * 1024 + r * 64 + lane] =
+                    acc[t][i][j][r];
+        }
+        __syncthreads();
+      }
+      if (wk == 0) {
+#pragma unroll
+        for (int i = 0; i < CI_T; ++i)
+#pragma unroll
+          for (int j = 0; j < CO_T; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float v = acc[t][i][j][r];
+#pragma unroll
+              for (int k = 1; k < WK; ++k)
+                v += red[(((((k - 1) * WCO + wco) * WCI + wci) * CI_T + i) * CO_T + j) * 1024 + r * 64 + lane];
+              const int ci = (wci * CI_T + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              const int co = (wco * CO_T + j) * 32 + l31;
+              pout[((size_t)t * CI + ci) * CO + co] = v;
+            }
+      }
+    }
+  }
+}
+
+template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO>
+int launch_tr(const WgradArgs& a, hipStream_t st) {
+  constexpr int WK = 4 / (WCI * WCO);
+  constexpr int CI = 32 * CI_T * WCI, CO = 32 * CO_T * WCO;
+  size_t lds = 2 * (size_t)NP * ((size_t)(TRW + 2 * HALO) * (32 + 2 * HALO) * CI + (size_t)TRW * 32 * CO) * 2;   // two tile buffers
+  const size_t red = (size_t)(WK - 1) * WCI * WCO * CI_T * CO_T * 1024 * sizeof(float);
+  if (red > lds) lds = red;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(a.strips * a.ci_slices * a.co_slices);
+  hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO>), grid, dim3(512), lds, st, a);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+// tile rows (TRW) must match c3d_wgrad_cfg(..., planes != 0)
+template <int NP>
+int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
+  switch (id) {
+    //                         TMAX CI_T CO_T WCI WCO TRW HALO
+    case 0: return launch_tr<NP, 1, 2, 4, 2, 2, 1, 0>(a, st);
+    case 1: return launch_tr<NP, 1, 2, 2, 2, 2, 1, 0>(a, st);
+    case 2: return launch_tr<NP, 1, 2, 2, 1, 1, 2, 0>(a, st);
+    case 3: return launch_tr<NP, 1, 1, 1, 1, 1, 4, 0>(a, st);
+    case 4: return halo <= 1 ? launch_tr<NP, 4, 1, 2, 1, 1, 2, 1>(a, st) : launch_tr<NP, 4, 1, 2, 1, 1, 2, 2>(a, st);
+    case 5: return halo <= 1 ? launch_tr<NP, 4, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 4, 1, 1, 1, 1, 4, 2>(a, st);
+    case 6: return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 2, 2, 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 2, 2, 2>(a, st);
+    default: return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, 2, 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, 2, 2>(a, st);
+  }
+}
+
+}  // namespace
+
+int c3d_wgrad_launch_tr(int planes, int id, int halo, const WgradArgs& a, hipStream_t st) {
+  return planes == 3 ? launch_tr_id<3>(id, halo, a, st) : launch_tr_id<1>(id, halo, a, st);
+}

@@ -3,6 +3,7 @@
 PyTorch is used for device memory and streams only; every function here launches the
 hand-written HIP kernels through ctypes and raises if the library refuses the call."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -241,6 +242,22 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     return out, stat_partial
 
 
+def _wgrad_kernel_name(ci, co, nt, halo):
+    """Mirrors c3d_wgrad_cfg() (csrc/wgrad_common.h) and the launch tables of wgrad_mfma.hip / wgrad_tr.hip."""
+    tr = MFMA_MODE != 0 and os.environ.get("C3D_WGRAD_TR", "1") != "0"
+    hl = 1 if halo <= 1 else 2
+    if nt == 1:
+        cfg = ("1, 2, 4, 2, 2, 1, 0" if (ci >= 96 and co >= 192) else "1, 2, 2, 2, 2, 1, 0" if (ci >= 96 and co >= 96)
+               else f"1, 2, 2, 1, 1, {2 if tr else 4}, 0" if co > 32 else "1, 1, 1, 1, 1, 4, 0")
+    elif nt == 4:
+        cfg = f"4, 1, 2, 1, 1, {2 if tr else 4}, {hl}" if co > 32 else f"4, 1, 1, 1, 1, 4, {hl}"
+    else:
+        cfg = f"9, 1, 1, 1, 2, 2, {hl}" if co > 32 else f"9, 1, 1, 1, 1, {2 if tr else 4}, {hl}"
+    if tr:
+        return f"wgrad_tr_kernel<{3 if MFMA_MODE == 2 else 1}, {cfg}>"
+    return f"wgrad_mfma_kernel<{cfg}, {'true' if MFMA_MODE == 1 else 'false'}>"
+
+
 def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0):
     """dw[:, cin_off:cin_off+src.C] (+)= sum_p dz[p] (x) transformed src[p + tap]."""
     d = L.WgradDesc()
@@ -260,14 +277,7 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0):
     d.partial = part.data_ptr()
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
     co, ci, nt = dw.shape[0], src.C, len(taps)
-    if nt == 1:      # mirrors cfg_for() in csrc/wgrad_mfma.hip
-        cfg = ("1, 2, 4, 2, 2, 1, 0" if (ci >= 96 and co >= 192) else "1, 2, 2, 2, 2, 1, 0" if (ci >= 96 and co >= 96)
-               else "1, 2, 2, 1, 1, 4, 0" if co > 32 else "1, 1, 1, 1, 1, 4, 0")
-    elif nt == 4:
-        cfg = "4, 1, 2, 1, 1, 4, 1" if co > 32 else "4, 1, 1, 1, 1, 4, 1"
-    else:
-        cfg = f"9, 1, 1, 1, {2 if co > 32 else 1}, {2 if co > 32 else 4}, {1 if halo <= 1 else 2}"
-    name = f"wgrad_mfma_kernel<{cfg}, {'true' if MFMA_MODE == 1 else 'false'}>"
+    name = _wgrad_kernel_name(ci, co, nt, halo)
     d.mfma_bf16 = MFMA_MODE
     with _Timed(name, 2.0 * b * h * w * dw.shape[0] * len(taps) * src.C, (h, w, ci, co, nt, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
