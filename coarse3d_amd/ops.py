@@ -272,13 +272,13 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0):
     d.Cin_total, d.cin_off = dw.shape[1], cin_off
     d.dw, d.accumulate = dw.data_ptr(), int(accumulate)
     d.lrelu_slope = slope
+    d.mfma_bf16 = MFMA_MODE           # the tiling (and with it the partial-sum size) depends on the engine
     n = L.lib().c3d_wgrad_partial_floats(C.byref(d))
     part = torch.empty(n, device=dz.device, dtype=torch.float32)
     d.partial = part.data_ptr()
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
     co, ci, nt = dw.shape[0], src.C, len(taps)
     name = _wgrad_kernel_name(ci, co, nt, halo)
-    d.mfma_bf16 = MFMA_MODE
     with _Timed(name, 2.0 * b * h * w * dw.shape[0] * len(taps) * src.C, (h, w, ci, co, nt, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
     return dw

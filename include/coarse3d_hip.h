@@ -118,7 +118,11 @@ int c3d_pack_weights_batch(const c3d_pack_entry* table_dev, int n, c3d_stream st
 /* dW[cout][cin_off + cin][t] (OIHW, full Cin_total) = sum_pixels dz[p][cout] * x[p + tap t][cin]
  * x is given as ONE transformed source (call once per source of a concatenated input).
  * Replaces autograd's conv weight gradient for the layers listed above.
- * `partial` is scratch of c3d_wgrad_partial_floats() floats.                                 */
+ * `partial` is scratch of c3d_wgrad_partial_floats() floats -- ask with the descriptor filled in
+ * completely: the tiling (and the scratch size) depends on mfma_bf16, shapes and taps.
+ * mfma_bf16 == 0: fp32 MFMA (wgrad_mfma.hip).  1 / 2: bf16 matrix pipe with the operands read
+ * through the LDS transpose read (wgrad_tr.hip) -- 1: operands rounded to bf16, 2: exact 3-plane
+ * split, eight of nine plane products (fp32-class).                                            */
 typedef struct {
   c3d_src x;                /* input of the forward conv (same transform as forward)      */
   const float* dz;          /* NHWC [B,H,W,Cout] gradient w.r.t. the conv output (pre-act) */
