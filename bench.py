@@ -271,6 +271,8 @@ def main():
     def peak_for(kernel_name):
         """Matrix-pipe ceiling of one kernel instance: conv_bfp / conv_x3 / wgrad_tr instances run on the bf16
         pipe (eight plane products per fp32 product in the "<3" instances); the rest on fp32 MFMA."""
+        if kernel_name.startswith("conv_pw3_kernel"):
+            return PEAK_BF16_MFMA_TFLOPS / 8.0
         if kernel_name.startswith(("conv_x3_kernel", "conv_bfp_kernel")):
             return PEAK_BF16_MFMA_TFLOPS / 8.0 if kernel_name.rstrip(">").endswith("3") or "x3" in kernel_name else PEAK_BF16_MFMA_TFLOPS
         if kernel_name.startswith("wgrad_mfma_kernel") and kernel_name.endswith("true>"):
@@ -442,8 +444,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16": ("bf16 activations in HBM + bf16 MFMA operands, f32 accumulate / statistics / master weights"
                                if args.storage == "bf16" else "bf16 MFMA operands, f32 accumulate/storage"),
-                      "bf16x3": "f32 via 3xbf16 exact split (conv + input-gradient kernels: 8 of 9 plane products, f32 "
-                                "accumulate; weight gradients on f32 MFMA; f32 storage everywhere)"}[args.matrix_dtype],
+                      "bf16x3": "f32 via 3xbf16 exact split (conv, input-gradient and weight-gradient kernels: 8 of 9 plane "
+                                "products on the bf16 matrix pipe, f32 accumulate; f32 storage everywhere)"}[args.matrix_dtype],
             "data": "synthetic",
             "config": {"workload": f"{args.dataset} {args.height}x{args.width}x5 range image, C={args.classes}, "
                                    f"bs={args.batch}/GPU, {type(model).__name__}{'' if args.net == 'salsanext' else args.net[-2:]} fwd+bwd + prototype bank + contrast "

@@ -27,6 +27,8 @@ struct ConvArgs {
 int c3d_conv_forward_bfp(ConvArgs& a, int planes, int tr, int halo, bool k32, hipStream_t st);
 // second-generation bf16x3 engine for 8-row tiles with 4 or 9 taps (conv_x3.hip); needs a mode | 2 pack
 int c3d_conv_forward_x3(ConvArgs& a, int halo, hipStream_t st);
+// wide pointwise bf16x3 engine, 8-row tiles, Cout > 64 (conv_pw3.hip); needs a mode | 2 pack
+int c3d_conv_forward_pw3(ConvArgs& a, hipStream_t st);
 
 namespace {
 
@@ -38,7 +40,11 @@ struct c3d_type_tag {
 // Epilogue of one workgroup tile: bias, LeakyReLU, (accumulating) store, per-tile channel
 // statistics [C][2][ntile].  acc[i][j] is the 32x32 MFMA accumulator of tile row wm + i*WM and
 // cout tile wn*NPW + j (lane l: cout l&31, pixels (r&3) + 8*(r>>2) + 4*(l>>5)).
-template <int TR, int NT, int WM, int WN, bool BF16_OUT = false>
+// ILV: cout sub-tile j of wave column wn is j*WN + wn (interleaved) instead of wn*NPW + j;
+// NTHR: threads of the workgroup.  SUBFAST: the straight-line path is chosen per 32-wide cout
+// sub-tile (a ragged last cout tile keeps it for its live sub-tiles); otherwise per workgroup tile
+// (fewer code paths -- the 4-wave kernels sit at their register limits).
+template <int TR, int NT, int WM, int WN, bool BF16_OUT = false, bool ILV = false, int NTHR = 256, bool SUBFAST = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TR / WM][NT / WN], float* smem, int tid,
                                               int lane, int half, int l31, int wm, int wn, int b, int x0, int y0,
                                               int n0, int mt, int ntile, size_t tile_pix) {
@@ -46,18 +52,56 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
   constexpr int NPW = NT / WN;
   constexpr int TN = 32 * NT;
   float s1[NPW], s2v[NPW];
-  const bool full_tile = (x0 + 32 <= a.W) && (y0 + TR <= a.H) && (n0 + TN <= a.Cout);
+  const bool full_pix = (x0 + 32 <= a.W) && (y0 + TR <= a.H) && (SUBFAST || n0 + 32 * NT <= a.Cout);
   const int ocs = a.out_cstride;
   const size_t obase_i = tile_pix * a.out_cstride + a.out_coff + n0 + l31;   // element index, + per-lane cout
-  // fast path (interior tiles): straight-line, no per-element predicates.  OT = float or __bf16 (bf16
-  // activation storage, values rounded RNE on store; the statistics below use the fp32 values)
+  const bool obf = BF16_OUT && a.out_bf16 != 0;      // engines that never store bf16 compile that path out
+  // one 32-wide cout sub-tile, any position: per-element predicates
+  auto slow_sub = [&](int j) {
+    const int co = n0 + (ILV ? j * WN + wn : wn * NPW + j) * 32 + l31;
+    const bool cok = co < a.Cout;
+    const float bias = (a.bias && cok) ? a.bias[co] : 0.f;
+    s1[j] = 0.f;
+    s2v[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int gy = y0 + wm + i * WM;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[i][j][r] + bias;
+        if (a.epi_lrelu) v = c3d_lrelu(v, a.slope);
+        if (cok && gy < a.H && gx < a.W) {
+          const size_t o = ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co;
+          if (a.accumulate) v += c3d_ld1(a.out, o, obf);
+          c3d_st1(a.out, o, obf, v);
+          s1[j] += v;
+          s2v[j] += v * v;
+        }
+      }
+    }
+  };
+  // tiles whose pixels are all inside the image (the vast majority): straight-line code, no
+  // per-element predicates, for every cout sub-tile that is completely live; a partially live
+  // sub-tile (Cout % 32 != 0) takes slow_sub, dead ones (ragged last cout tile) are skipped.
+  // OT = float or __bf16 (bf16 activation storage, values rounded RNE on store; the statistics
+  // below use the fp32 values)
   auto fast_epilogue = [&](auto accumulate_tag, auto type_tag) {
     constexpr bool ACC = decltype(accumulate_tag)::value;
     using OT = typename decltype(type_tag)::type;
     OT* obase = reinterpret_cast<OT*>(a.out) + obase_i;
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
-      const int cl = (wn * NPW + j) * 32;
+      const int cl = (ILV ? j * WN + wn : wn * NPW + j) * 32;
+      if constexpr (SUBFAST) {
+        const int rem = a.Cout - n0 - cl;          // wave-uniform
+        if (rem < 32) {
+          s1[j] = 0.f;
+          s2v[j] = 0.f;
+          if (rem > 0) slow_sub(j);
+          continue;
+        }
+      }
       const float bias = a.bias ? a.bias[n0 + cl + l31] : 0.f;
       s1[j] = 0.f;
       s2v[j] = 0.f;
@@ -81,41 +125,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
       }
     }
   };
-  const bool obf = BF16_OUT && a.out_bf16 != 0;      // engines that never store bf16 compile that path out
-  if (full_tile && !obf) {
+  if (full_pix && !obf) {
     if (!a.accumulate) fast_epilogue(std::false_type{}, c3d_type_tag<float>{});
     else fast_epilogue(std::true_type{}, c3d_type_tag<float>{});
-  } else if (full_tile) {
+  } else if (full_pix) {
     if constexpr (BF16_OUT) {
       if (!a.accumulate) fast_epilogue(std::false_type{}, c3d_type_tag<__bf16>{});
       else fast_epilogue(std::true_type{}, c3d_type_tag<__bf16>{});
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) {
-      const int co = n0 + (wn * NPW + j) * 32 + l31;
-      const bool cok = co < a.Cout;
-      const float bias = (a.bias && cok) ? a.bias[co] : 0.f;
-      s1[j] = 0.f;
-      s2v[j] = 0.f;
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const int gy = y0 + wm + i * WM;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          float v = acc[i][j][r] + bias;
-          if (a.epi_lrelu) v = c3d_lrelu(v, a.slope);
-          if (cok && gy < a.H && gx < a.W) {
-            const size_t o = ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co;
-            if (a.accumulate) v += c3d_ld1(a.out, o, obf);
-            c3d_st1(a.out, o, obf, v);
-            s1[j] += v;
-            s2v[j] += v * v;
-          }
-        }
-      }
-    }
+    for (int j = 0; j < NPW; ++j) slow_sub(j);
   }
   if (a.stat_partial) {
     __syncthreads();
@@ -125,13 +145,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
       float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
       float t2 = s2v[j] + __shfl_xor(s2v[j], 32, 64);
       if (half == 0) {
-        const int n = (wn * NPW + j) * 32 + l31;
+        const int n = (ILV ? j * WN + wn : wn * NPW + j) * 32 + l31;
         red[(wm * TN + n) * 2 + 0] = t1;
         red[(wm * TN + n) * 2 + 1] = t2;
       }
     }
     __syncthreads();
-    for (int n = tid; n < TN; n += 256) {
+    for (int n = tid; n < TN; n += NTHR) {
       if (n0 + n < a.Cout) {
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll

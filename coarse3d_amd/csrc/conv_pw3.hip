@@ -1,0 +1,246 @@
+// Wide pointwise (1x1) convolution in fp32-class arithmetic on the bf16 matrix pipe ("bf16x3":
+// c3d_conv_desc.mfma_bf16 == 2, 8-row tiles, one tap, Cout > 64, plane-carrying weight pack).
+//
+// Why a separate kernel.  On gfx950 VALU instructions and MFMAs of the same SIMD do not overlap,
+// not even across waves (tools/probes/coissue_probe.hip: t(both) = t(MFMA) + t(VALU) to 1 %), so
+// the exact 3-way bf16 split of the bf16x3 engine (~6 VALU instructions per staged element) is a
+// tax that no schedule hides: it has to be paid fewer times.  conv_bfp.hip's NP = 3 kernel splits a
+// 256-pixel input tile once per 64 output channels (11 times for the 704 -> 704 projector GEMM)
+// and splits the weights in every workgroup as well.  This kernel
+//   * computes 256 pixels x 256 (NT = 8) or 128 (NT = 4) output channels per workgroup: the input
+//     tile is split once per 256 / 128 couts -- 4x / 2x fewer split instructions per MFMA;
+//   * takes the weights pre-split (c3d_pack_weights(mode | 2) appends the three bf16 planes to
+//     the fp32 pack once per step): global -> LDS copies, no VALU work;
+//   * runs 8 waves (4 pixel-row groups x 2 cout groups, 2 x NT/2 MFMA tiles each) on a
+//     double-buffered LDS image (K chunk = 16 channels = one MFMA K step, 3 planes x (256 + 32*NT)
+//     rows x 32 B per buffer, unpadded swizzled rows as in conv_x3.hip): one barrier per chunk, the
+//     global loads of chunk c+2 are in flight while chunk c is multiplied;
+//   * deals the 32-wide cout sub-tiles to the two cout wave groups alternately, so a ragged last
+//     tile (704 = 256 + 256 + 192) keeps both groups equally busy and issues no MFMA on dead
+//     sub-tiles.
+// Arithmetic, on-load BatchNorm affine and epilogue exactly as conv_x3.hip / conv_bfp.hip NP = 3
+// (reference: pc_processor/models/salsanext_proto.py:41-62, 164-208, projector.py:18-23).
+#include "conv_x3_common.h"
+
+namespace {
+
+template <int NT>
+__global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
+  constexpr int TR = 8, CQ = 4;                    // 16 channels per K chunk
+  constexpr int TN = 32 * NT;
+  constexpr int WM = 4, WN = 2, RPW = 2, NPW = NT / WN;
+  constexpr int IN_ROWS = TR * 32;
+  constexpr int IN_PT = IN_ROWS * CQ / 512;        // 2
+  constexpr int W_PT = TN * CQ / 512;              // 2 (NT = 8) or 1 (NT = 4)
+  constexpr int BUF = 3 * (IN_ROWS + TN) * 16;     // bf16 elements per LDS buffer
+  static_assert(IN_ROWS * CQ % 512 == 0 && TN * CQ % 512 == 0, "staging units must tile the workgroup");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short* s_base = reinterpret_cast<unsigned short*>(smem);   // 2 x { [3][IN_ROWS][16], [3][TN][16] }
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave % WM, wn = wave / WM;
+
+  const int ntile = a.B * a.tiles_y * a.tiles_x;
+  const int logical = c3d_xcd_remap(blockIdx.x, ntile * a.ntn);
+  const int mt = logical / a.ntn;
+  const int n0 = (logical % a.ntn) * TN;
+  const int tx = mt % a.tiles_x;
+  const int ty = (mt / a.tiles_x) % a.tiles_y;
+  const int b = mt / (a.tiles_x * a.tiles_y);
+  const int x0 = tx * 32, y0 = ty * TR;
+
+  f32x16 acc[RPW][NPW];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i)
+#pragma unroll
+    for (int j = 0; j < NPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- staging state.  A load cursor walks the K chunks of the concatenated sources; everything
+  //      the loads need lives in registers as ready-made per-thread pointers that advance by one
+  //      chunk per step (a.src[s] is indexed only when the cursor enters a source): the first
+  //      version re-derived its addresses from a.src[s] per chunk and spent 0.44 of 1.96 ms of the
+  //      704x704 layer issuing eight loads per chunk.  Every load is unconditional -- pixels beyond
+  //      the image and couts beyond Cout are CLAMPED to valid ones (their products only reach
+  //      outputs the epilogue masks) -- so the waits are counted (s_waitcnt vmcnt(N)), not vmcnt(0).
+  //      (Tried on top: the input tile two chunks ahead in a second register set -- no change,
+  //      1.79 ms either way on the 704x704 layer; weight fragments of sub-tile j+1 read ahead of the
+  //      MFMAs of sub-tile j -- kept, neutral.  Phase ablation of that layer: matrix phase 1.1 ms,
+  //      staging 0.6 ms, epilogue + loop 0.24 ms, and the three simply add up.)
+  f32x4 pin[IN_PT];
+  u32x2 pw[W_PT][3];
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  bool paff = false, plr = false;          // on-load transform of the chunk held in pin
+  const int c4 = tid % CQ;                 // the channel quad of a thread is fixed
+  const size_t tile_pix = (size_t)(b * a.H + y0) * a.W + x0;
+  int pixrel[IN_PT];
+#pragma unroll
+  for (int i = 0; i < IN_PT; ++i) {
+    const int p = tid / CQ + i * (512 / CQ);
+    const int gx = min(x0 + (p & 31), a.W - 1), gy = min(y0 + (p >> 5), a.H - 1);
+    pixrel[i] = (gy - y0) * a.W + (gx - x0);
+  }
+  const size_t wplane = (size_t)a.Kq * a.Cout * 4;                             // bf16 elements per weight plane (T = 1)
+  const unsigned short* lw[W_PT];          // plane 0 of this thread's weight units at the cursor's K offset
+#pragma unroll
+  for (int i = 0; i < W_PT; ++i) {
+    const int u = tid + i * 512;
+    const int n = min(n0 + u % TN, a.Cout - 1), kq = u / TN;
+    lw[i] = reinterpret_cast<const unsigned short*>(a.wpack + wplane) + (size_t)(kq * a.Cout + n) * 4;   // behind the fp32 pack
+  }
+  const float* lin[IN_PT];
+  const float *lsc = nullptr, *lsh = nullptr;
+  int ls = 0, lc0 = 0, lC = 0;
+  bool llr = false;
+  auto open_src = [&](int s) {
+    const c3d_src& sr = a.src[s];
+#pragma unroll
+    for (int i = 0; i < IN_PT; ++i) lin[i] = sr.ptr + (tile_pix + pixrel[i]) * sr.cstride + sr.coff + c4 * 4;
+    lsc = sr.scale ? sr.scale + c4 * 4 : nullptr;
+    lsh = sr.scale ? sr.shift + c4 * 4 : nullptr;
+    llr = sr.lrelu != 0;
+    lC = sr.C;
+    lc0 = 0;
+  };
+  open_src(0);
+  auto load_chunk = [&]() {                // loads the cursor's chunk, then moves the cursor on
+#pragma unroll
+    for (int i = 0; i < IN_PT; ++i) pin[i] = *reinterpret_cast<const f32x4*>(lin[i]);
+    paff = lsc != nullptr;
+    plr = llr;
+    if (paff) {
+      psc = *reinterpret_cast<const f32x4*>(lsc);
+      psh = *reinterpret_cast<const f32x4*>(lsh);
+    }
+#pragma unroll
+    for (int i = 0; i < W_PT; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) pw[i][p] = *reinterpret_cast<const u32x2*>(lw[i] + p * wplane);
+#pragma unroll
+    for (int i = 0; i < W_PT; ++i) lw[i] += (size_t)a.Cout * 16;
+    lc0 += 16;
+    if (lc0 >= lC) {
+      if (++ls < a.nsrc) open_src(ls);
+    } else {
+#pragma unroll
+      for (int i = 0; i < IN_PT; ++i) lin[i] += 16;
+      if (paff) {
+        lsc += 16;
+        lsh += 16;
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    unsigned short* s_in = s_base + buf * BUF;
+    unsigned short* s_w = s_in + 3 * IN_ROWS * 16;
+#pragma unroll
+    for (int i = 0; i < IN_PT; ++i) {
+      f32x4 v = pin[i];
+      if (paff) v = v * psc + psh;
+      if (plr) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q], a.slope);
+      }
+      u32x2 pl[3];
+      split4x3(v, pl);
+      const int R = tid / CQ + i * (512 / CQ);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(s_in + (p * IN_ROWS + R) * 16 + swz_quad(R, c4)) = pl[p];
+    }
+#pragma unroll
+    for (int i = 0; i < W_PT; ++i) {
+      const int u = tid + i * 512;
+      const int R = u % TN, kq = u / TN;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(s_w + (p * TN + R) * 16 + swz_quad(R, kq)) = pw[i][p];
+    }
+  };
+
+  // live 32-wide cout sub-tiles of this tile, dealt alternately to the two cout wave groups
+  const int live = min(NT, (a.Cout - n0 + 31) / 32);
+  const int nj = (live - wn + WN - 1) / WN;
+  auto mfma_chunk = [&](int buf, auto nj_tag) {
+    constexpr int NJ = decltype(nj_tag)::value;
+    const unsigned short* s_in = s_base + buf * BUF;
+    const unsigned short* s_w = s_in + 3 * IN_ROWS * 16;
+    bf16x8 ap[3][RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int R = (wm + i * WM) * 32 + l31;
+      const int o = R * 16 + swz_half(R, half);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ap[p][i] = *reinterpret_cast<const bf16x8*>(s_in + p * IN_ROWS * 16 + o);
+    }
+    // the weight fragments of sub-tile j+1 are read while the 16 MFMAs of sub-tile j issue
+    bf16x8 bp[2][3];
+    auto load_b = [&](int j) {
+      const int R = (j * WN + wn) * 32 + l31;
+      const int o = R * 16 + swz_half(R, half);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bp[j & 1][p] = *reinterpret_cast<const bf16x8*>(s_w + p * TN * 16 + o);
+    };
+    if (NJ > 0) load_b(0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (j + 1 < NJ) load_b(j + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      // eight of the nine plane products, smallest first; only l*l (< 2^-32 |a||b|) is dropped
+#define C3D_PLANE(PA, PB) \
+  _Pragma("unroll") for (int i = 0; i < RPW; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA][i], bp[j & 1][PB], acc[i][j], 0, 0, 0);
+      C3D_PLANE(2, 1) C3D_PLANE(1, 2) C3D_PLANE(2, 0) C3D_PLANE(0, 2) C3D_PLANE(1, 1) C3D_PLANE(1, 0) C3D_PLANE(0, 1)
+      C3D_PLANE(0, 0)
+#undef C3D_PLANE
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  const int nchunks = a.Kq / 4;            // K / 16
+  load_chunk();
+  store_chunk(0);
+  if (nchunks > 1) load_chunk();
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nchunks) {
+      store_chunk(cur ^ 1);                // chunk c+1, loaded while chunk c-1 was multiplied
+      if (c + 2 < nchunks) load_chunk();
+    }
+    if (nj >= NPW) mfma_chunk(cur, std::integral_constant<int, NPW>{});
+    else if (NPW > 3 && nj == 3) mfma_chunk(cur, std::integral_constant<int, (NPW > 3 ? 3 : 1)>{});
+    else if (NPW > 2 && nj == 2) mfma_chunk(cur, std::integral_constant<int, (NPW > 2 ? 2 : 1)>{});
+    else if (nj == 1) mfma_chunk(cur, std::integral_constant<int, 1>{});
+    __syncthreads();                       // the other buffer is complete, this one is free again
+  }
+  conv_epilogue<TR, NT, WM, WN, false, true, 512, true>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
+                                                  tile_pix);
+}
+
+template <int NT>
+int launch_pw3(ConvArgs& a, hipStream_t st) {
+  size_t lds = (size_t)2 * 3 * (8 * 32 + 32 * NT) * 16 * 2;
+  const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
+  if (lds < red) lds = red;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw3_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
+  dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
+  hipLaunchKernelGGL((conv_pw3_kernel<NT>), grid, dim3(512), lds, st, a);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+// called by c3d_conv_forward for mfma_bf16 == 2, 8-row tiles, one tap, Cout > 64; a.wpack must be a
+// c3d_pack_weights(mode | 2) pack (fp32 image followed by the three bf16 planes)
+int c3d_conv_forward_pw3(ConvArgs& a, hipStream_t st) {
+  return a.Cout > 128 ? launch_pw3<8>(a, st) : launch_pw3<4>(a, st);
+}

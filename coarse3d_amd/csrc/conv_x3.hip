@@ -23,33 +23,10 @@
 // GEMM view, tile shape (8 x 32 pixels x 32*NT couts), on-load BatchNorm affine and epilogue as
 // conv_mfma.hip (reference: pc_processor/models/salsanext_proto.py:41-62, 82-132, 164-208).
 #include <type_traits>
-#include "conv_common.h"
+#include "conv_x3_common.h"
 
 
 namespace {
-
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void split4x3(f32x4 v, u32x2 (&out)[3]) {
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-  f32x4 r = v;
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    bf16x4 h;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) h[q] = (__bf16)r[q];
-    out[p] = __builtin_bit_cast(u32x2, h);
-    if (p < 2) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) r[q] -= (float)h[q];
-    }
-  }
-}
-
-// element offset (bf16 units) of channel quad c4 (0..3) inside the 16-channel row R
-__device__ __forceinline__ int swz_quad(int R, int c4) { return (((c4 >> 1) ^ ((R >> 3) & 1)) << 3) + ((c4 & 1) << 2); }
-// element offset of the 8-channel fragment `half` inside row R
-__device__ __forceinline__ int swz_half(int R, int half) { return (half ^ ((R >> 3) & 1)) << 3; }
 
 template <int NT, int HALO, int TT>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {

@@ -133,7 +133,9 @@ def pack_weights(w, mode=0, c_off=0, c_cnt=None, kpad=None):
     if kpad is None:
         kpad = (k + 15) // 16 * 16
     numel = t * (kpad // 4) * n * 4
-    planes = MFMA_MODE == 2 and t > 1      # bf16x3 engine for multi-tap convs: the pre-split bf16 planes follow the fp32 image
+    # bf16x3 engine: the pre-split bf16 planes follow the fp32 image for the kernels that read them
+    # (multi-tap convs: csrc/conv_x3.hip; 1x1 convs with more than 64 outputs: csrc/conv_pw3.hip)
+    planes = MFMA_MODE == 2 and (t > 1 or n > 64)
     dst = torch.empty(numel * 5 // 2 if planes else numel, device=w.device, dtype=torch.float32)
     L.check(L.lib().c3d_pack_weights(_p(w), _p(dst), cout, cin, t, mode | (2 if planes else 0), c_off, c_cnt, kpad,
                                      _stream()), "c3d_pack_weights")
@@ -209,6 +211,7 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     if MFMA_MODE == 2 and len(taps) > 1 and not getattr(wpack, "c3d_planes", False):
         raise RuntimeError("bf16x3 mode needs weight packs made after ops.set_matrix_precision('bf16x3')")
     d.wpack = wpack.data_ptr()
+    d.wpack_planes = int(bool(getattr(wpack, "c3d_planes", False)))
     d.bias = bias.data_ptr() if bias is not None else None
     d.epi_lrelu = int(lrelu)
     d.lrelu_slope = slope            # 0 = the SalsaNext default 0.01
@@ -226,6 +229,8 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     k32 = tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs)
     if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
         name = f"conv_x3_kernel<{2 if cout > 32 else 1}, {hh}, {nt_}>"
+    elif MFMA_MODE == 2 and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes:     # csrc/conv_pw3.hip
+        name = f"conv_pw3_kernel<{8 if cout > 128 else 4}>"
     elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
         np_ = 3 if MFMA_MODE == 2 else 1
         name = (f"conv_bfp_kernel<8, {2 if cout > 32 else 1}, 32, 0, 1, {np_}>" if k32 else

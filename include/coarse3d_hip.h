@@ -85,10 +85,13 @@ typedef struct {
                                accumulate/storage -- opt-in mixed precision (BASELINE config 2).
                                2: every fp32 operand split exactly into three bf16 planes, eight of
                                the nine plane products accumulated in fp32 (fp32-class result on the
-                               bf16 pipe); multi-tap convs then need a c3d_pack_weights(mode | 2) pack */
+                               bf16 pipe); multi-tap convs then need a c3d_pack_weights(mode | 2) pack
+                               (wpack_planes = 1) */
   int32_t out_bf16;         /* 1: `out` is bf16 (values rounded RNE on store, accumulate reads bf16);
                                the statistics partials are taken from the fp32 values; mfma_bf16 == 1 only */
-  int32_t reserved;
+  int32_t wpack_planes;     /* 1: wpack came from c3d_pack_weights(mode | 2): the three bf16 planes of the
+                               weights follow the fp32 image.  Required by the multi-tap bf16x3 kernels;
+                               1x1 convs with Cout > 64 then take the wide kernel of conv_pw3.hip       */
 } c3d_conv_desc;
 
 /* y = epilogue(conv(transform(cat(src)))) as an implicit GEMM on fp32 MFMA.

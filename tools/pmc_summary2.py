@@ -5,7 +5,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.OrderedDict()
 for r in rows:
     k = r["Kernel_Name"]
-    if not any(s in k for s in ("wgrad_", "conv_bfp", "conv_x3", "conv_mfma")):
+    if not any(s in k for s in ("wgrad_", "conv_bfp", "conv_x3", "conv_mfma", "conv_pw3")):
         continue
     agg.setdefault(k.replace("(anonymous namespace)::", "").replace("void ", "")[:52], {}).setdefault(r["Dispatch_Id"], {})[r["Counter_Name"]] = float(r["Counter_Value"])
 for k, disp in agg.items():
