@@ -272,7 +272,7 @@ def main():
         """Matrix-pipe ceiling of one kernel instance: conv_bfp / conv_x3 / wgrad_tr instances run on the bf16
         pipe (eight plane products per fp32 product in the "<3" instances); the rest on fp32 MFMA."""
         if kernel_name.startswith("conv_pw3_kernel"):
-            return PEAK_BF16_MFMA_TFLOPS / 8.0
+            return PEAK_BF16_MFMA_TFLOPS / 8.0 if kernel_name.endswith("3>") else PEAK_BF16_MFMA_TFLOPS
         if kernel_name.startswith(("conv_x3_kernel", "conv_bfp_kernel")):
             return PEAK_BF16_MFMA_TFLOPS / 8.0 if kernel_name.rstrip(">").endswith("3") or "x3" in kernel_name else PEAK_BF16_MFMA_TFLOPS
         if kernel_name.startswith("wgrad_mfma_kernel") and kernel_name.endswith("true>"):

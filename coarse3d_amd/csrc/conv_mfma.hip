@@ -308,7 +308,7 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
       C3D_REQUIRE(d->wpack_planes, "conv: multi-tap bf16x3 convs need a c3d_pack_weights(mode | 2) pack (wpack_planes = 1)");
       return c3d_conv_forward_x3(a, halo, st);
     }
-    if (d->mfma_bf16 == 2 && tr == 8 && d->ntaps == 1 && d->Cout > 64 && d->wpack_planes) return c3d_conv_forward_pw3(a, st);
+    if (tr == 8 && d->ntaps == 1 && d->Cout > 64 && d->wpack_planes) return c3d_conv_forward_pw3(a, d->mfma_bf16 == 2 ? 3 : 1, st);
     return c3d_conv_forward_bfp(a, d->mfma_bf16 == 2 ? 3 : 1, tr, halo, k32, st);
   }
   if (tr == 8 && d->ntaps == 1) {

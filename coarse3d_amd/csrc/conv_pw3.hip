@@ -24,7 +24,9 @@
 
 namespace {
 
-template <int NT>
+// NP = 3: bf16x3 (exact split, eight plane products).  NP = 1: "bf16" mode -- operands rounded to
+// bf16 (the h plane of the pack IS the RNE-rounded weight), one product, fp32 or bf16 tensors.
+template <int NT, int NP>
 __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
   constexpr int TR = 8, CQ = 4;                    // 16 channels per K chunk
   constexpr int TN = 32 * NT;
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
   constexpr int IN_ROWS = TR * 32;
   constexpr int IN_PT = IN_ROWS * CQ / 512;        // 2
   constexpr int W_PT = TN * CQ / 512;              // 2 (NT = 8) or 1 (NT = 4)
-  constexpr int BUF = 3 * (IN_ROWS + TN) * 16;     // bf16 elements per LDS buffer
+  constexpr int BUF = NP * (IN_ROWS + TN) * 16;    // bf16 elements per LDS buffer
   static_assert(IN_ROWS * CQ % 512 == 0 && TN * CQ % 512 == 0, "staging units must tile the workgroup");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
   //      MFMAs of sub-tile j -- kept, neutral.  Phase ablation of that layer: matrix phase 1.1 ms,
   //      staging 0.6 ms, epilogue + loop 0.24 ms, and the three simply add up.)
   f32x4 pin[IN_PT];
-  u32x2 pw[W_PT][3];
+  u32x2 pw[W_PT][NP];
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   bool paff = false, plr = false;          // on-load transform of the chunk held in pin
   const int c4 = tid % CQ;                 // the channel quad of a thread is fixed
@@ -92,14 +94,16 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
     const int n = min(n0 + u % TN, a.Cout - 1), kq = u / TN;
     lw[i] = reinterpret_cast<const unsigned short*>(a.wpack + wplane) + (size_t)(kq * a.Cout + n) * 4;   // behind the fp32 pack
   }
-  const float* lin[IN_PT];
+  const char* lin[IN_PT];                  // byte pointers: a source is fp32 or (NP = 1 only) bf16
   const float *lsc = nullptr, *lsh = nullptr;
   int ls = 0, lc0 = 0, lC = 0;
-  bool llr = false;
+  bool llr = false, lbf = false;
   auto open_src = [&](int s) {
     const c3d_src& sr = a.src[s];
+    lbf = NP == 1 && sr.bf16 != 0;
 #pragma unroll
-    for (int i = 0; i < IN_PT; ++i) lin[i] = sr.ptr + (tile_pix + pixrel[i]) * sr.cstride + sr.coff + c4 * 4;
+    for (int i = 0; i < IN_PT; ++i)
+      lin[i] = reinterpret_cast<const char*>(sr.ptr) + ((tile_pix + pixrel[i]) * sr.cstride + sr.coff + c4 * 4) * (lbf ? 2 : 4);
     lsc = sr.scale ? sr.scale + c4 * 4 : nullptr;
     lsh = sr.scale ? sr.shift + c4 * 4 : nullptr;
     llr = sr.lrelu != 0;
@@ -108,8 +112,17 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
   };
   open_src(0);
   auto load_chunk = [&]() {                // loads the cursor's chunk, then moves the cursor on
+    if (lbf) {
 #pragma unroll
-    for (int i = 0; i < IN_PT; ++i) pin[i] = *reinterpret_cast<const f32x4*>(lin[i]);
+      for (int i = 0; i < IN_PT; ++i) {
+        const c3d_u32x2 r = *reinterpret_cast<const c3d_u32x2*>(lin[i]);
+        pin[i] = f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+                       __uint_as_float(r[1] & 0xffff0000u)};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < IN_PT; ++i) pin[i] = *reinterpret_cast<const f32x4*>(lin[i]);
+    }
     paff = lsc != nullptr;
     plr = llr;
     if (paff) {
@@ -119,7 +132,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < W_PT; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) pw[i][p] = *reinterpret_cast<const u32x2*>(lw[i] + p * wplane);
+      for (int p = 0; p < NP; ++p) pw[i][p] = *reinterpret_cast<const u32x2*>(lw[i] + p * wplane);
 #pragma unroll
     for (int i = 0; i < W_PT; ++i) lw[i] += (size_t)a.Cout * 16;
     lc0 += 16;
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
       if (++ls < a.nsrc) open_src(ls);
     } else {
 #pragma unroll
-      for (int i = 0; i < IN_PT; ++i) lin[i] += 16;
+      for (int i = 0; i < IN_PT; ++i) lin[i] += lbf ? 32 : 64;
       if (paff) {
         lsc += 16;
         lsh += 16;
@@ -136,7 +149,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
   };
   auto store_chunk = [&](int buf) {
     unsigned short* s_in = s_base + buf * BUF;
-    unsigned short* s_w = s_in + 3 * IN_ROWS * 16;
+    unsigned short* s_w = s_in + NP * IN_ROWS * 16;
 #pragma unroll
     for (int i = 0; i < IN_PT; ++i) {
       f32x4 v = pin[i];
@@ -145,18 +158,18 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q], a.slope);
       }
-      u32x2 pl[3];
-      split4x3(v, pl);
+      u32x2 pl[NP];
+      split4_planes<NP>(v, pl);
       const int R = tid / CQ + i * (512 / CQ);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(s_in + (p * IN_ROWS + R) * 16 + swz_quad(R, c4)) = pl[p];
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_in + (p * IN_ROWS + R) * 16 + swz_quad(R, c4)) = pl[p];
     }
 #pragma unroll
     for (int i = 0; i < W_PT; ++i) {
       const int u = tid + i * 512;
       const int R = u % TN, kq = u / TN;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(s_w + (p * TN + R) * 16 + swz_quad(R, kq)) = pw[i][p];
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_w + (p * TN + R) * 16 + swz_quad(R, kq)) = pw[i][p];
     }
   };
 
@@ -166,22 +179,22 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
   auto mfma_chunk = [&](int buf, auto nj_tag) {
     constexpr int NJ = decltype(nj_tag)::value;
     const unsigned short* s_in = s_base + buf * BUF;
-    const unsigned short* s_w = s_in + 3 * IN_ROWS * 16;
-    bf16x8 ap[3][RPW];
+    const unsigned short* s_w = s_in + NP * IN_ROWS * 16;
+    bf16x8 ap[NP][RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int R = (wm + i * WM) * 32 + l31;
       const int o = R * 16 + swz_half(R, half);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) ap[p][i] = *reinterpret_cast<const bf16x8*>(s_in + p * IN_ROWS * 16 + o);
+      for (int p = 0; p < NP; ++p) ap[p][i] = *reinterpret_cast<const bf16x8*>(s_in + p * IN_ROWS * 16 + o);
     }
     // the weight fragments of sub-tile j+1 are read while the 16 MFMAs of sub-tile j issue
-    bf16x8 bp[2][3];
+    bf16x8 bp[2][NP];
     auto load_b = [&](int j) {
       const int R = (j * WN + wn) * 32 + l31;
       const int o = R * 16 + swz_half(R, half);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bp[j & 1][p] = *reinterpret_cast<const bf16x8*>(s_w + p * TN * 16 + o);
+      for (int p = 0; p < NP; ++p) bp[j & 1][p] = *reinterpret_cast<const bf16x8*>(s_w + p * TN * 16 + o);
     };
     if (NJ > 0) load_b(0);
 #pragma unroll
@@ -191,7 +204,9 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
       // eight of the nine plane products, smallest first; only l*l (< 2^-32 |a||b|) is dropped
 #define C3D_PLANE(PA, PB) \
   _Pragma("unroll") for (int i = 0; i < RPW; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA][i], bp[j & 1][PB], acc[i][j], 0, 0, 0);
-      C3D_PLANE(2, 1) C3D_PLANE(1, 2) C3D_PLANE(2, 0) C3D_PLANE(0, 2) C3D_PLANE(1, 1) C3D_PLANE(1, 0) C3D_PLANE(0, 1)
+      if constexpr (NP == 3) {
+        C3D_PLANE(2, 1) C3D_PLANE(1, 2) C3D_PLANE(2, 0) C3D_PLANE(0, 2) C3D_PLANE(1, 1) C3D_PLANE(1, 0) C3D_PLANE(0, 1)
+      }
       C3D_PLANE(0, 0)
 #undef C3D_PLANE
       __builtin_amdgcn_sched_barrier(0);
@@ -215,32 +230,33 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
     else if (nj == 1) mfma_chunk(cur, std::integral_constant<int, 1>{});
     __syncthreads();                       // the other buffer is complete, this one is free again
   }
-  conv_epilogue<TR, NT, WM, WN, false, true, 512, true>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
+  conv_epilogue<TR, NT, WM, WN, NP == 1, true, 512, true>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
                                                   tile_pix);
 }
 
-template <int NT>
+template <int NT, int NP>
 int launch_pw3(ConvArgs& a, hipStream_t st) {
-  size_t lds = (size_t)2 * 3 * (8 * 32 + 32 * NT) * 16 * 2;
+  size_t lds = (size_t)2 * NP * (8 * 32 + 32 * NT) * 16 * 2;
   const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
   if (lds < red) lds = red;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw3_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw3_kernel<NT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     attr_set = true;
   }
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
-  hipLaunchKernelGGL((conv_pw3_kernel<NT>), grid, dim3(512), lds, st, a);
+  hipLaunchKernelGGL((conv_pw3_kernel<NT, NP>), grid, dim3(512), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;
 }
 
 }  // namespace
 
-// called by c3d_conv_forward for mfma_bf16 == 2, 8-row tiles, one tap, Cout > 64; a.wpack must be a
-// c3d_pack_weights(mode | 2) pack (fp32 image followed by the three bf16 planes)
-int c3d_conv_forward_pw3(ConvArgs& a, hipStream_t st) {
-  return a.Cout > 128 ? launch_pw3<8>(a, st) : launch_pw3<4>(a, st);
+// called by c3d_conv_forward for mfma_bf16 == 1 / 2 (planes = 1 / 3), 8-row tiles, one tap, Cout > 64;
+// a.wpack must be a c3d_pack_weights(mode | 2) pack (fp32 image followed by the three bf16 planes)
+int c3d_conv_forward_pw3(ConvArgs& a, int planes, hipStream_t st) {
+  if (planes == 3) return a.Cout > 128 ? launch_pw3<8, 3>(a, st) : launch_pw3<4, 3>(a, st);
+  return a.Cout > 128 ? launch_pw3<8, 1>(a, st) : launch_pw3<4, 1>(a, st);
 }

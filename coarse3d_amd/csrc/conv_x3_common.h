@@ -23,6 +23,19 @@ __device__ __forceinline__ void split4x3(f32x4 v, u32x2 (&out)[3]) {
   }
 }
 
+template <int NP>
+__device__ __forceinline__ void split4_planes(f32x4 v, u32x2 (&out)[NP]) {
+  if constexpr (NP == 3) {
+    split4x3(v, out);
+  } else {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h[q] = (__bf16)v[q];
+    out[0] = __builtin_bit_cast(u32x2, h);
+  }
+}
+
 // LDS rows are 32 B (16 channels) with NO padding; the two 16-B halves of row R are swapped when
 // bit 3 of R is set, which makes every ds_read_b128 fragment read conflict-free.
 // element offset (bf16 units) of channel quad c4 (0..3) inside the 16-channel row R

@@ -133,9 +133,10 @@ def pack_weights(w, mode=0, c_off=0, c_cnt=None, kpad=None):
     if kpad is None:
         kpad = (k + 15) // 16 * 16
     numel = t * (kpad // 4) * n * 4
-    # bf16x3 engine: the pre-split bf16 planes follow the fp32 image for the kernels that read them
-    # (multi-tap convs: csrc/conv_x3.hip; 1x1 convs with more than 64 outputs: csrc/conv_pw3.hip)
-    planes = MFMA_MODE == 2 and (t > 1 or n > 64)
+    # bf16-pipe engines: the pre-split bf16 planes follow the fp32 image for the kernels that read them
+    # (bf16x3 multi-tap convs: csrc/conv_x3.hip; 1x1 convs with more than 64 outputs in both bf16 modes:
+    # csrc/conv_pw3.hip -- the "bf16" mode reads the first plane only, which is the RNE-rounded weight)
+    planes = (MFMA_MODE == 2 and t > 1) or (MFMA_MODE != 0 and t == 1 and n > 64)
     dst = torch.empty(numel * 5 // 2 if planes else numel, device=w.device, dtype=torch.float32)
     L.check(L.lib().c3d_pack_weights(_p(w), _p(dst), cout, cin, t, mode | (2 if planes else 0), c_off, c_cnt, kpad,
                                      _stream()), "c3d_pack_weights")
@@ -160,7 +161,7 @@ class PackCache:
                                  # baked the old table's address must not be replayed any more
 
     def get(self, w, mode=0, c_off=0, c_cnt=None, kpad=None):
-        key = (w.data_ptr(), tuple(w.shape), mode, c_off, c_cnt, kpad, MFMA_MODE == 2)   # parameter storage is stable across steps
+        key = (w.data_ptr(), tuple(w.shape), mode, c_off, c_cnt, kpad, MFMA_MODE)   # parameter storage is stable across steps
         ent = self.entries.get(key)
         if ent is not None and self.fresh:
             return ent[5]
@@ -229,8 +230,8 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     k32 = tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs)
     if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
         name = f"conv_x3_kernel<{2 if cout > 32 else 1}, {hh}, {nt_}>"
-    elif MFMA_MODE == 2 and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes:     # csrc/conv_pw3.hip
-        name = f"conv_pw3_kernel<{8 if cout > 128 else 4}>"
+    elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes:     # csrc/conv_pw3.hip
+        name = f"conv_pw3_kernel<{8 if cout > 128 else 4}, {3 if MFMA_MODE == 2 else 1}>"
     elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
         np_ = 3 if MFMA_MODE == 2 else 1
         name = (f"conv_bfp_kernel<8, {2 if cout > 32 else 1}, 32, 0, 1, {np_}>" if k32 else
