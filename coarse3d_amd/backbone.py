@@ -458,10 +458,11 @@ class Backbone:
         dict name -> preallocated gradient tensor (reference layout); returned filled."""
         P = self.P
         if grads is None:
-            grads = {k: torch.zeros_like(v) for k, v in P.items()
+            grads = {k: torch.empty_like(v) for k, v in P.items()
                      if v.is_floating_point() and v.dim() > 0 and not k.endswith(("running_mean", "running_var"))
                      and k not in ("prototypes", "feat_norm.weight", "feat_norm.bias", "mask_norm.weight",
                                    "mask_norm.bias")}
+            torch._foreach_zero_(list(grads.values()))      # a few multi-tensor launches instead of ~100 fills
         self.grads = grads
         d0b, d1b, d2b, d3b = self.skips
         def done(tag):

@@ -193,9 +193,10 @@ class RangeNetBackbone(Backbone):
     def backward(self, d_prob=None, d_feat=None, grads=None):
         """d_prob [B,H,Wo,C], d_feat [B,H,W,256] (NHWC).  ``grads``: name -> preallocated gradient."""
         if grads is None:
-            grads = {k: torch.zeros_like(v) for k, v in self.P.items()
+            grads = {k: torch.empty_like(v) for k, v in self.P.items()
                      if v.is_floating_point() and v.dim() > 0 and not k.endswith(("running_mean", "running_var"))
                      and k != "prototypes" and not k.startswith(("feat_norm", "mask_norm"))}
+            torch._foreach_zero_(list(grads.values()))      # a few multi-tensor launches instead of ~100 fills
         self.grads = grads
         def hook(tag):                                       # see Backbone.backward
             if self.on_block_done is not None:

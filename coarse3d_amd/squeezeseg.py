@@ -162,9 +162,10 @@ class SqueezeSegBackbone(RangeNetBackbone):
     def backward(self, d_prob=None, d_feat=None, grads=None):
         """d_prob [B,H,W,C], d_feat [B,H,W,256] (NHWC).  ``grads``: name -> preallocated gradient."""
         if grads is None:
-            grads = {k: torch.zeros_like(v) for k, v in self.P.items()
+            grads = {k: torch.empty_like(v) for k, v in self.P.items()
                      if v.is_floating_point() and v.dim() > 0 and not k.endswith(("running_mean", "running_var"))
                      and k != "prototypes" and not k.startswith(("feat_norm", "mask_norm", "head1", "head2", "head3", "head4"))}
+            torch._foreach_zero_(list(grads.values()))      # a few multi-tensor launches instead of ~100 fills
         self.grads = grads
 
         def hook(tag):                                       # see Backbone.backward

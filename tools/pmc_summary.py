@@ -5,7 +5,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.OrderedDict()
 for r in rows:
     k = r["Kernel_Name"]
-    if "mfma" not in k and "bfp" not in k and "x3" not in k:
+    if not any(t in k for t in ("mfma", "bfp", "x3", "pw3", "wgrad_tr")):
         continue
     key = (k.replace("(anonymous namespace)::", "").replace("void ", "")[:44], r["Dispatch_Id"])
     agg.setdefault(key, {})[r["Counter_Name"]] = float(r["Counter_Value"])
