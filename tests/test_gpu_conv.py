@@ -21,6 +21,12 @@ CASES = [
     (2, 2, 64, [256], 256, 3, 2, 2),
     (1, 32, 32, [32], 20, 1, 1, 0),
     (1, 8, 64, [128], 400, 1, 1, 0),
+    # wide 1x1 layers (conv_pw3.hip in the bf16-pipe modes): three cout tiles with a ragged last one
+    # (704 = 256 + 256 + 192), two sources, ragged W; 160 = one 256-wide tile with 5 live sub-tiles;
+    # 96 = one 128-wide tile with 3 live sub-tiles
+    (1, 16, 70, [32, 48], 704, 1, 1, 0),
+    (2, 8, 33, [64], 160, 1, 1, 0),
+    (1, 8, 64, [16], 96, 1, 1, 0),
 ]
 
 
@@ -100,7 +106,11 @@ def test_bf16_operand_mode(B, H, W, srcC, Cout, k, dil, pad):
     shs = [torch.randn(c, generator=g) * 0.3 for c in srcC]
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
     bias = torch.randn(Cout, generator=g) * 0.1
-    xin = torch.cat([x * s[None, :, None, None] + t[None, :, None, None] for x, s, t in zip(xs, scs, shs)], 1)
+    # the kernel's on-load affine is ONE fused multiply-add: emulate it in float64 and round once to fp32
+    # (two fp32 roundings put a few operands on the other side of a bf16 rounding boundary, and with 704
+    # output channels sharing one flipped operand that showed as 5e-4)
+    xin = torch.cat([(x.double() * s[None, :, None, None].double() + t[None, :, None, None].double()).float()
+                     for x, s, t in zip(xs, scs, shs)], 1)
     xin_b = _bf(xin).double().requires_grad_(True)
     w_b = _bf(w).double().requires_grad_(True)
     z = F.conv2d(xin_b, w_b, bias.double(), padding=pad, dilation=dil)
