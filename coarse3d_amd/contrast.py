@@ -89,7 +89,10 @@ def contrast_mem_loss(feats, prob, labels, keep_mask, proto_queue, temperature=0
     m = proto_queue.shape[1]
     q = proto_queue.detach()[1:]
     if perms is None:
-        perms = torch.stack([torch.randperm(m, device=dev) for _ in range(c - 1)])
+        # one uniformly random row order per class: argsort of iid keys, two launches instead of the
+        # ~100 tiny ones of C-1 torch.randperm calls (contrast_loss.py draws them with randperm; the
+        # parity tests inject ``perms``)
+        perms = torch.rand(c - 1, m, device=dev).argsort(dim=1)
     q = torch.gather(q, 1, perms.to(dev)[:, :, None].expand(-1, -1, d)).reshape((c - 1) * m, d).contiguous()
     qn, _ = ops.l2norm(q, 1e-12, want_norm=False)
     ncols = (c - 1) * m

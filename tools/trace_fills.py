@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Which Python lines launch fill kernels in one training step (torch profiler with stacks); run on the GPU box."""
+import collections, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from coarse3d_amd import ops
+from coarse3d_amd.pc_processor.models import SalsaNextProto
+from coarse3d_amd.trainer import TrainStep
+ops.set_matrix_precision(sys.argv[1] if len(sys.argv) > 1 else "bf16x3")
+dev = "cuda"
+torch.manual_seed(1)
+model = SalsaNextProto(5, 20, 20, 0, use_prototype=True, dataset="SemanticKitti").to(dev).train()
+ts = TrainStep(model, 20, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512, loss_w_ce_2d=1.0, loss_w_lov_2d=1.0,
+               loss_w_contrast=0.1, feature_mean=bench.FEATURE_MEAN, feature_std=bench.FEATURE_STD, proto_loss=True,
+               inputs_resident=True)
+batches = [bench.synth_batch(8, 64, 2048, 20, 1000 + s, dev, 1e-3) for s in range(3)]
+for s in range(2):
+    ts.step(*batches[s], epoch=10)
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    ts.step(*batches[2], epoch=10)
+    torch.cuda.synchronize()
+agg = collections.Counter()
+for ev in prof.events():
+    if ev.name in ("aten::fill_", "aten::zero_"):
+        chain, p = [], ev.cpu_parent
+        while p is not None and len(chain) < 4:
+            chain.append(p.name)
+            p = p.cpu_parent
+        agg[ev.name + " <- " + " <- ".join(chain)] += 1
+for k, v in agg.most_common(30):
+    print(v, k)
