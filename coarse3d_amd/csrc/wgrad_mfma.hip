@@ -25,8 +25,8 @@ namespace {
 
 // BF = false: fp32 MFMA (default parity path).  BF = true: operands rounded to bf16 (RNE) when
 // read from LDS, v_mfma_f32_32x32x16_bf16 with k = 16 consecutive pixels per step (lane l:
-// channel l&31, pixels 8*(l>>5)..+7), fp32 accumulation -- the opt-in "bf16" mode.  The
-// fp32-accurate "bf16x3" mode keeps the fp32-MFMA weight gradient.
+// channel l&31, pixels 8*(l>>5)..+7), fp32 accumulation -- the first-generation "bf16" mode, kept
+// behind C3D_WGRAD_TR=0 for A/B measurements; both bf16-pipe modes run wgrad_tr.hip by default.
 template <int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool BF>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   constexpr int WK = 4 / (WCI * WCO);
