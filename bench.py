@@ -459,29 +459,50 @@ def main():
             # the same step on the fp32-MFMA engine (v_mfma_f32_32x32x2_f32), timed the same way, for comparison
             del ts, wrapped, model, res
             torch.cuda.empty_cache()
-            ops.set_matrix_precision("f32")
-            torch.manual_seed(1)
-            m2 = (SalsaNextProto(5, args.classes, 20, 0, use_prototype=True, dataset=args.dataset) if args.net == "salsanext"
-                  else RangeNetProto(layers=int(args.net[-2:]), nclasses=args.classes, dataset=args.dataset, use_prototype=True)
-                  if args.net.startswith("rangenet")
-                  else SqueezeSegV3Proto(nclasses=args.classes, layers=int(args.net[-2:]), dataset=args.dataset, use_prototype=True))
-            m2 = m2.to(dev).train()
-            ts2 = TrainStep(m2, args.classes, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512, loss_w_ce_2d=1.0,
-                            loss_w_lov_2d=1.0, loss_w_contrast=0.1, feature_mean=FEATURE_MEAN, feature_std=FEATURE_STD,
-                            proto_loss=True, inputs_resident=True)
             k2 = min(args.steps, 10)
-            for s_ in range(min(args.warmup, 2) or 1):
-                ts2.step(*batches[s_], epoch=10)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for s_ in range(k2):
-                ts2.step(*batches[(args.warmup + s_) % total_steps], epoch=10)
-            torch.cuda.synchronize()
-            e2 = time.perf_counter() - t1
-            out["engines"] = {"f32_mfma": {"value": round(args.batch * k2 / e2, 3), "ms_per_step": round(e2 / k2 * 1e3, 3),
-                                           "steps": k2, "dtype": "f32 (v_mfma_f32_32x32x2_f32 everywhere)"},
-                              "note": "`value` is the bf16x3 engine's; this is the same step on the fp32-MFMA engine "
-                                      "(python bench.py --matrix-dtype f32 gives its full roofline object)"}
+
+            def quick_run(dtype, wgrad_stream):
+                """value / ms_per_step of k2 steps of the same workload on another engine configuration"""
+                ops.set_matrix_precision(dtype)
+                prev = os.environ.get("C3D_WGRAD_STREAM")
+                os.environ["C3D_WGRAD_STREAM"] = wgrad_stream        # read when the backbone is built
+                try:
+                    torch.manual_seed(1)
+                    m2 = (SalsaNextProto(5, args.classes, 20, 0, use_prototype=True, dataset=args.dataset) if args.net == "salsanext"
+                          else RangeNetProto(layers=int(args.net[-2:]), nclasses=args.classes, dataset=args.dataset, use_prototype=True)
+                          if args.net.startswith("rangenet")
+                          else SqueezeSegV3Proto(nclasses=args.classes, layers=int(args.net[-2:]), dataset=args.dataset, use_prototype=True))
+                    m2 = m2.to(dev).train()
+                    ts2 = TrainStep(m2, args.classes, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512, loss_w_ce_2d=1.0,
+                                    loss_w_lov_2d=1.0, loss_w_contrast=0.1, feature_mean=FEATURE_MEAN, feature_std=FEATURE_STD,
+                                    proto_loss=True, inputs_resident=True)
+                    for s_ in range(min(args.warmup, 2) or 1):
+                        ts2.step(*batches[s_], epoch=10)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for s_ in range(k2):
+                        ts2.step(*batches[(args.warmup + s_) % total_steps], epoch=10)
+                    torch.cuda.synchronize()
+                    e2 = time.perf_counter() - t1
+                finally:
+                    if prev is None:
+                        os.environ.pop("C3D_WGRAD_STREAM", None)
+                    else:
+                        os.environ["C3D_WGRAD_STREAM"] = prev
+                del ts2, m2
+                torch.cuda.empty_cache()
+                return {"value": round(args.batch * k2 / e2, 3), "ms_per_step": round(e2 / k2 * 1e3, 3), "steps": k2}
+
+            f32_run = quick_run("f32", os.environ.get("C3D_WGRAD_STREAM", "auto"))
+            f32_run["dtype"] = "f32 (v_mfma_f32_32x32x2_f32 everywhere)"
+            overlap_run = quick_run("bf16x3", "1")
+            overlap_run["note"] = ("the headline engine with the weight-gradient chain of the backward pass on a second HIP stream "
+                                   "(C3D_WGRAD_STREAM=1; what data-parallel runs use): weight gradients then execute under the "
+                                   "BatchNorm-backward / elementwise kernels of the main chain.  Off by default on one GPU because the "
+                                   "kernels of the two streams share the CUs and every per-kernel duration of `roofline` would inflate")
+            out["engines"] = {"f32_mfma": f32_run, "bf16x3_wgrad_on_second_stream": overlap_run,
+                              "note": "`value` is the bf16x3 engine's on one stream; these are the same step on the fp32-MFMA engine "
+                                      "(python bench.py --matrix-dtype f32 gives its full roofline object) and with the second stream on"}
             ops.set_matrix_precision(args.matrix_dtype)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = (cpu_baseline(args.classes, args.height, args.width) if args.net == "salsanext"
