@@ -395,6 +395,10 @@ def main():
                     "all_mfma_kernels": {"achieved": round(all_fl / all_sec / 1e12, 2),
                                          "frac": round(all_ideal / all_sec, 4),
                                          "frac_note": "time at each kernel's own matrix-pipe peak / measured time",
+                                         "achieved_vs_fp32_mfma_peak": round(all_fl / all_sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                         "achieved_vs_fp32_mfma_peak_note": "the same fp32-class TFLOP/s against the 157.3 TFLOP/s "
+                                                                            "ceiling of the fp32 MFMA instructions the reference "
+                                                                            "arithmetic would run on (round 1's yardstick)",
                                          "ms_per_step": round(all_sec / all_steps * 1e3, 2),
                                          "measured_in": "last warm-up step" if all_steps == 1 else "timed steps"}}
     ops.KERNEL_EVENTS = None
