@@ -237,3 +237,49 @@ def _random_shape_cases(ops, rnd, dev):
             ops.conv_wgrad(src, dzd, dw, taps, cin_off=off)
             off += c
         assert rel_err(dw.cpu(), w_ref.grad) < 1e-4, tag
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,dil,pad", [
+    (2, 64, 2048, 32, 32, 3, 1, 1),      # 16 tiles per strip: the steady-state loop of the producer waves
+    (1, 64, 2048, 64, 48, 3, 2, 2),      # dilation-2 halo, ragged cout
+    (4, 32, 1024, 160, 224, 1, 1, 0),    # 128x256 slices (ragged in both), 32 tiles per strip
+    (1, 64, 2040, 32, 64, 2, 2, 1),      # 2x2 taps, W % 32 != 0: border tiles inside long strips
+])
+def test_weight_gradient_long_strips(mode, B, H, W, Cin, Cout, k, dil, pad):
+    """Weight gradients at sizes where every workgroup walks many pixel tiles (the unit cases above
+    give each workgroup one or two): fp64 reference computed by PyTorch on the device.  fp32-class
+    engines 1e-4 of max|ref| as everywhere; the bf16 engine against the same reference on bf16-rounded
+    operands (2e-4)."""
+    from coarse3d_amd import ops
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(B * 31 + Cin + Cout + k)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g)
+    dz = torch.randn(B, H, W, Cout, device=dev, generator=g)
+    sc = torch.rand(Cin, device=dev, generator=g) + 0.5
+    sh = torch.randn(Cin, device=dev, generator=g) * 0.1
+    taps = ops.conv_taps(k, k, dil, pad)
+    ops.set_matrix_precision(mode, storage="f32") if mode == "bf16" else ops.set_matrix_precision(mode)
+    try:
+        dw = torch.zeros(Cout, Cin, k, k, device=dev)
+        ops.conv_wgrad(ops.Source(x, sc, sh, lrelu=True), dz, dw, taps)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_matrix_precision("f32")
+    xt = F.leaky_relu((x.double() * sc.double() + sh.double()).float(), 0.01)          # one fused multiply-add, as the kernel
+    dzr = dz
+    if mode == "bf16":
+        xt, dzr = _bf(xt), _bf(dz)
+    ci_n, co_n = min(Cin, 40), min(Cout, 40)                                              # a channel subset keeps the fp64 conv small
+    wref = torch.zeros(co_n, ci_n, k, k, device=dev, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xt[..., :ci_n].double().permute(0, 3, 1, 2), wref, padding=pad, dilation=dil)
+    (gref,) = torch.autograd.grad(y, wref, dzr[..., :co_n].double().permute(0, 3, 1, 2)[:, :, :y.shape[2], :y.shape[3]])
+    e = rel_err(dw[:co_n, :ci_n].double(), gref)
+    assert e < (2e-4 if mode == "bf16" else 1e-4), e
+    if Cin > 40 or Cout > 40:                                                            # and the far corner of the slices
+        c0, o0 = Cin - min(Cin, 24), Cout - min(Cout, 24)
+        wref = torch.zeros(Cout - o0, Cin - c0, k, k, device=dev, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(xt[..., c0:].double().permute(0, 3, 1, 2), wref, padding=pad, dilation=dil)
+        (gref,) = torch.autograd.grad(y, wref, dzr[..., o0:].double().permute(0, 3, 1, 2)[:, :, :y.shape[2], :y.shape[3]])
+        e = rel_err(dw[o0:, c0:].double(), gref)
+        assert e < (2e-4 if mode == "bf16" else 1e-4), e
