@@ -385,29 +385,47 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
       const int row = ks >> 1, px0 = (ks & 1) * 16;
       const int Rd = row * 32 + px0 + lp;
       const int Rx0 = (row + HALO) * TWh + HALO + px0 + lp;
+      // Consecutive MFMAs must write DIFFERENT accumulators: a chain of dependent
+      // v_mfma_f32_32x32x16_bf16 issues at 20.7 ns per instruction, four interleaved chains at 15.8,
+      // eight at 15.0 (tools/probes/mfma_chain_probe.hip) -- the first version of this loop ran the
+      // eight plane products of one (tap, cin tile, cout tile) back to back, 38 % slower than the
+      // pipe allows.  So a group of TG taps x JG cout tiles x all cin tiles shares each plane pair:
+      // 3-4 accumulators in rotation.  (Measured effect on whole kernels: none, 0.66-0.68 ms either
+      // way on the 64 -> 64 3x3 layers -- the gaps of the dependent chain were being filled by the
+      // producer wave's VALU instructions, which share the SIMD's issue with the MFMAs; the kernel's
+      // time is matrix-pipe time + VALU time + waits in both orders.)
+      constexpr int JG = CO_T >= 2 ? 2 : 1;                                   // cout tiles per group
+      constexpr int TG = TMAX == 1 ? 1 : (TMAX % 3 == 0 ? 3 : (4 / (JG * CI_T) > 1 ? 4 / (JG * CI_T) : 1));   // taps per group
+      static_assert(TMAX % TG == 0 && CO_T % JG == 0, "tap / cout-tile groups must divide the loops");
 #pragma unroll
-      for (int j = 0; j < CO_T; ++j) {
-        bf16x8 bp[NP];
+      for (int j0 = 0; j0 < CO_T; j0 += JG) {
+        bf16x8 bp[JG][NP];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) bp[p] = tr_frag<NSD>(s_dz + p * DROWS * CO, Rd, (wco * CO_T + j) * 32 + lc);
+        for (int jg = 0; jg < JG; ++jg)
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t)
+          for (int p = 0; p < NP; ++p)
+            bp[jg][p] = tr_frag<NSD>(s_dz + p * DROWS * CO, Rd, (wco * CO_T + j0 + jg) * 32 + lc);
 #pragma unroll
-          for (int i = 0; i < CI_T; ++i) {
-            bf16x8 ap[NP];
+        for (int t0 = 0; t0 < TMAX; t0 += TG) {
+          bf16x8 ap[TG][CI_T][NP];
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
-              ap[p] = tr_frag<NSX>(s_x + p * XROWS * CI, Rx0 + tapoff[t], (wci * CI_T + i) * 32 + lc);
-            if constexpr (NP == 3) {
-              // eight of the nine plane products, smallest first
-#define C3D_PLANE(PA, PB) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA], bp[PB], acc[t][i][j], 0, 0, 0);
-              C3D_PLANE(2, 1) C3D_PLANE(1, 2) C3D_PLANE(2, 0) C3D_PLANE(0, 2) C3D_PLANE(1, 1) C3D_PLANE(1, 0)
-              C3D_PLANE(0, 1) C3D_PLANE(0, 0)
-#undef C3D_PLANE
-            } else {
-              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[0], acc[t][i][j], 0, 0, 0);
-            }
+          for (int tg = 0; tg < TG; ++tg)
+#pragma unroll
+            for (int i = 0; i < CI_T; ++i)
+#pragma unroll
+              for (int p = 0; p < NP; ++p)
+                ap[tg][i][p] = tr_frag<NSX>(s_x + p * XROWS * CI, Rx0 + tapoff[t0 + tg], (wci * CI_T + i) * 32 + lc);
+#define C3D_PLANE(PA, PB)                                                                   \
+  _Pragma("unroll") for (int tg = 0; tg < TG; ++tg) _Pragma("unroll") for (int i = 0; i < CI_T; ++i)  \
+      _Pragma("unroll") for (int jg = 0; jg < JG; ++jg) acc[t0 + tg][i][j0 + jg] =          \
+          __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[tg][i][PA], bp[jg][PB], acc[t0 + tg][i][j0 + jg], 0, 0, 0);
+          if constexpr (NP == 3) {
+            // eight of the nine plane products, smallest first
+            C3D_PLANE(2, 1) C3D_PLANE(1, 2) C3D_PLANE(2, 0) C3D_PLANE(0, 2) C3D_PLANE(1, 1) C3D_PLANE(1, 0) C3D_PLANE(0, 1)
           }
+          C3D_PLANE(0, 0)
+#undef C3D_PLANE
+        }
       }
     }
     }
