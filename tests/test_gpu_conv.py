@@ -188,7 +188,7 @@ def _random_shape_cases(ops, rnd, dev):
         B, H, W = rnd.choice([1, 2, 3]), rnd.choice([1, 2, 3, 5, 6, 8, 12, 17]), rnd.choice([7, 32, 33, 64, 95])
         nsrc = rnd.choice([1, 1, 2, 3])
         srcC = [rnd.choice([16, 32, 48]) for _ in range(nsrc)]
-        Cout = rnd.choice([16, 20, 32, 48, 64, 96])
+        Cout = rnd.choice([16, 20, 32, 48, 64, 96, 160, 272])      # > 64: the wide pointwise kernel in the bf16-pipe modes
         g = torch.Generator().manual_seed(case)
         Cin = sum(srcC)
         wide = [c + rnd.choice([0, 16]) for c in srcC]                 # sources live inside wider tensors
