@@ -33,7 +33,9 @@
 // coissue_probe.hip) shows that on gfx950 VALU instructions of one wave and MFMAs of another wave
 // on the same SIMD simply add up (t(both) = t(MFMA) + t(VALU) to 1 %), so the plane split is a tax
 // of ~0.6 ms on top of ~1.2 ms of matrix time here and cannot be hidden by scheduling -- only
-// removed (fewer re-splits per element: wider slices or planes kept in HBM).
+// removed (fewer re-splits per element: wider slices.  dz kept as pre-split planes in HBM was built
+// and measured: bit-identical, 1 % slower for the step -- three 8-byte loads per unit instead of one
+// 16-byte load cost what the saved split instructions gain).
 #include <type_traits>
 #include "wgrad_common.h"
 
