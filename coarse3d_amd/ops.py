@@ -252,13 +252,14 @@ def _wgrad_kernel_name(ci, co, nt, halo):
     """Mirrors c3d_wgrad_cfg() (csrc/wgrad_common.h) and the launch tables of wgrad_mfma.hip / wgrad_tr.hip."""
     tr = MFMA_MODE != 0 and os.environ.get("C3D_WGRAD_TR", "1") != "0"
     hl = 1 if halo <= 1 else 2
+    x3 = tr and MFMA_MODE == 2          # three planes: the smaller pixel tiles of c3d_wgrad_cfg
     if nt == 1:
         cfg = ("1, 2, 4, 2, 2, 1, 0" if (ci >= 96 and co >= 192) else "1, 2, 2, 2, 2, 1, 0" if (ci >= 96 and co >= 96)
                else f"1, 2, 2, 1, 1, {2 if tr else 4}, 0" if co > 32 else "1, 1, 1, 1, 1, 4, 0")
     elif nt == 4:
-        cfg = f"4, 1, 2, 1, 1, {2 if tr else 4}, {hl}" if co > 32 else f"4, 1, 1, 1, 1, 4, {hl}"
+        cfg = f"4, 1, 2, 1, 1, {2 if x3 else 4}, {hl}" if co > 32 else f"4, 1, 1, 1, 1, 4, {hl}"
     else:
-        cfg = f"9, 1, 1, 1, 2, 2, {hl}" if co > 32 else f"9, 1, 1, 1, 1, {2 if tr else 4}, {hl}"
+        cfg = f"9, 1, 1, 1, 2, {4 if (tr and not x3) else 2}, {hl}" if co > 32 else f"9, 1, 1, 1, 1, {2 if x3 else 4}, {hl}"
     if tr:
         return f"wgrad_tr_kernel<{3 if MFMA_MODE == 2 else 1}, {cfg}>"
     return f"wgrad_mfma_kernel<{cfg}, {'true' if MFMA_MODE == 1 else 'false'}>"
