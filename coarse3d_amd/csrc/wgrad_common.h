@@ -38,7 +38,7 @@ inline WgCfg c3d_wgrad_cfg(int T, int Cin, int Cout, int planes) {
   // (one plane: a tile costs a third of the LDS and next to no matrix time; the kernel is then bound by
   //  the per-tile synchronisation, so it takes 4-row tiles everywhere)
   if (T <= 4) return Cout > 32 ? WgCfg{4, 32, 64, planes == 3 ? 2 : 4} : WgCfg{5, 32, 32, 4};
-  return Cout > 32 ? WgCfg{6, 32, 64, planes == 1 ? 4 : 2} : WgCfg{7, 32, 32, planes == 3 ? 2 : 4};
+  return Cout > 32 ? WgCfg{6, 32, 64, planes == 1 ? 4 : 2} : WgCfg{7, 32, 32, 4};
 }
 
 // wgrad_tr.hip

@@ -506,7 +506,7 @@ int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
     case 4: return halo <= 1 ? launch_tr<NP, 4, 1, 2, 1, 1, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 4, 1, 2, 1, 1, (NP == 1 ? 4 : 2), 2>(a, st);
     case 5: return halo <= 1 ? launch_tr<NP, 4, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 4, 1, 1, 1, 1, 4, 2>(a, st);
     case 6: return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 2>(a, st);
-    default: return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, (NP == 1 ? 4 : 2), 2>(a, st);
+    default: return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, 4, 2>(a, st);
   }
 }
 

@@ -259,7 +259,7 @@ def _wgrad_kernel_name(ci, co, nt, halo):
     elif nt == 4:
         cfg = f"4, 1, 2, 1, 1, {2 if x3 else 4}, {hl}" if co > 32 else f"4, 1, 1, 1, 1, 4, {hl}"
     else:
-        cfg = f"9, 1, 1, 1, 2, {4 if (tr and not x3) else 2}, {hl}" if co > 32 else f"9, 1, 1, 1, 1, {2 if x3 else 4}, {hl}"
+        cfg = f"9, 1, 1, 1, 2, {4 if (tr and not x3) else 2}, {hl}" if co > 32 else f"9, 1, 1, 1, 1, 4, {hl}"
     if tr:
         return f"wgrad_tr_kernel<{3 if MFMA_MODE == 2 else 1}, {cfg}>"
     return f"wgrad_mfma_kernel<{cfg}, {'true' if MFMA_MODE == 1 else 'false'}>"
