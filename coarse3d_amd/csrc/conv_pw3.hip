@@ -72,7 +72,9 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
   //      (Tried on top: the input tile two chunks ahead in a second register set -- no change,
   //      1.79 ms either way on the 704x704 layer; weight fragments of sub-tile j+1 read ahead of the
   //      MFMAs of sub-tile j -- kept, neutral.  Phase ablation of that layer: matrix phase 1.1 ms,
-  //      staging 0.6 ms, epilogue + loop 0.24 ms, and the three simply add up.)
+  //      staging 0.6 ms, epilogue + loop 0.24 ms, and the three simply add up.  In the one-plane mode:
+  //      two / four chunks per barrier -- 0.71 -> 0.64 ms on that layer, 303.9 -> 304.7 img/s for the
+  //      step, not kept.)
   f32x4 pin[IN_PT];
   u32x2 pw[W_PT][NP];
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
