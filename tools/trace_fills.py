@@ -24,7 +24,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     torch.cuda.synchronize()
 agg = collections.Counter()
 for ev in prof.events():
-    if ev.name in ("aten::fill_", "aten::zero_"):
+    if ev.name in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::clone", "aten::contiguous", "aten::cat", "aten::stack"):
         chain, p = [], ev.cpu_parent
         while p is not None and len(chain) < 4:
             chain.append(p.name)
