@@ -45,6 +45,12 @@ def set_matrix_precision(kind, storage=None):
     STORAGE_BF16 = kind == "bf16" and storage != "f32"
 
 
+def matrix_precision_state():
+    """(kind, storage) to hand back to ``set_matrix_precision`` -- for code that switches engines temporarily."""
+    kind = {v: k for k, v in _MODES.items()}[MFMA_MODE]
+    return kind, (("bf16" if STORAGE_BF16 else "f32") if kind == "bf16" else None)
+
+
 def act_dtype():
     """dtype of the activations a fresh backbone pass should produce."""
     return torch.bfloat16 if STORAGE_BF16 else torch.float32

@@ -21,3 +21,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _matrix_engine_is_the_requested_one(request):
+    """`C3D_MATRIX=<engine> pytest -m gpu` claims the whole suite ran on that engine: a test that switches
+    engines and forgets to switch back would silently move every later test to another one (round 2 found
+    exactly that: `finally: set_matrix_precision("f32")`).  Checked before and after every GPU test."""
+    want = os.environ.get("C3D_MATRIX")
+    if not want or "gpu" not in request.keywords:
+        yield
+        return
+    from coarse3d_amd import ops
+    assert ops.matrix_precision_state()[0] == want, f"engine is {ops.matrix_precision_state()[0]} before the test, not {want}"
+    yield
+    assert ops.matrix_precision_state()[0] == want, f"the test left the engine at {ops.matrix_precision_state()[0]}, not {want}"

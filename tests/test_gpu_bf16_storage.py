@@ -30,9 +30,10 @@ def close32(got, ref, what, tol=1e-5):
 @pytest.fixture(autouse=True)
 def bf16_mode():
     from coarse3d_amd import ops
+    prev = ops.matrix_precision_state()
     ops.set_matrix_precision("bf16")
     yield
-    ops.set_matrix_precision("f32")
+    ops.set_matrix_precision(*prev)
 
 
 def test_glue_kernels_bf16_vs_fp32_storage():

@@ -11,6 +11,7 @@ import weights as W
 from oracle import coarse3d_oracle as oc
 
 pytestmark = pytest.mark.gpu
+_PREV = []          # matrix-engine states to restore: the suite may run under C3D_MATRIX=<engine>
 DEV = "cuda"
 
 
@@ -133,6 +134,7 @@ def test_bf16_matrix_mode_at_config2_size():
     b, h, w, ncls = 8, 64, 2048, 20
     outs = {}
     for kind in ("f32", "bf16"):
+        _PREV.append(ops.matrix_precision_state())
         ops.set_matrix_precision(kind)
         try:
             torch.manual_seed(1)
@@ -147,7 +149,7 @@ def test_bf16_matrix_mode_at_config2_size():
             del m, ts, res
             torch.cuda.empty_cache()
         finally:
-            ops.set_matrix_precision("f32")
+            ops.set_matrix_precision(*_PREV.pop())
     for k in ("ce", "lov", "contrast", "loss"):
         assert torch.isfinite(outs["bf16"][k]).all()
     dp = (outs["f32"]["pred_2d"] - outs["bf16"]["pred_2d"]).abs()
@@ -169,6 +171,7 @@ def test_bf16_matrix_mode_tracks_fp32():
     b, h, w, ncls = 2, 64, 512, 20
     outs = {}
     for kind in ("f32", "bf16"):
+        _PREV.append(ops.matrix_precision_state())
         ops.set_matrix_precision(kind)
         try:
             torch.manual_seed(1)
@@ -181,7 +184,7 @@ def test_bf16_matrix_mode_tracks_fp32():
             res = ts.step(x, tr, ev, epoch=0)
             outs[kind] = (res, {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
         finally:
-            ops.set_matrix_precision("f32")
+            ops.set_matrix_precision(*_PREV.pop())
     r32, g32 = outs["f32"]
     r16, g16 = outs["bf16"]
     dp = (r32["pred_2d"] - r16["pred_2d"]).abs()

@@ -5,6 +5,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+_PREV = []          # matrix-engine states to restore: the suite may run under C3D_MATRIX=<engine>
 
 
 def rel_err(a, b):
@@ -121,6 +122,7 @@ def test_bf16_operand_mode(B, H, W, srcC, Cout, k, dil, pad):
     dev = "cuda"
     taps = ops.conv_taps(k, k, dil, pad)
     srcs = [ops.Source(ops.to_nhwc(x).to(dev), s.to(dev), t.to(dev)) for x, s, t in zip(xs, scs, shs)]
+    _PREV.append(ops.matrix_precision_state())
     ops.set_matrix_precision("bf16")
     try:
         wp = ops.pack_weights(w.to(dev), mode=0)
@@ -147,7 +149,7 @@ def test_bf16_operand_mode(B, H, W, srcC, Cout, k, dil, pad):
         e = rel_err(dw.cpu().double(), w_b.grad)
         assert e < 2e-4, e
     finally:
-        ops.set_matrix_precision("f32")
+        ops.set_matrix_precision(*_PREV.pop())
 
 
 @pytest.mark.parametrize("B,H,W,srcC,Cout,k,dil,pad", CASES)
@@ -157,11 +159,12 @@ def test_split_bf16_mode_is_fp32_accurate(B, H, W, srcC, Cout, k, dil, pad):
     weight gradient (operands through the LDS transpose read, csrc/wgrad_tr.hip).  Same bar as the fp32 MFMA path: 1e-4 of max|ref| against
     plain PyTorch fp32."""
     from coarse3d_amd import ops
+    _PREV.append(ops.matrix_precision_state())
     ops.set_matrix_precision("bf16x3")
     try:
         test_conv_forward_and_grads(B, H, W, srcC, Cout, k, dil, pad)
     finally:
-        ops.set_matrix_precision("f32")
+        ops.set_matrix_precision(*_PREV.pop())
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
@@ -175,11 +178,12 @@ def test_conv_engine_random_shapes(mode):
     from coarse3d_amd import ops
     rnd = random.Random(1234)
     dev = "cuda"
+    _PREV.append(ops.matrix_precision_state())
     ops.set_matrix_precision(mode)
     try:
         _random_shape_cases(ops, rnd, dev)
     finally:
-        ops.set_matrix_precision("f32")
+        ops.set_matrix_precision(*_PREV.pop())
 
 
 def _random_shape_cases(ops, rnd, dev):
@@ -259,13 +263,14 @@ def test_weight_gradient_long_strips(mode, B, H, W, Cin, Cout, k, dil, pad):
     sc = torch.rand(Cin, device=dev, generator=g) + 0.5
     sh = torch.randn(Cin, device=dev, generator=g) * 0.1
     taps = ops.conv_taps(k, k, dil, pad)
+    _PREV.append(ops.matrix_precision_state())
     ops.set_matrix_precision(mode, storage="f32") if mode == "bf16" else ops.set_matrix_precision(mode)
     try:
         dw = torch.zeros(Cout, Cin, k, k, device=dev)
         ops.conv_wgrad(ops.Source(x, sc, sh, lrelu=True), dz, dw, taps)
         torch.cuda.synchronize()
     finally:
-        ops.set_matrix_precision("f32")
+        ops.set_matrix_precision(*_PREV.pop())
     xt = F.leaky_relu((x.double() * sc.double() + sh.double()).float(), 0.01)          # one fused multiply-add, as the kernel
     dzr = dz
     if mode == "bf16":
