@@ -219,7 +219,7 @@ def main():
     ap.add_argument("--matrix-dtype", choices=("f32", "bf16", "bf16x3"), default="bf16x3",
                     help="matrix engine of conv / input-gradient kernels.  bf16x3 (default): every fp32 operand split "
                          "EXACTLY into three bf16 planes, eight of the nine plane products accumulated in fp32 on the "
-                         "bf16 MFMA pipe -- fp32-class results (the whole -m gpu parity suite passes unchanged in this "
+                         "bf16 MFMA pipe -- fp32-class results (the whole -m gpu parity suite passes in this "
                          "mode: tests/test_gpu_configs.py::test_whole_gpu_suite_passes_on_the_exact_split_bf16_engine); "
                          "f32: the fp32-MFMA engine (also timed, reported under `engines`); bf16: opt-in mixed "
                          "precision (operands rounded to bf16, fp32 accumulate and storage; BASELINE configs[2])")

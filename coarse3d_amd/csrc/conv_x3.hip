@@ -4,7 +4,7 @@
 // Arithmetic: every fp32 operand is split exactly into three bf16 planes (x = h + m + l) and
 // eight of the nine plane products are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 -- only
 // l*l (< 2^-32 |a||b|) is dropped, so every product is exact far below fp32 resolution and the
-// result carries fp32 accumulation rounding only (the whole parity suite passes unchanged in this
+// result carries fp32 accumulation rounding only (the whole parity suite passes in this
 // mode: C3D_MATRIX=bf16x3).  Eight bf16 MFMAs cost half the issue time of the fp32 MFMAs they
 // replace; the first-generation kernel could not cash that in because its LDS image (three
 // planes of the input tile AND of all nine weight taps, padded rows: 130-145 KB) left ONE
