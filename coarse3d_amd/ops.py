@@ -20,7 +20,8 @@ KERNEL_EVENT_FILTER = None       # None = every MFMA launch; else only launches 
 #   1 "bf16"   operands rounded to bf16 inside the kernels, fp32 accumulate; activations stored as bf16
 #              (STORAGE_BF16) or fp32 -- opt-in mixed precision, BASELINE configs[2]
 #   2 "bf16x3" fp32 operands split exactly into three bf16 planes, eight of nine plane products per step on
-#              the bf16 matrix pipe: fp32-class results (csrc/conv_x3.hip, csrc/conv_bfp.hip); what bench.py runs
+#              the bf16 matrix pipe (six in the weight gradient, whose error is the fp32 accumulation's either
+#              way): fp32-class results (csrc/conv_x3.hip, conv_pw3.hip, conv_bfp.hip, wgrad_tr.hip); what bench.py runs
 _MODES = {"f32": 0, "bf16": 1, "bf16x3": 2}
 # C3D_MATRIX=bf16x3 python -m pytest tests -m gpu   runs the WHOLE parity suite on the exact-split engine
 MFMA_MODE = _MODES[__import__("os").environ.get("C3D_MATRIX", "f32")]

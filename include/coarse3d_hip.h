@@ -125,7 +125,8 @@ int c3d_pack_weights_batch(const c3d_pack_entry* table_dev, int n, c3d_stream st
  * completely: the tiling (and the scratch size) depends on mfma_bf16, shapes and taps.
  * mfma_bf16 == 0: fp32 MFMA (wgrad_mfma.hip).  1 / 2: bf16 matrix pipe with the operands read
  * through the LDS transpose read (wgrad_tr.hip) -- 1: operands rounded to bf16, 2: exact 3-plane
- * split, eight of nine plane products (fp32-class).                                            */
+ * split, six of the nine plane products (a sum over >= 10^4 pixels: against float64 the result is
+ * as accurate as with eight, its error is the fp32 accumulation's; measured in wgrad_tr.hip).   */
 typedef struct {
   c3d_src x;                /* input of the forward conv (same transform as forward)      */
   const float* dz;          /* NHWC [B,H,W,Cout] gradient w.r.t. the conv output (pre-act) */

@@ -155,8 +155,9 @@ def test_bf16_operand_mode(B, H, W, srcC, Cout, k, dil, pad):
 @pytest.mark.parametrize("B,H,W,srcC,Cout,k,dil,pad", CASES)
 def test_split_bf16_mode_is_fp32_accurate(B, H, W, srcC, Cout, k, dil, pad):
     """'bf16x3': conv / dgrad split every fp32 operand exactly into three bf16 planes while
-    staging and accumulate eight of the nine plane products in fp32 on the bf16 matrix pipe; so does the
-    weight gradient (operands through the LDS transpose read, csrc/wgrad_tr.hip).  Same bar as the fp32 MFMA path: 1e-4 of max|ref| against
+    staging and accumulate eight of the nine plane products in fp32 on the bf16 matrix pipe; the weight
+    gradient six (operands through the LDS transpose read, csrc/wgrad_tr.hip: a sum over all pixels, as
+    accurate against float64 with six as with eight).  Same bar as the fp32 MFMA path: 1e-4 of max|ref| against
     plain PyTorch fp32."""
     from coarse3d_amd import ops
     _PREV.append(ops.matrix_precision_state())
