@@ -271,10 +271,14 @@ def main():
     def peak_for(kernel_name):
         """Matrix-pipe ceiling of one kernel instance: conv_bfp / conv_x3 / wgrad_tr instances run on the bf16
         pipe (eight plane products per fp32 product in the "<3" instances); the rest on fp32 MFMA."""
-        if kernel_name.startswith("conv_pw3_kernel"):
-            return PEAK_BF16_MFMA_TFLOPS / 8.0 if kernel_name.endswith("3>") else PEAK_BF16_MFMA_TFLOPS
-        if kernel_name.startswith(("conv_x3_kernel", "conv_bfp_kernel")):
-            return PEAK_BF16_MFMA_TFLOPS / 8.0 if kernel_name.rstrip(">").endswith("3") or "x3" in kernel_name else PEAK_BF16_MFMA_TFLOPS
+        if kernel_name.startswith("conv_pw3_kernel"):        # <NT, NP, SIX>
+            if ", 3, " not in kernel_name:
+                return PEAK_BF16_MFMA_TFLOPS
+            return PEAK_BF16_MFMA_TFLOPS / (6.0 if kernel_name.endswith("true>") else 8.0)
+        if kernel_name.startswith("conv_x3_kernel"):         # <NT, HALO, TT, SIX>
+            return PEAK_BF16_MFMA_TFLOPS / (6.0 if kernel_name.endswith("true>") else 8.0)
+        if kernel_name.startswith("conv_bfp_kernel"):
+            return PEAK_BF16_MFMA_TFLOPS / 8.0 if kernel_name.rstrip(">").endswith("3") else PEAK_BF16_MFMA_TFLOPS
         if kernel_name.startswith("wgrad_mfma_kernel") and kernel_name.endswith("true>"):
             return PEAK_BF16_MFMA_TFLOPS
         if kernel_name.startswith("wgrad_tr_kernel"):
@@ -383,8 +387,10 @@ def main():
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2),
                     "peak": round(peak_tf, 1), "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak_tf, 4),
                     "peak_note": ("fp32-equivalent ceiling of the exact-split engine: dense bf16 MFMA peak 2500 / 8 plane "
-                                  "products (six products would be 416.7; they measured ~4x the fp32 engine's gradient "
-                                  "noise and are not used)") if peak_tf == PEAK_BF16_MFMA_TFLOPS / 8.0 else
+                                  "products (forward convs; the gradient kernels run six products: 416.7)")
+                                 if peak_tf == PEAK_BF16_MFMA_TFLOPS / 8.0 else
+                                 "fp32-equivalent ceiling of the exact-split engine with six plane products: 2500 / 6"
+                                 if peak_tf == PEAK_BF16_MFMA_TFLOPS / 6.0 else
                                  "fp32 MFMA peak (MI355X_MICROARCH.md)",
                     "traffic": traffic,
                     "traffic_source": (f"committed PMC pass profiles/{PMC_FILE.format(tag=tag)} (2*FETCH_SIZE + WRITE_SIZE "
@@ -448,9 +454,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16": ("bf16 activations in HBM + bf16 MFMA operands, f32 accumulate / statistics / master weights"
                                if args.storage == "bf16" else "bf16 MFMA operands, f32 accumulate/storage"),
-                      "bf16x3": "f32 via 3xbf16 exact split on the bf16 matrix pipe, f32 accumulate (conv and input-gradient "
-                                "kernels: 8 of 9 plane products; weight-gradient kernels: 6 of 9 -- their error against "
-                                "float64 is the fp32 accumulation's either way, measured); f32 storage everywhere"}[args.matrix_dtype],
+                      "bf16x3": "f32 via 3xbf16 exact split on the bf16 matrix pipe, f32 accumulate (forward convs: 8 of 9 "
+                                "plane products; input-gradient and weight-gradient kernels: 6 of 9 -- measured: no effect "
+                                "on gradient error against float64, the whole parity suite passes on this engine); f32 "
+                                "storage everywhere"}[args.matrix_dtype],
             "data": "synthetic",
             "config": {"workload": f"{args.dataset} {args.height}x{args.width}x5 range image, C={args.classes}, "
                                    f"bs={args.batch}/GPU, {type(model).__name__}{'' if args.net == 'salsanext' else args.net[-2:]} fwd+bwd + prototype bank + contrast "

@@ -390,7 +390,7 @@ class Backbone:
                     acc = False
                 else:
                     acc = True
-                ops.conv_forward([ops.Source(dz)], wd, None, cs, ntaps, out=s.grad, accumulate=acc)
+                ops.conv_forward([ops.Source(dz)], wd, None, cs, ntaps, out=s.grad, accumulate=acc, grad=True)
             off += cs
         rec.out.grad = None
 

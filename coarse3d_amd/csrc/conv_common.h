@@ -21,6 +21,7 @@ struct ConvArgs {
   int ntn;                   // number of cout tiles
   float slope;               // LeakyReLU slope of the on-load and epilogue activations
   int out_bf16;              // out is bf16 (conv_bfp NP = 1 only)
+  int six;                   // bf16x3: six plane products instead of eight (input-gradient convs, mfma_bf16 == 3)
 };
 
 // bf16-plane kernels (conv_bfp.hip): planes = 1 (bf16) or 3 (bf16x3)

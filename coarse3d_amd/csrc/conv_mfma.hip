@@ -301,15 +301,17 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   a.ntn = 1;
   hipStream_t st = (hipStream_t)stream;
   if (d->mfma_bf16) {      // opt-in precision modes on the bf16 matrix pipe (conv_bfp.hip)
-    C3D_REQUIRE(d->mfma_bf16 == 1 || d->mfma_bf16 == 2, "conv: mfma_bf16 must be 0, 1 or 2");
+    C3D_REQUIRE(d->mfma_bf16 >= 1 && d->mfma_bf16 <= 3, "conv: mfma_bf16 must be 0, 1, 2 or 3");
     bool k32 = true;
     for (int s = 0; s < d->nsrc; ++s) k32 = k32 && (d->src[s].C % 32 == 0);
-    if (d->mfma_bf16 == 2 && tr == 8 && d->ntaps > 1) {
+    const bool x3 = d->mfma_bf16 >= 2;      // 3 = the exact-split engine with six plane products (input gradients)
+    a.six = d->mfma_bf16 == 3;
+    if (x3 && tr == 8 && d->ntaps > 1) {
       C3D_REQUIRE(d->wpack_planes, "conv: multi-tap bf16x3 convs need a c3d_pack_weights(mode | 2) pack (wpack_planes = 1)");
       return c3d_conv_forward_x3(a, halo, st);
     }
-    if (tr == 8 && d->ntaps == 1 && d->Cout > 64 && d->wpack_planes) return c3d_conv_forward_pw3(a, d->mfma_bf16 == 2 ? 3 : 1, st);
-    return c3d_conv_forward_bfp(a, d->mfma_bf16 == 2 ? 3 : 1, tr, halo, k32, st);
+    if (tr == 8 && d->ntaps == 1 && d->Cout > 64 && d->wpack_planes) return c3d_conv_forward_pw3(a, x3 ? 3 : 1, st);
+    return c3d_conv_forward_bfp(a, x3 ? 3 : 1, tr, halo, k32, st);
   }
   if (tr == 8 && d->ntaps == 1) {
     // pointwise convs are plain GEMMs: deeper K chunk (32) and up to 128 output channels per

@@ -205,8 +205,10 @@ def num_mtiles(b, h, w):
 
 
 def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=None, out_coff=0,
-                 accumulate=False, stat_partial=None, slope=0.0):
-    """y = [LeakyReLU](conv(cat(transformed srcs)) + bias); optional per-tile channel stats."""
+                 accumulate=False, stat_partial=None, slope=0.0, grad=False):
+    """y = [LeakyReLU](conv(cat(transformed srcs)) + bias); optional per-tile channel stats.
+    ``grad``: this launch is an input-gradient convolution (transposed weights, negated taps): the
+    bf16x3 engine then accumulates six plane products instead of eight (c3d_conv_desc.mfma_bf16 = 3)."""
     d = L.ConvDesc()
     d.nsrc = len(srcs)
     for i, s in enumerate(srcs):
@@ -236,9 +238,9 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
     k32 = tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs)
     if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
-        name = f"conv_x3_kernel<{2 if cout > 32 else 1}, {hh}, {nt_}>"
+        name = f"conv_x3_kernel<{2 if cout > 32 else 1}, {hh}, {nt_}, {'true' if grad else 'false'}>"
     elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes:     # csrc/conv_pw3.hip
-        name = f"conv_pw3_kernel<{8 if cout > 128 else 4}, {3 if MFMA_MODE == 2 else 1}>"
+        name = f"conv_pw3_kernel<{8 if cout > 128 else 4}, {3 if MFMA_MODE == 2 else 1}, {'true' if (grad and MFMA_MODE == 2) else 'false'}>"
     elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
         np_ = 3 if MFMA_MODE == 2 else 1
         name = (f"conv_bfp_kernel<8, {2 if cout > 32 else 1}, 32, 0, 1, {np_}>" if k32 else
@@ -248,7 +250,7 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         name = f"conv_mfma_kernel<8, {4 if wide else (2 if cout > 32 else 1)}, 32, 0, 1>"
     else:
         name = f"conv_mfma_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}>"
-    d.mfma_bf16 = MFMA_MODE
+    d.mfma_bf16 = 3 if (MFMA_MODE == 2 and grad) else MFMA_MODE
     with _Timed(name, 2.0 * b * h * w * cout * len(taps) * sum(s.C for s in srcs),
                 (h, w, sum(s.C for s in srcs), cout, nt_, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_forward(C.byref(d), _stream()), "c3d_conv_forward")

@@ -91,7 +91,7 @@ class RangeNetBackbone(Backbone):
             acc = src.grad is not None
             if not acc:
                 src.grad = torch.empty_like(src.t)
-            ops.conv_forward([ops.Source(dz)], wd, None, cin, ops.negate_taps(taps), out=src.grad, accumulate=acc)
+            ops.conv_forward([ops.Source(dz)], wd, None, cin, ops.negate_taps(taps), out=src.grad, accumulate=acc, grad=True)
 
     def _up(self, name, t):
         """ConvTranspose2d([1,4], stride [1,2], padding [0,1]) + bias -> BN -> LReLU, materialised."""

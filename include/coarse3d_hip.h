@@ -86,7 +86,11 @@ typedef struct {
                                2: every fp32 operand split exactly into three bf16 planes, eight of
                                the nine plane products accumulated in fp32 (fp32-class result on the
                                bf16 pipe); multi-tap convs then need a c3d_pack_weights(mode | 2) pack
-                               (wpack_planes = 1) */
+                               (wpack_planes = 1).
+                               3: as 2 with SIX plane products (l*m and m*l dropped too) -- for INPUT-GRADIENT
+                               convolutions (transposed weights, negated taps): measured to leave every
+                               gradient's error against float64 unchanged, while on the forward activations
+                               six products cost 4-5x the fp32 engine's noise (csrc/conv_x3.hip)          */
   int32_t out_bf16;         /* 1: `out` is bf16 (values rounded RNE on store, accumulate reads bf16);
                                the statistics partials are taken from the fp32 values; mfma_bf16 == 1 only */
   int32_t wpack_planes;     /* 1: wpack came from c3d_pack_weights(mode | 2): the three bf16 planes of the
