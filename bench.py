@@ -271,10 +271,8 @@ def main():
     def peak_for(kernel_name):
         """Matrix-pipe ceiling of one kernel instance: conv_bfp / conv_x3 / wgrad_tr instances run on the bf16
         pipe (eight plane products per fp32 product in the "<3" instances); the rest on fp32 MFMA."""
-        if kernel_name.startswith("conv_pw3_kernel"):        # <NT, NP, SIX>
-            if ", 3, " not in kernel_name:
-                return PEAK_BF16_MFMA_TFLOPS
-            return PEAK_BF16_MFMA_TFLOPS / (6.0 if kernel_name.endswith("true>") else 8.0)
+        if kernel_name.startswith("conv_pw3_kernel"):        # <NT, NP>; NP = 3 runs six plane products
+            return PEAK_BF16_MFMA_TFLOPS / 6.0 if kernel_name.endswith(", 3>") else PEAK_BF16_MFMA_TFLOPS
         if kernel_name.startswith("conv_x3_kernel"):         # <NT, HALO, TT, SIX>
             return PEAK_BF16_MFMA_TFLOPS / (6.0 if kernel_name.endswith("true>") else 8.0)
         if kernel_name.startswith("conv_bfp_kernel"):
@@ -454,10 +452,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16": ("bf16 activations in HBM + bf16 MFMA operands, f32 accumulate / statistics / master weights"
                                if args.storage == "bf16" else "bf16 MFMA operands, f32 accumulate/storage"),
-                      "bf16x3": "f32 via 3xbf16 exact split on the bf16 matrix pipe, f32 accumulate (forward convs: 8 of 9 "
-                                "plane products; input-gradient and weight-gradient kernels: 6 of 9 -- measured: no effect "
-                                "on gradient error against float64, the whole parity suite passes on this engine); f32 "
-                                "storage everywhere"}[args.matrix_dtype],
+                      "bf16x3": "f32 via 3xbf16 exact split on the bf16 matrix pipe, f32 accumulate (3x3 / 2x2 forward convs: 8 of "
+                                "9 plane products; wide 1x1 convs, input-gradient and weight-gradient kernels: 6 of 9 -- "
+                                "measured: no effect on any error against float64 or the oracle, the whole parity suite "
+                                "passes on this engine); f32 storage everywhere"}[args.matrix_dtype],
             "data": "synthetic",
             "config": {"workload": f"{args.dataset} {args.height}x{args.width}x5 range image, C={args.classes}, "
                                    f"bs={args.batch}/GPU, {type(model).__name__}{'' if args.net == 'salsanext' else args.net[-2:]} fwd+bwd + prototype bank + contrast "

@@ -240,7 +240,7 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
         name = f"conv_x3_kernel<{2 if cout > 32 else 1}, {hh}, {nt_}, {'true' if grad else 'false'}>"
     elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes:     # csrc/conv_pw3.hip
-        name = f"conv_pw3_kernel<{8 if cout > 128 else 4}, {3 if MFMA_MODE == 2 else 1}, {'true' if (grad and MFMA_MODE == 2) else 'false'}>"
+        name = f"conv_pw3_kernel<{8 if cout > 128 else 4}, {3 if MFMA_MODE == 2 else 1}>"
     elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
         np_ = 3 if MFMA_MODE == 2 else 1
         name = (f"conv_bfp_kernel<8, {2 if cout > 32 else 1}, 32, 0, 1, {np_}>" if k32 else
