@@ -1,11 +1,13 @@
 """Records the parity figures the GPU tests measure (agreement rates, error maxima) in
-gpurun_out/parity_measured.json, so that the thresholds in the tests can be held at <= 2x what
+gpurun_out/parity_measured[_<engine>].json, so that the thresholds in the tests can be held at <= 2x what
 was actually measured (the round's file is committed as profiles/roundN_parity_measured.json)."""
 import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.path.join(ROOT, "gpurun_out", "parity_measured.json")
+# a run under C3D_MATRIX=<engine> keeps its own report: the figures of the two engines differ
+_ENGINE = os.environ.get("C3D_MATRIX")
+PATH = os.path.join(ROOT, "gpurun_out", f"parity_measured_{_ENGINE}.json" if _ENGINE else "parity_measured.json")
 
 
 def record(name, value):
