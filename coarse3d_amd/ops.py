@@ -35,6 +35,16 @@ MFMA_MODE = _MODES[__import__("os").environ.get("C3D_MATRIX", "f32")]
 STORAGE_BF16 = MFMA_MODE == 1 and __import__("os").environ.get("C3D_BF16_STORAGE", "1") != "0"
 
 
+# bf16x3 engine: forward 3x3 / 2x2 convolutions run six instead of eight plane products when their output has at
+# least this many pixels (B*H*W).  With six, each product is off by up to 2^-23 |a||b|; what the following
+# BatchNorm makes of that depends on its population: measured (tools/noise_probe.py, gradient error against the
+# float64 oracle relative to the fp32 oracle's own) 4.6x at 1 344 pixels (the 1x24x56 POSS case of
+# tests/test_gpu_backbone.py: eight products 0.3x), but 0.79 vs 0.84 at 65 536 (2x64x512), 1.15 vs 1.19 at
+# 144 640 (4x40x904), 2.2 vs 2.6 at 36 480 (2x40x456; the fp32 engine: 2.4) -- indistinguishable from eight
+# and from the fp32-MFMA engine.  tests/test_gpu_backbone.py::test_gradient_noise_at_a_realistic_population holds it.
+SIX_FWD_MIN_PIXELS = 32768
+
+
 def set_matrix_precision(kind, storage=None):
     """kind: "f32" | "bf16" | "bf16x3".  storage ("bf16" | "f32", "bf16" mode only; default "bf16")."""
     global MFMA_MODE, STORAGE_BF16
@@ -250,7 +260,12 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         name = f"conv_mfma_kernel<8, {4 if wide else (2 if cout > 32 else 1)}, 32, 0, 1>"
     else:
         name = f"conv_mfma_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}>"
-    d.mfma_bf16 = 3 if (MFMA_MODE == 2 and grad) else MFMA_MODE
+    # six plane products: every input gradient, and forward multi-tap convs whose BatchNorm population is large
+    # (SIX_FWD_MIN_PIXELS).  conv_pw3 runs six in every launch (the flag is ignored there).
+    six = MFMA_MODE == 2 and (grad or (nt_ > 1 and tr == 8 and b * h * w >= SIX_FWD_MIN_PIXELS))
+    if six and not grad:
+        name = name.replace(", false>", ", true>")
+    d.mfma_bf16 = 3 if six else MFMA_MODE
     with _Timed(name, 2.0 * b * h * w * cout * len(taps) * sum(s.C for s in srcs),
                 (h, w, sum(s.C for s in srcs), cout, nt_, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_forward(C.byref(d), _stream()), "c3d_conv_forward")
