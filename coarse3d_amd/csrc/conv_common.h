@@ -29,7 +29,7 @@ int c3d_conv_forward_bfp(ConvArgs& a, int planes, int tr, int halo, bool k32, hi
 // second-generation bf16x3 engine for 8-row tiles with 4 or 9 taps (conv_x3.hip); needs a mode | 2 pack
 int c3d_conv_forward_x3(ConvArgs& a, int halo, hipStream_t st);
 // wide pointwise engine on the bf16 pipe, 8-row tiles, Cout > 64 (conv_pw3.hip; planes = 1 or 3); needs a mode | 2 pack
-int c3d_conv_forward_pw3(ConvArgs& a, int planes, hipStream_t st);
+int c3d_conv_forward_pw3(ConvArgs& a, int planes, bool wide, hipStream_t st);   // wide: 256-cout tiles, else 128
 
 namespace {
 

@@ -20,6 +20,7 @@
 // Grid: 1-D, cout tile fastest, XCD-remapped: the workgroups that share one input tile (and
 // neighbouring tiles that share halos) run on the same XCD and hit its L2.
 #include <type_traits>
+#include <cstdlib>
 #include "conv_common.h"
 
 namespace {
@@ -255,6 +256,12 @@ extern "C" int c3d_conv_num_mtiles(int B, int H, int W) {
   return B * ((H + tr - 1) / tr) * ((W + 31) / 32);
 }
 
+// smallest grid the wide pointwise kernel is launched with (see c3d_conv_forward); C3D_PW3_MIN_WG overrides (tuning)
+static int c3d_pw3_min_workgroups() {
+  const char* e = getenv("C3D_PW3_MIN_WG");
+  return e ? atoi(e) : 128;
+}
+
 extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   C3D_REQUIRE(d != nullptr, "conv: null descriptor");
   C3D_REQUIRE(d->nsrc >= 1 && d->nsrc <= C3D_MAX_SRC, "conv: nsrc must be 1..3");
@@ -310,7 +317,16 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
       C3D_REQUIRE(d->wpack_planes, "conv: multi-tap bf16x3 convs need a c3d_pack_weights(mode | 2) pack (wpack_planes = 1)");
       return c3d_conv_forward_x3(a, halo, st);
     }
-    if (tr == 8 && d->ntaps == 1 && d->Cout > 64 && d->wpack_planes) return c3d_conv_forward_pw3(a, x3 ? 3 : 1, st);
+    if (tr == 8 && d->ntaps == 1 && d->Cout > 64 && d->wpack_planes) {
+      // eight-wave workgroups of 256 x 256 (or 128) outputs -- unless that leaves most of the 256 CUs idle (the 8 x 256
+      // and 4 x 128 levels of the encoder have 64 / 32 pixel tiles per batch): then narrower tiles, down to conv_bfp's
+      // 64-wide four-wave workgroups
+      static const int fill = c3d_pw3_min_workgroups();
+      const int px_tiles = d->B * a.tiles_x * a.tiles_y;
+      bool wide = d->Cout > 128;
+      if (wide && px_tiles * ((d->Cout + 255) / 256) < fill) wide = false;
+      if (wide || px_tiles * ((d->Cout + 127) / 128) >= fill) return c3d_conv_forward_pw3(a, x3 ? 3 : 1, wide, st);
+    }
     return c3d_conv_forward_bfp(a, x3 ? 3 : 1, tr, halo, k32, st);
   }
   if (tr == 8 && d->ntaps == 1) {

@@ -264,7 +264,7 @@ int launch_pw3(ConvArgs& a, hipStream_t st) {
 
 // called by c3d_conv_forward for mfma_bf16 == 1 / 2 (planes = 1 / 3), 8-row tiles, one tap, Cout > 64;
 // a.wpack must be a c3d_pack_weights(mode | 2) pack (fp32 image followed by the three bf16 planes)
-int c3d_conv_forward_pw3(ConvArgs& a, int planes, hipStream_t st) {
-  if (planes == 3) return a.Cout > 128 ? launch_pw3<8, 3>(a, st) : launch_pw3<4, 3>(a, st);
-  return a.Cout > 128 ? launch_pw3<8, 1>(a, st) : launch_pw3<4, 1>(a, st);
+int c3d_conv_forward_pw3(ConvArgs& a, int planes, bool wide, hipStream_t st) {
+  if (planes == 3) return wide ? launch_pw3<8, 3>(a, st) : launch_pw3<4, 3>(a, st);
+  return wide ? launch_pw3<8, 1>(a, st) : launch_pw3<4, 1>(a, st);
 }

@@ -214,6 +214,19 @@ def num_mtiles(b, h, w):
     return L.lib().c3d_conv_num_mtiles(b, h, w)
 
 
+def _pw3_tile(b, h, w, cout):
+    """Cout sub-tiles (8 = 256 couts, 4 = 128) of the wide pointwise kernel for this launch, 0 = the grid would leave
+    most CUs idle and conv_bfp's 64-wide workgroups run instead.  Mirrors c3d_conv_forward() in csrc/conv_mfma.hip."""
+    fill = int(os.environ.get("C3D_PW3_MIN_WG", "128"))
+    px_tiles = b * ((w + 31) // 32) * ((h + 7) // 8)
+    wide = cout > 128
+    if wide and px_tiles * ((cout + 255) // 256) < fill:
+        wide = False
+    if wide or px_tiles * ((cout + 127) // 128) >= fill:
+        return 8 if wide else 4
+    return 0
+
+
 def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=None, out_coff=0,
                  accumulate=False, stat_partial=None, slope=0.0, grad=False):
     """y = [LeakyReLU](conv(cat(transformed srcs)) + bias); optional per-tile channel stats.
@@ -249,8 +262,8 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     k32 = tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs)
     if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
         name = f"conv_x3_kernel<{2 if cout > 32 else 1}, {hh}, {nt_}, {'true' if grad else 'false'}>"
-    elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes:     # csrc/conv_pw3.hip
-        name = f"conv_pw3_kernel<{8 if cout > 128 else 4}, {3 if MFMA_MODE == 2 else 1}>"
+    elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
+        name = f"conv_pw3_kernel<{_pw3_tile(b, h, w, cout)}, {3 if MFMA_MODE == 2 else 1}>"
     elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
         np_ = 3 if MFMA_MODE == 2 else 1
         name = (f"conv_bfp_kernel<8, {2 if cout > 32 else 1}, 32, 0, 1, {np_}>" if k32 else
