@@ -286,7 +286,7 @@ int launch_bfp_taps(ConvArgs& a, int halo, hipStream_t st) {
 
 template <int NP>
 int dispatch_bfp(ConvArgs& a, int tr, int halo, bool k32, hipStream_t st) {
-  const bool wide = a.Cout > 32;
+  const bool wide = c3d_wide_cout_tiles(a);
   if (tr == 8 && a.T == 1 && k32) return wide ? launch_bfp<8, 2, 32, 0, 1, NP>(a, st) : launch_bfp<8, 1, 32, 0, 1, NP>(a, st);
   if (tr == 8) return wide ? launch_bfp_taps<8, 2, NP>(a, halo, st) : launch_bfp_taps<8, 1, NP>(a, halo, st);
   if (tr == 4) return wide ? launch_bfp_taps<4, 2, NP>(a, halo, st) : launch_bfp_taps<4, 1, NP>(a, halo, st);

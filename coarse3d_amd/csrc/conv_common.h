@@ -1,5 +1,6 @@
 // Pieces shared by the fp32-MFMA and the bf16-plane convolution kernels.
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "../../include/coarse3d_hip.h"
@@ -23,6 +24,18 @@ struct ConvArgs {
   int out_bf16;              // out is bf16 (conv_bfp NP = 1 only)
   int six;                   // bf16x3: six plane products instead of eight (input-gradient convs, mfma_bf16 == 3)
 };
+
+// 64-cout tiles (two 32-wide sub-tiles per workgroup) unless the grid would then cover too few CUs -- the 8 x 256 and
+// 4 x 128 levels of the encoder have 64 / 32 pixel tiles per batch of 8 -- in which case 32-cout tiles double the
+// workgroups.  C3D_NARROW_MIN_WG overrides the threshold (tuning).  Mirrored by ops._wide_cout_tiles().
+inline bool c3d_wide_cout_tiles(const ConvArgs& a) {
+  if (a.Cout <= 32) return false;
+  static const int min_wg = [] {
+    const char* e = getenv("C3D_NARROW_MIN_WG");
+    return e ? atoi(e) : 192;
+  }();
+  return a.B * a.tiles_x * a.tiles_y * ((a.Cout + 63) / 64) >= min_wg;
+}
 
 // bf16-plane kernels (conv_bfp.hip): planes = 1 (bf16) or 3 (bf16x3)
 int c3d_conv_forward_bfp(ConvArgs& a, int planes, int tr, int halo, bool k32, hipStream_t st);

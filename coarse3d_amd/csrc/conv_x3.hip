@@ -281,5 +281,5 @@ int launch_x3_taps(ConvArgs& a, int halo, hipStream_t st) {
 // called by c3d_conv_forward for mfma_bf16 == 2, 8-row tiles, 4 or 9 taps; a.wpack must be a
 // c3d_pack_weights(mode | 2) pack (fp32 image followed by the three bf16 planes)
 int c3d_conv_forward_x3(ConvArgs& a, int halo, hipStream_t st) {
-  return a.Cout > 32 ? launch_x3_taps<2>(a, halo, st) : launch_x3_taps<1>(a, halo, st);
+  return c3d_wide_cout_tiles(a) ? launch_x3_taps<2>(a, halo, st) : launch_x3_taps<1>(a, halo, st);
 }

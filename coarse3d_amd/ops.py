@@ -214,6 +214,15 @@ def num_mtiles(b, h, w):
     return L.lib().c3d_conv_num_mtiles(b, h, w)
 
 
+def _wide_cout_tiles(b, h, w, cout, tr):
+    """64-cout tiles, or 32-cout ones when the 64-wide grid would cover too few CUs: c3d_wide_cout_tiles() in
+    csrc/conv_common.h."""
+    if cout <= 32:
+        return False
+    min_wg = int(os.environ.get("C3D_NARROW_MIN_WG", "192"))
+    return b * ((w + 31) // 32) * ((h + tr - 1) // tr) * ((cout + 63) // 64) >= min_wg
+
+
 def _pw3_tile(b, h, w, cout):
     """Cout sub-tiles (8 = 256 couts, 4 = 128) of the wide pointwise kernel for this launch, 0 = the grid would leave
     most CUs idle and conv_bfp's 64-wide workgroups run instead.  Mirrors c3d_conv_forward() in csrc/conv_mfma.hip."""
@@ -261,13 +270,14 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
     k32 = tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs)
     if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
-        name = f"conv_x3_kernel<{2 if cout > 32 else 1}, {hh}, {nt_}, {'true' if grad else 'false'}>"
+        name = f"conv_x3_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, {nt_}, {'true' if grad else 'false'}>"
     elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
         name = f"conv_pw3_kernel<{_pw3_tile(b, h, w, cout)}, {3 if MFMA_MODE == 2 else 1}>"
     elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
         np_ = 3 if MFMA_MODE == 2 else 1
-        name = (f"conv_bfp_kernel<8, {2 if cout > 32 else 1}, 32, 0, 1, {np_}>" if k32 else
-                f"conv_bfp_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}, {np_}>")
+        wide_ = _wide_cout_tiles(b, h, w, cout, tr)
+        name = (f"conv_bfp_kernel<8, {2 if wide_ else 1}, 32, 0, 1, {np_}>" if k32 else
+                f"conv_bfp_kernel<{tr}, {2 if (wide_ or tr == 2) else 1}, 16, {hh}, {nt_}, {np_}>")
     elif k32:         # mirrors c3d_conv_forward / launch_taps() in csrc/conv_mfma.hip
         wide = cout > 64 and (cout + 127) // 128 * 128 <= (cout + 63) // 64 * 64
         name = f"conv_mfma_kernel<8, {4 if wide else (2 if cout > 32 else 1)}, 32, 0, 1>"

@@ -11,6 +11,8 @@ Config keys follow tasks/weak_segmentation/option.py:43-49 / config_semantic_kit
 the prototype update (Sinkhorn + EMA + bank exchange, salsanext_proto.py:337-402) inside the
 step -- what BASELINE.json's north star measures; bench.py and the golden step test opt in.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -50,8 +52,13 @@ class TrainStep:
         self.contrast = ContrastMEMLoss(ignore_label=ignore_cls, temperature=temperature, num_anchor=num_anchor)
         self.mean = torch.as_tensor(feature_mean, dtype=torch.float32, device=dev) if feature_mean is not None else None
         self.std = torch.as_tensor(feature_std, dtype=torch.float32, device=dev) if feature_std is not None else None
-        # trainer.py:146-151: AdamW(params, lr) -- cfg.weight_decay is NOT passed (default 0.01)
-        self.optimizer = optimizer or torch.optim.AdamW(self.net.parameters(), lr=lr)
+        # trainer.py:146-151: AdamW(params, lr) -- cfg.weight_decay is NOT passed (default 0.01).  On the device the
+        # same optimiser runs in its fused form (one multi-tensor launch per ~30 tensors instead of ~20 elementwise
+        # passes over the 192 parameter tensors: 0.38 -> 0.1 ms per step); C3D_FUSED_ADAMW=0 keeps the default form.
+        if optimizer is None:
+            fused = dev.type == "cuda" and os.environ.get("C3D_FUSED_ADAMW", "1") != "0"
+            optimizer = torch.optim.AdamW(self.net.parameters(), lr=lr, **({"fused": True} if fused else {}))
+        self.optimizer = optimizer
         self.scheduler = scheduler
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         # True: the caller guarantees that the label tensors handed to step() are complete in HBM
