@@ -112,9 +112,13 @@ __global__ __launch_bounds__(256) void pl_bucket_kernel(PlArgs a) {
   }
 }
 
-// grid (C, B).  Radix select (4 x 8 bits) of the k-th largest key of the pair's bucket.
-__global__ __launch_bounds__(256) void pl_select_kernel(PlArgs a) {
+// grid (C, B).  Radix select (4 x 8 bits) of the k-th largest key of the pair's bucket.  1024 threads per pair and a
+// parallel suffix scan over the 256 bins (five passes over ~7 000 keys on 256 threads plus four serial bin walks by
+// thread 0 took 80 us).
+constexpr int PL_THREADS = 1024;
+__global__ __launch_bounds__(PL_THREADS) void pl_select_kernel(PlArgs a) {
   __shared__ int hist[256];
+  __shared__ int suf[2][256];
   __shared__ unsigned int s_prefix, s_k, s_take;
   const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int cnt = a.cnt[b * a.C + c];
@@ -131,24 +135,37 @@ __global__ __launch_bounds__(256) void pl_select_kernel(PlArgs a) {
   }
   __syncthreads();
   for (int level = 3; level >= 0; --level) {
-    hist[tid] = 0;
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
     const unsigned prefix = s_prefix;
+    const unsigned kk = s_k;
     const unsigned mask_hi = level == 3 ? 0u : (0xFFFFFFFFu << ((level + 1) * 8));
-    for (int i = tid; i < cnt; i += 256) {
+    for (int i = tid; i < cnt; i += PL_THREADS) {
       const unsigned key = keys[i];
       if ((key & mask_hi) == prefix) atomicAdd(&hist[(key >> (level * 8)) & 255], 1);
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned kk = s_k;
-      int bin = 255;
-      for (; bin > 0; --bin) {
-        if ((unsigned)hist[bin] >= kk) break;
-        kk -= hist[bin];
+    // inclusive suffix sums S[bin] = sum_{j >= bin} hist[j]; the k-th largest key lies in the highest bin with
+    // S[bin] >= kk (bin 0 if none, as the serial walk from bin 255 down did)
+    if (tid < 256) suf[0][tid] = hist[tid];
+    __syncthreads();
+    int cur = 0;
+    for (int o = 1; o < 256; o <<= 1) {
+      if (tid < 256) {
+        int x = suf[cur][tid];
+        if (tid + o < 256) x += suf[cur][tid + o];
+        suf[cur ^ 1][tid] = x;
       }
-      s_prefix = prefix | ((unsigned)bin << (level * 8));
-      s_k = kk;  // rank of the k-th element inside this bin
+      __syncthreads();
+      cur ^= 1;
+    }
+    if (tid < 256) {
+      const unsigned S = (unsigned)suf[cur][tid];
+      const unsigned Sn = tid < 255 ? (unsigned)suf[cur][tid + 1] : 0u;
+      if ((S >= kk && Sn < kk) || (tid == 0 && S < kk)) {
+        s_prefix = prefix | ((unsigned)tid << (level * 8));
+        s_k = kk - Sn;  // rank of the k-th element inside this bin
+      }
     }
     __syncthreads();
   }
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(256) void pl_select_kernel(PlArgs a) {
   const unsigned thr = s_prefix;
   if (tid == 0) s_take = s_k;
   __syncthreads();
-  for (int i = tid; i < cnt; i += 256) {
+  for (int i = tid; i < cnt; i += PL_THREADS) {
     const unsigned key = keys[i];
     bool take = key > thr;
     if (key == thr) take = atomicSub(&s_take, 1u) - 1u < 0x80000000u;  // ties: measure-zero event
@@ -178,17 +195,30 @@ __global__ void pl_finalize_kernel(const int32_t* __restrict__ amax, const uint8
 
 // ---------------------------------------------------------------- anchor sampling (L2)
 // slot[b*C+c] = rank of the pair among present ones in (b, c) order, or -1; T = number present
-__global__ void pair_slots_kernel(const int32_t* __restrict__ counts, int npairs, int C, int ignore,
-                                  int32_t* __restrict__ slot, int32_t* __restrict__ T) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    int t = 0;
-    for (int p = 0; p < npairs; ++p) {
-      const bool present = (p % C) != ignore && counts[p] > 0;
-      slot[p] = present ? t : -1;
-      t += present ? 1 : 0;
+__global__ __launch_bounds__(256) void pair_slots_kernel(const int32_t* __restrict__ counts, int npairs, int C, int ignore,
+                                                         int32_t* __restrict__ slot, int32_t* __restrict__ T) {
+  // one block; block-wide inclusive scan of the "present" flags, 256 pairs per round (a single thread walking the
+  // B*C pairs took 16 us)
+  __shared__ int sc[256];
+  const int tid = threadIdx.x;
+  int base = 0;
+  for (int p0 = 0; p0 < npairs; p0 += 256) {
+    const int p = p0 + tid;
+    const bool present = p < npairs && (p % C) != ignore && counts[p] > 0;
+    sc[tid] = present ? 1 : 0;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      int x = sc[tid];
+      if (tid >= o) x += sc[tid - o];
+      __syncthreads();
+      sc[tid] = x;
+      __syncthreads();
     }
-    *T = t;
+    if (p < npairs) slot[p] = present ? base + sc[tid] - 1 : -1;
+    base += sc[255];
+    __syncthreads();
   }
+  if (tid == 0) *T = base;
 }
 
 struct SampleArgs {
@@ -380,18 +410,32 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(float* __restrict__ l
   }
 }
 
-// loss = sum(row_loss) / (T*A)   (single block, fp64 fold)
-__global__ __launch_bounds__(256) void infonce_reduce_kernel(const float* __restrict__ row_loss,
-                                                             const int32_t* __restrict__ T, int A,
-                                                             float* __restrict__ loss) {
-  __shared__ double red[4];
+// loss = sum(row_loss) / (T*A)   (single block of 1024 threads, fp64 fold; four independent loads per trip -- a
+// 256-thread dependent walk over the 77 824 rows took 70 us)
+__global__ __launch_bounds__(1024) void infonce_reduce_kernel(const float* __restrict__ row_loss,
+                                                              const int32_t* __restrict__ T, int A,
+                                                              float* __restrict__ loss) {
+  __shared__ double red[16];
   const int Tn = *T;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < Tn * A; i += 256) s += (double)row_loss[i];
-  s = c3d_wave_sum_d(s);
+  const int n = Tn * A;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * 1024 < n; i += 4 * 1024) {
+    const float a = row_loss[i], b = row_loss[i + 1024], c = row_loss[i + 2048], d = row_loss[i + 3072];
+    s0 += (double)a;
+    s1 += (double)b;
+    s2 += (double)c;
+    s3 += (double)d;
+  }
+  for (; i < n; i += 1024) s0 += (double)row_loss[i];
+  double s = c3d_wave_sum_d((s0 + s1) + (s2 + s3));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) *loss = Tn > 0 ? (float)((red[0] + red[1] + red[2] + red[3]) / ((double)Tn * A)) : 0.f;
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += red[k];
+    *loss = Tn > 0 ? (float)(t / ((double)Tn * A)) : 0.f;
+  }
 }
 
 }  // namespace
@@ -429,7 +473,7 @@ extern "C" int c3d_pl_select(const float* w_pl, const int32_t* amax, const int64
   C3D_CHECK_LAUNCH();
   hipLaunchKernelGGL(pl_bucket_kernel<true>, dim3(chunks, B), dim3(256), 0, ST, a);
   C3D_CHECK_LAUNCH();
-  hipLaunchKernelGGL(pl_select_kernel, dim3(C, B), dim3(256), 0, ST, a);
+  hipLaunchKernelGGL(pl_select_kernel, dim3(C, B), dim3(PL_THREADS), 0, ST, a);
   C3D_CHECK_LAUNCH();
   hipLaunchKernelGGL(pl_finalize_kernel, dim3(nb_for((size_t)B * n, 256)), dim3(256), 0, ST, amax, chosen, eval_label,
                      train_label, (size_t)B * n, ignore_label, labels_out, mask_out);
@@ -441,7 +485,7 @@ extern "C" int c3d_anchor_sample(const float* weights, const int32_t* counts, co
                                  const double* uniforms, int B, int n, int C, int A, int ignore_label, int32_t* slot,
                                  float* cum, int32_t* anchor_idx, int32_t* anchor_img, int32_t* anchor_cls, int32_t* T,
                                  c3d_stream stream) {
-  hipLaunchKernelGGL(pair_slots_kernel, dim3(1), dim3(64), 0, ST, counts, B * C, C, ignore_label, slot, T);
+  hipLaunchKernelGGL(pair_slots_kernel, dim3(1), dim3(256), 0, ST, counts, B * C, C, ignore_label, slot, T);
   C3D_CHECK_LAUNCH();
   SampleArgs a{weights, counts, idx, slot, uniforms, cum, n, C, A, anchor_idx, anchor_img, anchor_cls};
   hipLaunchKernelGGL(anchor_sample_kernel, dim3(C, B), dim3(256), 0, ST, a);
@@ -473,7 +517,7 @@ extern "C" int c3d_infonce_rows(float* logits, int ld, const int32_t* row_cls, c
   hipLaunchKernelGGL(infonce_rows_kernel, dim3(nb_for((size_t)Tmax * A, 4)), dim3(256), 0, ST, logits, ld, row_cls, T,
                      Tmax, A, M, ncols, temperature, base_temperature, row_loss);
   C3D_CHECK_LAUNCH();
-  hipLaunchKernelGGL(infonce_reduce_kernel, dim3(1), dim3(256), 0, ST, row_loss, T, A, loss);
+  hipLaunchKernelGGL(infonce_reduce_kernel, dim3(1), dim3(1024), 0, ST, row_loss, T, A, loss);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void proto_nearest_kernel(const float* __restr
 // thread, fetched coalesced through LDS), one wave scan + one barrier pair per iteration.
 constexpr int CSEG = 8;
 
-__global__ __launch_bounds__(256) void compact_hist_kernel(const int64_t* __restrict__ labels,
+__global__ __launch_bounds__(1024) void compact_hist_kernel(const int64_t* __restrict__ labels,
                                                            const uint8_t* __restrict__ keep, int n, int ncls, int seg_len,
                                                            int32_t* __restrict__ seg_counts) {   // [groups][CSEG][ncls]
   __shared__ int h[64];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void compact_hist_kernel(const int64_t* __rest
   const int64_t* lab = labels + (size_t)g * n;
   const uint8_t* kp = keep ? keep + (size_t)g * n : nullptr;
   const int e = min(n, (sg + 1) * seg_len);
-  for (int i = sg * seg_len + threadIdx.x; i < e; i += 256) {
+  for (int i = sg * seg_len + threadIdx.x; i < e; i += 1024) {      // 1024 threads: 16 trips per 16 384-label segment, not 64
     int64_t l = lab[i];
     if (kp && !kp[i]) l = 0;
     if (l >= 0 && l < ncls) atomicAdd(&h[(int)l], 1);
@@ -224,8 +224,8 @@ struct LearnArgs {
 // normalisation (salsanext_proto.py:376-395, :402); one wave per prototype row.  f [M][D] (LDS,
 // overwritten), cnt [M], tot = sum(cnt).
 __device__ __forceinline__ void proto_ema_rows(float* f, const float* cnt, float tot, bool any, const float* pin,
-                                               float* pout, int M, int D, float momentum, int lane, int wv) {
-  for (int m = wv; m < M; m += 4) {
+                                               float* pout, int M, int D, float momentum, int lane, int wv, int nwaves) {
+  for (int m = wv; m < M; m += nwaves) {
     float ss = 0.f;
     for (int d = lane; d < D; d += 64) ss += f[m * D + d] * f[m * D + d];
     const float inv = 1.f / fmaxf(sqrtf(c3d_wave_sum(ss)), 1e-12f);
@@ -262,15 +262,19 @@ __device__ __forceinline__ int group32_argmax(float v, int idx) {
   return idx;
 }
 
-// one workgroup per class; 8 labelled pixels in flight, 32 lanes (sub-prototype m, or class k for
-// the nearest-prototype vote) per pixel
-__global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
+// one workgroup of 1024 threads per class; 32 labelled pixels in flight, 32 lanes (sub-prototype m, or class k for
+// the nearest-prototype vote) per pixel.  (The whole kernel is a chain of dependent gathers over the class's
+// labelled pixels -- ~55 per class at 0.1 % labels -- so its time is trips x memory latency: 8 pixels in flight
+// on 256 threads took 91 us.)
+constexpr int LEARN_THREADS = 1024;
+constexpr int LEARN_SUBS = LEARN_THREADS / 32;
+__global__ __launch_bounds__(LEARN_THREADS) void proto_learn_kernel(LearnArgs a) {
   extern __shared__ float sm[];
-  double* red = reinterpret_cast<double*>(sm);          // [8][32] slot partials
-  float* u = sm + 512;                                  // [32] row scalings
-  int* s_r = reinterpret_cast<int*>(sm + 512 + 32);     // [256] staged pixel rows
+  double* red = reinterpret_cast<double*>(sm);          // [LEARN_SUBS][32] slot partials
+  float* u = sm + 2 * LEARN_SUBS * 32;                  // [32] row scalings
+  int* s_r = reinterpret_cast<int*>(u + 32);            // [256] staged pixel rows
   int* s_m = s_r + 256;                                 // [256] staged assignments
-  float* f = sm + 512 + 32 + 512;                       // [M][D]
+  float* f = u + 32 + 512;                              // [M][D]
   float* cnt = f + a.M * a.D;                           // [M]
   const int c = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
     for (int b = 0; b < a.B; ++b) {
       const int cb = a.counts[b * a.C + c];
       const int32_t* src = a.idx + ((size_t)b * a.C + c) * a.n;
-      for (int i = tid; i < cb; i += 256) rows[nc + i] = src[i] + b * a.n;
+      for (int i = tid; i < cb; i += LEARN_THREADS) rows[nc + i] = src[i] + b * a.n;
       nc += cb;
     }
     __threadfence_block();
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
     for (int it = 0; it < 3; ++it) {
       double acc = 0.0;
       const float um = u[m];
-      for (int i = sub; i < nc; i += 8) {
+      for (int i = sub; i < nc; i += LEARN_SUBS) {
         const float* s = a.sim + (size_t)rows[i] * MC + c;
         const float e = m < M ? expf(s[m * a.C] / 0.05f) : 0.f;
         const float colsum = group32_sum(e * um);
@@ -310,8 +314,7 @@ __global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
       __syncthreads();
       if (tid < 32) {
         double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k * 32 + tid];
+        for (int k = 0; k < LEARN_SUBS; ++k) t += red[k * 32 + tid];
         // row step: u[m] = 1 / (K * sum_i E[i][m] v[i])  (independent of the previous u)
         u[tid] = tid < M ? (float)(1.0 / ((double)M * t)) : 0.f;
       }
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
     }
     // ---- assignment per labelled pixel
     const float um = u[m];
-    for (int i = sub; i < nc; i += 8) {
+    for (int i = sub; i < nc; i += LEARN_SUBS) {
       const int r = rows[i];
       const float* s = a.sim + (size_t)r * MC + c;
       const float e = m < M ? expf(s[m * a.C] / 0.05f) * um : 0.f;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
     }
   }
   // ---- masked reduction f[m][:] = sum feat rows, cnt[m]
-  for (int j = tid; j < M * D; j += 256) f[j] = 0.f;
+  for (int j = tid; j < M * D; j += LEARN_THREADS) f[j] = 0.f;
   if (tid < M) cnt[tid] = 0.f;
   __threadfence_block();
   __syncthreads();
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
       s_m[tid] = a.assign[r];
     }
     __syncthreads();
-    for (int d = tid; d < D; d += 256) {
+    for (int d = tid; d < D; d += LEARN_THREADS) {
       for (int ii = 0; ii < cn; ii += 8) {      // 8 feature rows in flight per thread
         float v[8];
         int mm[8];
@@ -385,13 +388,13 @@ __global__ __launch_bounds__(256) void proto_learn_kernel(LearnArgs a) {
   }
   if (a.fsum) {          // data parallel "prototype sums" mode: hand the sums to the exchange, EMA later
     float* o = a.fsum + (size_t)c * M * (D + 1);
-    for (int j = tid; j < M * D; j += 256) o[(j / D) * (D + 1) + j % D] = f[j];
+    for (int j = tid; j < M * D; j += LEARN_THREADS) o[(j / D) * (D + 1) + j % D] = f[j];
     if (tid < M) o[tid * (D + 1) + D] = cnt[tid];
     return;
   }
   float tot = 0.f;
   for (int m = 0; m < M; ++m) tot += cnt[m];
-  proto_ema_rows(f, cnt, tot, nc > 0, pin, pout, M, D, a.momentum, lane, wv);
+  proto_ema_rows(f, cnt, tot, nc > 0, pin, pout, M, D, a.momentum, lane, wv, LEARN_THREADS / 64);
 }
 
 // EMA from (all-reduced) sums: fsum [C][M][D+1] -> protos_out; one workgroup per class
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(256) void proto_ema_kernel(const float* __restrict_
   __syncthreads();
   float tot = 0.f;
   for (int m = 0; m < M; ++m) tot += cnt[m];
-  proto_ema_rows(f, cnt, tot, c != ignore, protos + (size_t)c * M * D, protos_out + (size_t)c * M * D, M, D, momentum, lane, wv);
+  proto_ema_rows(f, cnt, tot, c != ignore, protos + (size_t)c * M * D, protos_out + (size_t)c * M * D, M, D, momentum, lane, wv, 4);
 }
 
 }  // namespace
@@ -440,7 +443,7 @@ extern "C" int c3d_group_compact(const int64_t* labels, const uint8_t* keep, int
   C3D_REQUIRE(ncls <= 64, "group_compact: at most 64 classes");
   C3D_REQUIRE(seg_scratch != nullptr, "group_compact: scratch of groups*8*ncls int32 required");
   int seg_len = ((n + CSEG - 1) / CSEG + 4095) / 4096 * 4096;      // whole 4096-label iterations per segment
-  hipLaunchKernelGGL(compact_hist_kernel, dim3(CSEG, groups), dim3(256), 0, ST, labels, keep, n, ncls, seg_len, seg_scratch);
+  hipLaunchKernelGGL(compact_hist_kernel, dim3(CSEG, groups), dim3(1024), 0, ST, labels, keep, n, ncls, seg_len, seg_scratch);
   C3D_CHECK_LAUNCH();
   hipLaunchKernelGGL(group_compact_kernel, dim3(ncls, groups, CSEG), dim3(256), 0, ST, labels, keep, n, ncls, seg_len,
                      seg_scratch, counts, idx);
@@ -467,8 +470,8 @@ extern "C" int c3d_proto_learn(const float* sim, const float* feat, const int32_
   const int N = B * n;
   LearnArgs a{sim, feat, pred, ln_w, ln_b, ln_eps, counts, idx, rows, B, n, noise, protos, protos_out, target, assign, N, M, C, D,
               ignore_label, momentum, fsum};
-  const size_t lds = (512 + 32 + 512 + (size_t)M * D + M) * sizeof(float);
-  hipLaunchKernelGGL(proto_learn_kernel, dim3(C), dim3(256), lds, ST, a);
+  const size_t lds = (2 * LEARN_SUBS * 32 + 32 + 512 + (size_t)M * D + M) * sizeof(float);
+  hipLaunchKernelGGL(proto_learn_kernel, dim3(C), dim3(LEARN_THREADS), lds, ST, a);
   C3D_CHECK_LAUNCH();
   return 0;
 }
