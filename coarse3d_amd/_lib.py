@@ -33,7 +33,8 @@ class WgradDesc(C.Structure):
                 ("ntaps", C.c_int32), ("tap_dy", C.c_int32 * 9), ("tap_dx", C.c_int32 * 9),
                 ("Cin_total", C.c_int32), ("cin_off", C.c_int32),
                 ("dw", C.c_void_p), ("accumulate", C.c_int32), ("partial", C.c_void_p), ("mfma_bf16", C.c_int32),
-                ("lrelu_slope", C.c_float), ("dz_bf16", C.c_int32), ("reserved", C.c_int32)]
+                ("lrelu_slope", C.c_float), ("dz_bf16", C.c_int32), ("reserved", C.c_int32),
+                ("bias_partial", C.c_void_p), ("dbias", C.c_void_p), ("bias_n", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class PackEntry(C.Structure):

@@ -371,11 +371,12 @@ class Backbone:
         w = self.P[f"{name}.weight"] if rec.weight is None else rec.weight
         dw = G[f"{name}.weight"] if rec.dweight is None else rec.dweight
         with self._fork(dz, pz):
-            if f"{name}.bias" in G:
-                ops.bias_from_partials(pz, G[f"{name}.bias"])
+            db = G.get(f"{name}.bias")       # folded by the first weight-gradient launch of the layer
             off = 0
             for s in rec.srcs:
-                ops.conv_wgrad(s.src(rec.src_lrelu), dz, dw, rec.taps, cin_off=off, slope=rec.slope)
+                ops.conv_wgrad(s.src(rec.src_lrelu), dz, dw, rec.taps, cin_off=off, slope=rec.slope,
+                               bias_partial=pz if db is not None else None, dbias=db)
+                db = None
                 off += s.t.shape[3]
         ntaps = ops.negate_taps(rec.taps)
         off = 0

@@ -279,16 +279,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
 }
 
 // dw[cout][cin_off + cin][t] (+)= sum_strips partial.  Block = 32 outputs x 8 strip lanes.
+// Blocks beyond `main_blocks` fold the layer's bias-gradient partials (one channel each; c3d_wgrad_desc.bias_partial).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                            int strips, int T, int CI, int CO, int ci_slices,
                                                            int co_slices, int Cin_src, int Cout, int Cin_total,
-                                                           int cin_off, int accumulate) {
+                                                           int cin_off, int accumulate, int main_blocks,
+                                                           const float* __restrict__ bias_partial, int bias_n,
+                                                           float* __restrict__ dbias) {
   __shared__ double red[8][32];
+  if ((int)blockIdx.x >= main_blocks) {
+    const int c = blockIdx.x - main_blocks;
+    const float* p = bias_partial + (size_t)c * 2 * bias_n;
+    double s = 0.0;
+    for (int t = threadIdx.x; t < bias_n; t += 256) s += (double)p[t];
+    s = c3d_wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dbias[c] = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    return;
+  }
   const size_t slice_floats = (size_t)T * CI * CO;
   const int nsl = ci_slices * co_slices;
   const size_t total = slice_floats * nsl;
   const int o = threadIdx.x & 31, lanek = threadIdx.x >> 5;
-  for (size_t base = (size_t)blockIdx.x * 32; base < total; base += (size_t)gridDim.x * 32) {
+  for (size_t base = (size_t)blockIdx.x * 32; base < total; base += (size_t)main_blocks * 32) {
     const size_t e = base + o;
     double s = 0.0;
     int t = 0, ci = 0, co = 0;
@@ -427,8 +441,11 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   const size_t total = (size_t)d->ntaps * c.CI * c.CO * a.ci_slices * a.co_slices;
   int blocks = (int)((total + 31) / 32);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.partial, d->dw, a.strips, d->ntaps, c.CI,
-                     c.CO, a.ci_slices, a.co_slices, d->x.C, d->Cout, d->Cin_total, d->cin_off, d->accumulate);
+  const bool bias = d->bias_partial != nullptr;
+  C3D_REQUIRE(!bias || (d->dbias != nullptr && d->bias_n > 0), "wgrad: bias_partial needs dbias and bias_n");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks + (bias ? d->Cout : 0)), dim3(256), 0, st, a.partial, d->dw, a.strips,
+                     d->ntaps, c.CI, c.CO, a.ci_slices, a.co_slices, d->x.C, d->Cout, d->Cin_total, d->cin_off, d->accumulate,
+                     blocks, d->bias_partial, d->bias_n, d->dbias);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -312,8 +312,10 @@ def _wgrad_kernel_name(ci, co, nt, halo):
     return f"wgrad_mfma_kernel<{cfg}, {'true' if MFMA_MODE == 1 else 'false'}>"
 
 
-def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0):
-    """dw[:, cin_off:cin_off+src.C] (+)= sum_p dz[p] (x) transformed src[p + tap]."""
+def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_partial=None, dbias=None):
+    """dw[:, cin_off:cin_off+src.C] (+)= sum_p dz[p] (x) transformed src[p + tap].
+    bias_partial [>=Cout, 2, n] + dbias [Cout]: the launch that folds the weight-gradient strips folds the layer's
+    bias-gradient partials too (instead of a separate bias_from_partials launch)."""
     d = L.WgradDesc()
     src.fill(d.x)
     b, h, w = src.t.shape[:3]
@@ -330,6 +332,10 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0):
     n = L.lib().c3d_wgrad_partial_floats(C.byref(d))
     part = torch.empty(n, device=dz.device, dtype=torch.float32)
     d.partial = part.data_ptr()
+    if bias_partial is not None:
+        if dbias is None or dbias.shape[0] != dw.shape[0] or bias_partial.shape[0] < dw.shape[0]:
+            raise ValueError("conv_wgrad: bias_partial needs a dbias of Cout entries")
+        d.bias_partial, d.dbias, d.bias_n = bias_partial.data_ptr(), dbias.data_ptr(), bias_partial.shape[2]
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
     co, ci, nt = dw.shape[0], src.C, len(taps)
     name = _wgrad_kernel_name(ci, co, nt, halo)

@@ -148,6 +148,13 @@ typedef struct {
   float lrelu_slope;        /* as in c3d_conv_desc                                         */
   int32_t dz_bf16;          /* 1: dz is bf16 (x.bf16 says the same for x); mfma_bf16 == 1 only */
   int32_t reserved;
+  /* optional: fold the layer's bias-gradient partials in the same launch that folds the weight-gradient strips
+   * (saves one tiny launch per conv layer): dbias[c] = sum_k bias_partial[c][0][k], k < bias_n, the
+   * [Cout][2][bias_n] partials c3d_bn_bwd_apply wrote (what c3d_bias_from_partials computes).  NULL = off. */
+  const float* bias_partial;
+  float* dbias;
+  int32_t bias_n;
+  int32_t reserved2;
 } c3d_wgrad_desc;
 int64_t c3d_wgrad_partial_floats(const c3d_wgrad_desc* d);
 int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream);
