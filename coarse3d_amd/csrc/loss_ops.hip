@@ -320,7 +320,11 @@ __global__ __launch_bounds__(256) void gather_l2_kernel(const float* __restrict_
   }
 }
 
-// dfeat[img[t]][idx[t][s]][:] += g * dx[t*A+s][:]  (atomic; anchors repeat)
+// dfeat[img[t]][idx[t][s]][:] += g * sum over the rows s' of pair t with idx[t][s'] == idx[t][s] of dx[t*A+s'][:].
+// Anchors repeat (sampling with replacement), but only INSIDE a pair t: a pixel carries one label, so the pixel sets
+// of different (image, class) pairs are disjoint.  One wave per row; the wave of the FIRST occurrence of a pixel in its
+// pair sums all of that pixel's rows in ascending s and does one plain read-modify-write -- no atomics, and the
+// result does not depend on the order in which waves run (bit-reproducible d feat).
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ dx, const int32_t* __restrict__ img,
                                                            const int32_t* __restrict__ idx, const int32_t* __restrict__ T,
                                                            int Tmax, int A, int n, int D, const float* __restrict__ gscale,
@@ -331,9 +335,39 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
   const int Tn = *T;
   const float g = gscale ? *gscale : 1.f;
   for (size_t r = wave; r < (size_t)Tn * A; r += nw) {
-    const int t = r / A;
-    float* dst = dfeat + ((size_t)img[t] * n + idx[r]) * D;
-    for (int d = lane; d < D; d += 64) unsafeAtomicAdd(dst + d, g * dx[r * D + d]);
+    const int t = r / A, s = (int)(r - (size_t)t * A);
+    const int32_t* grp = idx + (size_t)t * A;
+    const int mine = grp[s];
+    // an earlier row of the pair with the same pixel owns the sum
+    bool owner = true;
+    for (int base = 0; base < s && owner; base += 64) {
+      const int j = base + lane;
+      if (__ballot(j < s && grp[j] == mine)) owner = false;
+    }
+    if (!owner) continue;
+    float* dst = dfeat + ((size_t)img[t] * n + mine) * D;
+    const float* src = dx + (size_t)t * A * D;
+    for (int d0 = 0; d0 < D; d0 += 256) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int base = s & ~63; base < A; base += 64) {
+        const int j = base + lane;
+        unsigned long long m = __ballot(j >= s && j < A && grp[j] == mine);
+        while (m) {
+          const int q = base + __builtin_ctzll(m);
+          m &= m - 1;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int d = d0 + k * 64 + lane;
+            if (d < D) acc[k] += src[(size_t)q * D + d];
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int d = d0 + k * 64 + lane;
+        if (d < D) dst[d] += g * acc[k];
+      }
+    }
   }
 }
 

@@ -335,7 +335,9 @@ int c3d_anchor_sample(const float* weights, const int32_t* counts, const int32_t
 int c3d_gather_rows_l2(const float* feat, const int32_t* img, const int32_t* idx,
                        const int32_t* T, int Tmax, int A, int n, int D, float eps, float* out,
                        float* norm, c3d_stream stream);
-/* dfeat[img[t]][idx[t][s]] += (*gscale) * dx[t*A+s]   (atomic; gscale may be NULL)           */
+/* dfeat[img[t]][idx[t][s]] += (*gscale) * dx[t*A+s]   (gscale may be NULL).  Repeated pixels inside a pair t are
+ * summed in ascending s by one wave and added with a plain store (bit-reproducible); pixels must not repeat ACROSS
+ * pairs (they cannot: a pixel has one class -- contrast_pixel_loss.py anchor sampling is per (image, class)).      */
 int c3d_scatter_add_rows(const float* dx, const int32_t* img, const int32_t* idx,
                          const int32_t* T, int Tmax, int A, int n, int D, const float* gscale,
                          float* dfeat, c3d_stream stream);

@@ -222,3 +222,41 @@ def test_l2norm_and_residual():
     yy = torch.ones(2, 8, 16, 32, device=DEV)
     ops.axpy(a.to(DEV), yy, 0.5, True)
     assert rel(yy, 1 + 0.5 * a) < 1e-6
+
+
+@pytest.mark.parametrize("A,D", [(50, 256), (512, 256), (130, 96)])
+def test_scatter_add_rows_repeated_anchors_bit_reproducible(A, D):
+    """Gradient hand-over of the contrast loss (autograd of `feats[img, :, idx]` in contrast_pixel_loss.py): anchors
+    are drawn with replacement, so pixels repeat inside an (image, class) pair.  The kernel sums a pixel's rows in
+    ascending order in one wave (no atomics): exact against an ordered fp32 reference, identical across runs."""
+    from coarse3d_amd import ops
+    g = torch.Generator().manual_seed(17)
+    B, n, tmax, tn = 2, 4096, 12, 9
+    img = torch.zeros(tmax, dtype=torch.int32)
+    idx = torch.zeros(tmax, A, dtype=torch.int32)
+    for t in range(tn):                                  # pair t owns the pixels == t (mod tmax): disjoint across pairs
+        img[t] = t % B
+        pool = torch.arange(t, n, tmax)[torch.randperm(n // tmax, generator=g)[:max(3, A // 4)]]   # heavy repetition
+        idx[t] = pool[torch.randint(0, pool.numel(), (A,), generator=g)].to(torch.int32)
+    dx = torch.randn(tmax * A, D, generator=g)
+    gs = torch.tensor([0.37])
+    ref = torch.zeros(B, n, D)
+    acc = {}
+    for t in range(tn):
+        for s in range(A):                               # ascending s, fp32 adds: the kernel's order
+            key = (int(img[t]), int(idx[t, s]))
+            acc[key] = dx[t * A + s].clone() if key not in acc else acc[key] + dx[t * A + s]
+    for (b, p), v in acc.items():
+        ref[b, p] = gs * v
+    outs = []
+    for _ in range(3):
+        dfeat = torch.zeros(B, n, D, device=DEV)
+        ops.scatter_add_rows(dx.to(DEV), img.to(DEV), idx.to(DEV), torch.tensor([tn], dtype=torch.int32, device=DEV),
+                             tmax, A, n, dfeat, gs.to(DEV))
+        outs.append(dfeat.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], ref)
+    # accumulate semantics: a second call adds to what is there
+    ops.scatter_add_rows(dx.to(DEV), img.to(DEV), idx.to(DEV), torch.tensor([tn], dtype=torch.int32, device=DEV),
+                         tmax, A, n, dfeat, gs.to(DEV))
+    assert rel(dfeat, 2 * ref) < 1e-6
