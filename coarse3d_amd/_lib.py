@@ -8,7 +8,8 @@ import os
 import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcoarse3d_hip.so")
+# C3D_LIB: another build of the same library (same-box A/B of two kernel versions, tools/ab_env.sh)
+LIB_PATH = os.environ.get("C3D_LIB") or os.path.join(_HERE, "libcoarse3d_hip.so")
 
 
 class Src(C.Structure):

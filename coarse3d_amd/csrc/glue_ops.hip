@@ -41,57 +41,89 @@ __global__ void input_norm_kernel(const float* __restrict__ x, const int64_t* __
 
 // ---------------------------------------------------------------- first conv 5 -> 32 (VALU)
 // x NCHW [B,Cn,H,W] (Cn <= 8), w [32][Cn], out NHWC [B,HW,32]
+// HBM-bound (20 B in, 128 B out per pixel): eight lanes per pixel, four couts each -- every lane's store is one
+// 16-byte access and a wave writes 1 KB of consecutive bytes; the weights of the four couts live in registers.
+// (The first version computed 32 couts per lane and transposed through LDS with 4-byte stores: 179 us for the
+// 155 MB of the 8x64x2048 launch, 0.87 TB/s.)
 __global__ __launch_bounds__(256) void conv_in5_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, int Cn, int HW, int total_pix,
                                                        float* __restrict__ out, int bf) {
-  __shared__ float tile[256][33];
-  __shared__ float sw[32 * 8 + 32];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 32 * Cn; i += 256) sw[i] = w[i];
-  if (tid < 32) sw[256 + tid] = bias[tid];
-  __syncthreads();
-  const size_t p0 = (size_t)blockIdx.x * 256;
-  const size_t p = p0 + tid;
-  if (p < (size_t)total_pix) {
-    const int b = p / HW, hw = p % HW;
-    float xv[8];
-    for (int c = 0; c < Cn; ++c) xv[c] = x[((size_t)b * Cn + c) * HW + hw];
-#pragma unroll 4
-    for (int co = 0; co < 32; ++co) {
-      float acc = sw[256 + co];
-      for (int c = 0; c < Cn; ++c) acc = fmaf(sw[co * Cn + c], xv[c], acc);
-      tile[tid][co] = c3d_lrelu(acc);
-    }
+  const int tid = threadIdx.x, q = tid & 7;
+  float wr[4][8], br[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    br[k] = bias[q * 4 + k];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) wr[k][c] = c < Cn ? w[(q * 4 + k) * Cn + c] : 0.f;
   }
-  __syncthreads();
-  for (int i = tid; i < 256 * 32; i += 256) {
-    const int pp = i >> 5, co = i & 31;
-    if (p0 + pp < (size_t)total_pix) c3d_st1(out, (p0 + pp) * 32 + co, bf & 1, tile[pp][co]);
+  const int step = gridDim.x * 32;
+#pragma unroll 2
+  for (int p = blockIdx.x * 32 + (tid >> 3); p < total_pix; p += step) {
+    const int b = p / HW, hw = p - b * HW;
+    const float* xp = x + (size_t)b * Cn * HW + hw;
+    float xv[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xv[c] = c < Cn ? xp[(size_t)c * HW] : 0.f;
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float acc = br[k];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc = fmaf(wr[k][c], xv[c], acc);     // c >= Cn: fmaf(0, 0, acc) == acc
+      o[k] = c3d_lrelu(acc);
+    }
+    c3d_st4(out, (size_t)p * 32 + q * 4, bf & 1, o);
   }
 }
 
-// dW partial: [nblk][32][8]
+// dW partial: [nblk][32][8].  Eight lanes per pixel (16-byte dz loads, a wave reads 1 KB of consecutive bytes), 4 x 8
+// accumulators per lane, folded over the 32 pixel lanes of the workgroup at the end.
+// (First version: 4-byte dz loads, one pixel pair per wave instruction: 245 us per launch, 0.64 TB/s.)
 __global__ __launch_bounds__(256) void conv_in5_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                              int Cn, int HW, int total_pix, int pix_per_block,
                                                              float* __restrict__ partial, int bf) {
-  __shared__ float red[8][32][8];
-  const int tid = threadIdx.x, co = tid & 31, pl = tid >> 5;
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  __shared__ float red[4][32][8];
+  const int tid = threadIdx.x, q = tid & 7, wave = tid >> 6;
+  float acc[4][8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(p0 + pix_per_block, total_pix);
-  for (int p = p0 + pl; p < p1; p += 8) {
-    const int b = p / HW, hw = p % HW;
-    const float g = c3d_ld1(dz, (size_t)p * 32 + co, bf & 1);
-    for (int c = 0; c < Cn; ++c) acc[c] = fmaf(g, x[((size_t)b * Cn + c) * HW + hw], acc[c]);
-  }
-  for (int c = 0; c < 8; ++c) red[pl][co][c] = acc[c];
-  __syncthreads();
-  if (pl == 0) {
+#pragma unroll 2
+  for (int p = p0 + (tid >> 3); p < p1; p += 32) {
+    const int b = p / HW, hw = p - b * HW;
+    const f32x4 g = c3d_ld4(dz, (size_t)p * 32 + q * 4, bf & 1);
+    const float* xp = x + (size_t)b * Cn * HW + hw;
+#pragma unroll
     for (int c = 0; c < 8; ++c) {
-      float s = 0.f;
-      for (int k = 0; k < 8; ++k) s += red[k][co][c];
-      partial[((size_t)blockIdx.x * 32 + co) * 8 + c] = s;
+      const float xv = c < Cn ? xp[(size_t)c * HW] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k][c] = fmaf(g[k], xv, acc[k][c]);
     }
+  }
+  // the 8 pixel lanes of a wave (lane bits 3..5), then the 4 waves
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float v = acc[k][c];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      acc[k][c] = v;
+    }
+  if ((tid & 63) < 8) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) red[wave][q * 4 + k][c] = acc[k][c];
+  }
+  __syncthreads();
+  {
+    const int co = tid >> 3, c = tid & 7;
+    partial[((size_t)blockIdx.x * 32 + co) * 8 + c] = (red[0][co][c] + red[1][co][c]) + (red[2][co][c] + red[3][co][c]);
   }
 }
 
@@ -353,55 +385,99 @@ __global__ void catskip_bwd_kernel(PsBwdArgs p) {
 }
 
 // ---------------------------------------------------------------- channel softmax (+crop)
-// 32 lanes cooperate on one pixel (lane = channel): every load / store of a wave covers two whole
-// pixels contiguously, reductions over the classes are 5 shuffle steps.
-__device__ __forceinline__ float half_wave_sum(float v) {
+// One pixel per lane, its C <= 32 channels in registers (16-byte accesses when C and cs are multiples of 4).  Sums
+// over the classes keep the pairing of a 32-lane xor butterfly over the zero-padded classes (16, 8, 4, 2, 1): the
+// first version of these kernels ran 32 lanes per pixel with ten dependent cross-lane shuffles per pixel and was
+// bound by their latency (119 / 110 us per 8x64x2048 launch, 1.8 / 2.7 TB/s); these produce the same bits.
+__device__ __forceinline__ float butterfly32_sum(float (&h)[32]) {
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
-  return v;
+  for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+    for (int c = 0; c < o; ++c) h[c] = __fadd_rn(h[c], h[c + o]);
+  return h[0];
 }
-__device__ __forceinline__ float half_wave_max(float v) {
+template <bool V4>
+__device__ __forceinline__ void ld_row32(const float* __restrict__ p, int C, float fill, float (&v)[32]) {
+  if constexpr (V4) {
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 32));
-  return v;
+    for (int q = 0; q < 8; ++q) {
+      if (q * 4 < C) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p + q * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[q * 4 + k] = t[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[q * 4 + k] = fill;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) v[c] = c < C ? p[c] : fill;
+  }
+}
+template <bool V4>
+__device__ __forceinline__ void st_row32(float* __restrict__ p, int C, const float (&v)[32]) {
+  if constexpr (V4) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (q * 4 < C) *reinterpret_cast<f32x4*>(p + q * 4) = f32x4{v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+  } else {
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c < C) p[c] = v[c];
+  }
 }
 
 // logits [B,H,W,cs] (first C channels used) -> prob [B,Ho,Wo,C]
+template <bool V4>
 __global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ logits, int B, int H, int W, int cs,
                                                       int C, int Ho, int Wo, float* __restrict__ prob) {
-  const int c = threadIdx.x & 31;
-  const size_t total = (size_t)B * Ho * Wo;
-  for (size_t i = gtid() >> 5; i < total; i += gstride() >> 5) {
+  const int total = B * Ho * Wo;
+  for (int i = (int)gtid(); i < total; i += (int)gstride()) {
     const int x = i % Wo;
     const int y = (i / Wo) % Ho;
-    const int b = i / ((size_t)Wo * Ho);
-    const float v = c < C ? logits[((size_t)(b * H + y) * W + x) * cs + c] : -INFINITY;
-    const float mx = half_wave_max(v);
-    const float e = c < C ? expf(v - mx) : 0.f;
-    const float s = half_wave_sum(e);
-    if (c < C) prob[i * C + c] = e / s;
+    const int b = i / (Wo * Ho);
+    float v[32], e[32];
+    ld_row32<V4>(logits + ((size_t)(b * H + y) * W + x) * cs, C, -INFINITY, v);
+    float mx = v[0];
+#pragma unroll
+    for (int c = 1; c < 32; ++c) mx = fmaxf(mx, v[c]);
+#pragma unroll
+    for (int c = 0; c < 32; ++c) e[c] = c < C ? expf(v[c] - mx) : 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) v[c] = e[c];
+    const float s = butterfly32_sum(v);
+#pragma unroll
+    for (int c = 0; c < 32; ++c) e[c] = e[c] / s;
+    st_row32<V4>(prob + (size_t)i * C, C, e);
   }
 }
 
 // dlogits [B,H,W,cs] = p * (dp - sum(p*dp)) inside the crop, 0 elsewhere (incl. pad channels)
+template <bool V4>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ prob,
                                                           const float* __restrict__ dprob, int B, int H, int W, int cs,
                                                           int C, int Ho, int Wo, float* __restrict__ dlogits) {
-  const int c = threadIdx.x & 31;
-  const size_t total = (size_t)B * H * W;
-  for (size_t i = gtid() >> 5; i < total; i += gstride() >> 5) {
+  const int total = B * H * W;
+  for (int i = (int)gtid(); i < total; i += (int)gstride()) {
     const int x = i % W;
     const int y = (i / W) % H;
-    const int b = i / ((size_t)W * H);
-    float out = 0.f;
-    if (y < Ho && x < Wo) {                      // uniform over the 32 lanes of a pixel
+    const int b = i / (W * H);
+    float out[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) out[c] = 0.f;
+    if (y < Ho && x < Wo) {
       const size_t j = ((size_t)(b * Ho + y) * Wo + x) * C;
-      const float p = c < C ? prob[j + c] : 0.f;
-      const float g = c < C ? dprob[j + c] : 0.f;
-      const float dot = half_wave_sum(p * g);
-      out = p * (g - dot);
+      float p[32], g[32], t[32];
+      ld_row32<V4>(prob + j, C, 0.f, p);
+      ld_row32<V4>(dprob + j, C, 0.f, g);
+#pragma unroll
+      for (int c = 0; c < 32; ++c) t[c] = __fmul_rn(p[c], g[c]);
+      const float dot = butterfly32_sum(t);
+#pragma unroll
+      for (int c = 0; c < 32; ++c) out[c] = p[c] * (g[c] - dot);
     }
-    if (c < cs) dlogits[i * cs + c] = out;
+    st_row32<V4>(dlogits + (size_t)i * cs, cs, out);
   }
 }
 
@@ -582,7 +658,9 @@ extern "C" int c3d_conv_in5(const float* x_nchw, const float* w, const float* bi
                             c3d_stream stream) {
   C3D_REQUIRE(Cn <= 8, "conv_in5: at most 8 input channels");
   const int total = B * HW;
-  hipLaunchKernelGGL(conv_in5_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, x_nchw, w, bias, Cn, HW, total, out, bf16_mask);
+  int nb = (total + 31) / 32;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(conv_in5_kernel, dim3(nb), dim3(256), 0, ST, x_nchw, w, bias, Cn, HW, total, out, bf16_mask);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -702,8 +780,13 @@ extern "C" int c3d_pixshuf_cat_bwd(const float* dout, const float* m3, const flo
 extern "C" int c3d_softmax(const float* logits, int B, int H, int W, int cs, int C, int Ho, int Wo, float* prob,
                            c3d_stream stream) {
   C3D_REQUIRE(C <= 32 && C <= cs, "softmax: at most 32 classes");
-  hipLaunchKernelGGL(softmax_kernel, dim3(nblocks((size_t)B * Ho * Wo * 32)), dim3(256), 0, ST, logits, B, H, W, cs, C,
-                     Ho, Wo, prob);
+  C3D_REQUIRE((int64_t)B * H * W < (1ll << 31), "softmax: more than 2^31 pixels");
+  if (C % 4 == 0 && cs % 4 == 0)
+    hipLaunchKernelGGL(softmax_kernel<true>, dim3(nblocks((size_t)B * Ho * Wo)), dim3(256), 0, ST, logits, B, H, W, cs, C,
+                       Ho, Wo, prob);
+  else
+    hipLaunchKernelGGL(softmax_kernel<false>, dim3(nblocks((size_t)B * Ho * Wo)), dim3(256), 0, ST, logits, B, H, W, cs, C,
+                       Ho, Wo, prob);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -711,8 +794,13 @@ extern "C" int c3d_softmax(const float* logits, int B, int H, int W, int cs, int
 extern "C" int c3d_softmax_bwd(const float* prob, const float* dprob, int B, int H, int W, int cs, int C, int Ho,
                                int Wo, float* dlogits, c3d_stream stream) {
   C3D_REQUIRE(C <= 32 && cs <= 32, "softmax_bwd: at most 32 classes / padded channels");
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(nblocks((size_t)B * H * W * 32)), dim3(256), 0, ST, prob, dprob, B, H, W, cs,
-                     C, Ho, Wo, dlogits);
+  C3D_REQUIRE((int64_t)B * H * W < (1ll << 31), "softmax_bwd: more than 2^31 pixels");
+  if (C % 4 == 0 && cs % 4 == 0)
+    hipLaunchKernelGGL(softmax_bwd_kernel<true>, dim3(nblocks((size_t)B * H * W)), dim3(256), 0, ST, prob, dprob, B, H, W,
+                       cs, C, Ho, Wo, dlogits);
+  else
+    hipLaunchKernelGGL(softmax_bwd_kernel<false>, dim3(nblocks((size_t)B * H * W)), dim3(256), 0, ST, prob, dprob, B, H, W,
+                       cs, C, Ho, Wo, dlogits);
   C3D_CHECK_LAUNCH();
   return 0;
 }
