@@ -347,6 +347,9 @@ __global__ __launch_bounds__(256) void gather_l2_kernel(const float* __restrict_
 // of different (image, class) pairs are disjoint.  One wave per row; the wave of the FIRST occurrence of a pixel in its
 // pair sums all of that pixel's rows in ascending s and does one plain read-modify-write -- no atomics, and the
 // result does not depend on the order in which waves run (bit-reproducible d feat).
+// Work item = (row, 64-channel chunk) per wave.  With weak labels a pair has a handful of labelled pixels and hundreds
+// of anchors, so an owner sums ~A/pixels rows: their loads are issued eight at a time (independent), the adds stay in
+// row order.  (One wave per whole row with one load in flight per duplicate: 425 us at the headline shape.)
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ dx, const int32_t* __restrict__ img,
                                                            const int32_t* __restrict__ idx, const int32_t* __restrict__ T,
                                                            int Tmax, int A, int n, int D, const float* __restrict__ gscale,
@@ -356,39 +359,47 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
   const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
   const int Tn = *T;
   const float g = gscale ? *gscale : 1.f;
-  for (size_t r = wave; r < (size_t)Tn * A; r += nw) {
+  const int DC = (D + 63) / 64;
+  for (size_t wi = wave; wi < (size_t)Tn * A * DC; wi += nw) {
+    const size_t r = wi / DC;
+    const int d = (int)(wi - r * DC) * 64 + lane;
     const int t = r / A, s = (int)(r - (size_t)t * A);
     const int32_t* grp = idx + (size_t)t * A;
     const int mine = grp[s];
     // an earlier row of the pair with the same pixel owns the sum
     bool owner = true;
-    for (int base = 0; base < s && owner; base += 64) {
-      const int j = base + lane;
-      if (__ballot(j < s && grp[j] == mine)) owner = false;
+    for (int base = 0; base < s && owner; base += 512) {
+      bool hit = false;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int j = base + k * 64 + lane;
+        hit |= (j < s ? grp[j] : -1) == mine;
+      }
+      if (__ballot(hit)) owner = false;
     }
     if (!owner) continue;
-    float* dst = dfeat + ((size_t)img[t] * n + mine) * D;
-    const float* src = dx + (size_t)t * A * D;
-    for (int d0 = 0; d0 < D; d0 += 256) {
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int base = s & ~63; base < A; base += 64) {
-        const int j = base + lane;
-        unsigned long long m = __ballot(j >= s && j < A && grp[j] == mine);
-        while (m) {
-          const int q = base + __builtin_ctzll(m);
-          m &= m - 1;
+    const float* src = dx + (size_t)t * A * D + d;
+    float acc = 0.f;
+    for (int base = s & ~63; base < A; base += 64) {
+      const int j = base + lane;
+      unsigned long long m = __ballot(j >= s && j < A && grp[j] == mine);
+      while (m) {
+        int q[8];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int d = d0 + k * 64 + lane;
-            if (d < D) acc[k] += src[(size_t)q * D + d];
-          }
+        for (int k = 0; k < 8; ++k) {
+          q[k] = m ? base + __builtin_ctzll(m) : -1;
+          m &= m - 1;          // 0 stays 0
         }
-      }
+        float x[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int d = d0 + k * 64 + lane;
-        if (d < D) dst[d] += g * acc[k];
+        for (int k = 0; k < 8; ++k) x[k] = (q[k] >= 0 && d < D) ? src[(size_t)q[k] * D] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += x[k];      // row order; absent rows add 0
       }
+    }
+    if (d < D) {
+      float* dst = dfeat + ((size_t)img[t] * n + mine) * D + d;
+      *dst += g * acc;
     }
   }
 }

@@ -224,8 +224,8 @@ def test_l2norm_and_residual():
     assert rel(yy, 1 + 0.5 * a) < 1e-6
 
 
-@pytest.mark.parametrize("A,D", [(50, 256), (512, 256), (130, 96)])
-def test_scatter_add_rows_repeated_anchors_bit_reproducible(A, D):
+@pytest.mark.parametrize("A,D,pool_n", [(50, 256, 12), (512, 256, 7), (130, 96, 40), (512, 256, 300)])
+def test_scatter_add_rows_repeated_anchors_bit_reproducible(A, D, pool_n):
     """Gradient hand-over of the contrast loss (autograd of `feats[img, :, idx]` in contrast_pixel_loss.py): anchors
     are drawn with replacement, so pixels repeat inside an (image, class) pair.  The kernel sums a pixel's rows in
     ascending order in one wave (no atomics): exact against an ordered fp32 reference, identical across runs."""
@@ -236,7 +236,7 @@ def test_scatter_add_rows_repeated_anchors_bit_reproducible(A, D):
     idx = torch.zeros(tmax, A, dtype=torch.int32)
     for t in range(tn):                                  # pair t owns the pixels == t (mod tmax): disjoint across pairs
         img[t] = t % B
-        pool = torch.arange(t, n, tmax)[torch.randperm(n // tmax, generator=g)[:max(3, A // 4)]]   # heavy repetition
+        pool = torch.arange(t, n, tmax)[torch.randperm(n // tmax, generator=g)[:pool_n]]   # weak labels: a handful of pixels per pair
         idx[t] = pool[torch.randint(0, pool.numel(), (A,), generator=g)].to(torch.int32)
     dx = torch.randn(tmax * A, D, generator=g)
     gs = torch.tensor([0.37])

@@ -32,6 +32,18 @@ def main():
             ("softmax", lambda: ops.softmax(logits, C), n * (128 + 80)),
             ("softmax_bwd", lambda: ops.softmax_bwd(prob, dprob, logits.shape), n * (80 + 80 + 128)),
             ("entropy_stats", lambda: ops.entropy_stats(prob), n * (80 + 12))]
+    feat = torch.randn(B, 32, 1024, 256, device=dev)
+    up = torch.empty(B, H, W, 256, device=dev)
+    dfeat = torch.randn(B, H, W, 256, device=dev)
+    dlow = torch.zeros_like(feat)
+    lvl = torch.randn(B, 8, 256, 256, device=dev)
+    cat = torch.empty(B, 32, 1024, 704, device=dev)
+    dcat = torch.randn(B, 32, 1024, 704, device=dev)
+    dlvl = torch.zeros_like(lvl)
+    rows += [("bilinear x2 256ch", lambda: ops.bilinear(feat, H, W, dst=up), n * 1024 + feat.numel() * 4),
+             ("bilinear_bwd x2 256ch", lambda: ops.bilinear_bwd(dlow, dfeat), n * 1024 + feat.numel() * 4),
+             ("bilinear x4 256ch->cat", lambda: ops.bilinear(lvl, 32, 1024, dst=cat, dcoff=448), B * 32 * 1024 * 1024 + lvl.numel() * 4),
+             ("bilinear_bwd x4 256ch", lambda: ops.bilinear_bwd(dlvl, dcat, dcoff=448, c=256), B * 32 * 1024 * 1024 + lvl.numel() * 4)]
     for name, fn, byts in rows:
         us = timeit(fn)
         print(f"{name:16s} {us:8.1f} us  {byts / us / 1e3:8.0f} GB/s")
