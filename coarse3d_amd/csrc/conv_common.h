@@ -132,7 +132,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
           float v = acc[i][j][r] + bias;
           if (a.epi_lrelu) v = c3d_lrelu(v, a.slope);
           if constexpr (ACC) v += old[r];
-          orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs] = (OT)v;
+          // fresh outputs leave with the nontemporal hint: the tile's halo / weight re-reads live on L2 hits and the
+          // output stream is never re-read by this kernel (same-box A/B of the step: 197.9 -> 199.2 img/s)
+          if constexpr (!ACC) __builtin_nontemporal_store((OT)v, &orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs]);
+          else orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs] = (OT)v;
           s1[j] += v;
           s2v[j] += v * v;
         }
