@@ -366,35 +366,56 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
     const int t = r / A, s = (int)(r - (size_t)t * A);
     const int32_t* grp = idx + (size_t)t * A;
     const int mine = grp[s];
-    // an earlier row of the pair with the same pixel owns the sum
-    bool owner = true;
-    for (int base = 0; base < s && owner; base += 512) {
-      bool hit = false;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int j = base + k * 64 + lane;
-        hit |= (j < s ? grp[j] : -1) == mine;
-      }
-      if (__ballot(hit)) owner = false;
-    }
-    if (!owner) continue;
     const float* src = dx + (size_t)t * A * D + d;
     float acc = 0.f;
-    for (int base = s & ~63; base < A; base += 64) {
-      const int j = base + lane;
-      unsigned long long m = __ballot(j >= s && j < A && grp[j] == mine);
-      while (m) {
-        int q[8];
+    // sum the rows q[0..8) (ascending, -1 = none): loads first, adds in row order
+    auto add_rows = [&](unsigned long long& m, int base) {
+      int q[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        q[k] = m ? base + __builtin_ctzll(m) : -1;
+        m &= m - 1;          // 0 stays 0
+      }
+      float x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = (q[k] >= 0 && d < D) ? src[(size_t)q[k] * D] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += x[k];      // absent rows add 0
+    };
+    if (A <= 512) {
+      // the pair's whole index row in one round of loads: ownership test and duplicate masks come from registers
+      // (chunk-by-chunk scans, a dependent load each, cost 243 us once pseudo-labels make most anchors distinct)
+      int v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int j = k * 64 + lane;
+        v[k] = j < A ? grp[j] : -1;
+      }
+      bool hit = false;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) hit |= (k * 64 + lane < s) && v[k] == mine;
+      if (__ballot(hit)) continue;          // an earlier row of the pair with the same pixel owns the sum
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        unsigned long long m = __ballot(k * 64 + lane >= s && v[k] == mine);
+        while (m) add_rows(m, k * 64);
+      }
+    } else {
+      bool owner = true;
+      for (int base = 0; base < s && owner; base += 512) {
+        bool hit = false;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          q[k] = m ? base + __builtin_ctzll(m) : -1;
-          m &= m - 1;          // 0 stays 0
+          const int j = base + k * 64 + lane;
+          hit |= (j < s ? grp[j] : -1) == mine;
         }
-        float x[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = (q[k] >= 0 && d < D) ? src[(size_t)q[k] * D] : 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc += x[k];      // row order; absent rows add 0
+        if (__ballot(hit)) owner = false;
+      }
+      if (!owner) continue;
+      for (int base = s & ~63; base < A; base += 64) {
+        const int j = base + lane;
+        unsigned long long m = __ballot(j >= s && j < A && grp[j] == mine);
+        while (m) add_rows(m, base);
       }
     }
     if (d < D) {

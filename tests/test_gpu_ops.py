@@ -224,7 +224,7 @@ def test_l2norm_and_residual():
     assert rel(yy, 1 + 0.5 * a) < 1e-6
 
 
-@pytest.mark.parametrize("A,D,pool_n", [(50, 256, 12), (512, 256, 7), (130, 96, 40), (512, 256, 300)])
+@pytest.mark.parametrize("A,D,pool_n", [(50, 256, 12), (512, 256, 7), (130, 96, 40), (512, 256, 300), (700, 64, 90)])
 def test_scatter_add_rows_repeated_anchors_bit_reproducible(A, D, pool_n):
     """Gradient hand-over of the contrast loss (autograd of `feats[img, :, idx]` in contrast_pixel_loss.py): anchors
     are drawn with replacement, so pixels repeat inside an (image, class) pair.  The kernel sums a pixel's rows in
