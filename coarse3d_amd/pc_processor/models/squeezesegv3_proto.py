@@ -119,10 +119,9 @@ class SqueezeSegV3Proto(SalsaNextProto):
         return SqueezeSegBackbone(P, self.nclasses, self.dataset, reduce_fn, world, self._packs, self.layers,
                                   self._side_stream_for(P))
 
-    def _trainable(self):
-        skip = ("prototypes", "feat_norm.weight", "feat_norm.bias", "mask_norm.weight", "mask_norm.bias")
+    def _list_trainable(self):
         unused = ("head1.", "head2.", "head3.", "head4.")           # parameters the reference's forward never touches
-        return [(k, p) for k, p in self.named_parameters() if k not in skip and not k.startswith(unused)]
+        return [(k, p) for k, p in self.named_parameters() if k not in self._SKIP and not k.startswith(unused)]
 
     def _check_input(self, h, w):
         assert w % 8 == 0, "input width must be a multiple of 8 (three stride-2 stages)"

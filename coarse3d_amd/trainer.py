@@ -33,6 +33,12 @@ class TrainStep:
                  proto_loss=False, optimizer=None, scheduler=None, inputs_resident=False):
         self.model = model
         self.net = model.module if hasattr(model, "module") else model
+        # This step owns zero_grad / backward / optimizer.step: on a plain (unwrapped) model the backward pass may
+        # write the gradients into one persistent buffer and bind param.grad itself (models that know the switch;
+        # under a wrapper -- DistributedDataParallel hooks, coarse3d_amd.dist.DataParallel -- gradients keep going
+        # through autograd / the wrapper's flat buffer).
+        if self.net is model and hasattr(model, "_bind_grads") and os.environ.get("C3D_BIND_GRADS", "1") != "0":
+            model._bind_grads = True
         self.n_classes = n_classes
         self.n_epochs = n_epochs
         self.w_ce, self.w_lov, self.w_con = loss_w_ce_2d, loss_w_lov_2d, loss_w_contrast
