@@ -22,7 +22,7 @@ from collections import OrderedDict
 
 import torch
 
-from . import ops
+from . import contrast, ops
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -481,7 +481,9 @@ class Backbone:
         if embed:
             feat_a, z0, emb, embn, norm = self.tape["embed"]
             d_embn = torch.empty_like(embn)
-            ops.bilinear_bwd(d_embn, d_feat.contiguous())
+            d_feat = d_feat.contiguous()
+            # the contrast loss marks the ~10^3 pixel rows of its dense gradient that are not zero (contrast.take_row_hint)
+            ops.bilinear_bwd(d_embn, d_feat, rowmask=contrast.take_row_hint(d_feat))
             d_emb = ops.l2norm_bwd(embn, norm, d_embn, 1e-12)
             self._conv_backward("projector.proj.3", d_emb)
         logits = self.tape["cls_head"].out

@@ -5,6 +5,9 @@ tasks/weak_segmentation/trainer.py:447-518 (``entropy_based_selection``).  Every
 shape-static and free of host synchronisation: absent (image, class) pairs are masked on the
 device instead of being skipped by Python loops."""
 import numpy as np
+import os
+import weakref
+
 import torch
 
 from . import ops
@@ -31,6 +34,39 @@ def entropy_selection(prob_nhwc, train_label, eval_label, select_ratio, noise=No
     return labels.view(b, h, w), mask.view(b, h, w)
 
 
+# ---- row-sparsity hint for the gradient of the embedding
+# d(loss)/d(feats) is a dense [B,H,W,D] tensor (1 GB at the headline shape) with ~10^3 non-zero pixel rows of 10^6.
+# The tensor handed to autograd stays dense and complete; next to it the backward publishes a bitmap of the rows it
+# wrote.  A consumer that receives THIS tensor object (a view whose base it is) may skip rows whose bit is clear --
+# the backbone's bilinear adjoint does (its 1 GB read drops to the marked rows).  One slot, consumed on first use, held
+# by weak reference: a gradient that autograd summed with another one, copied, or that comes from elsewhere never
+# matches.  C3D_SPARSE_DFEAT=0 switches it off.
+SPARSE_HINT_ON = os.environ.get("C3D_SPARSE_DFEAT", "1") != "0"
+_row_hint = None
+
+
+def _publish_row_hint(dfeat, rowmask):
+    global _row_hint
+    _row_hint = (weakref.ref(dfeat), dfeat._version, rowmask)
+
+
+def take_row_hint(t):
+    """Bitmap of the non-zero pixel rows of ``t`` if ``t`` is (a view of) the gradient the contrast loss produced in
+    this backward pass and nothing has written to it since; else None.  Clears the slot."""
+    global _row_hint
+    hint, _row_hint = _row_hint, None
+    if hint is None or t is None:
+        return None
+    ref, version, rowmask = hint
+    src = ref()
+    if src is None:
+        return None
+    base = t._base if t._base is not None else t
+    if base is not src or t._version != version or t.data_ptr() != src.data_ptr() or t.numel() != src.numel():
+        return None
+    return rowmask
+
+
 class _ContrastFn(torch.autograd.Function):
     """loss = InfoNCE(anchors sampled from feats, prototype queue); d(loss)/d(feats) is a sparse
     scatter-add of at most B*(C-1)*A rows (the reference zero-fills a dense [B,HW,D] tensor per
@@ -53,7 +89,11 @@ class _ContrastFn(torch.autograd.Function):
         dx = ops.l2norm_bwd(st["anchors"], st["norm"], da)
         dfeat = torch.zeros(b, h, w, d, device=feat.device, dtype=torch.float32)
         gs = g.reshape(1).to(torch.float32).contiguous()
-        ops.scatter_add_rows(dx, st["img"], st["idx"], st["T"], tmax, a, n, dfeat, gs)
+        # one bit per pixel that received a row: a hint for whoever consumes this (dense, complete) gradient next
+        rowmask = torch.zeros((b * n + 31) // 32, device=feat.device, dtype=torch.int32) if SPARSE_HINT_ON else None
+        ops.scatter_add_rows(dx, st["img"], st["idx"], st["T"], tmax, a, n, dfeat, gs, rowmask=rowmask)
+        if rowmask is not None:
+            _publish_row_hint(dfeat, rowmask)
         return dfeat.permute(0, 3, 1, 2), None
 
 

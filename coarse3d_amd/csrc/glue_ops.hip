@@ -580,7 +580,8 @@ __device__ __forceinline__ float bl_weight(int d, int s, float ratio, int n) {
 // once per candidate row.  Summation order (rows outer, columns inner, both ascending) as in the first version.
 constexpr int BL_NX = 8;
 template <int V>
-__global__ __launch_bounds__(256) void bilinear_bwd_kernel(BlArgs p, int accumulate, int chunks_per_row, int q_shift) {
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(BlArgs p, int accumulate, int chunks_per_row, int q_shift,
+                                                           const uint32_t* __restrict__ rowmask) {
   const int Q = p.C / V;
   const int row_elems = p.Ws * Q;
   float* dsrc = const_cast<float*>(p.src);
@@ -608,9 +609,10 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(BlArgs p, int accumul
           const float wy = bl_weight(yd, ys, p.ry, p.Hs);
           if (wy == 0.f) continue;
           const size_t g0 = ((size_t)b * p.Hd + yd) * p.Wd * p.dcs + p.dcoff;
+          const unsigned m0 = (unsigned)((b * p.Hd + yd) * p.Wd);      // destination pixel index of column 0
 #pragma unroll
           for (int j = 0; j < BL_NX; ++j) {
-            if (wxr[j] != 0.f) {
+            if (wxr[j] != 0.f && (!rowmask || ((rowmask[(m0 + xlo + j) >> 5] >> ((m0 + xlo + j) & 31)) & 1u))) {
               c3d_vec<V> g = c3d_vld<V>(p.dst, g0 + (size_t)((xlo + j) * p.dcs + c), p.bf & 2);
               g *= (wy * wxr[j]);
               acc += g;
@@ -619,6 +621,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(BlArgs p, int accumul
           for (int xd = xlo + BL_NX; xd <= xhi; ++xd) {
             const float wx = bl_weight(xd, xs, p.rx, p.Ws);
             if (wx == 0.f) continue;
+            if (rowmask && !((rowmask[(m0 + xd) >> 5] >> ((m0 + xd) & 31)) & 1u)) continue;
             c3d_vec<V> g = c3d_vld<V>(p.dst, g0 + (size_t)(xd * p.dcs + c), p.bf & 2);
             g *= (wy * wx);
             acc += g;
@@ -882,7 +885,8 @@ extern "C" int c3d_bilinear(const float* src, int Hs, int Ws, int scs, int scoff
 }
 
 extern "C" int c3d_bilinear_bwd(float* dsrc, int Hs, int Ws, int scs, int scoff, const float* ddst, int Hd, int Wd,
-                                int dcs, int dcoff, int B, int C, int accumulate, int bf16_mask, c3d_stream stream) {
+                                int dcs, int dcoff, int B, int C, int accumulate, int bf16_mask, const uint32_t* ddst_rowmask,
+                                c3d_stream stream) {
   C3D_REQUIRE(C % 4 == 0 && scs % 4 == 0 && dcs % 4 == 0 && scoff % 4 == 0 && dcoff % 4 == 0,
               "bilinear_bwd: channel counts/strides must be multiples of 4");
   BlArgs p = bl_args(dsrc, Hs, Ws, scs, scoff, const_cast<float*>(ddst), Hd, Wd, dcs, dcoff, B, C);
@@ -891,11 +895,12 @@ extern "C" int c3d_bilinear_bwd(float* dsrc, int Hs, int Ws, int scs, int scoff,
   const int V = (bf16_mask && C % 8 == 0 && scs % 8 == 0 && dcs % 8 == 0 && scoff % 8 == 0 && dcoff % 8 == 0) ? 8 : 4;
   const int chunks = bl_chunks(Ws * (C / V), BL_IT_BWD);
   C3D_REQUIRE((int64_t)B * Hs * chunks < (1ll << 31), "bilinear_bwd: grid too large");
+  C3D_REQUIRE(!ddst_rowmask || (int64_t)B * Hd * Wd < (1ll << 32), "bilinear_bwd: row mask needs < 2^32 destination pixels");
   const int grid = B * Hs * chunks;
   if (V == 8)
-    hipLaunchKernelGGL(bilinear_bwd_kernel<8>, dim3(grid), dim3(256), 0, ST, p, accumulate, chunks, bl_shift(C / 8));
+    hipLaunchKernelGGL(bilinear_bwd_kernel<8>, dim3(grid), dim3(256), 0, ST, p, accumulate, chunks, bl_shift(C / 8), ddst_rowmask);
   else
-    hipLaunchKernelGGL(bilinear_bwd_kernel<4>, dim3(grid), dim3(256), 0, ST, p, accumulate, chunks, bl_shift(C / 4));
+    hipLaunchKernelGGL(bilinear_bwd_kernel<4>, dim3(grid), dim3(256), 0, ST, p, accumulate, chunks, bl_shift(C / 4), ddst_rowmask);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void gather_l2_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ dx, const int32_t* __restrict__ img,
                                                            const int32_t* __restrict__ idx, const int32_t* __restrict__ T,
                                                            int Tmax, int A, int n, int D, const float* __restrict__ gscale,
-                                                           float* __restrict__ dfeat) {
+                                                           float* __restrict__ dfeat, uint32_t* __restrict__ rowmask) {
   const int lane = threadIdx.x & 63;
   const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -421,6 +421,10 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
     if (d < D) {
       float* dst = dfeat + ((size_t)img[t] * n + mine) * D + d;
       *dst += g * acc;
+    }
+    if (rowmask && d == 0) {                 // one lane per written row (an OR: order-free)
+      const size_t pix = (size_t)img[t] * n + mine;
+      atomicOr(&rowmask[pix >> 5], 1u << (pix & 31));
     }
   }
 }
@@ -595,9 +599,9 @@ extern "C" int c3d_gather_rows_l2(const float* feat, const int32_t* img, const i
 }
 
 extern "C" int c3d_scatter_add_rows(const float* dx, const int32_t* img, const int32_t* idx, const int32_t* T, int Tmax,
-                                    int A, int n, int D, const float* gscale, float* dfeat, c3d_stream stream) {
+                                    int A, int n, int D, const float* gscale, float* dfeat, uint32_t* rowmask, c3d_stream stream) {
   hipLaunchKernelGGL(scatter_rows_kernel, dim3(nb_for((size_t)Tmax * A, 4)), dim3(256), 0, ST, dx, img, idx, T, Tmax, A,
-                     n, D, gscale, dfeat);
+                     n, D, gscale, dfeat, rowmask);
   C3D_CHECK_LAUNCH();
   return 0;
 }

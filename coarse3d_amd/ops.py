@@ -560,12 +560,15 @@ def bilinear(src, hd, wd, dst=None, dcoff=0, c=None, scoff=0, out_dtype=None):
     return dst
 
 
-def bilinear_bwd(dsrc, ddst, dcoff=0, c=None, scoff=0, accumulate=False):
+def bilinear_bwd(dsrc, ddst, dcoff=0, c=None, scoff=0, accumulate=False, rowmask=None):
+    """rowmask: int32 bitmap over the pixels of ddst (scatter_add_rows writes it); clear bit = known zeros, not read."""
     b, hs, ws, scs = dsrc.shape
     _, hd, wd, dcs = ddst.shape
     c = c or scs
+    if rowmask is not None and (rowmask.dtype != torch.int32 or rowmask.numel() * 32 < b * hd * wd):
+        raise ValueError("bilinear_bwd: rowmask must be int32 with one bit per destination pixel")
     _call("c3d_bilinear_bwd", _dp(dsrc), hs, ws, scs, scoff, _dp(ddst), hd, wd, dcs, dcoff, b, c, int(accumulate),
-          _bf(dsrc, ddst), _stream())
+          _bf(dsrc, ddst), _dp(rowmask), _stream())
     return dsrc
 
 
@@ -689,10 +692,11 @@ def gather_rows_l2(feat, img, idx, t, tmax, a, n, eps=1e-12):
     return out, norm
 
 
-def scatter_add_rows(dx, img, idx, t, tmax, a, n, dfeat, gscale=None):
+def scatter_add_rows(dx, img, idx, t, tmax, a, n, dfeat, gscale=None, rowmask=None):
+    """rowmask: optional pre-zeroed int32 bitmap ((B*n + 31)//32 words); the bit of every written row gets set."""
     d = dx.shape[-1]
     _call("c3d_scatter_add_rows", _dp(dx), _dp(img), _dp(idx), _dp(t), tmax, a, n, d, _dp(gscale), _dp(dfeat),
-          _stream())
+          _dp(rowmask), _stream())
     return dfeat
 
 

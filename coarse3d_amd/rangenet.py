@@ -18,7 +18,7 @@ from collections import OrderedDict
 
 import torch
 
-from . import ops
+from . import contrast, ops
 from .backbone import Act, Backbone
 
 SLOPE = 0.1                      # nn.LeakyReLU(0.1)
@@ -205,7 +205,8 @@ class RangeNetBackbone(Backbone):
         if d_feat is not None and self.return_feat:
             feat_a, z0, emb, embn, norm = self.tape["embed"]
             d_embn = torch.empty_like(embn)
-            ops.bilinear_bwd(d_embn, d_feat.contiguous())
+            d_feat = d_feat.contiguous()
+            ops.bilinear_bwd(d_embn, d_feat, rowmask=contrast.take_row_hint(d_feat))
             d_emb = ops.l2norm_bwd(embn, norm, d_embn, 1e-12)
             self._conv_backward("projector.proj.3", d_emb)
             self._conv_backward("projector.proj.0", z0.grad)

@@ -261,9 +261,11 @@ int c3d_softmax_bwd(const float* prob, const float* dprob, int B, int H, int W, 
 int c3d_bilinear(const float* src, int Hs, int Ws, int scs, int scoff, float* dst, int Hd,
                  int Wd, int dcs, int dcoff, int B, int C, int bf16_mask, c3d_stream stream);
 /* dsrc (+)= bilinear^T(ddst): deterministic gather over the destination pixels that read each
- * source pixel (no atomics); accumulate != 0 adds to the existing dsrc                        */
+ * source pixel (no atomics); accumulate != 0 adds to the existing dsrc.  ddst_rowmask (may be NULL): one bit per
+ * destination pixel (bit p & 31 of word p >> 5, p = (b*Hd + y)*Wd + x); pixels whose bit is clear are known to hold
+ * zeros and are not read (the contrast loss' gradient touches ~10^3 of 10^6 pixels: c3d_scatter_add_rows writes the mask) */
 int c3d_bilinear_bwd(float* dsrc, int Hs, int Ws, int scs, int scoff, const float* ddst, int Hd,
-                     int Wd, int dcs, int dcoff, int B, int C, int accumulate, int bf16_mask, c3d_stream stream);
+                     int Wd, int dcs, int dcoff, int B, int C, int accumulate, int bf16_mask, const uint32_t* ddst_rowmask, c3d_stream stream);
 /* F.normalize(p=2) over rows of [n][C] (:485; eps 1e-12); norm may be NULL                  */
 int c3d_l2norm(const float* x, int64_t n, int C, float eps, float* y, float* norm, int bf16_mask,
                c3d_stream stream);
@@ -337,10 +339,11 @@ int c3d_gather_rows_l2(const float* feat, const int32_t* img, const int32_t* idx
                        float* norm, c3d_stream stream);
 /* dfeat[img[t]][idx[t][s]] += (*gscale) * dx[t*A+s]   (gscale may be NULL).  Repeated pixels inside a pair t are
  * summed in ascending s by one wave and added with a plain store (bit-reproducible); pixels must not repeat ACROSS
- * pairs (they cannot: a pixel has one class -- contrast_pixel_loss.py anchor sampling is per (image, class)).      */
+ * pairs (they cannot: a pixel has one class -- contrast_pixel_loss.py anchor sampling is per (image, class)).
+ * rowmask (may be NULL, else pre-zeroed, (B*n + 31)/32 words): bit img*n + pixel is set for every row written.    */
 int c3d_scatter_add_rows(const float* dx, const int32_t* img, const int32_t* idx,
                          const int32_t* T, int Tmax, int A, int n, int D, const float* gscale,
-                         float* dfeat, c3d_stream stream);
+                         float* dfeat, uint32_t* rowmask, c3d_stream stream);
 /* InfoNCE over cosine logits [Tmax*A][ld] (first ncols=(C-1)*M columns valid, column class
  * 1 + j/M): replaces logits by d(mean loss)/d(logits) in place, row_loss per row, *loss.     */
 int c3d_infonce_rows(float* logits, int ld, const int32_t* row_cls, const int32_t* T, int Tmax,

@@ -260,3 +260,39 @@ def test_scatter_add_rows_repeated_anchors_bit_reproducible(A, D, pool_n):
     ops.scatter_add_rows(dx.to(DEV), img.to(DEV), idx.to(DEV), torch.tensor([tn], dtype=torch.int32, device=DEV),
                          tmax, A, n, dfeat, gs.to(DEV))
     assert rel(dfeat, 2 * ref) < 1e-6
+
+
+def test_row_mask_hint_scatter_and_bilinear_adjoint():
+    """The contrast loss' dense gradient carries a bitmap of its non-zero pixel rows (c3d_scatter_add_rows) which the
+    bilinear adjoint may use to skip known-zero rows: identical result with and without it; the hint is handed over
+    only for the very tensor it was made for."""
+    from coarse3d_amd import contrast, ops
+    g = torch.Generator().manual_seed(23)
+    B, H, W, D, A, tmax, tn = 2, 16, 64, 64, 20, 6, 5
+    n = H * W
+    img = torch.zeros(tmax, dtype=torch.int32)
+    idx = torch.zeros(tmax, A, dtype=torch.int32)
+    for t in range(tn):
+        img[t] = t % B
+        pool = torch.arange(t, n, tmax)[torch.randperm(n // tmax, generator=g)[:9]]
+        idx[t] = pool[torch.randint(0, 9, (A,), generator=g)].to(torch.int32)
+    dx = torch.randn(tmax * A, D, generator=g).to(DEV)
+    dfeat = torch.zeros(B, H, W, D, device=DEV)
+    mask = torch.zeros((B * n + 31) // 32, dtype=torch.int32, device=DEV)
+    ops.scatter_add_rows(dx, img.to(DEV), idx.to(DEV), torch.tensor([tn], dtype=torch.int32, device=DEV), tmax, A, n, dfeat,
+                         rowmask=mask)
+    bits = ((mask.cpu().view(-1, 1) >> torch.arange(32, dtype=torch.int32)) & 1).flatten()[:B * n].bool()
+    assert torch.equal(bits, (dfeat.cpu().view(B * n, D) != 0).any(1))
+    a = ops.bilinear_bwd(torch.empty(B, H // 2, W // 2, D, device=DEV), dfeat)
+    b = ops.bilinear_bwd(torch.empty(B, H // 2, W // 2, D, device=DEV), dfeat, rowmask=mask)
+    assert torch.equal(a, b) and float(a.abs().max()) > 0
+    up = ops.bilinear_bwd(torch.empty(B, 4 * H, 4 * W, D, device=DEV), dfeat, rowmask=mask)      # a down-sampling adjoint too
+    assert torch.equal(up, ops.bilinear_bwd(torch.empty(B, 4 * H, 4 * W, D, device=DEV), dfeat))
+    # hand-over: only (views of) the published tensor, once, and only while unmodified
+    contrast._publish_row_hint(dfeat, mask)
+    assert contrast.take_row_hint(dfeat.clone()) is None and contrast.take_row_hint(dfeat) is None     # slot consumed
+    contrast._publish_row_hint(dfeat, mask)
+    assert contrast.take_row_hint(dfeat.permute(0, 3, 1, 2).permute(0, 2, 3, 1)) is mask
+    contrast._publish_row_hint(dfeat, mask)
+    dfeat.mul_(2.0)
+    assert contrast.take_row_hint(dfeat) is None

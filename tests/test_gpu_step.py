@@ -399,3 +399,50 @@ def test_prototype_sums_exchange_mode():
     l2 = banks["zero"][0] / banks["zero"][0].norm(dim=-1, keepdim=True)
     assert float((banks["zero"][1] - l2).abs().max()) < 1e-6
     assert float((banks["fused"][1] - l2).abs().max()) > 1e-6
+
+
+def test_fast_paths_of_the_training_step_change_nothing():
+    """Two shortcuts of TrainStep on a plain model -- param.grad bound to one persistent buffer instead of going through
+    AccumulateGrad, and the contrast loss' row bitmap letting the bilinear adjoint skip known-zero rows of the dense
+    embedding gradient -- against the same step with both switched off: identical loss, gradients and update."""
+    from coarse3d_amd import contrast, ops
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    from coarse3d_amd.trainer import TrainStep
+    b, h, w, ncls = 2, 32, 64, 20
+    x, tr, ev = W.synthetic_batch(b, h, w, ncls, 5, 0.02, gh=8, gw=16)
+    masks = {k: v.to(DEV) for k, v in W.dropout_masks_for(None, b, 6).items()}
+    results, taken = [], []
+    orig_take = contrast.take_row_hint
+    for fast in (False, True):
+        torch.manual_seed(3)
+        m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True)
+        m.load_state_dict(W.closed_form_state(nclasses=ncls))
+        m.to(DEV).train()
+        m.dropout_masks = masks
+        m.gumbel_noise = torch.ones(b * h * w, 20, device=DEV)
+        ts = TrainStep(m, ncls, proto_loss=True, lr=1e-3, num_anchor=64, loss_w_contrast=0.5, entropy_selection=False)
+        m._bind_grads = fast
+        contrast.SPARSE_HINT_ON = fast
+
+        def spy(t):
+            r = orig_take(t)
+            taken.append(r is not None)
+            return r
+        contrast.take_row_hint = spy
+        try:
+            torch.manual_seed(11)                      # the anchor sampler draws its uniforms from torch's generator
+            res = ts.step(x.to(DEV), tr.to(DEV), ev.to(DEV), epoch=10)
+        finally:
+            contrast.take_row_hint = orig_take
+            contrast.SPARSE_HINT_ON = True
+        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+        if fast:
+            assert m._own_flat is not None and m.cls_head.weight.grad.data_ptr() == m._own_flat[2]["cls_head.weight"].data_ptr()
+        results.append((float(res["loss"]), float(res["contrast"].detach()), grads, {k: p.detach().clone() for k, p in m.named_parameters()}))
+    assert taken == [False, True], taken               # the hint reaches the backbone through autograd, and only when on
+    assert results[0][1] > 0 and results[0][0] == results[1][0]
+    assert results[0][2].keys() == results[1][2].keys()
+    for k in results[0][2]:
+        assert torch.equal(results[0][2][k], results[1][2][k]), k
+    for k in results[0][3]:
+        assert torch.equal(results[0][3][k], results[1][3][k]), k
