@@ -368,6 +368,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   }
 
   // ---- consumer waves
+  // (tried: 32-wide channel tiles dealt to the waves interleaved, dead tiles of a ragged last slice skipped under
+  //  wave-uniform tests -- 704 = 5.5 x 128 = 2.75 x 256 leaves 16 % dead MFMAs.  The scalar branches around the
+  //  MFMAs cost every instance more than the dead work: 704x704 layer 1.97 -> 2.11 ms, the step 197 -> 191 img/s.)
   f32x16 acc[TMAX][CI_T][CO_T];
 #pragma unroll
   for (int t = 0; t < TMAX; ++t)
