@@ -44,6 +44,8 @@ def main():
              ("bilinear_bwd x2 256ch", lambda: ops.bilinear_bwd(dlow, dfeat), n * 1024 + feat.numel() * 4),
              ("bilinear x4 256ch->cat", lambda: ops.bilinear(lvl, 32, 1024, dst=cat, dcoff=448), B * 32 * 1024 * 1024 + lvl.numel() * 4),
              ("bilinear_bwd x4 256ch", lambda: ops.bilinear_bwd(dlvl, dcat, dcoff=448, c=256), B * 32 * 1024 * 1024 + lvl.numel() * 4)]
+    lnw, lnb = torch.rand(256, device=dev), torch.randn(256, device=dev)
+    rows += [("rownorm_ln_l2 256ch", lambda: ops.rownorm_ln_l2(up.view(n, 256), lnw, lnb), n * 2048)]
     for name, fn, byts in rows:
         us = timeit(fn)
         print(f"{name:16s} {us:8.1f} us  {byts / us / 1e3:8.0f} GB/s")
