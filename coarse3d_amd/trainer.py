@@ -63,7 +63,22 @@ class TrainStep:
         # passes over the 192 parameter tensors: 0.38 -> 0.1 ms per step); C3D_FUSED_ADAMW=0 keeps the default form.
         if optimizer is None:
             fused = dev.type == "cuda" and os.environ.get("C3D_FUSED_ADAMW", "1") != "0"
-            optimizer = torch.optim.AdamW(self.net.parameters(), lr=lr, **({"fused": True} if fused else {}))
+            flat = (fused and getattr(model, "_bind_grads", False) and os.environ.get("C3D_FLAT_ADAMW", "1") != "0")
+            views = None
+            if flat:
+                named, names, _ = model._cached()
+                views = model._bound_grad_views(names)    # None while some param.grad is pending (e.g. a second TrainStep)
+            if views is not None:
+                # one parameter group, one formula: step all tensors as ONE flat buffer (coarse3d_amd/optim.py)
+                from .optim import FlatAdamW
+                optimizer = FlatAdamW(named, views, model._own_flat[1], lr=lr)
+                own = model._own_flat
+                model.invalidate_caches()             # parameter storage moved into the flat buffer
+                model._own_flat = own
+                if hasattr(model, "_packs"):
+                    model._packs = ops.PackCache()
+            else:
+                optimizer = torch.optim.AdamW(self.net.parameters(), lr=lr, **({"fused": True} if fused else {}))
         self.optimizer = optimizer
         self.scheduler = scheduler
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None

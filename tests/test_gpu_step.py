@@ -402,9 +402,10 @@ def test_prototype_sums_exchange_mode():
 
 
 def test_fast_paths_of_the_training_step_change_nothing():
-    """Two shortcuts of TrainStep on a plain model -- param.grad bound to one persistent buffer instead of going through
-    AccumulateGrad, and the contrast loss' row bitmap letting the bilinear adjoint skip known-zero rows of the dense
-    embedding gradient -- against the same step with both switched off: identical loss, gradients and update."""
+    """Three shortcuts of TrainStep on a plain model -- param.grad bound to one persistent buffer instead of going through
+    AccumulateGrad, the contrast loss' row bitmap letting the bilinear adjoint skip known-zero rows of the dense
+    embedding gradient, and AdamW stepping all parameters as one flat buffer (coarse3d_amd/optim.py) -- against the same
+    steps with all of them off and torch's per-parameter fused AdamW: identical losses, gradients and parameters."""
     from coarse3d_amd import contrast, ops
     from coarse3d_amd.pc_processor.models import SalsaNextProto
     from coarse3d_amd.trainer import TrainStep
@@ -420,7 +421,12 @@ def test_fast_paths_of_the_training_step_change_nothing():
         m.to(DEV).train()
         m.dropout_masks = masks
         m.gumbel_noise = torch.ones(b * h * w, 20, device=DEV)
-        ts = TrainStep(m, ncls, proto_loss=True, lr=1e-3, num_anchor=64, loss_w_contrast=0.5, entropy_selection=False)
+        # slow variant: stock per-parameter fused AdamW handed in, gradients through AccumulateGrad, no row hint;
+        # fast variant: TrainStep's defaults (FlatAdamW over one flat parameter / gradient buffer, bound gradients, hint)
+        opt = None if fast else torch.optim.AdamW(m.parameters(), lr=1e-3, fused=True)
+        ts = TrainStep(m, ncls, proto_loss=True, lr=1e-3, num_anchor=64, loss_w_contrast=0.5, entropy_selection=False,
+                       optimizer=opt)
+        assert (type(ts.optimizer).__name__ == "FlatAdamW") == fast
         m._bind_grads = fast
         contrast.SPARSE_HINT_ON = fast
 
@@ -438,11 +444,16 @@ def test_fast_paths_of_the_training_step_change_nothing():
         grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
         if fast:
             assert m._own_flat is not None and m.cls_head.weight.grad.data_ptr() == m._own_flat[2]["cls_head.weight"].data_ptr()
-        results.append((float(res["loss"]), float(res["contrast"].detach()), grads, {k: p.detach().clone() for k, p in m.named_parameters()}))
+        for extra in range(2):                          # two more updates: moments and bias corrections in play
+            torch.manual_seed(12 + extra)
+            res2 = ts.step(x.to(DEV), tr.to(DEV), ev.to(DEV), epoch=10)
+        results.append((float(res["loss"]), float(res["contrast"].detach()), grads,
+                        {k: p.detach().clone() for k, p in m.named_parameters()}, float(res2["loss"])))
     assert taken == [False, True], taken               # the hint reaches the backbone through autograd, and only when on
     assert results[0][1] > 0 and results[0][0] == results[1][0]
     assert results[0][2].keys() == results[1][2].keys()
     for k in results[0][2]:
         assert torch.equal(results[0][2][k], results[1][2][k]), k
     for k in results[0][3]:
-        assert torch.equal(results[0][3][k], results[1][3][k]), k
+        assert torch.equal(results[0][3][k], results[1][3][k]), k         # parameters after three updates
+    assert results[0][4] == results[1][4]
