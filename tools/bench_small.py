@@ -44,6 +44,10 @@ def main():
              ("bilinear_bwd x2 256ch", lambda: ops.bilinear_bwd(dlow, dfeat), n * 1024 + feat.numel() * 4),
              ("bilinear x4 256ch->cat", lambda: ops.bilinear(lvl, 32, 1024, dst=cat, dcoff=448), B * 32 * 1024 * 1024 + lvl.numel() * 4),
              ("bilinear_bwd x4 256ch", lambda: ops.bilinear_bwd(dlvl, dcat, dcoff=448, c=256), B * 32 * 1024 * 1024 + lvl.numel() * 4)]
+    xin = torch.randn(B, H, W, 64, device=dev); mk = torch.rand(B, 64, device=dev)
+    dpo = torch.randn(B, H // 2, W // 2, 64, device=dev)
+    rows += [("maskpool 64ch", lambda: ops.maskpool(xin, mk, True), n * 256 * 1.25),
+             ("maskpool_bwd 64ch", lambda: ops.maskpool_bwd(dpo, mk, None, (B, H, W, 64), True), n * 256 * 1.25)]
     lnw, lnb = torch.rand(256, device=dev), torch.randn(256, device=dev)
     rows += [("rownorm_ln_l2 256ch", lambda: ops.rownorm_ln_l2(up.view(n, 256), lnw, lnb), n * 2048)]
     for name, fn, byts in rows:
