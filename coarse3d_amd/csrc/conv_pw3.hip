@@ -242,6 +242,327 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
                                                   tile_pix);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 3: the same tile, arithmetic and LDS image, with the staging dealt INTO the MFMA stream.
+//
+// profiles/round3_coissue_probe.md: one wave hides <= 5 plain VALU / one ds_write_b64 / two ds_read_b128 per
+// v_mfma_f32_32x32x16_bf16 gap at no cost (32.3 -> 35 cycles per MFMA); what does not hide is packed-f32 VALU
+// (v_pk_fma/mul/add_f32: +18 cycles for one per gap) -- which is what hipcc makes of every float4 expression,
+// and what round 2's "VALU and MFMA do not overlap" measured.  conv_pw3_kernel above runs its phases in
+// lockstep (all eight waves split + store chunk c+1, then all eight multiply chunk c, one barrier per
+// chunk), so matrix 1.10 ms + staging 0.60 ms + 0.24 ms simply add up on the 704 -> 704 layer.
+// Here every wave's chunk iteration is ONE basic block: the 6 * NJ MFMA pairs of chunk c, and between
+// consecutive pairs a slice ("atoms") of the work that stages chunk c+1 and requests chunk c+2:
+//     a(i,e)   BatchNorm affine + LeakyReLU of two channels of input unit i         6 VALU (scalar f32 only)
+//     h/m/l    one bf16 plane of that pair + the exact residual                     5 / 5 / 1 VALU
+//     ds_write_b64 of a finished plane of a unit / of a pre-split weight unit        1 LDS store
+//     the global loads of chunk c+2 (as soon as the registers they land in are free)
+// pinned in source order by __builtin_amdgcn_sched_barrier(0) after every pair (this file is compiled
+// without packed-f32 ops, see NOPK in the Makefile).  Everything inside the block is unconditional: a source
+// without BatchNorm loads scale = 1 / shift = 0 from a 32-byte constant with a zero pointer step, a source
+// without LeakyReLU uses slope 1 (max(v, 1 * v) = v), the cursor is clamped at the last chunk.  The values
+// that reach LDS, the product order and the epilogue are those of conv_pw3_kernel: outputs are bit-identical
+// (tests/test_gpu_conv.py::test_fused_pointwise_kernel_is_bit_identical_to_the_phased_one).
+__device__ float c3d_unit_affine[8] = {1.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void c3d_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    c3d_static_for<I + 1, N>(f);
+  }
+}
+
+// The staging work of one chunk as a sequence of atoms (kind, unit, plane, element pair), in issue order:
+// per input unit  XF e0, XF e1 (affine + LeakyReLU), LIN (reload the unit's registers with chunk c+2), then per
+// plane two SPLIT atoms and the unit's ds_write_b64; the weight units (three stores + their reload) are dealt
+// between the input units so that the LDS stores are spread evenly; the scale / shift reload comes last.
+enum { A_XF, A_LIN, A_SPLIT, A_STIN, A_STW, A_LW, A_LAFF };
+struct c3d_atom_seq {
+  int n;
+  int kind[96], u[96], p[96], e[96];
+};
+constexpr c3d_atom_seq c3d_make_atoms(int in_pt, int w_pt) {
+  c3d_atom_seq s{};
+  int n = 0, wdone = 0;
+  for (int i = 0; i < in_pt; ++i) {
+    for (int e = 0; e < 2; ++e) { s.kind[n] = A_XF; s.u[n] = i; s.e[n] = e; ++n; }
+    s.kind[n] = A_LIN; s.u[n] = i; ++n;
+    for (int p = 0; p < 3; ++p) {
+      for (int e = 0; e < 2; ++e) { s.kind[n] = A_SPLIT; s.u[n] = i; s.p[n] = p; s.e[n] = e; ++n; }
+      s.kind[n] = A_STIN; s.u[n] = i; s.p[n] = p; ++n;
+    }
+    if (wdone < w_pt) {
+      for (int p = 0; p < 3; ++p) { s.kind[n] = A_STW; s.u[n] = wdone; s.p[n] = p; ++n; }
+      s.kind[n] = A_LW; s.u[n] = wdone; ++n;
+      ++wdone;
+    }
+  }
+  for (; wdone < w_pt; ++wdone) {
+    for (int p = 0; p < 3; ++p) { s.kind[n] = A_STW; s.u[n] = wdone; s.p[n] = p; ++n; }
+    s.kind[n] = A_LW; s.u[n] = wdone; ++n;
+  }
+  s.kind[n] = A_LAFF; ++n;
+  s.n = n;
+  return s;
+}
+
+// WN = 2: eight waves (4 pixel-row groups x 2 cout groups), one workgroup per CU -- round 2's geometry.
+// WN = 1: four waves per workgroup and TWO workgroups per CU: the barrier bubbles, the prologue and the
+//         epilogue of one workgroup (0.5 of the 704 -> 704 layer's time on the eight-wave form: the matrix pipe
+//         is busy 0.55-0.6 of the time) run under the other workgroup's MFMAs.
+template <int NT, int WN>
+__global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void conv_pw3f_kernel(ConvArgs a) {
+  constexpr int NP = 3, TR = 8, CQ = 4;
+  constexpr int TN = 32 * NT;
+  constexpr int WM = 4, RPW = 2, NPW = NT / WN;
+  constexpr int NTHR = 64 * WM * WN;
+  constexpr int IN_ROWS = TR * 32;
+  constexpr int IN_PT = IN_ROWS * CQ / NTHR;       // input units (4 channels of a pixel) per thread
+  constexpr int W_PT = TN * CQ / NTHR;             // weight units (4 channels of a cout) per thread
+  constexpr int BUF = NP * (IN_ROWS + TN) * 16;    // bf16 elements per LDS buffer
+  static_assert(IN_ROWS * CQ % NTHR == 0 && TN * CQ % NTHR == 0 && NT % WN == 0, "staging units must tile the workgroup");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short* s_base = reinterpret_cast<unsigned short*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the
+  const int half = lane >> 5, l31 = lane & 31;                                   // sub-tile dispatch below must be
+  const int wm = wave % WM, wn = wave / WM;                                      // scalar branches
+
+  const int ntile = a.B * a.tiles_y * a.tiles_x;
+  const int logical = c3d_xcd_remap(blockIdx.x, ntile * a.ntn);
+  const int mt = logical / a.ntn;
+  const int n0 = (logical % a.ntn) * TN;
+  const int tx = mt % a.tiles_x;
+  const int ty = (mt / a.tiles_x) % a.tiles_y;
+  const int b = mt / (a.tiles_x * a.tiles_y);
+  const int x0 = tx * 32, y0 = ty * TR;
+
+  f32x16 acc[RPW][NPW];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i)
+#pragma unroll
+    for (int j = 0; j < NPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- load cursor.  Every load is a buffer load: the descriptor (base of the tile in the current source / of
+  //      the weight planes) and the K offset (soffset) live in SGPRs, the per-thread part is a 32-bit voffset that
+  //      only changes when the cursor enters another source -- no per-chunk pointer arithmetic in VGPRs.
+  const int c4 = tid % CQ;
+  const size_t tile_pix = (size_t)(b * a.H + y0) * a.W + x0;
+  const unsigned wplane_b = (unsigned)a.Kq * a.Cout * 8;                         // bytes per bf16 weight plane (T = 1)
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.wpack) + (size_t)a.Kq * a.Cout * 4, 0, 0x7fffffff, 0x00020000);   // planes follow the fp32 pack
+  int vw[W_PT];
+#pragma unroll
+  for (int i = 0; i < W_PT; ++i) {
+    const int u = tid + i * NTHR;
+    const int n = min(n0 + u % TN, a.Cout - 1), kq = u / TN;
+    vw[i] = (kq * a.Cout + n) * 8;
+  }
+  __amdgpu_buffer_rsrc_t rs_in, rs_sc, rs_sh;
+  int vin[IN_PT];
+  const int vaff = c4 * 16;
+  int lstep = 0;                           // per-chunk step of the scale / shift offset (bytes; 0: the unit constant)
+  float lslope = 1.f;
+  int ls = 0, lc0 = 0, lC = 0, lk = 0;     // source, channel inside it, its width, global chunk index
+  auto open_src = [&](int s) {
+    const c3d_src& sr = a.src[s];
+    rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sr.ptr) + tile_pix * sr.cstride + sr.coff, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < IN_PT; ++i) {
+      const int p = tid / CQ + i * (NTHR / CQ);
+      const int gx = min(x0 + (p & 31), a.W - 1), gy = min(y0 + (p >> 5), a.H - 1);
+      vin[i] = (((gy - y0) * a.W + (gx - x0)) * sr.cstride + c4 * 4) * 4;
+    }
+    if (sr.scale) {
+      rs_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sr.scale), 0, 0x7fffffff, 0x00020000);
+      rs_sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sr.shift), 0, 0x7fffffff, 0x00020000);
+      lstep = 64;
+    } else {
+      rs_sc = __builtin_amdgcn_make_buffer_rsrc(c3d_unit_affine, 0, 0x7fffffff, 0x00020000);
+      rs_sh = __builtin_amdgcn_make_buffer_rsrc(c3d_unit_affine + 4, 0, 0x7fffffff, 0x00020000);
+      lstep = 0;
+    }
+    lslope = sr.lrelu ? a.slope : 1.f;
+    lC = sr.C;
+    lc0 = 0;
+  };
+  open_src(0);
+  const int nchunks = a.Kq / 4;            // K / 16
+  auto advance = [&]() {                   // cursor -> next chunk; stays on the last one (clamped re-loads)
+    if (lk + 1 < nchunks) {
+      ++lk;
+      lc0 += 16;
+      if (lc0 >= lC) open_src(++ls);
+    }
+  };
+
+  // ---- registers of the chunks in flight
+  f32x4 pin[IN_PT];
+  u32x2 pw[W_PT][NP];
+  f32x4 psc, psh;
+  float pslope;
+  auto load_in = [&](int i) { pin[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vin[i], lc0 * 4, 0)); };
+  auto load_aff = [&]() {
+    const int so = (lstep >> 6) * lc0 * 4;
+    psc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_sc, vaff, so, 0));
+    psh = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_sh, vaff, so, 0));
+    pslope = lslope;
+  };
+  auto load_w = [&](int i) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      pw[i][p] = __builtin_amdgcn_raw_buffer_load_b64(rs_w, vw[i], lk * a.Cout * 32 + p * wplane_b, 0);
+  };
+
+  constexpr c3d_atom_seq SEQ = c3d_make_atoms(IN_PT, W_PT);
+  constexpr int NATOM = SEQ.n;
+  f32x4 sv;                                // the unit being split: transformed values, then the residuals
+  unsigned pl[2];                          // the plane being formed (4 bf16 of the unit)
+  auto atom = [&](auto k_tag, unsigned short* s_in, unsigned short* s_w) {
+    constexpr int k = decltype(k_tag)::value;
+    constexpr int kind = SEQ.kind[k], i = SEQ.u[k], p = SEQ.p[k], e = SEQ.e[k];
+    if constexpr (kind == A_XF) {
+#pragma unroll
+      for (int q = 2 * e; q < 2 * e + 2; ++q) {
+        const float v = __builtin_fmaf(pin[i][q], psc[q], psh[q]);
+        sv[q] = __builtin_fmaxf(v, v * pslope);
+      }
+    } else if constexpr (kind == A_LIN) {
+      load_in(i);
+    } else if constexpr (kind == A_LAFF) {
+      load_aff();
+    } else if constexpr (kind == A_STW) {
+      const int u = tid + i * NTHR;
+      const int R = u % TN, kq = u / TN;
+      *reinterpret_cast<u32x2*>(s_w + (p * TN + R) * 16 + swz_quad(R, kq)) = pw[i][p];
+    } else if constexpr (kind == A_LW) {
+      load_w(i);
+    } else if constexpr (kind == A_SPLIT) {
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      bf16x2 h;
+      h[0] = (__bf16)sv[2 * e];
+      h[1] = (__bf16)sv[2 * e + 1];
+      const unsigned pk = __builtin_bit_cast(unsigned, h);     // one v_cvt_pk_bf16_f32
+      pl[e] = pk;
+      if constexpr (p < 2) {                                   // exact residuals: x - bf16(x) is representable
+        sv[2 * e] -= __uint_as_float(pk << 16);
+        sv[2 * e + 1] -= __uint_as_float(pk & 0xffff0000u);
+      }
+    } else {   // A_STIN
+      const int R = tid / CQ + i * (NTHR / CQ);
+      *reinterpret_cast<u32x2*>(s_in + (p * IN_ROWS + R) * 16 + swz_quad(R, c4)) = u32x2{pl[0], pl[1]};
+    }
+  };
+
+  // live 32-wide cout sub-tiles of this tile, dealt alternately to the cout wave groups
+  const int live = min(NT, (a.Cout - n0 + 31) / 32);
+  const int nj = (live - wn + WN - 1) / WN;
+
+  // one chunk: the MFMAs of buffer `cur` with (STAGE) the atoms of the next chunk into the other buffer
+  auto chunk = [&](int cur, auto nj_tag, auto stage_tag) {
+    constexpr int NJ = decltype(nj_tag)::value;
+    constexpr bool STAGE = decltype(stage_tag)::value;
+    const unsigned short* s_in = s_base + cur * BUF;
+    const unsigned short* s_w = s_in + NP * IN_ROWS * 16;
+    unsigned short* d_in = s_base + (cur ^ 1) * BUF;
+    unsigned short* d_w = d_in + NP * IN_ROWS * 16;
+    if constexpr (NJ == 0) {
+      if constexpr (STAGE) c3d_static_for<0, NATOM>([&](auto k) { atom(k, d_in, d_w); });
+    } else {
+      // six of the nine plane products, smallest first: (A plane, B plane)
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+      constexpr int NS = 6 * NJ;                    // MFMA pairs = slots
+      bf16x8 ap[NP][RPW];
+      // weight fragments: plane 0 (first and last product of a sub-tile) double-buffered, planes 1 and 2 re-read
+      // right after their last product of sub-tile j for sub-tile j+1
+      bf16x8 b0[2], b1, b2;
+      auto read_a = [&](int p) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+          const int R = (wm + i * WM) * 32 + l31;
+          ap[p][i] = *reinterpret_cast<const bf16x8*>(s_in + p * IN_ROWS * 16 + R * 16 + swz_half(R, half));
+        }
+      };
+      auto read_b = [&](int j, int p) {
+        const int R = (j * WN + wn) * 32 + l31;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(s_w + p * TN * 16 + R * 16 + swz_half(R, half));
+        if (p == 0) b0[j & 1] = v;
+        else if (p == 1) b1 = v;
+        else b2 = v;
+      };
+      // fragments in the order the products need them
+      read_a(2); read_b(0, 0); read_a(0); read_b(0, 2); read_a(1); read_b(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      c3d_static_for<0, NS>([&](auto s_tag) {
+        constexpr int s = decltype(s_tag)::value, j = s / 6, q = s % 6;
+        if constexpr (j + 1 < NJ) {
+          if constexpr (q == 0) read_b(j + 1, 0);
+          if constexpr (q == 2) read_b(j + 1, 2);      // plane 2's only product of sub-tile j was q = 1
+          if constexpr (q == 5) read_b(j + 1, 1);      // plane 1's last product is q = 4
+        }
+        const bf16x8 bq = PB[q] == 0 ? b0[j & 1] : (PB[q] == 1 ? b1 : b2);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA[q]][i], bq, acc[i][j], 0, 0, 0);
+        if constexpr (STAGE) c3d_static_for<(s * NATOM) / NS, ((s + 1) * NATOM) / NS>([&](auto k) { atom(k, d_in, d_w); });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+  };
+
+  // prologue: chunk 0 into registers, then through the atoms into buffer 0 (which also request chunk 1)
+#pragma unroll
+  for (int i = 0; i < IN_PT; ++i) load_in(i);
+  load_aff();
+#pragma unroll
+  for (int i = 0; i < W_PT; ++i) load_w(i);
+  advance();
+  c3d_static_for<0, NATOM>([&](auto k) { atom(k, s_base, s_base + NP * IN_ROWS * 16); });
+  advance();
+  __syncthreads();
+  // the number of live sub-tiles is fixed for the launch: one copy of the K loop per value, so that each loop
+  // body is a single basic block with its own register allocation
+  auto k_loop = [&](auto nj_tag) {
+    for (int c = 0; c + 1 < nchunks; ++c) {
+      chunk(c & 1, nj_tag, std::true_type{});      // multiplies chunk c, stages chunk c+1, requests chunk c+2
+      advance();
+      __syncthreads();                             // the other buffer is complete, this one is free again
+    }
+    chunk((nchunks - 1) & 1, nj_tag, std::false_type{});
+    __syncthreads();                               // the epilogue reuses the LDS
+  };
+  if (nj >= NPW) k_loop(std::integral_constant<int, NPW>{});
+  else if (NPW > 3 && nj == 3) k_loop(std::integral_constant<int, (NPW > 3 ? 3 : 1)>{});
+  else if (NPW > 2 && nj == 2) k_loop(std::integral_constant<int, (NPW > 2 ? 2 : 1)>{});
+  else if (nj == 1) k_loop(std::integral_constant<int, 1>{});
+  else k_loop(std::integral_constant<int, 0>{});
+  conv_epilogue<TR, NT, WM, WN, false, true, NTHR, true>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
+                                                         tile_pix);
+}
+
+template <int NT, int WN>
+int launch_pw3f(ConvArgs& a, hipStream_t st) {
+  constexpr int NP = 3;
+  size_t lds = (size_t)2 * NP * (8 * 32 + 32 * NT) * 16 * 2;
+  const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
+  if (lds < red) lds = red;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw3f_kernel<NT, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
+  dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
+  hipLaunchKernelGGL((conv_pw3f_kernel<NT, WN>), grid, dim3(256 * WN), lds, st, a);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int NT, int NP>
 int launch_pw3(ConvArgs& a, hipStream_t st) {
   size_t lds = (size_t)2 * NP * (8 * 32 + 32 * NT) * 16 * 2;
@@ -265,6 +586,15 @@ int launch_pw3(ConvArgs& a, hipStream_t st) {
 // called by c3d_conv_forward for mfma_bf16 == 1 / 2 (planes = 1 / 3), 8-row tiles, one tap, Cout > 64;
 // a.wpack must be a c3d_pack_weights(mode | 2) pack (fp32 image followed by the three bf16 planes)
 int c3d_conv_forward_pw3(ConvArgs& a, int planes, bool wide, hipStream_t st) {
-  if (planes == 3) return wide ? launch_pw3<8, 3>(a, st) : launch_pw3<4, 3>(a, st);
+  if (planes == 3) {
+    // C3D_PW3_FUSED=0: round 2's phased kernel (same-box A/B and the bit-identity test; read per launch on purpose)
+    const char* e = getenv("C3D_PW3_FUSED");
+    const bool fused = !(e && e[0] == '0');
+    // C3D_PW3_FUSED: 1 = eight waves, 256 / 128 couts per workgroup; 2 (default) = four waves x 128 couts, two
+    // workgroups per CU
+    if (fused && e && e[0] == '1') return wide ? launch_pw3f<8, 2>(a, st) : launch_pw3f<4, 2>(a, st);
+    if (fused) return launch_pw3f<4, 1>(a, st);
+    return wide ? launch_pw3<8, 3>(a, st) : launch_pw3<4, 3>(a, st);
+  }
   return wide ? launch_pw3<8, 1>(a, st) : launch_pw3<4, 1>(a, st);
 }

@@ -289,3 +289,43 @@ def test_weight_gradient_long_strips(mode, B, H, W, Cin, Cout, k, dil, pad):
         (gref,) = torch.autograd.grad(y, wref, dzr[..., o0:].double().permute(0, 3, 1, 2)[:, :, :y.shape[2], :y.shape[3]])
         e = rel_err(dw[o0:, c0:].double(), gref)
         assert e < (2e-4 if mode == "bf16" else 1e-4), e
+
+
+@pytest.mark.parametrize("B,H,W,srcC,Cout,affine,lrelu", [
+    (2, 16, 70, [32, 48], 704, True, True),       # three cout tiles, ragged last one, two sources, ragged W
+    (1, 8, 64, [704], 704, True, False),          # the projector shape (44 K chunks)
+    (2, 8, 33, [64], 160, False, False),          # raw source (unit affine constant, slope 1)
+    (1, 8, 64, [16], 96, True, True),             # 128-wide tile, a single K chunk
+    (1, 16, 64, [256], 400, False, True),         # the prototype-similarity shape (ragged 400 = 256 + 144)
+])
+def test_fused_pointwise_kernel_is_bit_identical_to_the_phased_one(B, H, W, srcC, Cout, affine, lrelu, monkeypatch):
+    """conv_pw3f_kernel (round 3: staging dealt into the MFMA stream) stores the same bf16 planes, multiplies
+    the same six plane products in the same order and shares the epilogue with round 2's conv_pw3_kernel:
+    outputs and BatchNorm partials must agree bit for bit (csrc/conv_pw3.hip)."""
+    from coarse3d_amd import ops
+    prev = ops.matrix_precision_state()
+    ops.set_matrix_precision("bf16x3")
+    try:
+        g = torch.Generator().manual_seed(Cout + H)
+        dev = "cuda"
+        srcs = []
+        for c in srcC:
+            x = torch.randn(B, H, W, c, generator=g).to(dev)
+            sc = (torch.rand(c, generator=g) + 0.5).to(dev) if affine else None
+            sh = (torch.randn(c, generator=g) * 0.3).to(dev) if affine else None
+            srcs.append(ops.Source(x, sc, sh, lrelu=lrelu))
+        w = (torch.randn(Cout, sum(srcC), 1, 1, generator=g) / sum(srcC) ** 0.5).to(dev)
+        bias = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+        wp = ops.pack_weights(w, mode=0)
+        outs = {}
+        for fused in ("2", "1", "0"):       # four waves x 128 couts (default) / eight waves x 256 couts / round 2's phased kernel
+            monkeypatch.setenv("C3D_PW3_FUSED", fused)
+            y, part = ops.conv_forward(srcs, wp, bias, Cout, [(0, 0)], lrelu=True, stats=True)
+            torch.cuda.synchronize()
+            outs[fused] = (y.clone(), part.clone())
+        for fused in ("2", "1"):
+            assert torch.equal(outs[fused][0], outs["0"][0])
+            assert torch.equal(outs[fused][1], outs["0"][1])
+        assert float(outs["0"][0].abs().max()) > 0
+    finally:
+        ops.set_matrix_precision(*prev)
