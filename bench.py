@@ -271,6 +271,8 @@ def main():
     def peak_for(kernel_name):
         """Matrix-pipe ceiling of one kernel instance: conv_bfp / conv_x3 / wgrad_tr instances run on the bf16
         pipe (eight plane products per fp32 product in the "<3" instances); the rest on fp32 MFMA."""
+        if kernel_name.startswith("conv_pw3f_kernel"):       # <NT, WN>: the fused bf16x3 kernel, six plane products
+            return PEAK_BF16_MFMA_TFLOPS / 6.0
         if kernel_name.startswith("conv_pw3_kernel"):        # <NT, NP>; NP = 3 runs six plane products
             return PEAK_BF16_MFMA_TFLOPS / 6.0 if kernel_name.endswith(", 3>") else PEAK_BF16_MFMA_TFLOPS
         if kernel_name.startswith("conv_x3_kernel"):         # <NT, HALO, TT, SIX>

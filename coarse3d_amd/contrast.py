@@ -146,5 +146,6 @@ def contrast_mem_loss(feats, prob, labels, keep_mask, proto_queue, temperature=0
                  img=a_img, idx=a_idx, T=t, tmax=tmax, a=a, loss=loss)
     out = _ContrastFn.apply(feats, state)
     if return_debug:
-        return out, dict(idx=a_idx, img=a_img, cls=a_cls, T=t, row_loss=row_loss)
+        return out, dict(idx=a_idx, img=a_img, cls=a_cls, T=t, row_loss=row_loss, weights=w_anchor, counts=counts,
+                         candidates=idx, uniforms=uniforms)
     return out

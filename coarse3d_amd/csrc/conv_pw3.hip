@@ -259,11 +259,14 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
 //     the global loads of chunk c+2 (as soon as the registers they land in are free)
 // pinned in source order by __builtin_amdgcn_sched_barrier(0) after every pair (this file is compiled
 // without packed-f32 ops, see NOPK in the Makefile).  Everything inside the block is unconditional: a source
-// without BatchNorm loads scale = 1 / shift = 0 from a 32-byte constant with a zero pointer step, a source
+// without BatchNorm loads scale = 1 / shift = 0 from a constant with a zero per-chunk step, a source
 // without LeakyReLU uses slope 1 (max(v, 1 * v) = v), the cursor is clamped at the last chunk.  The values
 // that reach LDS, the product order and the epilogue are those of conv_pw3_kernel: outputs are bit-identical
 // (tests/test_gpu_conv.py::test_fused_pointwise_kernel_is_bit_identical_to_the_phased_one).
-__device__ float c3d_unit_affine[8] = {1.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f};
+// scale (16 x 1) and shift (16 x 0) of a source without BatchNorm: every thread reads its channel quad of a 16-channel
+// chunk, the per-chunk step is zero
+__device__ float c3d_unit_affine[32] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f,
+                                        0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 template <int I, int N, class F>
 __device__ __forceinline__ void c3d_static_for(F&& f) {
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void conv_pw3f_kernel(Co
       lstep = 64;
     } else {
       rs_sc = __builtin_amdgcn_make_buffer_rsrc(c3d_unit_affine, 0, 0x7fffffff, 0x00020000);
-      rs_sh = __builtin_amdgcn_make_buffer_rsrc(c3d_unit_affine + 4, 0, 0x7fffffff, 0x00020000);
+      rs_sh = __builtin_amdgcn_make_buffer_rsrc(c3d_unit_affine + 16, 0, 0x7fffffff, 0x00020000);
       lstep = 0;
     }
     lslope = sr.lrelu ? a.slope : 1.f;
@@ -587,13 +590,19 @@ int launch_pw3(ConvArgs& a, hipStream_t st) {
 // a.wpack must be a c3d_pack_weights(mode | 2) pack (fp32 image followed by the three bf16 planes)
 int c3d_conv_forward_pw3(ConvArgs& a, int planes, bool wide, hipStream_t st) {
   if (planes == 3) {
-    // C3D_PW3_FUSED=0: round 2's phased kernel (same-box A/B and the bit-identity test; read per launch on purpose)
+    // Geometry of the fused kernel (mirrored by ops._pw3_kernel_name): eight waves x 256 / 128 couts per workgroup;
+    // with a short K (<= 256 channels: the prologue, the epilogue and the barrier bubbles are a large share of a
+    // workgroup's life) and couts that tile by 128, four waves x 128 couts with TWO workgroups per CU, which run those
+    // under each other's MFMAs (128 -> 384 at 8x32x1024: 0.181 -> 0.159 ms; 704 -> 704: 1.16 vs 1.22, so long K stays
+    // on eight waves).  C3D_PW3_FUSED = 0: round 2's phased kernel, 1 / 2: force eight / four waves (same-box A/B and
+    // the bit-identity test; read per launch on purpose).
     const char* e = getenv("C3D_PW3_FUSED");
-    const bool fused = !(e && e[0] == '0');
-    // C3D_PW3_FUSED: 1 = eight waves, 256 / 128 couts per workgroup; 2 (default) = four waves x 128 couts, two
-    // workgroups per CU
-    if (fused && e && e[0] == '1') return wide ? launch_pw3f<8, 2>(a, st) : launch_pw3f<4, 2>(a, st);
-    if (fused) return launch_pw3f<4, 1>(a, st);
+    const char mode = e ? e[0] : 'a';
+    const bool four = mode == '2' || (mode != '1' && a.Kq * 4 <= 256 && a.Cout % 128 == 0);
+    if (mode != '0') {
+      if (four) return launch_pw3f<4, 1>(a, st);
+      return wide ? launch_pw3f<8, 2>(a, st) : launch_pw3f<4, 2>(a, st);
+    }
     return wide ? launch_pw3<8, 3>(a, st) : launch_pw3<4, 3>(a, st);
   }
   return wide ? launch_pw3<8, 1>(a, st) : launch_pw3<4, 1>(a, st);

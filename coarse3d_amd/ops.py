@@ -16,15 +16,18 @@ from . import _lib as L
 KERNEL_EVENTS = None
 KERNEL_EVENT_FILTER = None       # None = every MFMA launch; else only launches of this kernel instance
 # Matrix-pipe mode of the MFMA engines (c3d_conv_desc.mfma_bf16):
-#   0 "f32"    fp32 MFMA -- the parity path and the default
+#   2 "bf16x3" (the library default since round 3 -- what bench.py measures is what an importer gets)
+#              fp32 operands split exactly into three bf16 planes, six or eight of the nine plane products per
+#              step on the bf16 matrix pipe, fp32 accumulate: fp32-class results (csrc/conv_x3.hip, conv_pw3.hip,
+#              conv_bfp.hip, wgrad_tr.hip); every `pytest -m gpu` test runs on it
+#   0 "f32"    v_mfma_f32_32x32x2_f32 everywhere (== an fmaf chain): the strict-IEEE engine; the whole GPU suite is
+#              re-run on it by tests/test_gpu_configs.py::test_whole_gpu_suite_passes_on_the_strict_fp32_engine
 #   1 "bf16"   operands rounded to bf16 inside the kernels, fp32 accumulate; activations stored as bf16
 #              (STORAGE_BF16) or fp32 -- opt-in mixed precision, BASELINE configs[2]
-#   2 "bf16x3" fp32 operands split exactly into three bf16 planes, eight of nine plane products per step on
-#              the bf16 matrix pipe (six in the weight gradient, whose error is the fp32 accumulation's either
-#              way): fp32-class results (csrc/conv_x3.hip, conv_pw3.hip, conv_bfp.hip, wgrad_tr.hip); what bench.py runs
 _MODES = {"f32": 0, "bf16": 1, "bf16x3": 2}
-# C3D_MATRIX=bf16x3 python -m pytest tests -m gpu   runs the WHOLE parity suite on the exact-split engine
-MFMA_MODE = _MODES[__import__("os").environ.get("C3D_MATRIX", "f32")]
+DEFAULT_MATRIX = "bf16x3"
+# C3D_MATRIX=f32 python -m pytest tests -m gpu   runs the WHOLE parity suite on the strict fp32-MFMA engine
+MFMA_MODE = _MODES[__import__("os").environ.get("C3D_MATRIX", DEFAULT_MATRIX)]
 
 
 # Activation storage of the "bf16" mode (BASELINE configs[2]): True = the backbone's activations and their
@@ -236,6 +239,20 @@ def _pw3_tile(b, h, w, cout):
     return 0
 
 
+def _pw3_kernel_name(nt, k, cout):
+    """Kernel instance c3d_conv_forward_pw3() launches (csrc/conv_pw3.hip): bf16x3 runs the fused kernel
+    conv_pw3f_kernel<NT, WN> -- WN = 2: eight waves, WN = 1: four waves x 128 couts, two workgroups per CU
+    (short K, couts a multiple of 128) -- the "bf16" mode round 2's conv_pw3_kernel<NT, 1>."""
+    if MFMA_MODE != 2:
+        return f"conv_pw3_kernel<{nt}, 1>"
+    mode = os.environ.get("C3D_PW3_FUSED", "a")[:1]
+    if mode == "0":
+        return f"conv_pw3_kernel<{nt}, 3>"
+    if mode == "2" or (mode != "1" and k <= 256 and cout % 128 == 0):
+        return "conv_pw3f_kernel<4, 1>"
+    return f"conv_pw3f_kernel<{nt}, 2>"
+
+
 def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=None, out_coff=0,
                  accumulate=False, stat_partial=None, slope=0.0, grad=False):
     """y = [LeakyReLU](conv(cat(transformed srcs)) + bias); optional per-tile channel stats.
@@ -272,7 +289,7 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
         name = f"conv_x3_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, {nt_}, {'true' if grad else 'false'}>"
     elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
-        name = f"conv_pw3_kernel<{_pw3_tile(b, h, w, cout)}, {3 if MFMA_MODE == 2 else 1}>"
+        name = _pw3_kernel_name(_pw3_tile(b, h, w, cout), sum(s.C for s in srcs), cout)
     elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
         np_ = 3 if MFMA_MODE == 2 else 1
         wide_ = _wide_cout_tiles(b, h, w, cout, tr)

@@ -9,7 +9,13 @@ over single flat buffers is ONE launch instead of six multi-tensor launches of ~
 
 The parameters keep their identity (``p.data`` becomes a view of the flat buffer), ``param_groups`` lists them as
 usual (learning-rate schedulers work unchanged), and the gradients are expected in the model's persistent flat gradient
-buffer (``SalsaNextProto._bound_grad_views``); a gradient that arrived any other way is copied in first."""
+buffer (``SalsaNextProto._bound_grad_views``); a gradient that arrived any other way is copied in first.
+``state_dict()`` / ``load_state_dict()`` speak torch.optim.AdamW's checkpoint layout.
+
+One difference from per-parameter AdamW is structural: the flat update steps EVERY parameter, so it is only used when
+every parameter receives a gradient in every step.  ``TrainStep`` therefore falls back to ``torch.optim.AdamW`` when
+``contrast_warmup > 0`` (the projector has no gradient during the warm-up epochs; the reference's AdamW skips such
+parameters -- no weight decay, no step count -- and so must we)."""
 import torch
 
 
@@ -50,6 +56,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._check_aliasing()
         for p, v in zip(self._params, self.grad_views):
             g = p.grad
             if g is None:
@@ -63,15 +70,70 @@ class FlatAdamW(torch.optim.Optimizer):
                             weight_decay=grp["weight_decay"], eps=grp["eps"], maximize=False, grad_scale=None, found_inf=None)
         return loss
 
-    def state_dict(self):
-        return {"flat": True, "step": self.step_t.clone(), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+    def _check_aliasing(self):
+        """``p.data`` must still be the views of ``flat_param`` made in __init__: model.double() / .to(device) /
+        load_state_dict(assign=True) rebind it, and the flat update would then move an orphaned buffer while the
+        model silently stops training."""
+        lo = self.flat_param.data_ptr()
+        hi = lo + self.flat_param.numel() * 4
+        for p in (self._params[0], self._params[-1]):
+            if not (lo <= p.data_ptr() < hi) or p.dtype != torch.float32:
+                raise RuntimeError("FlatAdamW: a parameter no longer lives in the flat buffer (dtype / device change or "
+                                   "load_state_dict(assign=True) after the optimiser was built): rebuild the optimiser")
 
+    def state_dict(self):
+        """The layout of ``torch.optim.AdamW.state_dict()`` -- what the reference writes into its checkpoints
+        (tasks/weak_segmentation/main.py:141,154) and reads back with ``optimizer.load_state_dict``
+        (trainer.py:129): per-parameter ``state[i] = {step, exp_avg, exp_avg_sq}`` sliced from the flat buffers and
+        ``param_groups`` with parameter indices, so that checkpoints move freely between this optimiser,
+        torch.optim.AdamW and the reference.  Before the first step the state is empty, as torch's is."""
+        groups = [dict({k: v for k, v in g.items() if k != "params"}, params=list(range(len(self._params))))
+                  for g in self.param_groups]
+        state = {}
+        if float(self.step_t) > 0:
+            off = 0
+            for i, p in enumerate(self._params):
+                n = p.numel()
+                state[i] = {"step": self.step_t.clone(), "exp_avg": self.exp_avg[off:off + n].view_as(p).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).clone()}
+                off += n
+        return {"state": state, "param_groups": groups}
+
+    @torch.no_grad()
     def load_state_dict(self, sd):
-        if not sd.get("flat"):
-            raise ValueError("FlatAdamW.load_state_dict: not a FlatAdamW state (per-parameter AdamW states have another layout)")
-        self.step_t.copy_(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        """Accepts the standard AdamW layout (from this class, torch.optim.AdamW or a reference checkpoint) and the
+        flat layout round 2 wrote (``{"flat": True, step, exp_avg, exp_avg_sq}``).  One update covers all
+        parameters, so the per-parameter step counts must agree (they do whenever all parameters were trained
+        together, which is the only way the reference trains them)."""
+        if sd.get("flat"):
+            self.step_t.copy_(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        else:
+            if len(sd["param_groups"]) != 1 or len(sd["param_groups"][0]["params"]) != len(self._params):
+                raise ValueError("FlatAdamW.load_state_dict: expected one parameter group over the same parameters")
+            state = sd["state"]
+            ids = sd["param_groups"][0]["params"]
+            if not state:
+                self.step_t.zero_()
+                self.exp_avg.zero_()
+                self.exp_avg_sq.zero_()
+            else:
+                if any(i not in state for i in ids):
+                    raise ValueError("FlatAdamW.load_state_dict: AdamW state is missing for some parameters (the flat "
+                                     "update steps all of them together)")
+                steps = {float(state[i]["step"]) for i in ids}
+                if len(steps) != 1:
+                    raise ValueError(f"FlatAdamW.load_state_dict: per-parameter step counts differ ({sorted(steps)[:4]}...): "
+                                     "load this checkpoint into torch.optim.AdamW (TrainStep(..., optimizer=...))")
+                self.step_t.fill_(steps.pop())
+                off = 0
+                for i, p in zip(ids, self._params):
+                    n = p.numel()
+                    if state[i]["exp_avg"].numel() != n:
+                        raise ValueError(f"FlatAdamW.load_state_dict: state {i} does not fit its parameter")
+                    self.exp_avg[off:off + n].copy_(state[i]["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[off:off + n].copy_(state[i]["exp_avg_sq"].reshape(-1))
+                    off += n
         for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+            g.update({k: v for k, v in s.items() if k != "params"})

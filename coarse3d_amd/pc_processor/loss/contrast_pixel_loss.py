@@ -18,6 +18,9 @@ class ContrastMEMLoss(nn.Module):
         # test hooks: injected randomness (float64 uniforms [T, A], queue permutations [C-1, M])
         self.uniforms = None
         self.perms = None
+        # test hook: keep the sampled anchors of the last call ({idx, img, cls, T, row_loss}, device tensors)
+        self.keep_debug = False
+        self.last_debug = None
 
     def forward(self, feats=None, output=None, labels=None, keep_mask=None, proto_queue=None):
         assert proto_queue is not None
@@ -26,6 +29,9 @@ class ContrastMEMLoss(nn.Module):
         queue = proto_queue.squeeze(0)
         if self.is_debug:
             print("queue size, max views : ", queue.shape)
-        return contrast.contrast_mem_loss(feats, output, labels, keep_mask, queue, self.temperature,
-                                          self.base_temperature, self.num_anchor, self.ignore_label,
-                                          self.uniforms, self.perms)
+        res = contrast.contrast_mem_loss(feats, output, labels, keep_mask, queue, self.temperature,
+                                         self.base_temperature, self.num_anchor, self.ignore_label,
+                                         self.uniforms, self.perms, return_debug=self.keep_debug)
+        if self.keep_debug:
+            res, self.last_debug = res
+        return res

@@ -41,6 +41,12 @@ class GraphedInference:
         # never free or move what a captured graph still points at.
         self._packs = ops.PackCache()
 
+    def _storage_signature(self):
+        """Addresses of everything the captured kernels read by raw pointer besides the pack table: parameters
+        (conv biases, BatchNorm affine, the repack sources) and buffers (running statistics).  FlatAdamW rebinds every
+        ``p.data`` into its flat buffer, ``model.float()/.to()`` and ``load_state_dict(assign=True)`` move storage too."""
+        return tuple(t.data_ptr() for t in list(self.model.parameters()) + list(self.model.buffers()))
+
     def _capture(self, x):
         static_x = x.clone()
         side = torch.cuda.Stream()
@@ -56,12 +62,19 @@ class GraphedInference:
                 out = self.model(static_x, return_feat=self.return_feat)
             if self._packs.generation != gen:
                 raise RuntimeError("the weight-pack table was rebuilt during graph capture")
-        return g, static_x, out, gen
+        return g, static_x, out, self._storage_signature()
 
     def __call__(self, x):
+        if self.model.training:
+            raise ValueError("GraphedInference replays the eval-mode forward: call model.eval() first")
+        sig = self._storage_signature()
+        if self._graphs and any(v[3] != sig for v in self._graphs.values()):
+            # parameter / buffer storage moved since the capture (an optimiser flattened the parameters, the model was
+            # cast or re-loaded): every captured graph -- and this object's weight packs -- point at stale or freed
+            # memory.  Drop them all and re-capture from the live tensors.
+            self._graphs.clear()
+            self._packs = ops.PackCache()
         key = tuple(x.shape)
-        if key in self._graphs and self._graphs[key][3] != self._packs.generation:
-            del self._graphs[key]                        # parameters moved (e.g. load_state_dict to new storage): re-capture
         if key not in self._graphs:
             self._graphs[key] = self._capture(x)
         g, static_x, out, _ = self._graphs[key]

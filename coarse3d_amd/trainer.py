@@ -63,7 +63,9 @@ class TrainStep:
         # passes over the 192 parameter tensors: 0.38 -> 0.1 ms per step); C3D_FUSED_ADAMW=0 keeps the default form.
         if optimizer is None:
             fused = dev.type == "cuda" and os.environ.get("C3D_FUSED_ADAMW", "1") != "0"
-            flat = (fused and getattr(model, "_bind_grads", False) and os.environ.get("C3D_FLAT_ADAMW", "1") != "0")
+            # (not with a contrast warm-up: parameters without a gradient must be skipped, see coarse3d_amd/optim.py)
+            flat = (fused and getattr(model, "_bind_grads", False) and contrast_warmup == 0
+                    and os.environ.get("C3D_FLAT_ADAMW", "1") != "0")
             views = None
             if flat:
                 named, names, _ = model._cached()

@@ -25,14 +25,15 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(autouse=True)
 def _matrix_engine_is_the_requested_one(request):
-    """`C3D_MATRIX=<engine> pytest -m gpu` claims the whole suite ran on that engine: a test that switches
-    engines and forgets to switch back would silently move every later test to another one (round 2 found
-    exactly that: `finally: set_matrix_precision("f32")`).  Checked before and after every GPU test."""
-    want = os.environ.get("C3D_MATRIX")
-    if not want or "gpu" not in request.keywords:
+    """Every GPU test runs on ONE engine: the library default (bf16x3, what bench.py measures) or the one
+    `C3D_MATRIX=<engine> pytest -m gpu` asks for.  A test that switches engines and forgets to switch back would
+    silently move every later test to another one (round 2 found exactly that: `finally:
+    set_matrix_precision("f32")`).  Checked before and after every GPU test."""
+    if "gpu" not in request.keywords:
         yield
         return
     from coarse3d_amd import ops
+    want = os.environ.get("C3D_MATRIX", ops.DEFAULT_MATRIX)
     assert ops.matrix_precision_state()[0] == want, f"engine is {ops.matrix_precision_state()[0]} before the test, not {want}"
     yield
     assert ops.matrix_precision_state()[0] == want, f"the test left the engine at {ops.matrix_precision_state()[0]}, not {want}"

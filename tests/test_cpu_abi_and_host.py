@@ -152,3 +152,81 @@ def test_module_caches_follow_the_parameters():
     masks = m._draw_masks(3, "cpu")
     assert all(t.is_contiguous() and t.shape[0] == 3 for t in masks.values())
     assert set(float(x) for x in torch.cat([t.flatten() for t in masks.values()]).unique()) <= {0.0, 1.0 / 0.8}
+
+
+def test_flat_adamw_checkpoints_are_torch_adamw_checkpoints():
+    """the reference saves ``optimizer.state_dict()`` (tasks/weak_segmentation/main.py:141,154) and
+    resumes with ``optimizer.load_state_dict`` (trainer.py:129).  FlatAdamW must write and read that layout:
+    state moves FlatAdamW -> torch.optim.AdamW -> FlatAdamW with identical continued updates; round 2's flat
+    layout still loads; a parameter that left the flat buffer makes step() raise instead of training nothing."""
+    import torch
+    from coarse3d_amd.optim import FlatAdamW
+
+    def make(seed):
+        g = torch.Generator().manual_seed(seed)
+        ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in [(4, 3), (7,), (2, 2, 2)]]
+        return [(f"p{i}", p) for i, p in enumerate(ps)]
+
+    def grads(step, shapes):
+        g = torch.Generator().manual_seed(100 + step)
+        return [torch.randn(s, generator=g) for s in shapes]
+
+    named = make(0)
+    shapes = [tuple(p.shape) for _, p in named]
+    total = sum(p.numel() for _, p in named)
+    flat_grad = torch.zeros(total)
+    views, off = {}, 0
+    for n, p in named:
+        views[n] = flat_grad[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    opt = FlatAdamW(named, views, flat_grad, lr=1e-2)
+    assert opt.state_dict()["state"] == {}                               # like torch before the first step
+    ref_params = [torch.nn.Parameter(p.detach().clone()) for _, p in make(0)]
+    ref = torch.optim.AdamW(ref_params, lr=1e-2)
+    for step in range(3):
+        for (n, p), rp, gr in zip(named, ref_params, grads(step, shapes)):
+            views[n].copy_(gr)
+            p.grad = views[n]
+            rp.grad = gr.clone()
+        opt.step()
+        ref.step()
+    for (_, p), rp in zip(named, ref_params):
+        assert torch.allclose(p, rp, rtol=1e-6, atol=1e-7)
+    sd = opt.state_dict()
+    assert set(sd) == {"state", "param_groups"} and sd["param_groups"][0]["params"] == [0, 1, 2]
+    assert set(sd["state"][1]) == {"step", "exp_avg", "exp_avg_sq"} and sd["state"][2]["exp_avg"].shape == (2, 2, 2)
+    # FlatAdamW checkpoint -> torch.optim.AdamW -> continue; and the torch checkpoint -> a fresh FlatAdamW -> continue
+    cont_params = [torch.nn.Parameter(p.detach().clone()) for _, p in named]
+    cont = torch.optim.AdamW(cont_params, lr=1e-2)
+    cont.load_state_dict(sd)
+    named2 = [(n, torch.nn.Parameter(p.detach().clone())) for n, p in named]
+    fg2 = torch.zeros(total)
+    views2, off = {}, 0
+    for n, p in named2:
+        views2[n] = fg2[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    opt2 = FlatAdamW(named2, views2, fg2, lr=1e-2)
+    opt2.load_state_dict(ref.state_dict())
+    for (n, p), cp, rp, gr in zip(named2, cont_params, ref_params, grads(7, shapes)):
+        views2[n].copy_(gr)
+        p.grad = views2[n]
+        cp.grad = gr.clone()
+        rp.grad = gr.clone()
+    opt2.step()
+    cont.step()
+    ref.step()
+    for (_, p), cp, rp in zip(named2, cont_params, ref_params):
+        assert torch.allclose(p, rp, rtol=1e-6, atol=1e-7) and torch.allclose(cp, rp, rtol=1e-6, atol=1e-7)
+    # round 2's flat layout is still accepted
+    opt2.load_state_dict({"flat": True, "step": opt.step_t, "exp_avg": opt.exp_avg, "exp_avg_sq": opt.exp_avg_sq,
+                          "param_groups": [{"lr": 5e-3}]})
+    assert opt2.param_groups[0]["lr"] == 5e-3 and float(opt2.step_t) == 3
+    # per-parameter step counts that differ cannot be expressed by one flat update
+    bad = ref.state_dict()
+    bad["state"][1]["step"] = bad["state"][1]["step"] + 1
+    with pytest.raises(ValueError):
+        opt2.load_state_dict(bad)
+    # a parameter that left the flat buffer
+    named2[0][1].data = named2[0][1].data.clone()
+    with pytest.raises(RuntimeError):
+        opt2.step()

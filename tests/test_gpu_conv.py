@@ -292,11 +292,12 @@ def test_weight_gradient_long_strips(mode, B, H, W, Cin, Cout, k, dil, pad):
 
 
 @pytest.mark.parametrize("B,H,W,srcC,Cout,affine,lrelu", [
-    (2, 16, 70, [32, 48], 704, True, True),       # three cout tiles, ragged last one, two sources, ragged W
-    (1, 8, 64, [704], 704, True, False),          # the projector shape (44 K chunks)
-    (2, 8, 33, [64], 160, False, False),          # raw source (unit affine constant, slope 1)
-    (1, 8, 64, [16], 96, True, True),             # 128-wide tile, a single K chunk
-    (1, 16, 64, [256], 400, False, True),         # the prototype-similarity shape (ragged 400 = 256 + 144)
+    # (every launch has >= 128 workgroups: below that c3d_conv_forward routes 1x1 layers to conv_bfp's narrow tiles)
+    (2, 16, 1030, [32, 48], 704, True, True),     # three cout tiles, ragged last one, two sources, ragged W
+    (1, 32, 1024, [704], 704, True, False),       # the projector shape (44 K chunks)
+    (2, 16, 1000, [64], 160, False, False),       # raw source (unit affine constant, slope 1)
+    (4, 8, 1024, [16], 96, True, True),           # 128-wide tile, a single K chunk
+    (1, 64, 512, [256], 400, False, True),        # the prototype-similarity shape (ragged 400 = 256 + 144)
 ])
 def test_fused_pointwise_kernel_is_bit_identical_to_the_phased_one(B, H, W, srcC, Cout, affine, lrelu, monkeypatch):
     """conv_pw3f_kernel (round 3: staging dealt into the MFMA stream) stores the same bf16 planes, multiplies
@@ -328,4 +329,66 @@ def test_fused_pointwise_kernel_is_bit_identical_to_the_phased_one(B, H, W, srcC
             assert torch.equal(outs[fused][1], outs["0"][1])
         assert float(outs["0"][0].abs().max()) > 0
     finally:
+        ops.set_matrix_precision(*prev)
+
+
+def test_fused_pointwise_kernel_random_configurations():
+    """Both geometries of the fused kernel against the phased one, bit for bit, over 24 seeded random launch
+    configurations: 1-3 sources at channel offsets inside wider tensors, each with or without BatchNorm affine /
+    LeakyReLU, ragged W, couts that leave ragged tiles, output at a channel offset of a wider tensor, accumulate
+    mode, with and without bias / statistics, forward packs and input-gradient (transposed, sliced) packs."""
+    import os
+    import random
+    from coarse3d_amd import ops
+    rnd = random.Random(77)
+    dev = "cuda"
+    prev = ops.matrix_precision_state()
+    ops.set_matrix_precision("bf16x3")
+    saved = os.environ.get("C3D_PW3_FUSED")
+    try:
+        for case in range(24):
+            g = torch.Generator().manual_seed(1000 + case)
+            B, H, W = rnd.choice([(2, 16, 1024), (1, 32, 1000), (4, 8, 1024), (1, 64, 520)])
+            nsrc = rnd.choice([1, 1, 2, 3])
+            srcC = [rnd.choice([16, 32, 64, 128, 256]) for _ in range(nsrc)]
+            Cout = rnd.choice([96, 128, 160, 256, 272, 384, 400, 704])
+            srcs = []
+            for c in srcC:
+                wide = c + rnd.choice([0, 16, 32])
+                coff = rnd.choice([0, wide - c])
+                x = torch.randn(B, H, W, wide, generator=g).to(dev)
+                aff = rnd.random() < 0.6
+                sc = (torch.rand(c, generator=g) + 0.5).to(dev) if aff else None
+                sh = (torch.randn(c, generator=g) * 0.3).to(dev) if aff else None
+                srcs.append(ops.Source(x, sc, sh, C=c, coff=coff, lrelu=rnd.random() < 0.5))
+            K = sum(srcC)
+            if rnd.random() < 0.35:      # input-gradient launch: transposed pack of a slice of a wider layer
+                cin_total = Cout + rnd.choice([0, 64])
+                w = (torch.randn(K, cin_total, 1, 1, generator=g) / K ** 0.5).to(dev)
+                wp = ops.pack_weights(w, mode=1, c_off=cin_total - Cout, c_cnt=Cout, kpad=K)
+            else:
+                w = (torch.randn(Cout, K, 1, 1, generator=g) / K ** 0.5).to(dev)
+                wp = ops.pack_weights(w, mode=0)
+            bias = (torch.randn(Cout, generator=g) * 0.1).to(dev) if rnd.random() < 0.5 else None
+            ocoff = rnd.choice([0, 4, 32])
+            base = torch.randn(B, H, W, Cout + ocoff + rnd.choice([0, 4]), generator=g).to(dev)
+            acc, stats, lrelu = rnd.random() < 0.4, rnd.random() < 0.5, rnd.random() < 0.5
+            outs = {}
+            for fused in ("0", "1", "2"):
+                os.environ["C3D_PW3_FUSED"] = fused
+                out = base.clone()
+                _, part = ops.conv_forward(srcs, wp, bias, Cout, [(0, 0)], lrelu=lrelu, stats=stats, out=out, out_coff=ocoff,
+                                           accumulate=acc)
+                torch.cuda.synchronize()
+                outs[fused] = (out, part)
+            tag = (case, B, H, W, srcC, Cout, ocoff, acc, stats)
+            for fused in ("1", "2"):
+                assert torch.equal(outs[fused][0], outs["0"][0]), (tag, fused)
+                if stats:
+                    assert torch.equal(outs[fused][1], outs["0"][1]), (tag, fused)
+    finally:
+        if saved is None:
+            os.environ.pop("C3D_PW3_FUSED", None)
+        else:
+            os.environ["C3D_PW3_FUSED"] = saved
         ops.set_matrix_precision(*prev)
