@@ -454,11 +454,16 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16": ("bf16 activations in HBM + bf16 MFMA operands, f32 accumulate / statistics / master weights"
                                if args.storage == "bf16" else "bf16 MFMA operands, f32 accumulate/storage"),
-                      "bf16x3": "f32 via 3xbf16 exact split on the bf16 matrix pipe, f32 accumulate (6 of 9 plane products; 8 of 9 "
-                                "in forward 3x3 / 2x2 convs whose output has fewer than 32768 pixels, where a small BatchNorm "
-                                "population amplifies the difference -- measured: gradient error against float64 equal to the "
-                                "fp32 engine's either way at real batch sizes, the whole parity suite passes on this engine); "
-                                "f32 storage everywhere"}[args.matrix_dtype],
+                      "bf16x3": "f32 via 3xbf16 exact split on the bf16 matrix pipe (the library's default engine), f32 accumulate; "
+                                "6 of 9 plane products (8 of 9 in forward 3x3 / 2x2 convs whose output has fewer than 32768 "
+                                "pixels, where a small BatchNorm population amplifies the difference); f32 storage everywhere.  "
+                                "Parity as measured on MI355X (profiles/round3_parity_measured.json): forward / logits / "
+                                "prototypes <= 1e-4 of the reference on every golden; pseudo-label maps identical; anchor "
+                                "selection bit-exact on identical weights, and END TO END 2303 of 2304 anchor draws of the "
+                                "reference's golden step identical (one draw lies 6.7 fp32 ulps from its bin edge and lands "
+                                "on the neighbouring candidate; the strict fp32-MFMA engine, --matrix-dtype f32: 2304 of "
+                                "2304); whole-network gradient error vs the reference golden: median 1.1e-2 (fp32-MFMA engine "
+                                "6.1e-3; per-layer float64 check 7e-7 on both)"}[args.matrix_dtype],
             "data": "synthetic",
             "config": {"workload": f"{args.dataset} {args.height}x{args.width}x5 range image, C={args.classes}, "
                                    f"bs={args.batch}/GPU, {type(model).__name__}{'' if args.net == 'salsanext' else args.net[-2:]} fwd+bwd + prototype bank + contrast "

@@ -229,7 +229,7 @@ def test_full_training_step_vs_golden():
         bi, cls = int(dbg["img"][t_]), int(dbg["cls"][t_])
         k = int(cnt[bi, cls])
         pix = cand[bi, cls, :k].long()
-        wv = wts.reshape(wts.shape[0], -1)[bi, pix].float()
+        wv = wts.reshape(cnt.shape[0], -1)[bi, pix].float()
         cdf = torch.cumsum(wv, 0)                       # fp32, sequential semantics up to summation order
         cdf = cdf / cdf[-1]
         pos_got = int((pix == int(got_idx[t_, a_])).nonzero()[0])
