@@ -275,7 +275,7 @@ def main():
             return PEAK_BF16_MFMA_TFLOPS / 6.0
         if kernel_name.startswith("conv_pw3_kernel"):        # <NT, NP>; NP = 3 runs six plane products
             return PEAK_BF16_MFMA_TFLOPS / 6.0 if kernel_name.endswith(", 3>") else PEAK_BF16_MFMA_TFLOPS
-        if kernel_name.startswith("conv_x3_kernel"):         # <NT, HALO, TT, SIX>
+        if kernel_name.startswith(("conv_x3_kernel", "conv_x3f_kernel")):   # <NT, HALO, TT, SIX>
             return PEAK_BF16_MFMA_TFLOPS / (6.0 if kernel_name.endswith("true>") else 8.0)
         if kernel_name.startswith("conv_bfp_kernel"):
             return PEAK_BF16_MFMA_TFLOPS / 8.0 if kernel_name.rstrip(">").endswith("3") else PEAK_BF16_MFMA_TFLOPS

@@ -201,10 +201,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
 #define C3D_PLANE(PA, PB)                                                                          \
   _Pragma("unroll") for (int i = 0; i < RPW; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)  \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA][i], bp[PB][j], acc[i][j], 0, 0, 0);
+      // (the three 2^-16-class products m*m, l*h, h*l in this order: the fused kernel below wants a tap to open with
+      //  planes other than the ones the previous tap closed with, and the two kernels stay bit-identical)
       if constexpr (!SIX) {
-        C3D_PLANE(2, 1) C3D_PLANE(1, 2)
+        C3D_PLANE(2, 1) C3D_PLANE(1, 2) C3D_PLANE(2, 0) C3D_PLANE(0, 2) C3D_PLANE(1, 1)
+      } else {
+        C3D_PLANE(1, 1) C3D_PLANE(2, 0) C3D_PLANE(0, 2)
       }
-      C3D_PLANE(2, 0) C3D_PLANE(0, 2) C3D_PLANE(1, 1) C3D_PLANE(1, 0) C3D_PLANE(0, 1)
+      C3D_PLANE(1, 0) C3D_PLANE(0, 1)
       C3D_PLANE(0, 0)
 #undef C3D_PLANE
     }
@@ -246,6 +250,372 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
   conv_epilogue<TR, NT, WM, WN>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 3: the same tile, LDS image, arithmetic and product order with the staging dealt into the MFMA
+// stream (profiles/round3_coissue_probe.md; the method of conv_pw3.hip's fused kernel).  What changes against
+// conv_x3_kernel above:
+//   * the split of the NEXT chunk's input tile (affine, LeakyReLU, three planes: ~25 scalar VALU per unit)
+//     runs between the MFMAs of the current chunk and leaves the planes in registers; only their LDS stores
+//     (3 x IN_PT ds_write_b64 per thread) remain between two barriers, once per chunk -- the input tile stays
+//     single-buffered (two workgroups per CU);
+//   * the weight slab is double-buffered (+18 KB): the next tap row's planes are stored while the current one is
+//     multiplied, so a tap row costs one barrier instead of two (4 per chunk instead of 6);
+//   * the fragments of the next tap are read while the current tap is multiplied (each plane right after
+//     its last product; the B plane that closes one tap and opens the next is double-buffered), so the LDS
+//     latency is exposed once per tap row instead of once per tap;
+//   * every load is a buffer load (descriptor + K offset in SGPRs, one 32-bit voffset per unit; pixels outside
+//     the image and couts beyond Cout carry an out-of-range voffset and read zeros): the next chunk's input is
+//     requested in the first tap row and converted in the later ones (a tap row's time of lead, and the raw
+//     values and the planes never fill their registers at the same time), weights one tap row ahead;
+//   * no packed-f32 VALU (NOPK in the Makefile).
+// Outputs are bit-identical to conv_x3_kernel (tests/test_gpu_conv.py::test_fused_multitap_kernel_...).
+__device__ float c3d_x3_unit_affine[32] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f,
+                                           0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void c3d_x3_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    c3d_x3_static_for<I + 1, N>(f);
+  }
+}
+
+// plane products of one tap in issue order (A plane, B plane), smallest first
+template <bool SIX>
+struct c3d_x3_products {
+  static constexpr int N = SIX ? 6 : 8;
+  static constexpr int pa(int q) {
+    constexpr int six[6] = {1, 2, 0, 1, 0, 0}, eight[8] = {2, 1, 2, 0, 1, 1, 0, 0};
+    return SIX ? six[q] : eight[q];
+  }
+  static constexpr int pb(int q) {
+    constexpr int six[6] = {1, 0, 2, 0, 1, 0}, eight[8] = {1, 2, 0, 2, 1, 0, 1, 0};
+    return SIX ? six[q] : eight[q];
+  }
+  static constexpr int last_a(int p) { int l = -1; for (int q = 0; q < N; ++q) if (pa(q) == p) l = q; return l; }
+  static constexpr int last_b(int p) { int l = -1; for (int q = 0; q < N; ++q) if (pb(q) == p) l = q; return l; }
+};
+
+template <int NT, int HALO, int TT, bool SIX>
+__global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
+  constexpr int TR = 8, CQ = 4;                    // 16 channels per K chunk
+  constexpr int TWh = 32 + 2 * HALO, THh = TR + 2 * HALO;
+  constexpr int TN = 32 * NT;
+  constexpr int WM = 4, WN = 1, RPW = 2, NPW = NT;
+  constexpr int G = (TT == 9) ? 3 : TT;            // taps per staged weight group (tap row)
+  constexpr int NG = TT / G;
+  constexpr int IN_ROWS = THh * TWh;
+  constexpr int IN_UNITS = IN_ROWS * CQ;
+  constexpr int IN_PT = (IN_UNITS + 255) / 256;
+  constexpr int WG_ROWS = G * TN;
+  constexpr int W_UNITS = WG_ROWS * CQ;
+  constexpr int W_PT = (W_UNITS + 255) / 256;
+  using PR = c3d_x3_products<SIX>;
+  constexpr int NQ = PR::N;
+
+  // LDS rows are padded to whole staging units (64 rows per unit index): unit i of a thread is row tid/4 + 64 i,
+  // always -- lanes past the end of the tile / slab read zeros (out-of-range voffset) and store them into pad rows
+  // nobody reads, so the staging needs no predicates, no clamps and no per-unit address registers
+  constexpr int IN_ROWS_P = IN_PT * 64, WG_ROWS_P = W_PT * 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short* s_in = reinterpret_cast<unsigned short*>(smem);   // [3][IN_ROWS_P][16]
+  unsigned short* s_w0 = s_in + 3 * IN_ROWS_P * 16;                 // 2 x [3][WG_ROWS_P][16]
+  constexpr int WBUF = 3 * WG_ROWS_P * 16;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave, wn = 0;
+
+  const int ntile = a.B * a.tiles_y * a.tiles_x;
+  const int logical = c3d_xcd_remap(blockIdx.x, ntile * a.ntn);
+  const int mt = logical / a.ntn;
+  const int n0 = (logical % a.ntn) * TN;
+  const int tx = mt % a.tiles_x;
+  const int ty = (mt / a.tiles_x) % a.tiles_y;
+  const int b = mt / (a.tiles_x * a.tiles_y);
+  const int x0 = tx * 32, y0 = ty * TR;
+  const size_t tile_pix = (size_t)(b * a.H + y0) * a.W + x0;
+
+  f32x16 acc[RPW][NPW];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i)
+#pragma unroll
+    for (int j = 0; j < NPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- load cursors.  Units past the end of the tile / slab repeat the last one (same value to the same LDS
+  //      address); pixels outside the image and couts beyond Cout get an out-of-range voffset (reads as zero).
+  constexpr unsigned OOB = 0xfffffff0u;
+  const int c4 = tid % CQ;
+  const int r0 = tid / CQ;                 // LDS row of unit 0; unit i: r0 + 64 i (same swizzle: 64 keeps bit 3)
+  unsigned inb = 0;                        // bit i: unit i is a pixel inside the image
+#pragma unroll
+  for (int i = 0; i < IN_PT; ++i) {
+    const int p = r0 + 64 * i;
+    const int px = p % TWh, py = p / TWh;
+    const int gx = x0 + px - HALO, gy = y0 + py - HALO;
+    if (p < IN_ROWS && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H) inb |= 1u << i;
+  }
+  const unsigned wplane_b = (unsigned)a.T * a.Kq * a.Cout * 8;                  // bytes per bf16 weight plane
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.wpack) + (size_t)a.T * a.Kq * a.Cout * 4, 0, 3 * wplane_b, 0x00020000);
+  // weight unit i: u = tid + 256 i -> cout n = u % TN, row r = u / TN = kq + 4 * tap-in-row; slab row tg * TN + n
+  unsigned vw[W_PT];
+#pragma unroll
+  for (int i = 0; i < W_PT; ++i) {
+    const int u = tid + i * 256;
+    const int n = u % TN;
+    const int r = u / TN;
+    const int kq = r % CQ, tg = r / CQ;
+    vw[i] = (u < W_UNITS && n0 + n < a.Cout) ? (unsigned)(((tg * a.Kq + kq) * a.Cout + n0 + n) * 8) : OOB;
+  }
+  // LDS byte offsets of unit 0 (plane 0): input row r0, weight row (tid / TN / 4) * TN + tid % TN; unit i adds a constant
+  const int wR0 = (tid / TN / CQ) * TN + tid % TN, wkq0 = (tid / TN) % CQ;
+  static_assert(256 % TN == 0 && (256 / TN) % CQ == 0 || TN == 64 || TN == 32, "weight units advance by whole tap rows");
+  constexpr int W_ROW_STEP = (256 / TN / CQ) * TN;     // slab rows between consecutive units of a thread
+  __amdgpu_buffer_rsrc_t rs_in, rs_sc, rs_sh;
+  unsigned vin[IN_PT];
+  const int vaff = c4 * 16;
+  int lstep = 0;
+  float lslope = 1.f;
+  int ls = 0, lc0 = 0, lC = 0, lk = 0;     // input cursor: source, channel inside it, its width, chunk index
+  const unsigned img_bytes_per_c = (unsigned)a.B * a.H * a.W * 4;
+  auto open_src = [&](int s) {
+    const c3d_src& sr = a.src[s];
+    rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sr.ptr), 0, img_bytes_per_c * sr.cstride, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < IN_PT; ++i) {
+      const int p = r0 + 64 * i;
+      const int prel = (p / TWh - HALO) * a.W + (p % TWh - HALO);
+      vin[i] = ((inb >> i) & 1u) ? (unsigned)(((tile_pix + prel) * sr.cstride + sr.coff + c4 * 4) * 4) : OOB;
+    }
+    if (sr.scale) {
+      rs_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sr.scale), 0, 0x7fffffff, 0x00020000);
+      rs_sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sr.shift), 0, 0x7fffffff, 0x00020000);
+      lstep = 64;
+    } else {
+      rs_sc = __builtin_amdgcn_make_buffer_rsrc(c3d_x3_unit_affine, 0, 0x7fffffff, 0x00020000);
+      rs_sh = __builtin_amdgcn_make_buffer_rsrc(c3d_x3_unit_affine + 16, 0, 0x7fffffff, 0x00020000);
+      lstep = 0;
+    }
+    lslope = sr.lrelu ? a.slope : 1.f;
+    lC = sr.C;
+    lc0 = 0;
+  };
+  open_src(0);
+  const int nchunks = a.Kq / 4;
+  auto advance = [&]() {                   // input cursor -> next chunk; stays on the last one
+    if (lk + 1 < nchunks) {
+      ++lk;
+      lc0 += 16;
+      if (lc0 >= lC) open_src(++ls);
+    }
+  };
+  int wq = 0;                              // weight cursor: (chunk, tap row) pairs in multiplication order
+  const int nwq = nchunks * NG;
+
+  // ---- registers in flight
+  f32x4 pin[IN_PT];                        // raw input of the chunk after next (after its atoms ran: of the one after)
+  u32x2 npl[IN_PT][3];                     // the next chunk's planes, waiting for the store phase
+  u32x2 pw[W_PT][3];
+  f32x4 psc, psh;
+  float pslope;
+  auto load_in = [&](int i) { pin[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vin[i], lc0 * 4, 0)); };
+  auto load_aff = [&]() {
+    const int so = (lstep >> 6) * lc0 * 4;
+    psc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_sc, vaff, so, 0));
+    psh = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_sh, vaff, so, 0));
+    pslope = lslope;
+  };
+  auto load_w = [&](int i) {               // weight unit i of pair wq (clamped to the last pair)
+    const int q = min(wq, nwq - 1);
+    const int chunk = q / NG, g = q % NG;
+    const int so = (g * G * a.Kq + chunk * 4) * a.Cout * 8;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) pw[i][p] = __builtin_amdgcn_raw_buffer_load_b64(rs_w, vw[i], so + p * wplane_b, 0);
+  };
+
+  // ---- atoms of the NEXT chunk's input, two lists: LOAD (the units' raw values + scale / shift, issued early in the
+  //      current chunk's first tap row) and CONV (per unit: XF e0, XF e1 -- affine, LeakyReLU, zero outside the image --
+  //      then two SPLIT halves per plane), which run in the later tap rows, a tap row's time after the loads: raw values
+  //      and planes never fill their registers together.  (Four taps = ONE tap row per chunk: 96 MFMAs are not enough
+  //      lead for an HBM load -- 0.21 -> 0.26 ms on 64 -> 64 2x2 -- and reloading a unit right after its XF atoms, one
+  //      chunk earlier, spills at 64 couts per workgroup: the 2x2 convs stay on conv_x3_kernel.)
+  static_assert(NG > 1, "the fused schedule needs more than one tap row per chunk");
+  f32x4 sv;
+  constexpr int LOAD_ATOMS = IN_PT + 1;            // + scale / shift
+  constexpr int CONV_ATOMS = IN_PT * 8;
+  constexpr int W_ATOMS = W_PT * 4;
+  auto load_atom = [&](auto k_tag) {
+    constexpr int k = decltype(k_tag)::value;
+    if constexpr (k == IN_PT) load_aff();
+    else load_in(k);
+  };
+  auto conv_atom = [&](auto k_tag) {
+    constexpr int k = decltype(k_tag)::value;
+    constexpr int i = k / 8, r = k % 8;
+    if constexpr (r < 2) {
+      const bool in = (inb >> i) & 1u;
+#pragma unroll
+      for (int q = 2 * r; q < 2 * r + 2; ++q) {
+        const float v = __builtin_fmaf(pin[i][q], psc[q], psh[q]);
+        sv[q] = in ? __builtin_fmaxf(v, v * pslope) : 0.f;     // zero padding AFTER the transform
+      }
+    } else {
+      constexpr int p = (r - 2) / 2, e = (r - 2) % 2;
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      bf16x2 h;
+      h[0] = (__bf16)sv[2 * e];
+      h[1] = (__bf16)sv[2 * e + 1];
+      const unsigned pk = __builtin_bit_cast(unsigned, h);
+      npl[i][p][e] = pk;
+      if constexpr (p < 2) {
+        sv[2 * e] -= __uint_as_float(pk << 16);
+        sv[2 * e + 1] -= __uint_as_float(pk & 0xffff0000u);
+      }
+    }
+  };
+  auto w_atom = [&](auto k_tag, unsigned short* s_w) {
+    constexpr int k = decltype(k_tag)::value;
+    constexpr int i = k / 4, r = k % 4;
+    if constexpr (r < 3) {
+      *reinterpret_cast<u32x2*>(s_w + (r * WG_ROWS_P + wR0 + i * W_ROW_STEP) * 16 + swz_quad(wR0, wkq0)) = pw[i][r];
+    } else {
+      load_w(i);
+    }
+  };
+  auto store_in = [&]() {
+#pragma unroll
+    for (int i = 0; i < IN_PT; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<u32x2*>(s_in + (p * IN_ROWS_P + r0 + 64 * i) * 16 + swz_quad(r0, c4)) = npl[i][p];
+  };
+
+  const int nj = min(NPW, (a.Cout - n0 + 31) / 32);   // live 32-wide cout sub-tiles (ragged last tile)
+
+  // one tap row (G taps) of the current chunk out of slab buffer `wb`, with the weight atoms of the next pair
+  // (into the other buffer) and input atoms [IA0, IA1) of the next chunk dealt between the products
+  auto group = [&](auto g_tag, int wb, auto nj_tag) {
+    constexpr int g = decltype(g_tag)::value;
+    constexpr int NJ = decltype(nj_tag)::value;
+    // atoms of this tap row, in issue order: [LOAD (first tap row only)] [weights of the next pair] [CONV share]
+    constexpr int NL = g == 0 ? LOAD_ATOMS : 0;
+    constexpr int CG = NG - 1;                        // tap rows that convert: all but the first
+    constexpr int CA0 = g == 0 ? 0 : ((g - 1) * CONV_ATOMS) / CG;
+    constexpr int CA1 = g == 0 ? 0 : (g * CONV_ATOMS) / CG;
+    constexpr int NA = NL + W_ATOMS + (CA1 - CA0);
+    constexpr int NS = G * NQ;                        // slots = products
+    const unsigned short* s_w = s_w0 + wb * WBUF;
+    unsigned short* d_w = s_w0 + (wb ^ 1) * WBUF;
+    bf16x8 ap[3][RPW];
+    bf16x8 bq[3][NJ];
+    // (no plane both closes a tap and opens the next one -- static_assert below -- so one register set per plane)
+    static_assert(PR::last_a(PR::pa(0)) != NQ - 1 && PR::last_b(PR::pb(0)) != NQ - 1, "a tap must not open with the plane it closed with");
+    auto read_a = [&](int tg, int p) {
+      const int t = g * G + tg;
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int R = (wm + i * WM + HALO + a.dy[t]) * TWh + HALO + a.dx[t] + l31;
+        ap[p][i] = *reinterpret_cast<const bf16x8*>(s_in + p * IN_ROWS_P * 16 + R * 16 + swz_half(R, half));
+      }
+    };
+    auto read_b = [&](int tg, int p) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int R = tg * TN + j * 32 + l31;
+        bq[p][j] = *reinterpret_cast<const bf16x8*>(s_w + p * WG_ROWS_P * 16 + R * 16 + swz_half(R, half));
+      }
+    };
+    // first tap: all six fragments, in the order the products need them
+    c3d_x3_static_for<0, NQ>([&](auto q_tag) {
+      constexpr int q = decltype(q_tag)::value;
+      bool first_a = true, first_b = true;
+      for (int r = 0; r < q; ++r) {
+        if (PR::pa(r) == PR::pa(q)) first_a = false;
+        if (PR::pb(r) == PR::pb(q)) first_b = false;
+      }
+      if (first_a) read_a(0, PR::pa(q));
+      if (first_b) read_b(0, PR::pb(q));
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    c3d_x3_static_for<0, NS>([&](auto s_tag) {
+      constexpr int s = decltype(s_tag)::value, tg = s / NQ, q = s % NQ;
+      constexpr int PA = PR::pa(q), PB = PR::pb(q);
+#pragma unroll
+      for (int i = 0; i < RPW; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA][i], bq[PB][j], acc[i][j], 0, 0, 0);
+      // fragments of the next tap: each plane right after its last product of this tap
+      if constexpr (tg + 1 < G) {
+        if constexpr (PR::last_a(PA) == q) read_a(tg + 1, PA);
+        if constexpr (PR::last_b(PB) == q) read_b(tg + 1, PB);
+      }
+      c3d_x3_static_for<(s * NA) / NS, ((s + 1) * NA) / NS>([&](auto k_tag) {
+        constexpr int k = decltype(k_tag)::value;
+        if constexpr (k < NL) load_atom(k_tag);
+        else if constexpr (k < NL + W_ATOMS) w_atom(std::integral_constant<int, k - NL>{}, d_w);
+        else conv_atom(std::integral_constant<int, CA0 + k - NL - W_ATOMS>{});
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // ---- prologue: chunk 0 / pair 0 into LDS, pair 1 into registers; the input cursor then points at chunk 1
+  c3d_x3_static_for<0, LOAD_ATOMS>([&](auto k) { load_atom(k); });
+#pragma unroll
+  for (int i = 0; i < W_PT; ++i) load_w(i);
+  ++wq;
+  c3d_x3_static_for<0, CONV_ATOMS>([&](auto k) { conv_atom(k); });
+  c3d_x3_static_for<0, W_ATOMS>([&](auto k) { w_atom(k, s_w0); });   // pair 0 -> buffer 0; requests pair 1
+  store_in();
+  advance();
+  ++wq;
+  __syncthreads();
+
+  auto k_loop = [&](auto nj_tag) {
+    int wb = 0;
+    for (int c = 0; c < nchunks; ++c) {
+      c3d_x3_static_for<0, NG>([&](auto g_tag) {
+        group(g_tag, wb, nj_tag);      // multiplies tap row g of chunk c; stores pair +1 into the other slab buffer and
+        ++wq;                          // requests pair +2; first row: requests chunk c+1, later rows: convert it
+        wb ^= 1;
+        __syncthreads();               // the other slab buffer is complete; everyone is done with this one
+      });
+      if (c + 1 < nchunks) {
+        store_in();                    // chunk c+1's planes (the barrier above: every wave is done reading chunk c)
+        advance();
+        __syncthreads();
+      }
+    }
+  };
+  if (NPW == 1 || nj >= NPW) k_loop(std::integral_constant<int, NPW>{});
+  else k_loop(std::integral_constant<int, 1>{});
+  conv_epilogue<TR, NT, WM, WN>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
+}
+
+template <int NT, int HALO, int TT, bool SIX>
+int launch_x3f_s(ConvArgs& a, hipStream_t st) {
+  constexpr int G = (TT == 9) ? 3 : TT;
+  constexpr int IN_PT = ((8 + 2 * HALO) * (32 + 2 * HALO) * 4 + 255) / 256, W_PT = (G * 32 * NT * 4 + 255) / 256;
+  size_t lds = (size_t)3 * (IN_PT * 64 + 2 * W_PT * 64) * 16 * 2;      // rows padded to whole staging units
+  const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
+  if (lds < red) lds = red;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3f_kernel<NT, HALO, TT, SIX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
+  dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
+  hipLaunchKernelGGL((conv_x3f_kernel<NT, HALO, TT, SIX>), grid, dim3(256), lds, st, a);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int NT, int HALO, int TT, bool SIX>
 int launch_x3_s(ConvArgs& a, hipStream_t st) {
   constexpr int G = (TT == 9) ? 3 : TT;
@@ -267,6 +637,12 @@ int launch_x3_s(ConvArgs& a, hipStream_t st) {
 
 template <int NT, int HALO, int TT>
 int launch_x3(ConvArgs& a, hipStream_t st) {
+  if constexpr (TT == 9) {
+    // the fused kernel; C3D_X3_FUSED=0: round 2's phased kernel (same-box A/B and the bit-identity test; read per
+    // launch on purpose)
+    const char* e = getenv("C3D_X3_FUSED");
+    if (!(e && e[0] == '0')) return a.six ? launch_x3f_s<NT, HALO, TT, true>(a, st) : launch_x3f_s<NT, HALO, TT, false>(a, st);
+  }
   return a.six ? launch_x3_s<NT, HALO, TT, true>(a, st) : launch_x3_s<NT, HALO, TT, false>(a, st);
 }
 

@@ -287,7 +287,10 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
     k32 = tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs)
     if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
-        name = f"conv_x3_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, {nt_}, {'true' if grad else 'false'}>"
+        # nine taps: the fused kernel (round 3), four taps: the phased one; C3D_X3_FUSED=0 forces the phased one
+        fused_ = nt_ == 9 and os.environ.get("C3D_X3_FUSED", "1")[:1] != "0"
+        name = (f"conv_x3{'f' if fused_ else ''}_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, {nt_}, "
+                f"{'true' if grad else 'false'}>")
     elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
         name = _pw3_kernel_name(_pw3_tile(b, h, w, cout), sum(s.C for s in srcs), cout)
     elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
@@ -302,7 +305,9 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         name = f"conv_mfma_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}>"
     # six plane products: every input gradient, and forward multi-tap convs whose BatchNorm population is large
     # (SIX_FWD_MIN_PIXELS).  conv_pw3 runs six in every launch (the flag is ignored there).
-    six = MFMA_MODE == 2 and (grad or (nt_ > 1 and tr == 8 and b * h * w >= SIX_FWD_MIN_PIXELS))
+    # (C3D_SIX=0: eight products everywhere -- the probe switch behind DESIGN.md's "where the plane products matter")
+    six = (MFMA_MODE == 2 and (grad or (nt_ > 1 and tr == 8 and b * h * w >= SIX_FWD_MIN_PIXELS))
+           and os.environ.get("C3D_SIX", "1") != "0")
     if six and not grad:
         name = name.replace(", false>", ", true>")
     d.mfma_bf16 = 3 if six else MFMA_MODE

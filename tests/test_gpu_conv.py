@@ -392,3 +392,62 @@ def test_fused_pointwise_kernel_random_configurations():
         else:
             os.environ["C3D_PW3_FUSED"] = saved
         ops.set_matrix_precision(*prev)
+
+
+def test_fused_multitap_kernel_is_bit_identical_to_the_phased_one():
+    """conv_x3f_kernel (round 3: the next chunk's split and the next tap row's weights dealt into the MFMA stream,
+    fragments one tap ahead, buffer loads) against conv_x3_kernel, bit for bit, over 28 seeded random launches: all
+    three tap patterns, 1-3 sources at channel offsets with or without BatchNorm affine / LeakyReLU, ragged H / W
+    (zero padding after the transform at every border), 32- and 64-wide cout tiles with ragged couts, output at a
+    channel offset, accumulate mode, eight and six plane products (forward / input-gradient launches)."""
+    import os
+    import random
+    from coarse3d_amd import ops
+    rnd = random.Random(99)
+    dev = "cuda"
+    prev = ops.matrix_precision_state()
+    ops.set_matrix_precision("bf16x3")
+    saved = os.environ.get("C3D_X3_FUSED")
+    try:
+        for case in range(28):
+            g = torch.Generator().manual_seed(2000 + case)
+            k, dil, pad = rnd.choice([(3, 1, 1), (3, 2, 2), (2, 2, 1)])
+            B, H, W = rnd.choice([(2, 16, 256), (1, 24, 200), (3, 8, 97), (1, 64, 160), (8, 8, 256)])
+            nsrc = rnd.choice([1, 1, 2, 3])
+            srcC = [rnd.choice([16, 32, 64]) for _ in range(nsrc)]
+            Cout = rnd.choice([32, 48, 64, 80, 128, 256])
+            srcs = []
+            for c in srcC:
+                wide = c + rnd.choice([0, 16])
+                coff = rnd.choice([0, wide - c])
+                x = torch.randn(B, H, W, wide, generator=g).to(dev)
+                aff = rnd.random() < 0.6
+                sc = (torch.rand(c, generator=g) + 0.5).to(dev) if aff else None
+                sh = (torch.randn(c, generator=g) * 0.3).to(dev) if aff else None
+                srcs.append(ops.Source(x, sc, sh, C=c, coff=coff, lrelu=rnd.random() < 0.5))
+            K = sum(srcC)
+            w = (torch.randn(Cout, K, k, k, generator=g) / (K * k * k) ** 0.5).to(dev)
+            wp = ops.pack_weights(w, mode=0)
+            bias = (torch.randn(Cout, generator=g) * 0.1).to(dev) if rnd.random() < 0.5 else None
+            ocoff = rnd.choice([0, 4, 32])
+            base = torch.randn(B, H, W, Cout + ocoff + rnd.choice([0, 4]), generator=g).to(dev)
+            acc, stats, lrelu, six = rnd.random() < 0.4, rnd.random() < 0.5, rnd.random() < 0.5, rnd.random() < 0.5
+            taps = ops.conv_taps(k, k, dil, pad)
+            outs = {}
+            for fused in ("0", "1"):
+                os.environ["C3D_X3_FUSED"] = fused
+                out = base.clone()
+                _, part = ops.conv_forward(srcs, wp, bias, Cout, taps, lrelu=lrelu, stats=stats, out=out, out_coff=ocoff,
+                                           accumulate=acc, grad=six)
+                torch.cuda.synchronize()
+                outs[fused] = (out, part)
+            tag = (case, k, dil, B, H, W, srcC, Cout, ocoff, acc, stats, six)
+            assert torch.equal(outs["1"][0], outs["0"][0]), tag
+            if stats:
+                assert torch.equal(outs["1"][1], outs["0"][1]), tag
+    finally:
+        if saved is None:
+            os.environ.pop("C3D_X3_FUSED", None)
+        else:
+            os.environ["C3D_X3_FUSED"] = saved
+        ops.set_matrix_precision(*prev)
