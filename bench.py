@@ -227,6 +227,10 @@ def main():
     ap.add_argument("--storage", choices=("bf16", "f32"), default="bf16",
                     help="activation storage of --matrix-dtype bf16 (BASELINE configs[2]): bf16 tensors in HBM "
                          "(default) or fp32 tensors with bf16 MFMA operands only")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as ONE hipGraph (TrainStep(graph=True): two eager steps, capture, replay).  The "
+                         "default is launch-by-launch, which keeps live HIP events around the dominant kernel inside the "
+                         "timed region; the default run reports the captured step under `engines.graph_replay`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--kernel-table", default=None, help="write a per-(kernel, layer shape) timing table (JSON) here")
@@ -295,8 +299,10 @@ def main():
     wrapped = D.DataParallel(model) if (world > 1 or single_rank_group or os.environ.get("C3D_FORCE_DP")) else model
     ts = TrainStep(wrapped, args.classes, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512,
                    loss_w_ce_2d=1.0, loss_w_lov_2d=1.0, loss_w_contrast=0.1, feature_mean=FEATURE_MEAN,
-                   feature_std=FEATURE_STD, proto_loss=True,
+                   feature_std=FEATURE_STD, proto_loss=True, graph=args.graph and world == 1 and not single_rank_group,
                    inputs_resident=True)      # the batches below are generated and synchronised before the timed region
+    if ts.graph and args.warmup < 3:
+        args.warmup = 3                       # two eager steps + the capture
     rate = 1e-4 if args.dataset == "SemanticPOSS" else 1e-3
     total_steps = args.warmup + args.steps
     batches = [synth_batch(args.batch, args.height, args.width, args.classes, 1000 + s + 7919 * rank, dev, rate)
@@ -326,7 +332,8 @@ def main():
     # per step costs ~2 % of the step, which would distort `value`).
     survey = None
     for s in range(args.warmup):
-        last = s == args.warmup - 1 and not args.no_kernel_events
+        # (captured step: the events can only bracket launches of an EAGER step -- the second warm-up step)
+        last = s == (1 if ts.graph else args.warmup - 1) and not args.no_kernel_events
         if last:
             ops.KERNEL_EVENTS = []
         ts.step(*batches[s], epoch=10)
@@ -338,7 +345,7 @@ def main():
     # JSON line below is the last thing this process writes to stdout
     import ctypes
     ctypes.CDLL(None).fflush(None)
-    if not args.no_kernel_events:
+    if not args.no_kernel_events and not ts.graph:
         ops.KERNEL_EVENTS = []
         if survey is not None:
             ops.KERNEL_EVENT_FILTER = max(survey[0].items(), key=lambda kv: kv[1][1])[0]
@@ -356,13 +363,16 @@ def main():
         elapsed = float(t)
 
     roofline = None
+    if ts.graph and survey is not None:     # per-kernel figures of a captured run: from its eager warm-up step
+        ops.KERNEL_EVENTS = [None]
     if ops.KERNEL_EVENTS:
-        per, table = summarise(ops.KERNEL_EVENTS, args.steps)
+        per, table = (summarise(ops.KERNEL_EVENTS, args.steps) if not ts.graph else survey)
         name, (fl, sec, n) = max(per.items(), key=lambda kv: kv[1][1])
         if survey is None:                   # no warm-up step: everything was bracketed in the timed region
             survey, all_steps = (per, table), args.steps
         else:
             all_steps = 1
+        timed_steps = 1 if ts.graph else args.steps    # captured run: the launches of ONE eager step were timed
         all_fl = sum(v[0] for v in survey[0].values())
         all_sec = sum(v[1] for v in survey[0].values())
         all_ideal = sum(v[0] / (peak_for(k) * 1e12) for k, v in survey[0].items())    # seconds at each kernel's own peak
@@ -396,7 +406,7 @@ def main():
                     "traffic_source": (f"committed PMC pass profiles/{PMC_FILE.format(tag=tag)} (2*FETCH_SIZE + WRITE_SIZE "
                                        "per launch of this kernel, separate rocprofv3 --pmc runs of this bench); not "
                                        "re-measured in this run") if traffic is not None else None,
-                    "launches_per_step": n // args.steps,
+                    "launches_per_step": n // timed_steps,
                     "avg_launch_us": round(sec / n * 1e6, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
                     "all_mfma_kernels": {"achieved": round(all_fl / all_sec / 1e12, 2),
                                          "frac": round(all_ideal / all_sec, 4),
@@ -406,7 +416,9 @@ def main():
                                                                             "ceiling of the fp32 MFMA instructions the reference "
                                                                             "arithmetic would run on (round 1's yardstick)",
                                          "ms_per_step": round(all_sec / all_steps * 1e3, 2),
-                                         "measured_in": "last warm-up step" if all_steps == 1 else "timed steps"}}
+                                         "measured_in": "last warm-up step" if all_steps == 1 else "timed steps"},
+                    "dominant_kernel_measured_in": ("the eager warm-up step before the capture (HIP events cannot bracket "
+                                                    "launches inside a replayed graph)") if ts.graph else "timed steps"}
     ops.KERNEL_EVENTS = None
     ops.KERNEL_EVENT_FILTER = None
     if roofline is not None and default_shape_for_step(args) and args.batch == 8:
@@ -479,7 +491,7 @@ def main():
             torch.cuda.empty_cache()
             k2 = min(args.steps, 10)
 
-            def quick_run(dtype, wgrad_stream):
+            def quick_run(dtype, wgrad_stream, graph=False):
                 """value / ms_per_step of k2 steps of the same workload on another engine configuration"""
                 ops.set_matrix_precision(dtype)
                 prev = os.environ.get("C3D_WGRAD_STREAM")
@@ -493,8 +505,8 @@ def main():
                     m2 = m2.to(dev).train()
                     ts2 = TrainStep(m2, args.classes, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512, loss_w_ce_2d=1.0,
                                     loss_w_lov_2d=1.0, loss_w_contrast=0.1, feature_mean=FEATURE_MEAN, feature_std=FEATURE_STD,
-                                    proto_loss=True, inputs_resident=True)
-                    for s_ in range(min(args.warmup, 2) or 1):
+                                    proto_loss=True, inputs_resident=True, graph=graph)
+                    for s_ in range(3 if graph else (min(args.warmup, 2) or 1)):
                         ts2.step(*batches[s_], epoch=10)
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
@@ -518,7 +530,12 @@ def main():
                                    "(C3D_WGRAD_STREAM=1; what data-parallel runs use): weight gradients then execute under the "
                                    "BatchNorm-backward / elementwise kernels of the main chain.  Off by default on one GPU because the "
                                    "kernels of the two streams share the CUs and every per-kernel duration of `roofline` would inflate")
-            out["engines"] = {"f32_mfma": f32_run, "bf16x3_wgrad_on_second_stream": overlap_run,
+            graph_run = quick_run("bf16x3", "0", graph=True)
+            graph_run["note"] = ("the headline step captured in ONE hipGraph and replayed (python bench.py --graph; "
+                                 "TrainStep(graph=True): bit-identical to the launch-by-launch step, tests/test_gpu_step.py).  "
+                                 "Launch by launch the host needs ~24 ms per step, so this matters where the GPU needs less "
+                                 "(32x1024 bs=16, the bf16 mode); at 64x2048 bs=8 the GPU is the bound either way")
+            out["engines"] = {"f32_mfma": f32_run, "bf16x3_wgrad_on_second_stream": overlap_run, "graph_replay": graph_run,
                               "note": "`value` is the bf16x3 engine's on one stream; these are the same step on the fp32-MFMA engine "
                                       "(python bench.py --matrix-dtype f32 gives its full roofline object) and with the second stream on"}
             ops.set_matrix_precision(args.matrix_dtype)

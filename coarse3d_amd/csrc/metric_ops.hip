@@ -165,15 +165,19 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict_
 }
 
 // ---- Lovasz: one workgroup per class over the P labelled pixels (P <= CAP, LDS-resident)
+// P_dev != nullptr: the number of labelled pixels is read from device memory (clamped to `P`, which is then the
+// capacity of idx and the row stride of grad) -- the launch is shape-static and capturable in a hipGraph.
 template <int CAP>
 __global__ __launch_bounds__(256) void lovasz_class_kernel(const float* __restrict__ prob, int cstride,
                                                            const int64_t* __restrict__ labels, const int64_t* __restrict__ idx,
-                                                           int P, float* __restrict__ loss_c, float* __restrict__ present,
-                                                           float* __restrict__ grad /* [C][P] */) {
+                                                           int P, const int* __restrict__ P_dev, float* __restrict__ loss_c,
+                                                           float* __restrict__ present, float* __restrict__ grad /* [C][stride] */) {
   extern __shared__ float lsm[];
   __shared__ float wsum[4];
   __shared__ double dsum[4];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int gstride = P;
+  if (P_dev) P = min(max(*P_dev, 0), P);
   int npow = 1;
   while (npow < P) npow <<= 1;                              // <= CAP (checked by the host)
   float* key = lsm;                                         // [npow] errors, sorted descending
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(256) void lovasz_class_kernel(const float* __restri
       loss_c[c] = 0.f;
       present[c] = 0.f;
     }
-    for (int p = tid; p < P; p += 256) grad[(size_t)c * P + p] = 0.f;
+    for (int p = tid; p < P; p += 256) grad[(size_t)c * gstride + p] = 0.f;
     return;
   }
   // bitonic sort, descending by key
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256) void lovasz_class_kernel(const float* __restri
     acc += (double)(e * jd);
     // d|fg - p|/dp = -1 (fg = 1), +1 (fg = 0); 0 where the error is exactly 0 (abs'(0) = 0)
     const float sgn = e == 0.f ? 0.f : (fg != 0.f ? -1.f : 1.f);
-    grad[(size_t)c * P + (v >> 1)] = jd * sgn;
+    grad[(size_t)c * gstride + (v >> 1)] = jd * sgn;
   }
   acc = c3d_wave_sum_d(acc);
   if (lane == 0) dsum[wv] = acc;
@@ -285,14 +289,16 @@ __global__ void lovasz_finish_kernel(const float* __restrict__ loss_c, const flo
 
 // dprob[idx[p]][c] += g / npresent * grad[c][p]
 __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const float* __restrict__ grad, const int64_t* __restrict__ idx, int P,
-                                                         int C, const float* __restrict__ stats, const float* __restrict__ gscale,
-                                                         float* __restrict__ dprob, int dstride) {
+                                                         const int* __restrict__ P_dev, int C, const float* __restrict__ stats,
+                                                         const float* __restrict__ gscale, float* __restrict__ dprob, int dstride) {
   const float np_ = stats[1];
   if (np_ <= 0.f) return;
+  const int gstride = P;
+  if (P_dev) P = min(max(*P_dev, 0), P);
   const float g = (gscale ? *gscale : 1.f) / np_;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)P * C; e += (int64_t)gridDim.x * 256) {
     const int p = (int)(e / C), c = (int)(e % C);
-    dprob[idx[p] * dstride + c] += g * grad[(size_t)c * P + p];
+    dprob[idx[p] * dstride + c] += g * grad[(size_t)c * gstride + p];
   }
 }
 
@@ -322,11 +328,10 @@ extern "C" int c3d_focal_backward(const float* prob, int C, int cstride, const i
 
 extern "C" int c3d_lovasz_max_pixels(void) { return 8192; }
 
-extern "C" int c3d_lovasz_forward(const float* prob, int C, int cstride, const int64_t* labels, const int64_t* idx, int P,
-                                  float* loss_c, float* present, float* grad, float* out, c3d_stream stream) {
+static int lovasz_forward_impl(const float* prob, int C, int cstride, const int64_t* labels, const int64_t* idx, int P,
+                               const int* P_dev, float* loss_c, float* present, float* grad, float* out, hipStream_t st) {
   C3D_REQUIRE(P >= 0 && P <= 8192, "lovasz: at most 8192 labelled pixels on the fused path");
   C3D_REQUIRE(C >= 1 && C <= 64, "lovasz: 1..64 classes");
-  hipStream_t st = (hipStream_t)stream;
   if (P == 0) {
     (void)hipMemsetAsync(loss_c, 0, sizeof(float) * C, st);
     (void)hipMemsetAsync(present, 0, sizeof(float) * C, st);
@@ -339,7 +344,7 @@ extern "C" int c3d_lovasz_forward(const float* prob, int C, int cstride, const i
     }
     int npow = 1;
     while (npow < P) npow <<= 1;
-    hipLaunchKernelGGL(lovasz_class_kernel<8192>, dim3(C), dim3(256), (size_t)npow * 8, st, prob, cstride, labels, idx, P,
+    hipLaunchKernelGGL(lovasz_class_kernel<8192>, dim3(C), dim3(256), (size_t)npow * 8, st, prob, cstride, labels, idx, P, P_dev,
                        loss_c, present, grad);
     C3D_CHECK_LAUNCH();
   }
@@ -348,11 +353,32 @@ extern "C" int c3d_lovasz_forward(const float* prob, int C, int cstride, const i
   return 0;
 }
 
+extern "C" int c3d_lovasz_forward(const float* prob, int C, int cstride, const int64_t* labels, const int64_t* idx, int P,
+                                  float* loss_c, float* present, float* grad, float* out, c3d_stream stream) {
+  return lovasz_forward_impl(prob, C, cstride, labels, idx, P, nullptr, loss_c, present, grad, out, (hipStream_t)stream);
+}
+
 extern "C" int c3d_lovasz_backward(const float* grad, const int64_t* idx, int P, int C, const float* stats,
                                    const float* gscale, float* dprob, int dstride, c3d_stream stream) {
   if (P <= 0) return 0;
-  hipLaunchKernelGGL(lovasz_bwd_kernel, dim3(blocks_for((int64_t)P * C)), dim3(256), 0, (hipStream_t)stream, grad, idx, P, C,
-                     stats, gscale, dprob, dstride);
+  hipLaunchKernelGGL(lovasz_bwd_kernel, dim3(blocks_for((int64_t)P * C)), dim3(256), 0, (hipStream_t)stream, grad, idx, P, nullptr,
+                     C, stats, gscale, dprob, dstride);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_lovasz_forward_dyn(const float* prob, int C, int cstride, const int64_t* labels, const int64_t* idx,
+                                      const int* P_dev, int P_cap, float* loss_c, float* present, float* grad, float* out,
+                                      c3d_stream stream) {
+  C3D_REQUIRE(P_dev != nullptr && P_cap >= 1, "lovasz_dyn: needs the device count and a capacity");
+  return lovasz_forward_impl(prob, C, cstride, labels, idx, P_cap, P_dev, loss_c, present, grad, out, (hipStream_t)stream);
+}
+
+extern "C" int c3d_lovasz_backward_dyn(const float* grad, const int64_t* idx, const int* P_dev, int P_cap, int C,
+                                       const float* stats, const float* gscale, float* dprob, int dstride, c3d_stream stream) {
+  C3D_REQUIRE(P_dev != nullptr && P_cap >= 1, "lovasz_dyn: needs the device count and a capacity");
+  hipLaunchKernelGGL(lovasz_bwd_kernel, dim3(blocks_for((int64_t)P_cap * C)), dim3(256), 0, (hipStream_t)stream, grad, idx, P_cap,
+                     P_dev, C, stats, gscale, dprob, dstride);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -824,6 +824,26 @@ def lovasz_forward(prob, labels, idx):
     return out, grad
 
 
+def lovasz_forward_dyn(prob, labels, idx, count):
+    """idx int64 [cap] (cap <= lovasz_max_pixels()), count int32 [1] on the device: the first ``count`` entries are
+    the labelled pixels.  Shape-static (hipGraph-capturable) form of ``lovasz_forward``; grad is [C, cap]."""
+    p, c, cs = _rows(prob)
+    cap = idx.numel()
+    loss_c = torch.empty(c, device=p.device, dtype=torch.float32)
+    present = torch.empty(c, device=p.device, dtype=torch.float32)
+    grad = torch.empty(c, cap, device=p.device, dtype=torch.float32)
+    out = torch.empty(2, device=p.device, dtype=torch.float32)
+    _call("c3d_lovasz_forward_dyn", _dp(p), c, cs, _dp(labels), _dp(idx), _dp(count), cap, _dp(loss_c), _dp(present),
+          _dp(grad), _dp(out), _stream())
+    return out, grad
+
+
+def lovasz_backward_dyn(grad, idx, count, stats, gscale, dprob):
+    _call("c3d_lovasz_backward_dyn", _dp(grad), _dp(idx), _dp(count), idx.numel(), grad.shape[0], _dp(stats), _dp(gscale),
+          _dp(dprob), dprob.shape[-1], _stream())
+    return dprob
+
+
 def lovasz_backward(grad, idx, stats, gscale, dprob):
     _call("c3d_lovasz_backward", _dp(grad), _dp(idx), idx.numel(), grad.shape[0], _dp(stats), _dp(gscale), _dp(dprob),
           dprob.shape[-1], _stream())

@@ -41,6 +41,10 @@ class FlatAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self.step_t = torch.zeros((), device=dev, dtype=torch.float32)
+        # the learning rate as a device scalar: a captured step (TrainStep(graph=True)) must not bake a Python float in;
+        # refreshed from param_groups[0]["lr"] (what schedulers write) by ``sync_lr`` outside the graph
+        self.lr_t = torch.full((), float(lr), device=dev, dtype=torch.float32)
+        self._lr_seen = float(lr)
         self._params = params
 
     def zero_grad(self, set_to_none=True):
@@ -64,11 +68,20 @@ class FlatAdamW(torch.optim.Optimizer):
             if g.data_ptr() != v.data_ptr():      # came through autograd's AccumulateGrad instead of the bound buffer
                 v.copy_(g)
         grp = self.param_groups[0]
+        if not (self.flat_param.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self.sync_lr()
         torch._foreach_add_([self.step_t], 1)
         torch._fused_adamw_([self.flat_param], [self.flat_grad], [self.exp_avg], [self.exp_avg_sq], [], [self.step_t],
-                            amsgrad=False, lr=float(grp["lr"]), beta1=grp["betas"][0], beta2=grp["betas"][1],
+                            amsgrad=False, lr=self.lr_t, beta1=grp["betas"][0], beta2=grp["betas"][1],
                             weight_decay=grp["weight_decay"], eps=grp["eps"], maximize=False, grad_scale=None, found_inf=None)
         return loss
+
+    def sync_lr(self):
+        """Copy param_groups[0]["lr"] into the device scalar the update reads (no-op while it is unchanged)."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_seen:
+            self.lr_t.fill_(lr)
+            self._lr_seen = lr
 
     def _check_aliasing(self):
         """``p.data`` must still be the views of ``flat_param`` made in __init__: model.double() / .to(device) /

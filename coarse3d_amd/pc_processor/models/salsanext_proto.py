@@ -173,6 +173,7 @@ class SalsaNextProto(nn.Module):
         self._block_done = None       # data parallel: called per block in backward order
         self._flat_grads = None
         self._bind_grads = False      # TrainStep: write the gradients into one persistent buffer and bind param.grad
+        self._static_bank = False     # TrainStep(graph=True): update the prototype bank in place instead of re-binding it
         self._own_flat = None
         self._cache = None
         self._side = None             # second HIP stream (weight-gradient chain of the backward pass)
@@ -241,6 +242,7 @@ class SalsaNextProto(nn.Module):
     _SKIP = ("prototypes", "feat_norm.weight", "feat_norm.bias", "mask_norm.weight", "mask_norm.bias")
     # class-level defaults (subclasses with their own __init__ inherit them)
     _bind_grads = False
+    _static_bank = False
     _own_flat = None
     _cache = None
 
@@ -339,7 +341,12 @@ class SalsaNextProto(nn.Module):
                 if proto_pl is not None:
                     self.prototypes = nn.Parameter(proto_pl.clone(), requires_grad=False)
                 if proto_loss:
-                    self.prototypes = nn.Parameter(res["new_bank"], requires_grad=False)
+                    if self._static_bank:
+                        # a captured training step (coarse3d_amd.trainer.TrainStep(graph=True)) replays kernels with
+                        # baked-in addresses: the bank is updated IN PLACE (callers re-read the attribute either way)
+                        self.prototypes.data.copy_(res["new_bank"])
+                    else:
+                        self.prototypes = nn.Parameter(res["new_bank"], requires_grad=False)
                     out["contrast_logits"] = res["contrast_logits"]
                     out["contrast_target"] = res["contrast_target"]
         return out

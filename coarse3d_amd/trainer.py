@@ -30,7 +30,7 @@ class TrainStep:
     def __init__(self, model, n_classes, *, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512,
                  loss_w_ce_2d=1.0, loss_w_lov_2d=1.0, loss_w_contrast=0.1, contrast_warmup=0,
                  entropy_selection=True, ignore_cls=0, cls_weight=None, feature_mean=None, feature_std=None,
-                 proto_loss=False, optimizer=None, scheduler=None, inputs_resident=False):
+                 proto_loss=False, optimizer=None, scheduler=None, inputs_resident=False, graph=None, graph_warmup=2):
         self.model = model
         self.net = model.module if hasattr(model, "module") else model
         # This step owns zero_grad / backward / optimizer.step: on a plain (unwrapped) model the backward pass may
@@ -92,11 +92,28 @@ class TrainStep:
         # (weak labels: always); otherwise the sync-free PyTorch-op restatements
         self.fused_loss_head = True
         self.pl_noise = None     # test hook: Exp(1) noise [B, C, HW] for the pseudo-label selection
+        # captured step (hipGraph): opt-in, C3D_GRAPH=1 makes it the default of this process
+        self.graph = (os.environ.get("C3D_GRAPH", "0") == "1") if graph is None else bool(graph)
+        if graph_warmup < 2:
+            raise ValueError("graph_warmup >= 2: the first eager step records the weight repacks the plan needs, the "
+                             "second builds the batched-repack table; neither may happen inside a capture")
+        self.graph_warmup = graph_warmup
+        self.capacity_check_every = 64
+        self._graphs = {}
+        self._eager_steps = 0
+        self._replays = 0
 
     def step(self, x, train_label, eval_label, epoch=0):
         """x [B,5,H,W] fp32, labels [B,H,W] int64 (0 = ignore).  Returns dict of 0-dim loss tensors
-        (still on the device: nothing here synchronises with the host except Lovasz' nonzero)."""
-        net = self.net
+        (still on the device: nothing here synchronises with the host except Lovasz' nonzero).
+
+        ``graph=True``: after ``graph_warmup`` eager steps the whole step -- input normalisation, forward,
+        prototype update, losses, pseudo-label selection, backward, AdamW: ~700 kernel launches -- is captured in
+        ONE hipGraph per (input shape, epoch) and replayed with a single launch (the host needs ~24 ms to enqueue
+        the launches of a step one by one; a 32x1024 step takes the GPU less than that).  The returned tensors
+        are then the graph's static outputs: they are overwritten by the next step."""
+        if self.graph:
+            return self._graph_step(x, train_label, eval_label, epoch)
         lov_valid = None
         if self.w_lov > 0 and self._side is not None:
             # The Lovasz loss needs the list of labelled pixels, whose length is data dependent (the
@@ -110,8 +127,16 @@ class TrainStep:
                 lov_valid = valid_indices(train_label, self.ignore_cls)
             torch.cuda.current_stream().wait_stream(self._side)
             lov_valid.record_stream(torch.cuda.current_stream())
+        res = self._body(x, train_label, eval_label, epoch, lov_valid, None)
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return res
+
+    def _body(self, x, train_label, eval_label, epoch, lov_valid, lov_count):
+        """Everything of the step that runs on the device.  ``lov_count`` (device int32 [1]): ``lov_valid`` is the
+        fixed-capacity list of ``loss_head.valid_indices_static`` (the shape-static, capturable form)."""
+        net = self.net
         wss_mask = train_label > 0
-        eval_mask = eval_label > 0
         if self.mean is not None:
             x = ops.input_norm(x.contiguous(), eval_label.contiguous(), self.mean, self.std)
         return_feat = epoch >= self.contrast_warmup
@@ -121,12 +146,12 @@ class TrainStep:
         total = pred.new_zeros(())
         res = {}
         fused = (self.fused_loss_head and lov_valid is not None and self.ignore_cls == 0
-                 and loss_head.fused_available(lov_valid.numel()))
+                 and (lov_count is not None or loss_head.fused_available(lov_valid.numel())))
         if fused:      # focal + Lovasz forward/backward on the HIP loss-head kernels
             if self.focal.alpha.device != pred.device:       # once: a per-step H2D copy would drain the stream
                 self.focal.alpha = self.focal.alpha.to(pred.device)
             ce, lov = loss_head.loss_head(pred, train_label, wss_mask, self.focal.alpha,
-                                          self.focal.gamma, lov_valid, self.w_ce > 0, self.w_lov > 0)
+                                          self.focal.gamma, lov_valid, self.w_ce > 0, self.w_lov > 0, count=lov_count)
             if self.w_ce > 0:
                 res["ce"] = ce
                 total = total + self.w_ce * ce
@@ -158,8 +183,76 @@ class TrainStep:
         if hasattr(self.model, "finish_gradients"):
             self.model.finish_gradients()
         self.optimizer.step()
-        if self.scheduler is not None:
-            self.scheduler.step()
         res["loss"] = total.detach()
         res["pred_2d"] = pred.detach()
         return res
+
+    # ------------------------------------------------------------------ captured step
+    def _graph_supported(self):
+        """The captured step covers the single-process configuration the bench and the reference's one-GPU runs use;
+        anything it cannot express raises here instead of replaying something else."""
+        if self.net is not self.model:
+            return "the model is wrapped (data parallel: the exchanges stay eager)"
+        if not (self.fused_loss_head and self.ignore_cls == 0 and self.w_lov > 0):
+            return "the captured step needs the fused loss head (ignore_cls == 0, Lovasz on)"
+        if self.pl_noise is not None or self.contrast.uniforms is not None or self.contrast.perms is not None:
+            return "injected randomness (test hooks) lives on the host"
+        if getattr(self.net, "dropout_masks", None) is not None or getattr(self.net, "gumbel_noise", None) is not None:
+            return "injected randomness (test hooks) lives on the host"
+        if not hasattr(self.net, "_static_bank"):
+            return "the model does not know the in-place bank update"
+        if os.environ.get("C3D_WGRAD_STREAM", "0") == "1":
+            return "the weight-gradient side stream is not part of the captured step"
+        return None
+
+    def _graph_step(self, x, train_label, eval_label, epoch):
+        why = self._graph_supported()
+        if why is not None:
+            raise RuntimeError(f"TrainStep(graph=True): {why}")
+        key = (tuple(x.shape), str(x.dtype), int(epoch))
+        ent = self._graphs.get(key)
+        opt = self.optimizer
+        if hasattr(opt, "sync_lr"):
+            opt.sync_lr()                                # schedulers write param_groups["lr"]; the graph reads a device scalar
+        if ent is None and self._eager_steps < self.graph_warmup:
+            # lazy initialisation (weight-pack table, kernel attributes, cuRAND-free philox state, the flat optimiser
+            # buffers) must happen outside a capture: the first steps run eagerly -- on the same shape-static loss
+            # head the graph uses, so that eager and captured steps are the same arithmetic
+            self._eager_steps += 1
+            self.net._static_bank = True
+            idx, cnt = loss_head.valid_indices_static(train_label, self.ignore_cls)
+            res = self._body(x, train_label, eval_label, epoch, idx, cnt)
+            self._check_capacity(cnt)
+            if self.scheduler is not None:
+                self.scheduler.step()
+            return res
+        if ent is None:
+            self.net._static_bank = True
+            sx, st, se = x.clone(), train_label.clone(), eval_label.clone()
+            self._check_capacity(loss_head.valid_indices_static(st, self.ignore_cls)[1])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                idx, cnt = loss_head.valid_indices_static(st, self.ignore_cls)
+                res = self._body(sx, st, se, epoch, idx, cnt)
+            res["lov_count"] = cnt
+            ent = self._graphs[key] = (g, sx, st, se, res)
+        g, sx, st, se, res = ent
+        sx.copy_(x)
+        st.copy_(train_label)
+        se.copy_(eval_label)
+        g.replay()
+        self._replays += 1
+        if self._replays % self.capacity_check_every == 1:
+            self._check_capacity(res["lov_count"])
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return res
+
+    def _check_capacity(self, count):
+        """More labelled pixels than the fused loss head sorts in LDS cannot go through the shape-static step (its
+        list would be truncated): checked on the first steps and then every ``capacity_check_every`` replays (one
+        4-byte read-back; with weak labels the count is ~1e3 of 8192)."""
+        n = int(count)
+        if n > ops.lovasz_max_pixels():
+            raise RuntimeError(f"TrainStep(graph=True): {n} labelled pixels exceed the fused loss head's capacity "
+                               f"({ops.lovasz_max_pixels()}); train fully supervised batches with graph=False")

@@ -392,6 +392,17 @@ int c3d_lovasz_forward(const float* prob, int C, int cstride, const int64_t* lab
 /* dprob[idx[p]][c] += (*gscale) / out[1] * grad[c][p]                                          */
 int c3d_lovasz_backward(const float* grad, const int64_t* idx, int P, int C, const float* stats,
                         const float* gscale, float* dprob, int dstride, c3d_stream stream);
+/* The same with the number of labelled pixels read from DEVICE memory (*P_dev, clamped to P_cap <=
+ * c3d_lovasz_max_pixels()): idx holds P_cap entries of which the first *P_dev are used, grad is [C][P_cap].  The
+ * launches are shape-static: the training step can be captured in a hipGraph and replayed on batches with
+ * different numbers of weak labels (the reference's host-side mask indexing, lovasz_softmax.py:140-160, becomes a
+ * device-side compaction + these kernels).                                                       */
+int c3d_lovasz_forward_dyn(const float* prob, int C, int cstride, const int64_t* labels,
+                           const int64_t* idx, const int* P_dev, int P_cap, float* loss_c, float* present,
+                           float* grad, float* out, c3d_stream stream);
+int c3d_lovasz_backward_dyn(const float* grad, const int64_t* idx, const int* P_dev, int P_cap, int C,
+                            const float* stats, const float* gscale, float* dprob, int dstride,
+                            c3d_stream stream);
 
 /* ------------------------------------------------------------------ kNN label clean-up
  * pc_processor/postproc/knn.py:36-142 (KNN.forward), un-batched as the reference: for each of

@@ -453,6 +453,50 @@ def test_graphed_inference_survives_a_training_step_on_the_same_model():
         gi(x)
 
 
+def test_captured_training_step_replays_bit_identically():
+    """TrainStep(graph=True): two eager steps, then the whole step (input normalisation, forward, prototype update,
+    focal + Lovasz, pseudo-label selection, contrast loss, backward, AdamW -- trainer.py:621-704) is captured in ONE
+    hipGraph and replayed.  Against the same steps issued launch by launch, from the same seed and on the same five
+    batches (different numbers of weak labels each: the Lovasz pixel list is compacted on the device): every loss,
+    every parameter, the prototype bank, the BatchNorm running statistics and the AdamW state agree bit for bit."""
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    from coarse3d_amd.trainer import TrainStep
+    b, h, w, ncls = 2, 32, 128, 20
+    batches = [W.synthetic_batch(b, h, w, ncls, 300 + i, 0.01 + 0.01 * i, gh=8, gw=16) for i in range(5)]
+    runs = []
+    for warm in (1000, 2):                  # never captured / captured after two eager steps
+        torch.manual_seed(21)
+        m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True).to(DEV).train()
+        ts = TrainStep(m, ncls, proto_loss=True, lr=2e-3, num_anchor=32, graph=True, graph_warmup=warm,
+                       feature_mean=[1.0, 0.1, 0.2, 0.3, 0.4], feature_std=[2.0, 1.0, 1.5, 0.5, 1.0])
+        torch.manual_seed(22)
+        losses = []
+        for i, (x, tr, ev) in enumerate(batches):
+            if i == 3:
+                ts.optimizer.param_groups[0]["lr"] = 5e-4      # what a scheduler does between steps
+            res = ts.step(x.to(DEV), tr.to(DEV), ev.to(DEV), epoch=10)
+            losses.append({k: res[k].clone() for k in ("loss", "ce", "lov", "contrast")})
+        torch.cuda.synchronize()
+        state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        opt = ts.optimizer.state_dict()
+        runs.append((losses, state, opt, ts))
+    assert len(runs[0][3]._graphs) == 0 and len(runs[1][3]._graphs) == 1 and runs[1][3]._replays == 3
+    for la, lb in zip(runs[0][0], runs[1][0]):
+        for k in la:
+            assert torch.equal(la[k], lb[k]), k
+    for k, v in runs[0][1].items():
+        assert torch.equal(v, runs[1][1][k]), k
+    for i, st in runs[0][2]["state"].items():
+        for k in ("step", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(st[k], runs[1][2]["state"][i][k]), (i, k)
+    assert float(runs[1][0][-1]["loss"]) != float(runs[1][0][0]["loss"])          # the model really trained
+    # what the captured step cannot express is refused, not silently replayed
+    ts = runs[1][3]
+    ts.pl_noise = torch.ones(1)
+    with pytest.raises(RuntimeError):
+        ts.step(*[t.to(DEV) for t in batches[0]], epoch=10)
+
+
 def test_prototype_sums_exchange_mode():
     """'Per-class prototype sums' exchange (DataParallel(proto_sync="sums")): the prototype kernel
     hands out the masked feature sums + counts, an (injected) reduction runs on them, and
