@@ -219,6 +219,7 @@ struct LearnArgs {
   int N, M, C, D, ignore;
   float momentum;
   float* fsum;           // NULL, or [C][M][D+1]: write the masked feature sums + counts, skip the EMA
+  const int32_t* cmap;   // NULL, or [N]: row of a (labelled) pixel in COMPACT sim / feat
 };
 
 // EMA of the class's prototypes with the l2-normalised feature sums, then the final l2
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(LEARN_THREADS) void proto_learn_kernel(LearnArgs a)
     for (int b = 0; b < a.B; ++b) {
       const int cb = a.counts[b * a.C + c];
       const int32_t* src = a.idx + ((size_t)b * a.C + c) * a.n;
-      for (int i = tid; i < cb; i += LEARN_THREADS) rows[nc + i] = src[i] + b * a.n;
+      for (int i = tid; i < cb; i += LEARN_THREADS) rows[nc + i] = src[i] + b * a.n;     // flat pixel ids
       nc += cb;
     }
     __threadfence_block();
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(LEARN_THREADS) void proto_learn_kernel(LearnArgs a)
       double acc = 0.0;
       const float um = u[m];
       for (int i = sub; i < nc; i += LEARN_SUBS) {
-        const float* s = a.sim + (size_t)rows[i] * MC + c;
+        const float* s = a.sim + (size_t)(a.cmap ? a.cmap[rows[i]] : rows[i]) * MC + c;
         const float e = m < M ? expf(s[m * a.C] / 0.05f) : 0.f;
         const float colsum = group32_sum(e * um);
         // v[i] of the previous column step (it == 0: uniform, cancels in the row step)
@@ -325,7 +326,8 @@ __global__ __launch_bounds__(LEARN_THREADS) void proto_learn_kernel(LearnArgs a)
     const float um = u[m];
     for (int i = sub; i < nc; i += LEARN_SUBS) {
       const int r = rows[i];
-      const float* s = a.sim + (size_t)r * MC + c;
+      const int cr = a.cmap ? a.cmap[r] : r;           // row of pixel r in sim / feat
+      const float* s = a.sim + (size_t)cr * MC + c;
       const float e = m < M ? expf(s[m * a.C] / 0.05f) * um : 0.f;
       const float colsum = group32_sum(e);
       const float qq = m < M ? e / colsum : -INFINITY;
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(LEARN_THREADS) void proto_learn_kernel(LearnArgs a)
       } else {
         // nearest-prototype class of this labelled pixel, computed here instead of for all N
         // pixels: argmax_k LayerNorm_C(max_m sim[r][m][k])   (salsanext_proto.py:506-507, :340)
-        const float* row = a.sim + (size_t)r * MC;
+        const float* row = a.sim + (size_t)cr * MC;
         const int k = m;                    // lane = class
         float mx = -INFINITY;
         if (k < a.C)
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(LEARN_THREADS) void proto_learn_kernel(LearnArgs a)
     const int cn = min(256, nc - i0);
     if (tid < cn) {
       const int r = rows[i0 + tid];
-      s_r[tid] = r;
+      s_r[tid] = a.cmap ? a.cmap[r] : r;
       s_m[tid] = a.assign[r];
     }
     __syncthreads();
@@ -466,11 +468,12 @@ extern "C" int c3d_proto_learn(const float* sim, const float* feat, const int32_
                                const float* ln_b, float ln_eps, const int32_t* counts,
                                const int32_t* idx, int32_t* rows, const float* noise, const float* protos,
                                float* protos_out, float* target, int32_t* assign, int B, int n, int M, int C, int D,
-                               int ignore_label, float momentum, float* fsum, c3d_stream stream) {
+                               int ignore_label, float momentum, float* fsum, const int32_t* cmap, c3d_stream stream) {
   C3D_REQUIRE(M <= 32, "proto_learn: at most 32 sub-prototypes per class");
+  C3D_REQUIRE(cmap == nullptr || pred == nullptr, "proto_learn: a precomputed argmax map is indexed by pixel; not with compact rows");
   const int N = B * n;
   LearnArgs a{sim, feat, pred, ln_w, ln_b, ln_eps, counts, idx, rows, B, n, noise, protos, protos_out, target, assign, N, M, C, D,
-              ignore_label, momentum, fsum};
+              ignore_label, momentum, fsum, cmap};
   const size_t lds = (2 * LEARN_SUBS * 32 + 32 + 512 + (size_t)M * D + M) * sizeof(float);
   hipLaunchKernelGGL(proto_learn_kernel, dim3(C), dim3(LEARN_THREADS), lds, ST, a);
   C3D_CHECK_LAUNCH();

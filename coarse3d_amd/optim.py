@@ -45,6 +45,9 @@ class FlatAdamW(torch.optim.Optimizer):
         # refreshed from param_groups[0]["lr"] (what schedulers write) by ``sync_lr`` outside the graph
         self.lr_t = torch.full((), float(lr), device=dev, dtype=torch.float32)
         self._lr_seen = float(lr)
+        # False: the update takes the learning rate as a Python float (double precision inside the kernel, bit-identical
+        # to torch.optim.AdamW(fused=True)); True (TrainStep(graph=True)): as the float32 device scalar above
+        self.tensor_lr = False
         self._params = params
 
     def zero_grad(self, set_to_none=True):
@@ -72,7 +75,8 @@ class FlatAdamW(torch.optim.Optimizer):
             self.sync_lr()
         torch._foreach_add_([self.step_t], 1)
         torch._fused_adamw_([self.flat_param], [self.flat_grad], [self.exp_avg], [self.exp_avg_sq], [], [self.step_t],
-                            amsgrad=False, lr=self.lr_t, beta1=grp["betas"][0], beta2=grp["betas"][1],
+                            amsgrad=False, lr=self.lr_t if self.tensor_lr else float(grp["lr"]), beta1=grp["betas"][0],
+                            beta2=grp["betas"][1],
                             weight_decay=grp["weight_decay"], eps=grp["eps"], maximize=False, grad_scale=None, found_inf=None)
         return loss
 

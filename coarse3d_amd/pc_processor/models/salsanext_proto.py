@@ -174,6 +174,7 @@ class SalsaNextProto(nn.Module):
         self._flat_grads = None
         self._bind_grads = False      # TrainStep: write the gradients into one persistent buffer and bind param.grad
         self._static_bank = False     # TrainStep(graph=True): update the prototype bank in place instead of re-binding it
+        self._labelled_hint = None    # TrainStep: (idx, count) of the labelled pixels for THIS forward (consumed by it)
         self._own_flat = None
         self._cache = None
         self._side = None             # second HIP stream (weight-gradient chain of the backward pass)
@@ -243,6 +244,7 @@ class SalsaNextProto(nn.Module):
     # class-level defaults (subclasses with their own __init__ inherit them)
     _bind_grads = False
     _static_bank = False
+    _labelled_hint = None
     _own_flat = None
     _cache = None
 
@@ -323,7 +325,8 @@ class SalsaNextProto(nn.Module):
         masks = self._draw_masks(b, x.device) if self.training else None
         named, names, _ = self._cached()
         pred, feat = _BackboneFn.apply(self, x, masks, bool(return_feat), names, *[p for _, p in named])
-        out = {"pred_2d": pred}
+        out = proto_ops.LazyOutputs({"pred_2d": pred})
+        labelled, self._labelled_hint = self._labelled_hint, None
         if not return_feat:
             return out
         out["feat_2d"] = feat
@@ -336,7 +339,8 @@ class SalsaNextProto(nn.Module):
                 res = proto_ops.prototype_step(
                     feat_nhwc, P, label.reshape(-1).long() if proto_loss else None, proto_loss,
                     noise=self.gumbel_noise, momentum=self.proto_mom, ignore_label=self.ignore_label,
-                    world_mean=self._bank_exchange(), ema_base=proto_pl, sums_reduce=self._proto_sums_reduce)
+                    world_mean=self._bank_exchange(), ema_base=proto_pl, sums_reduce=self._proto_sums_reduce,
+                    labelled=labelled)
                 self.prototypes.data.copy_(res["bank_l2"])          # in-place renormalisation (:502)
                 if proto_pl is not None:
                     self.prototypes = nn.Parameter(proto_pl.clone(), requires_grad=False)
@@ -347,6 +351,9 @@ class SalsaNextProto(nn.Module):
                         self.prototypes.data.copy_(res["new_bank"])
                     else:
                         self.prototypes = nn.Parameter(res["new_bank"], requires_grad=False)
-                    out["contrast_logits"] = res["contrast_logits"]
+                    if callable(res["contrast_logits"]):
+                        out.lazy["contrast_logits"] = res["contrast_logits"]
+                    else:
+                        out["contrast_logits"] = res["contrast_logits"]
                     out["contrast_target"] = res["contrast_target"]
         return out

@@ -33,12 +33,61 @@ def similarity(feat_nhwc, bank_l2, ln_w, ln_b):
     return rows, sim
 
 
+class LazyOutputs(dict):
+    """The forward's output dict with entries that are computed on first access (``lazy[key] = thunk``).  Used for
+    ``contrast_logits``: the [N, C*M] similarity map (1.7 GB at 8x64x2048) is part of the module's output surface
+    (salsanext_proto.py:529) but nothing inside the training step reads it -- the prototype update only needs the rows
+    of the labelled pixels.  Behaves as a dict everywhere else (``in``, ``keys``, ``items``, ``get`` materialise as needed)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.lazy = {}
+
+    def _force(self, key):
+        if key in self.lazy:
+            super().__setitem__(key, self.lazy.pop(key)())
+
+    def __getitem__(self, key):
+        self._force(key)
+        return super().__getitem__(key)
+
+    def get(self, key, default=None):
+        self._force(key)
+        return super().get(key, default)
+
+    def __contains__(self, key):
+        return key in self.lazy or super().__contains__(key)
+
+    def keys(self):
+        return list(super().keys()) + list(self.lazy)
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return super().__len__() + len(self.lazy)
+
+    def items(self):
+        for k in list(self.lazy):
+            self._force(k)
+        return super().items()
+
+    def values(self):
+        for k in list(self.lazy):
+            self._force(k)
+        return super().values()
+
+
 def prototype_step(feat_nhwc, P, label, proto_loss, noise=None, momentum=0.999, ignore_label=0,
-                   world_mean=None, want_nearest=False, ema_base=None, sums_reduce=None):  # label: [B, H*W] int64
+                   world_mean=None, want_nearest=False, ema_base=None, sums_reduce=None, labelled=None):  # label: [B, H*W] int64
     """One pass of salsanext_proto.py:494-530.
 
     P: dict with ``prototypes`` [C,M,D], ``feat_norm.*``, ``mask_norm.*``.  label: [N] int64 or
     None.  noise: Exp(1) variates [N, M] indexed by pixel (None -> drawn on device).
+    labelled: None, or (idx int64 [cap], count int32 [1]) -- the flat positions of the pixels with label != ignore in a
+    fixed-capacity buffer (``loss_head.valid_indices_static``; the caller guarantees count <= cap).  Then LayerNorm + l2
+    and the similarity GEMM run on THOSE rows only ("never materialise [N, 400]") and ``contrast_logits``
+    is a thunk that computes the full map if somebody asks for it.
     Returns dict(bank_l2, [nearest], [contrast_logits, contrast_target, new_bank])."""
     bank = P["prototypes"]
     c, m, d = bank.shape
@@ -48,8 +97,29 @@ def prototype_step(feat_nhwc, P, label, proto_loss, noise=None, momentum=0.999, 
         # the similarity map is unobservable in this mode (the reference computes and drops it);
         # the only side effect is the in-place renormalisation of the bank
         return {"bank_l2": bank_l2, "nearest": None, "pred": None}
-    rows, sim = similarity(feat_nhwc, bank_l2, P["feat_norm.weight"], P["feat_norm.bias"])
-    n = rows.shape[0]
+    b = feat_nhwc.shape[0]
+    n = feat_nhwc.numel() // d
+    sparse = learn and labelled is not None and not want_nearest
+    full_sim = lambda: similarity(feat_nhwc, bank_l2, P["feat_norm.weight"], P["feat_norm.bias"])[1]   # noqa: E731
+    cmap = None
+    if sparse:
+        idx, cnt = labelled
+        cap = idx.numel()
+        ar = torch.arange(cap, device=idx.device)
+        ok = ar < cnt
+        g = feat_nhwc.view(n, d).index_select(0, torch.where(ok, idx, torch.zeros_like(idx)))       # [cap, D]
+        rows = ops.rownorm_ln_l2(g, P["feat_norm.weight"], P["feat_norm.bias"])
+        w_oihw = bank_l2.permute(1, 0, 2).reshape(m * c, d, 1, 1).contiguous()
+        cpad = (cap + 31) // 32 * 32
+        if cpad != cap:
+            rp = torch.zeros(cpad, d, device=rows.device, dtype=torch.float32)
+            rp[:cap] = rows
+            rows = rp
+        sim = ops.gemm_rows(rows, ops.pack_weights(w_oihw, 0), m * c)
+        cmap = torch.empty(n + 1, device=idx.device, dtype=torch.int32)           # slot n swallows the padding entries
+        cmap.scatter_(0, torch.where(ok, idx, torch.full_like(idx, n)), ar.to(torch.int32))
+    else:
+        rows, sim = similarity(feat_nhwc, bank_l2, P["feat_norm.weight"], P["feat_norm.bias"])
     # nearest_proto_distance (:506-510) is only ever consumed through its argmax at LABELLED
     # pixels (prototype_learning :340-341): the full [N, C] map is materialised on request only
     nearest = pred = None
@@ -57,18 +127,18 @@ def prototype_step(feat_nhwc, P, label, proto_loss, noise=None, momentum=0.999, 
         nearest, pred = ops.proto_nearest(sim, m, c, P["mask_norm.weight"], P["mask_norm.bias"], want_nearest=True)
     out = {"bank_l2": bank_l2, "nearest": nearest, "pred": pred}
     if learn:
-        b = feat_nhwc.shape[0]
         lab = label.reshape(b, n // b).contiguous()
-        counts, idx = ops.group_compact(lab, c)
+        counts, idx_lists = ops.group_compact(lab, c)
         if noise is None:
             noise = torch.empty(n, m, device=rows.device, dtype=torch.float32).exponential_()
         base = bank_l2 if ema_base is None else ema_base.contiguous()   # proto_pl replaces the bank (:515-518)
-        new_bank, target = ops.proto_learn(sim, rows, pred, counts, idx, noise.contiguous(),
+        new_bank, target = ops.proto_learn(sim, rows, pred, counts, idx_lists, noise.contiguous(),
                                            base, m, c, ignore_label, momentum, P["mask_norm.weight"],
-                                           P["mask_norm.bias"], sums_reduce=sums_reduce)
+                                           P["mask_norm.bias"], sums_reduce=sums_reduce, cmap=cmap)
         if world_mean is not None and sums_reduce is None:
             # data parallel, reference semantics: mean over ranks of the per-rank updated banks
             # (salsanext_proto.py:397-400); with ``sums_reduce`` the ranks already agree
             new_bank = world_mean(new_bank)
-        out.update(contrast_logits=sim, contrast_target=target, new_bank=new_bank)
+        out.update(contrast_target=target, new_bank=new_bank)
+        out["contrast_logits"] = full_sim if sparse else sim        # a thunk in the sparse mode
     return out

@@ -92,6 +92,8 @@ class TrainStep:
         # (weak labels: always); otherwise the sync-free PyTorch-op restatements
         self.fused_loss_head = True
         self.pl_noise = None     # test hook: Exp(1) noise [B, C, HW] for the pseudo-label selection
+        # prototype similarity at the labelled pixels only (C3D_SPARSE_PROTO=0: the full [N, C*M] map every step)
+        self.sparse_proto = os.environ.get("C3D_SPARSE_PROTO", "1") != "0"
         # captured step (hipGraph): opt-in, C3D_GRAPH=1 makes it the default of this process
         self.graph = (os.environ.get("C3D_GRAPH", "0") == "1") if graph is None else bool(graph)
         if graph_warmup < 2:
@@ -99,6 +101,8 @@ class TrainStep:
                              "second builds the batched-repack table; neither may happen inside a capture")
         self.graph_warmup = graph_warmup
         self.capacity_check_every = 64
+        if self.graph and hasattr(self.optimizer, "tensor_lr"):
+            self.optimizer.tensor_lr = True          # a captured update must not bake a Python float in
         self._graphs = {}
         self._eager_steps = 0
         self._replays = 0
@@ -140,6 +144,16 @@ class TrainStep:
         if self.mean is not None:
             x = ops.input_norm(x.contiguous(), eval_label.contiguous(), self.mean, self.std)
         return_feat = epoch >= self.contrast_warmup
+        if (self.sparse_proto and return_feat and self.proto_loss and lov_valid is not None and self.ignore_cls == getattr(net, "ignore_label", None)
+                and hasattr(net, "_labelled_hint")):
+            # the prototype update only needs the embedding rows of the labelled pixels -- the list the Lovasz head uses
+            # (same labels, same ignore class): hand it to the forward so that LayerNorm + l2 + the similarity GEMM run
+            # on those rows instead of all B*H*W.  Capacity: the fused loss head's; more labelled pixels
+            # than that take the dense path.
+            if lov_count is not None:
+                net._labelled_hint = (lov_valid, lov_count)
+            elif lov_valid.numel() <= ops.lovasz_max_pixels():
+                net._labelled_hint = loss_head.valid_indices_static(train_label, self.ignore_cls)
         out = self.model(x, label=train_label if return_feat else None, eval_mask=wss_mask if return_feat else None,
                          return_feat=return_feat, proto_loss=self.proto_loss)
         pred = out["pred_2d"]

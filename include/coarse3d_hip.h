@@ -301,12 +301,15 @@ int c3d_label_hist(const int64_t* labels, int groups, int n, int ncls, int32_t* 
  * fsum = NULL: the bank is updated by the call (protos_out).  fsum = [C][M][D+1]: the masked
  * feature sums (and, in column D, the assignment counts) are written there instead and the bank
  * is left alone -- data-parallel ranks all-reduce fsum and finish with c3d_proto_ema (the
- * "per-class prototype sums" exchange).                                                        */
+ * "per-class prototype sums" exchange).
+ * cmap = NULL: sim / feat hold one row per pixel.  cmap = [B*n] int32: sim / feat are COMPACT -- only the
+ * labelled pixels were normalised and multiplied with the bank (their rows in any order) -- and cmap[pixel] is
+ * the pixel's row in them (read at labelled pixels only); target / noise stay indexed by pixel.       */
 int c3d_proto_learn(const float* sim, const float* feat, const int32_t* pred, const float* ln_w,
                     const float* ln_b, float ln_eps, const int32_t* counts, const int32_t* idx, int32_t* rows, const float* noise,
                     const float* protos, float* protos_out, float* target, int32_t* assign,
                     int B, int n, int M, int C, int D, int ignore_label, float momentum,
-                    float* fsum, c3d_stream stream);
+                    float* fsum, const int32_t* cmap, c3d_stream stream);
 /* EMA with the l2-normalised sums + final l2 normalisation (salsanext_proto.py:376-395, :402)  */
 int c3d_proto_ema(const float* fsum, const float* protos, float* protos_out, int M, int C, int D,
                   int ignore_label, float momentum, c3d_stream stream);

@@ -526,10 +526,11 @@ def test_prototype_sums_exchange_mode():
 
 
 def test_fast_paths_of_the_training_step_change_nothing():
-    """Three shortcuts of TrainStep on a plain model -- param.grad bound to one persistent buffer instead of going through
+    """Four shortcuts of TrainStep on a plain model -- param.grad bound to one persistent buffer instead of going through
     AccumulateGrad, the contrast loss' row bitmap letting the bilinear adjoint skip known-zero rows of the dense
-    embedding gradient, and AdamW stepping all parameters as one flat buffer (coarse3d_amd/optim.py) -- against the same
-    steps with all of them off and torch's per-parameter fused AdamW: identical losses, gradients and parameters."""
+    embedding gradient, AdamW stepping all parameters as one flat buffer (coarse3d_amd/optim.py), and the prototype
+    similarity computed for the labelled pixels only (coarse3d_amd/proto.py) -- against the same steps with
+    all of them off and torch's per-parameter fused AdamW: identical losses, gradients, parameters and prototype bank."""
     from coarse3d_amd import contrast, ops
     from coarse3d_amd.pc_processor.models import SalsaNextProto
     from coarse3d_amd.trainer import TrainStep
@@ -553,6 +554,7 @@ def test_fast_paths_of_the_training_step_change_nothing():
         assert (type(ts.optimizer).__name__ == "FlatAdamW") == fast
         m._bind_grads = fast
         contrast.SPARSE_HINT_ON = fast
+        ts.sparse_proto = fast             # prototype similarity at the labelled pixels only vs the full [N, C*M] map
 
         def spy(t):
             r = orig_take(t)
