@@ -202,17 +202,24 @@ class Backbone:
         do not depend on this block; they share the statistics exchange of this block's bn1."""
         m1 = self._mask(f"{name}.dropout1") if drop_out else None
         m2 = self._mask(f"{name}.dropout2") if drop_out else None
-        up_b = Act(ops.pixshuf_cat(xin.t, xin.scale, xin.shift, xin.mask, m1, m2, skip.t))
+        # cat(PixelShuffle(x), skip): without a Dropout2d mask on the concatenation (upBlock4 in training, every block
+        # in eval mode) the skip tensor is NOT copied -- conv1 (and its weight gradient) read it as a second source
+        # and the input-gradient conv writes its gradient straight into the skip's (SURVEY K6: the concat as an index
+        # remap on load; C3D_DIRECT_SKIP=0 restores the copy)
+        direct = (m2 is None and skip.scale is None and skip.t.dtype == xin.t.dtype
+                  and os.environ.get("C3D_DIRECT_SKIP", "1") != "0")
+        up_b = Act(ops.pixshuf_cat(xin.t, xin.scale, xin.shift, xin.mask, m1, m2, None if direct else skip.t))
+        c1_srcs = [up_b, skip] if direct else [up_b]
         if bn_group is not None:
-            e1 = self._conv(f"{name}.conv1", [up_b], 3, 1, 1, bn=f"{name}.bn1", defer_bn=bn_group)
+            e1 = self._conv(f"{name}.conv1", c1_srcs, 3, 1, 1, bn=f"{name}.bn1", defer_bn=bn_group)
             self._bn_forward_group(bn_group)
         else:
-            e1 = self._conv(f"{name}.conv1", [up_b], 3, 1, 1, bn=f"{name}.bn1")
+            e1 = self._conv(f"{name}.conv1", c1_srcs, 3, 1, 1, bn=f"{name}.bn1")
         e2 = self._conv(f"{name}.conv2", [e1], 3, 2, 2, bn=f"{name}.bn2")
         e3 = self._conv(f"{name}.conv3", [e2], 2, 2, 1, bn=f"{name}.bn3")
         a4 = self._conv(f"{name}.conv4", [e1, e2, e3], 1, 1, 0, bn=f"{name}.bn4")
         a4.mask = self._mask(f"{name}.dropout3") if drop_out else None
-        self.tape[f"{name}.head"] = (xin, skip, up_b, m1, m2)
+        self.tape[f"{name}.head"] = (xin, skip, up_b, m1, m2, direct)
         return a4
 
     # ------------------------------------------------------------------ forward
@@ -434,7 +441,7 @@ class Backbone:
         self._conv_backward(f"{name}.conv1", d)
 
     def _up_backward(self, name, k4=None):
-        xin, skip, up_b, m1, m2 = self.tape[f"{name}.head"]
+        xin, skip, up_b, m1, m2, direct = self.tape[f"{name}.head"]
         a4 = self.tape[f"{name}.conv4"].out
         self._conv_backward(f"{name}.conv4", a4.grad, k4)
         e1, e2, e3 = self.tape[f"{name}.conv4"].srcs
@@ -444,12 +451,15 @@ class Backbone:
         e2.grad = None
         self._conv_backward(f"{name}.conv1", e1.grad)
         e1.grad = None
-        if skip.grad is None:
-            skip.grad = torch.empty_like(skip.t)
-            acc = False
+        if direct:       # conv1's input-gradient launch already wrote / accumulated the skip's gradient
+            dxa = ops.pixshuf_cat_bwd(up_b.grad, xin.mask, m1, None, tuple(xin.t.shape), 0, None, False)
         else:
-            acc = True
-        dxa = ops.pixshuf_cat_bwd(up_b.grad, xin.mask, m1, m2, tuple(xin.t.shape), skip.t.shape[3], skip.grad, acc)
+            if skip.grad is None:
+                skip.grad = torch.empty_like(skip.t)
+                acc = False
+            else:
+                acc = True
+            dxa = ops.pixshuf_cat_bwd(up_b.grad, xin.mask, m1, m2, tuple(xin.t.shape), skip.t.shape[3], skip.grad, acc)
         up_b.grad = None
         self._accum(xin, dxa)
 

@@ -803,6 +803,8 @@ extern "C" int c3d_pixshuf_cat(const float* xa, const float* sc, const float* sh
   PsArgs p{xa, sc, sh, m3, m1, m2, skip, B, Hs, Ws, Cx, Cs, out, bf16_mask};
   hipLaunchKernelGGL(pixshuf_kernel, dim3(nblocks((size_t)B * Hs * Ws * (Cx / 4))), dim3(256), 0, ST, p);
   C3D_CHECK_LAUNCH();
+  if (Cs == 0) return 0;      // PixelShuffle only: the consumer reads the skip tensor as a second source (no copy)
+  C3D_REQUIRE(skip != nullptr, "pixshuf_cat: Cs > 0 needs the skip tensor");
   if (bf16_mask && Cs % 8 == 0 && (Cx / 4) % 8 == 0)
     hipLaunchKernelGGL(catskip_kernel<8>, dim3(nblocks((size_t)B * Hs * Ws * 4 * (Cs / 8))), dim3(256), 0, ST, p);
   else
@@ -817,6 +819,7 @@ extern "C" int c3d_pixshuf_cat_bwd(const float* dout, const float* m3, const flo
   PsBwdArgs p{dout, m3, m1, m2, B, Hs, Ws, Cx, Cs, dxa, dskip, skip_accumulate, bf16_mask};
   hipLaunchKernelGGL(pixshuf_bwd_kernel, dim3(nblocks((size_t)B * Hs * Ws * (Cx / 4))), dim3(256), 0, ST, p);
   C3D_CHECK_LAUNCH();
+  if (Cs == 0) return 0;
   if (bf16_mask && Cs % 8 == 0 && (Cx / 4) % 8 == 0)
     hipLaunchKernelGGL(catskip_bwd_kernel<8>, dim3(nblocks((size_t)B * Hs * Ws * 4 * (Cs / 8))), dim3(256), 0, ST, p);
   else

@@ -540,8 +540,10 @@ def maskpool_bwd(dout, mask, extra, shape, pool):
 
 
 def pixshuf_cat(xa, sc, sh, m3, m1, m2, skip):
+    """PixelShuffle(2) of BN(xa) (+ dropout masks) concatenated with ``skip``; ``skip=None``: the shuffled part only
+    (the consumer then takes the skip tensor as a second conv source instead of a copy of it)."""
     b, hs, ws, cx = xa.shape
-    cs = skip.shape[-1]
+    cs = skip.shape[-1] if skip is not None else 0
     out = torch.empty(b, 2 * hs, 2 * ws, cx // 4 + cs, device=xa.device, dtype=xa.dtype)
     _call("c3d_pixshuf_cat", _dp(xa), _dp(sc), _dp(sh), _dp(m3), _dp(m1), _dp(m2), _dp(skip), b, hs, ws, cx, cs,
           _dp(out), _bf(xa, skip, out), _stream())
