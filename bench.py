@@ -165,7 +165,11 @@ def launch_ranks(n):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+    # this pool's host driver only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 both RCCL's peer-to-peer
+    # setup and torch's cross-process tensor sharing fail with `hipIpcGetMemHandle: invalid argument`.  The image
+    # exports it already; it is only ADDED here when the caller's environment has lost it, never overridden.
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = []
     for r in range(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))

@@ -202,3 +202,26 @@ def test_rccl_exchange_points_in_a_single_rank_group():
     b = json.loads(rccl.stdout.strip().splitlines()[-1])      # the JSON line must be the LAST stdout line
     assert a["config"]["final_loss"] == b["config"]["final_loss"]
     assert b["n_gpus"] == 1 and b["value"] > 0
+
+
+@pytest.mark.parametrize("net", ["salsanext", "rangenet21", "squeezeseg21"])
+def test_every_backbone_reports_all_gradient_blocks_under_a_process_group(net):
+    """The bucketed gradient all-reduce sends a finished PREFIX of the flat gradient buffer, which is only right if
+    each backbone's backward reports its blocks in the order coarse3d_amd.dist.BACKWARD_ORDER lays them out --
+    FlatGradients.block_done raises on a tag out of order, finish() on a tag that never came.  Exercised for all three
+    backbones with the real exchange calls (1-rank RCCL group, is_dist() true): two training steps must complete, with
+    at least one gradient bucket and the SyncBatchNorm exchanges counted per step."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--net", net, "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--height", "64", "--width", "256", "--no-cpu-baseline", "--no-kernel-events", "--no-second-engine"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", C3D_SINGLE_RANK_COLLECTIVES="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    coll = line["config"]["collectives_per_step"]
+    assert coll["gradient_buckets"] >= 1 and coll["syncbn"] >= 2, coll
+    assert line["n_gpus"] == 1 and line["value"] > 0
