@@ -354,6 +354,8 @@ def main():
         if survey is not None:
             ops.KERNEL_EVENT_FILTER = max(survey[0].items(), key=lambda kv: kv[1][1])[0]
     counts0 = dict(D.COUNTS)
+    if world > 1 or single_rank_group:
+        D.EXPOSED = []                   # event-time what the main stream waits for each blocking exchange
     barrier()
     t0 = time.perf_counter()
     for s in range(args.warmup, total_steps):
@@ -458,6 +460,14 @@ def main():
     if n_ranks > 1 or single_rank_group:
         collectives = {k: round((D.COUNTS[k] - counts0[k]) / args.steps, 2) for k in D.COUNTS}
         collectives["total"] = round(sum(collectives.values()), 2)
+        if D.EXPOSED is not None:
+            ex = D.exposed_ms(D.EXPOSED)
+            D.EXPOSED = None
+            collectives["comm_exposed_ms"] = {k: round(v / args.steps, 3) for k, v in ex.items()}
+            collectives["comm_exposed_ms"]["total"] = round(sum(ex.values()) / args.steps, 3)
+            collectives["comm_exposed_note"] = ("HIP-event time per step between the issue and the completion of every BLOCKING "
+                                                "exchange on the main stream (SyncBatchNorm sums, prototype bank) and of the final "
+                                                "wait for the asynchronous gradient buckets: the communication nothing hides")
         collectives["note"] = ("syncbn: 43 forward + 43 backward BatchNorm layers, minus the exchanges batched with an "
                                "independent layer's; the weight-gradient stream runs under them")
     if rank == 0:

@@ -103,19 +103,35 @@ class Backbone:
     def _bn_forward_group(self, pending):
         """SyncBN for several layers with no data dependence between them: their fp64 sums travel
         in ONE all-reduce.  pending: list of (conv record, bn name, partial, count, momentum)."""
-        P = self.P
+        self._bn_group_end(self._bn_group_begin(pending))
+
+    def _bn_group_begin(self, pending):
+        """First half of ``_bn_forward_group``: fold the partials and START the exchange (asynchronously when the
+        exchange hook offers ``begin`` / ``end``: the caller queues independent kernels before ``_bn_group_end``)."""
         if not (self.train and self.reduce_fn is not None):
-            for rec, bn, partial, count, mom in pending:
-                rec.bn = self._bn_forward(bn, partial, rec.cout, count, mom)
-                rec.out.scale, rec.out.shift = rec.bn.scale, rec.bn.shift
-            return
+            return (pending, None, None)
         dev = pending[0][2].device
         buf = torch.empty(sum(p[0].cout for p in pending), 2, device=dev, dtype=torch.float64)
         off = 0
         for rec, bn, partial, count, mom in pending:
             ops.stat_reduce(partial, rec.cout, sums=buf[off:off + rec.cout])
             off += rec.cout
+        begin = getattr(self.reduce_fn, "begin", None)
+        if begin is not None:
+            return (pending, buf, ("async", begin(buf)))
         self.reduce_fn(buf)
+        return (pending, buf, None)
+
+    def _bn_group_end(self, state):
+        pending, buf, work = state
+        P = self.P
+        if buf is None:
+            for rec, bn, partial, count, mom in pending:
+                rec.bn = self._bn_forward(bn, partial, rec.cout, count, mom)
+                rec.out.scale, rec.out.shift = rec.bn.scale, rec.bn.shift
+            return
+        if work is not None:
+            self.reduce_fn.end(work[1])
         off = 0
         for rec, bn, partial, count, mom in pending:
             r = _BNRec()
@@ -183,8 +199,16 @@ class Backbone:
         return out
 
     def _res_block(self, name, xin, pooling=True, drop_out=True):
-        short = self._conv(f"{name}.conv1", [xin], 1, 1, 0, lrelu=True)
-        r1 = self._conv(f"{name}.conv2", [xin], 3, 1, 1, bn=f"{name}.bn1")
+        if self.train and self.reduce_fn is not None and hasattr(self.reduce_fn, "begin"):
+            # SyncBN: bn1's statistics exchange has independent work to hide under -- the shortcut 1x1 conv
+            grp = []
+            r1 = self._conv(f"{name}.conv2", [xin], 3, 1, 1, bn=f"{name}.bn1", defer_bn=grp)
+            pend = self._bn_group_begin(grp)
+            short = self._conv(f"{name}.conv1", [xin], 1, 1, 0, lrelu=True)
+            self._bn_group_end(pend)
+        else:
+            short = self._conv(f"{name}.conv1", [xin], 1, 1, 0, lrelu=True)
+            r1 = self._conv(f"{name}.conv2", [xin], 3, 1, 1, bn=f"{name}.bn1")
         r2 = self._conv(f"{name}.conv3", [r1], 3, 2, 2, bn=f"{name}.bn2")
         r3 = self._conv(f"{name}.conv4", [r2], 2, 2, 1, bn=f"{name}.bn3")
         a5 = self._conv(f"{name}.conv5", [r1, r2, r3], 1, 1, 0, bn=f"{name}.bn4")

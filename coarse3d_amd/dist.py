@@ -33,18 +33,72 @@ def is_dist():
 COUNTS = {"syncbn": 0, "gradient_buckets": 0, "prototype_bank": 0}
 
 
+# Exposed exchange time: bench.py sets EXPOSED to a list and every BLOCKING exchange on the main stream (the SyncBatchNorm
+# sums, the prototype bank) brackets itself with HIP events there -- what the main stream waited for each exchange, i.e. the
+# part of the communication nothing hides (`config.collectives_per_step.comm_exposed_ms`).  The gradient buckets are
+# asynchronous on torch.distributed's communication stream; their exposed part is the wait in FlatGradients.finish().
+EXPOSED = None
+
+
+class _exposed:
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __enter__(self):
+        self.on = EXPOSED is not None and torch.cuda.is_available()
+        if self.on:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e1.record()
+            EXPOSED.append((self.kind, self.e0, self.e1))
+
+
+def exposed_ms(events):
+    """{exchange kind: total milliseconds} of a list collected in ``EXPOSED`` (synchronises)."""
+    torch.cuda.synchronize()
+    out = {}
+    for kind, e0, e1 in events:
+        out[kind] = out.get(kind, 0.0) + e0.elapsed_time(e1)
+    return out
+
+
 def allreduce_sum_(t):
     """In-place sum over ranks (used for the fp64 BatchNorm sums)."""
     if is_dist():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        with _exposed("syncbn"):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
         COUNTS["syncbn"] += 1
     return t
+
+
+def _allreduce_sum_begin(t):
+    """Asynchronous form of ``allreduce_sum_``: the all-reduce is issued on torch.distributed's communication stream
+    (ordered after what the current stream has queued so far) and the caller keeps queueing independent work; the
+    returned handle's ``wait()`` makes the current stream wait for the result."""
+    if not is_dist():
+        return None
+    COUNTS["syncbn"] += 1
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def _allreduce_sum_end(work):
+    if work is not None:
+        with _exposed("syncbn"):
+            work.wait()
+
+
+allreduce_sum_.begin = _allreduce_sum_begin
+allreduce_sum_.end = _allreduce_sum_end
 
 
 def allreduce_proto_sums_(t):
     """In-place sum over ranks of the per-class prototype feature sums + counts."""
     if is_dist():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        with _exposed("prototype_bank"):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
         COUNTS["prototype_bank"] += 1
     return t
 
@@ -54,7 +108,8 @@ def world_mean(t):
     if not is_dist():
         return t
     t = t.clone().div_(dist.get_world_size())
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    with _exposed("prototype_bank"):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
     COUNTS["prototype_bank"] += 1
     return t
 
@@ -138,8 +193,9 @@ class FlatGradients:
             raise RuntimeError(f"backward finished without reporting gradient blocks {missing}")
         if is_dist():
             self._launch(self.flat.numel())
-            for w in self._works:
-                w.wait()
+            with _exposed("gradient_wait"):
+                for w in self._works:
+                    w.wait()
         self._works = []
 
     def all_reduce_mean(self, n_chunks=4):
