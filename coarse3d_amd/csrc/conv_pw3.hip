@@ -484,15 +484,20 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void conv_pw3f_kernel(Co
       // weight fragments: plane 0 (first and last product of a sub-tile) double-buffered, planes 1 and 2 re-read
       // right after their last product of sub-tile j for sub-tile j+1
       bf16x8 b0[2], b1, b2;
+      // (`fresh` is zero but opaque to the compiler, redefined per chunk: fragment addresses are recomputed next to
+      //  their reads instead of being hoisted into registers -- the four-wave form otherwise needs scratch, and a
+      //  kernel with scratch gets one workgroup per CU on this GPU)
+      int fresh = 0;
+      asm volatile("" : "+v"(fresh));
       auto read_a = [&](int p) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
-          const int R = (wm + i * WM) * 32 + l31;
+          const int R = (wm + i * WM) * 32 + l31 + fresh;
           ap[p][i] = *reinterpret_cast<const bf16x8*>(s_in + p * IN_ROWS * 16 + R * 16 + swz_half(R, half));
         }
       };
       auto read_b = [&](int j, int p) {
-        const int R = (j * WN + wn) * 32 + l31;
+        const int R = (j * WN + wn) * 32 + l31 + fresh;
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(s_w + p * TN * 16 + R * 16 + swz_half(R, half));
         if (p == 0) b0[j & 1] = v;
         else if (p == 1) b1 = v;

@@ -514,11 +514,17 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
     bf16x8 bq[3][NJ];
     // (no plane both closes a tap and opens the next one -- static_assert below -- so one register set per plane)
     static_assert(PR::last_a(PR::pa(0)) != NQ - 1 && PR::last_b(PR::pb(0)) != NQ - 1, "a tap must not open with the plane it closed with");
+    // (`fresh` is zero, but opaque to the compiler and redefined per tap row: the 2 x 9 fragment row addresses are then
+    //  recomputed next to their reads -- a few VALU in the MFMA shadow -- instead of being hoisted out of the chunk loop
+    //  into 18 registers, which pushed the 64-cout dilation-2 kernel into scratch; a kernel with scratch gets ONE
+    //  workgroup per CU on this GPU whatever its LDS and register budget says: matrix pipe busy 0.36 instead of 0.71)
+    int fresh = 0;
+    asm volatile("" : "+v"(fresh));
     auto read_a = [&](int tg, int p) {
       const int t = g * G + tg;
 #pragma unroll
       for (int i = 0; i < RPW; ++i) {
-        const int R = (wm + i * WM + HALO + a.dy[t]) * TWh + HALO + a.dx[t] + l31;
+        const int R = (wm + i * WM + HALO + a.dy[t]) * TWh + HALO + a.dx[t] + l31 + fresh;
         ap[p][i] = *reinterpret_cast<const bf16x8*>(s_in + p * IN_ROWS_P * 16 + R * 16 + swz_half(R, half));
       }
     };

@@ -117,6 +117,14 @@ __device__ __forceinline__ f32x4 c3d_ld4u(const float* p, size_t ubase, unsigned
   }
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void c3d_wg_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    c3d_wg_static_for<I + 1, N>(f);
+  }
+}
+
 template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO>
 __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   constexpr int WK = 4 / (WCI * WCO);
@@ -387,62 +395,92 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     {
     const unsigned short* s_x = s_base + cur * BUF;
     const unsigned short* s_dz = s_x + NP * XROWS * CI;
-#pragma unroll
-    for (int kk = 0; kk < KPW; ++kk) {
-      // (tried: issuing the transposed reads of step s+1 ahead of the MFMAs of step s -- the
-      //  matrix phase alone did not get faster (1.50 -> 1.53 ms on the 704x704 layer) and the extra
-      //  fragment registers spill in the staging phases: 2.15 -> 2.78 ms)
+    // Consecutive MFMAs must write DIFFERENT accumulators (a chain of dependent v_mfma_f32_32x32x16_bf16 issues at
+    // 20.7 ns per instruction, four interleaved chains at 15.8: tools/probes/mfma_chain_probe.hip), so a STAGE = TG taps
+    // x JG cout tiles x all cin tiles shares each plane pair: 3-4 accumulators in rotation.
+    //
+    // Round 3: the stages of a tile (K steps x cout-tile groups x tap groups) run as one software-pipelined stream.
+    // Every operand plane of stage s+1 is read right after its LAST product of stage s (the product order opens a stage
+    // with planes other than the ones the previous stage closed with), pinned by sched_barrier: the transposed reads
+    // of a stage fly under the MFMAs of the previous one, and their latency is exposed once per tile instead of once
+    // per stage -- with 18-24 MFMAs per stage that was a quarter of the consumer waves' time (round 2 tried the same
+    // prefetch with all of a stage's fragments in a second register set: no gain, because the producer waves' packed-f32
+    // VALU was taking the matrix pipe's issue slots, profiles/round3_coissue_probe.md; this file is now compiled
+    // without packed ops).
+    constexpr int JG = CO_T >= 2 ? 2 : 1;                                   // cout tiles per stage
+    constexpr int TG = TMAX == 1 ? 1 : (TMAX % 3 == 0 ? 3 : (4 / (JG * CI_T) > 1 ? 4 / (JG * CI_T) : 1));   // taps per stage
+    static_assert(TMAX % TG == 0 && CO_T % JG == 0, "tap / cout-tile groups must divide the loops");
+    constexpr int NJ0 = CO_T / JG, NT0 = TMAX / TG;
+    constexpr int NSTAGE = KPW * NJ0 * NT0;
+    // plane products in issue order (A plane, B plane): NP = 3: six of nine, smallest class first (m*m, l*h, h*l:
+    // 2^-16; m*h, h*m: 2^-8; h*h); NP = 1: the one product
+    constexpr int NQ = NP == 3 ? 6 : 1;
+    constexpr int PA[6] = {NP == 3 ? 1 : 0, 2, 0, 1, 0, 0}, PB[6] = {NP == 3 ? 1 : 0, 0, 2, 0, 1, 0};
+    auto last_use = [](const int (&pl)[6], int plane) constexpr {
+      int l = -1;
+      for (int q = 0; q < NQ; ++q)
+        if (pl[q] == plane) l = q;
+      return l;
+    };
+    bf16x8 ap[TG][CI_T][NP];
+    bf16x8 bp[JG][NP];
+    auto stage_rows = [&](int st, int& Rd, int& Rx0) {
+      const int kk = st / (NJ0 * NT0);
       const int ks = wk * KPW + kk;
       const int row = ks >> 1, px0 = (ks & 1) * 16;
-      const int Rd = row * 32 + px0 + lp;
-      const int Rx0 = (row + HALO) * TWh + HALO + px0 + lp;
-      // Consecutive MFMAs must write DIFFERENT accumulators: a chain of dependent
-      // v_mfma_f32_32x32x16_bf16 issues at 20.7 ns per instruction, four interleaved chains at 15.8,
-      // eight at 15.0 (tools/probes/mfma_chain_probe.hip) -- the first version of this loop ran the
-      // eight plane products of one (tap, cin tile, cout tile) back to back, 38 % slower than the
-      // pipe allows.  So a group of TG taps x JG cout tiles x all cin tiles shares each plane pair:
-      // 3-4 accumulators in rotation.  (Measured effect on whole kernels: none, 0.66-0.68 ms either
-      // way on the 64 -> 64 3x3 layers -- the gaps of the dependent chain were being filled by the
-      // producer wave's VALU instructions, which share the SIMD's issue with the MFMAs; the kernel's
-      // time is matrix-pipe time + VALU time + waits in both orders.)
-      constexpr int JG = CO_T >= 2 ? 2 : 1;                                   // cout tiles per group
-      constexpr int TG = TMAX == 1 ? 1 : (TMAX % 3 == 0 ? 3 : (4 / (JG * CI_T) > 1 ? 4 / (JG * CI_T) : 1));   // taps per group
-      static_assert(TMAX % TG == 0 && CO_T % JG == 0, "tap / cout-tile groups must divide the loops");
+      Rd = row * 32 + px0 + lp;
+      Rx0 = (row + HALO) * TWh + HALO + px0 + lp;
+    };
+    auto read_a = [&](int st, int p) {
+      int Rd, Rx0;
+      stage_rows(st, Rd, Rx0);
+      const int t0 = (st % NT0) * TG;
 #pragma unroll
-      for (int j0 = 0; j0 < CO_T; j0 += JG) {
-        bf16x8 bp[JG][NP];
+      for (int tg = 0; tg < TG; ++tg)
 #pragma unroll
-        for (int jg = 0; jg < JG; ++jg)
+        for (int i = 0; i < CI_T; ++i)
+          ap[tg][i][p] = tr_frag<NSX>(s_x + p * XROWS * CI, Rx0 + tapoff[t0 + tg], (wci * CI_T + i) * 32 + lc);
+    };
+    auto read_b = [&](int st, int p) {
+      int Rd, Rx0;
+      stage_rows(st, Rd, Rx0);
+      const int j0 = ((st / NT0) % NJ0) * JG;
 #pragma unroll
-          for (int p = 0; p < NP; ++p)
-            bp[jg][p] = tr_frag<NSD>(s_dz + p * DROWS * CO, Rd, (wco * CO_T + j0 + jg) * 32 + lc);
-#pragma unroll
-        for (int t0 = 0; t0 < TMAX; t0 += TG) {
-          bf16x8 ap[TG][CI_T][NP];
-#pragma unroll
-          for (int tg = 0; tg < TG; ++tg)
-#pragma unroll
-            for (int i = 0; i < CI_T; ++i)
-#pragma unroll
-              for (int p = 0; p < NP; ++p)
-                ap[tg][i][p] = tr_frag<NSX>(s_x + p * XROWS * CI, Rx0 + tapoff[t0 + tg], (wci * CI_T + i) * 32 + lc);
-#define C3D_PLANE(PA, PB)                                                                   \
-  _Pragma("unroll") for (int tg = 0; tg < TG; ++tg) _Pragma("unroll") for (int i = 0; i < CI_T; ++i)  \
-      _Pragma("unroll") for (int jg = 0; jg < JG; ++jg) acc[t0 + tg][i][j0 + jg] =          \
-          __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[tg][i][PA], bp[jg][PB], acc[t0 + tg][i][j0 + jg], 0, 0, 0);
-          if constexpr (NP == 3) {
-            // six of the nine plane products, smallest first (l*m, m*l and l*l dropped: see the file header;
-            // -DC3D_WGRAD_EIGHT restores the two 2^-24-level terms)
-#ifdef C3D_WGRAD_EIGHT
-            C3D_PLANE(2, 1) C3D_PLANE(1, 2)
-#endif
-            C3D_PLANE(2, 0) C3D_PLANE(0, 2) C3D_PLANE(1, 1) C3D_PLANE(1, 0) C3D_PLANE(0, 1)
-          }
-          C3D_PLANE(0, 0)
-#undef C3D_PLANE
-        }
+      for (int jg = 0; jg < JG; ++jg) bp[jg][p] = tr_frag<NSD>(s_dz + p * DROWS * CO, Rd, (wco * CO_T + j0 + jg) * 32 + lc);
+    };
+    // stage 0: every plane, in the order the products need them
+    c3d_wg_static_for<0, NQ>([&](auto q_tag) {
+      constexpr int q = decltype(q_tag)::value;
+      bool fa = true, fb = true;
+      for (int r = 0; r < q; ++r) {
+        if (PA[r] == PA[q]) fa = false;
+        if (PB[r] == PB[q]) fb = false;
       }
-    }
+      if (fa) read_a(0, PA[q]);
+      if (fb) read_b(0, PB[q]);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    c3d_wg_static_for<0, NSTAGE * NQ>([&](auto s_tag) {
+      constexpr int sq = decltype(s_tag)::value, st = sq / NQ, q = sq % NQ;
+      constexpr int t0 = (st % NT0) * TG, j0 = ((st / NT0) % NJ0) * JG;
+#pragma unroll
+      for (int tg = 0; tg < TG; ++tg)
+#pragma unroll
+        for (int i = 0; i < CI_T; ++i)
+#pragma unroll
+          for (int jg = 0; jg < JG; ++jg)
+            acc[t0 + tg][i][j0 + jg] =
+                __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[tg][i][PA[q]], bp[jg][PB[q]], acc[t0 + tg][i][j0 + jg], 0, 0, 0);
+      if constexpr (st + 1 < NSTAGE) {
+        constexpr int n = st + 1;
+        // A changes with the tap group or the K step, B with the cout group or the K step
+        constexpr bool a_new = (n % NT0) != (st % NT0) || n / (NJ0 * NT0) != st / (NJ0 * NT0);
+        constexpr bool b_new = ((n / NT0) % NJ0) != ((st / NT0) % NJ0) || n / (NJ0 * NT0) != st / (NJ0 * NT0);
+        if constexpr (a_new && last_use(PA, PA[q]) == q) read_a(n, PA[q]);
+        if constexpr (b_new && last_use(PB, PB[q]) == q) read_b(n, PB[q]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
     }
     __syncthreads();   // next buffer written, this one no longer read
   }
