@@ -32,7 +32,22 @@ FEATURE_MEAN = [12.12, 10.88, 0.23, -1.04, 0.21]     # config_semantic_kitti.yam
 FEATURE_STD = [12.32, 11.47, 6.91, 0.86, 0.16]       # config_semantic_kitti.yaml:148-153
 PEAK_FP32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md chip-level parameters
 PEAK_BF16_MFMA_TFLOPS = 2500.0                       # dense bf16 (no sparsity), same guide
-PMC_FILE = "round2{tag}_hbm.json"                    # committed per-kernel HBM-traffic capture (tools/profile_round.sh)
+# committed per-kernel HBM-traffic captures (tools/profile_round.sh <tag> <bench args>): one per (workload, engine)
+PMC_FILE = "round3_{tag}_hbm.json"
+
+
+def pmc_tag(args):
+    """Tag of the committed rocprofv3 capture that matches this command line (workload + matrix engine), or None."""
+    if args.net != "salsanext":
+        return None
+    key = (args.height, args.width, args.classes, args.dataset, args.batch)
+    wl = {(64, 2048, 20, "SemanticKitti", 8): "kitti", (32, 1024, 17, "SemanticKitti", 16): "nuscenes",
+          (32, 1024, 17, "nuScenes", 16): "nuscenes", (40, 1800, 14, "SemanticPOSS", 8): "poss"}.get(key)
+    if wl is None:
+        return None
+    if args.matrix_dtype == "bf16" and args.storage != "bf16":
+        return None
+    return f"{wl}_{args.matrix_dtype}"
 
 
 def synth_batch(b, h, w, ncls, seed, device, label_rate=1e-3):
@@ -369,6 +384,8 @@ def main():
         elapsed = float(t)
 
     roofline = None
+    pmc_all = None
+    tag = None
     if ts.graph and survey is not None:     # per-kernel figures of a captured run: from its eager warm-up step
         ops.KERNEL_EVENTS = [None]
     if ops.KERNEL_EVENTS:
@@ -391,13 +408,13 @@ def main():
         # HBM traffic of the same kernel from the PMC passes kept under profiles/ (2*FETCH_SIZE +
         # WRITE_SIZE, separate rocprofv3 --pmc runs of this bench; tools/profile_round.sh, tools/hbm_report.py)
         traffic = None
-        default_shape = args.batch == 8 and default_shape_for_step(args)
+        tag = pmc_tag(args)
+        pmc_all = None
         try:
-            if not default_shape:          # the PMC passes were collected on the headline workload only
-                raise KeyError("no PMC capture for this shape")
-            tag = {"f32": "", "bf16": "_bf16", "bf16x3": "_bf16x3"}[args.matrix_dtype]
-            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE.format(tag=tag))))
-            traffic = round(pmc[name]["hbm_bytes_per_launch"])
+            if tag is None:
+                raise KeyError("no PMC capture for this workload / engine")
+            pmc_all = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE.format(tag=tag))))
+            traffic = round(pmc_all[name]["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2),
@@ -409,7 +426,7 @@ def main():
                                  if peak_tf == PEAK_BF16_MFMA_TFLOPS / 6.0 else
                                  "fp32 MFMA peak (MI355X_MICROARCH.md)",
                     "traffic": traffic,
-                    "traffic_source": (f"committed PMC pass profiles/{PMC_FILE.format(tag=tag)} (2*FETCH_SIZE + WRITE_SIZE "
+                    "traffic_source": (f"committed PMC pass profiles/{PMC_FILE.format(tag=tag or '')} (2*FETCH_SIZE + WRITE_SIZE "
                                        "per launch of this kernel, separate rocprofv3 --pmc runs of this bench); not "
                                        "re-measured in this run") if traffic is not None else None,
                     "launches_per_step": n // timed_steps,
@@ -427,23 +444,29 @@ def main():
                                                     "launches inside a replayed graph)") if ts.graph else "timed steps"}
     ops.KERNEL_EVENTS = None
     ops.KERNEL_EVENT_FILTER = None
-    if roofline is not None and default_shape_for_step(args) and args.batch == 8:
+    if roofline is not None and pmc_all is not None:
         # the HBM-bound kernels of the conv blocks (north star: "achieved HBM GB/s for the conv blocks"):
-        # bytes = 2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes over this same bench command,
-        # time = that capture's kernel-trace average
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE.format(tag=""))))
-            rows = {}
-            wanted = ("bn_bwd_kernel", "bilinear_kernel", "bilinear_bwd_kernel", "affine_add_kernel", "maskpool_kernel",
-                      "maskpool_bwd_kernel", "catskip_kernel", "catskip_bwd_kernel", "l2norm_bwd_kernel", "rownorm_kernel")
-            for k, v in pmc.items():
-                if k.split("<")[0] in wanted:
-                    rows[k] = {"GBps": round(v["gbps"]), "frac_of_8TBps": round(v["gbps"] / 8000.0, 3),
-                               "ms_per_step": round(v["ms_per_step"], 3)}
-            roofline["hbm_kernels"] = {"source": f"profiles/{PMC_FILE.format(tag='')} (committed rocprofv3 PMC passes, not re-measured here)",
-                                       "peak_GBps": 8000, "kernels": rows}
-        except (OSError, KeyError, ValueError):
-            pass
+        # bytes = 2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes over this same bench command (same workload,
+        # same matrix engine), time = that capture's kernel-trace average
+        rows = {}
+        wanted = ("bn_bwd_kernel", "bilinear_kernel", "bilinear_bwd_kernel", "affine_add_kernel", "maskpool_kernel",
+                  "maskpool_bwd_kernel", "catskip_kernel", "catskip_bwd_kernel", "pixshuf_kernel", "pixshuf_bwd_kernel",
+                  "l2norm_bwd_kernel", "rownorm_kernel", "softmax_kernel", "softmax_bwd_kernel")
+        tot_ms = tot_bytes = 0.0
+        for k, v in pmc_all.items():
+            if k.split("<")[0] in wanted:
+                rows[k] = {"GBps": round(v["gbps"]), "frac_of_8TBps": round(v["gbps"] / 8000.0, 3),
+                           "ms_per_step": round(v["ms_per_step"], 3)}
+                tot_ms += v["ms_per_step"]
+                tot_bytes += v["hbm_bytes_per_launch"] * v["launches_per_step"]
+        roofline["hbm_kernels"] = {"source": f"profiles/{PMC_FILE.format(tag=tag)} (committed rocprofv3 PMC passes of this workload "
+                                             "and engine, not re-measured in this run)",
+                                   "peak_GBps": 8000, "ms_per_step": round(tot_ms, 3),
+                                   "achieved_GBps": round(tot_bytes / (tot_ms * 1e-3) / 1e9) if tot_ms else None,
+                                   "frac_of_8TBps": round(tot_bytes / (tot_ms * 1e-3) / 8e12, 3) if tot_ms else None,
+                                   "kernels": rows}
+        step_bytes = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in pmc_all.values())
+        roofline["step_hbm_traffic_GB"] = round(step_bytes / 1e9, 2)
     if roofline is not None and default_shape_for_step(args):
         # whole-step view with SURVEY 8d's normative algorithmic work per 64x2048 image and step
         # (533.5 GFLOP, 10.96 GB fp32): fraction of the fp32 matrix peak / of the 8 TB/s HBM peak
