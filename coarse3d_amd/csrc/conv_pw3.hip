@@ -1,10 +1,12 @@
 // Wide pointwise (1x1) convolution in fp32-class arithmetic on the bf16 matrix pipe ("bf16x3":
 // c3d_conv_desc.mfma_bf16 == 2, 8-row tiles, one tap, Cout > 64, plane-carrying weight pack).
 //
-// Why a separate kernel.  On gfx950 VALU instructions and MFMAs of the same SIMD do not overlap,
-// not even across waves (tools/probes/coissue_probe.hip: t(both) = t(MFMA) + t(VALU) to 1 %), so
-// the exact 3-way bf16 split of the bf16x3 engine (~6 VALU instructions per staged element) is a
-// tax that no schedule hides: it has to be paid fewer times.  conv_bfp.hip's NP = 3 kernel splits a
+// Why a separate kernel.  The exact 3-way bf16 split of the bf16x3 engine costs ~6 VALU instructions per staged
+// element.  (Round 2 believed that VALU and MFMA time simply add up on gfx950 and therefore only tried to pay the split
+// fewer times; round 3's probe -- profiles/round3_coissue_probe.md -- shows that plain VALU hides under the MFMAs and
+// that PACKED f32 VALU, which hipcc had made of the staging code, does not: see conv_pw3f_kernel below, which
+// the bf16x3 mode runs.  This phased kernel stays for the "bf16" mode and as the bit-identity reference.)
+// conv_bfp.hip's NP = 3 kernel splits a
 // 256-pixel input tile once per 64 output channels (11 times for the 704 -> 704 projector GEMM)
 // and splits the weights in every workgroup as well.  This kernel
 //   * computes 256 pixels x 256 (NT = 8) or 128 (NT = 4) output channels per workgroup: the input

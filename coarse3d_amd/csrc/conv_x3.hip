@@ -20,8 +20,8 @@
 //     one spills -- so 1x1 layers stay on conv_bfp.hip's NP = 3 kernel)
 //     (phase ablation, 64 -> 64 3x3 d2 at 8x64x2048: total 0.60 ms = matrix phase 0.39 (the pipe alone
 //     would take 0.25-0.30) + staging 0.11 (loads 0.06, split + LDS stores 0.05) + epilogue and loop
-//     0.09; VALU and MFMA time add up on gfx950, see conv_pw3.hip -- the split is cheap here
-//     because nine taps reuse every staged element)
+//     0.09 -- the phases of this kernel run in lockstep and its staging was packed-f32 VALU, so they
+//     add up; the fused kernel below deals the staging into the MFMA stream instead)
 //   * LDS rows are 32 B (16 channels) with NO padding; the two 16-B halves of row R are swapped
 //     when bit 3 of R is set, which makes every ds_read_b128 fragment read conflict-free.
 // GEMM view, tile shape (8 x 32 pixels x 32*NT couts), on-load BatchNorm affine and epilogue as

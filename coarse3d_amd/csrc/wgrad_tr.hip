@@ -35,13 +35,13 @@
 // loads of TWO further tiles in flight in registers (one tile per CU in flight left the kernel
 // bound by memory latency).  One barrier per tile.  Measured on the 704x704 1x1 layer at
 // 8x32x1024 (bf16x3): fp32-MFMA kernel 2.77 ms, this kernel 2.26 ms; consumer waves alone 1.57 ms,
-// producer waves alone 1.06 ms.  The two do NOT overlap beyond ~15 %: a probe (tools/probes/
-// coissue_probe.hip) shows that on gfx950 VALU instructions of one wave and MFMAs of another wave
-// on the same SIMD simply add up (t(both) = t(MFMA) + t(VALU) to 1 %), so the plane split is a tax
-// of ~0.6 ms on top of ~1.2 ms of matrix time here and cannot be hidden by scheduling -- only
-// removed (fewer re-splits per element: wider slices.  dz kept as pre-split planes in HBM was built
-// and measured: bit-identical, 1 % slower for the step -- three 8-byte loads per unit instead of one
-// 16-byte load cost what the saved split instructions gain).
+// producer waves alone 1.06 ms, and round 2 read the sum as "VALU and MFMA of one SIMD do not overlap".  Round 3
+// (profiles/round3_coissue_probe.md): plain VALU of the producer wave overlaps with the consumer wave's MFMAs
+// completely; what took the matrix pipe's issue slots were the PACKED f32 ops hipcc made of the staging code (5 136
+// v_pk_* in this file).  The file is now compiled without them (NOPK in the Makefile: -0.55 ms of weight-gradient
+// time per step) and the consumer stages are software-pipelined.  (dz kept as pre-split planes in HBM was built and
+// measured in round 2: bit-identical, 1 % slower for the step -- three 8-byte loads per unit instead of one 16-byte
+// load cost what the saved split instructions gain; DESIGN.md.)
 #include <type_traits>
 #include "wgrad_common.h"
 

