@@ -4,6 +4,9 @@
 // pc_processor/metrics/iou_eval.py:35-58 (IOUEval.addBatch: conf[pred][gt] += 1, int64).
 // Integer work, bit-exact: block-local [C][C] histograms in LDS, one 64-bit atomic per non-zero
 // cell per block (integer adds commute, so the result does not depend on scheduling).
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
 #include "common.h"
 #include "../../include/coarse3d_hip.h"
 
@@ -363,6 +366,193 @@ extern "C" int c3d_lovasz_backward(const float* grad, const int64_t* idx, int P,
   if (P <= 0) return 0;
   hipLaunchKernelGGL(lovasz_bwd_kernel, dim3(blocks_for((int64_t)P * C)), dim3(256), 0, (hipStream_t)stream, grad, idx, P, nullptr,
                      C, stats, gscale, dprob, dstride);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- Lovasz beyond the LDS capacity (fully supervised batches: up to B*H*W labelled pixels).  Same arithmetic as
+//      lovasz_class_kernel; the per-class sort of the P errors is a device-wide SEGMENTED radix sort (rocPRIM, the vendor's
+//      sort primitive -- as in csrc/voxel_ops.hip), the prefix sums run over chunks of LV_CHUNK ranks.
+namespace {
+constexpr int LV_CHUNK = 4096;
+
+// keys[c][p] = |fg - prob[idx[p]][c]|, vals[c][p] = 2p + fg
+__global__ __launch_bounds__(256) void lovasz_fill_kernel(const float* __restrict__ prob, int cstride, const int64_t* __restrict__ labels,
+                                                          const int64_t* __restrict__ idx, int P, int C, float* __restrict__ keys,
+                                                          uint32_t* __restrict__ vals) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)P * C; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e / P), p = (int)(e % P);
+    const int64_t i = idx[p];
+    const uint32_t fg = labels[i] == c;
+    keys[e] = fabsf((float)fg - prob[i * cstride + c]);
+    vals[e] = 2u * (uint32_t)p + fg;
+  }
+}
+
+// cnt[c][chunk] = foreground pixels among the chunk's ranks of the sorted order
+__global__ __launch_bounds__(256) void lovasz_count_kernel(const uint32_t* __restrict__ vals, int P, int nchunk, int32_t* __restrict__ cnt) {
+  __shared__ int red[4];
+  const int c = blockIdx.y, ch = blockIdx.x;
+  const int r0 = ch * LV_CHUNK, r1 = min(P, r0 + LV_CHUNK);
+  int n = 0;
+  for (int r = r0 + threadIdx.x; r < r1; r += 256) n += (int)(vals[(size_t)c * P + r] & 1u);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[c * nchunk + ch] = red[0] + red[1] + red[2] + red[3];
+}
+
+// jaccard gradient of one chunk of ranks: grad[c][p] = jd * sign, part[c][chunk] = sum e * jd
+__global__ __launch_bounds__(256) void lovasz_chunk_kernel(const float* __restrict__ keys, const uint32_t* __restrict__ vals, int P,
+                                                           int nchunk, const int32_t* __restrict__ cnt, float* __restrict__ grad,
+                                                           double* __restrict__ part) {
+  __shared__ float wsum[4];
+  __shared__ double dsum[4];
+  const int c = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int before = 0, total = 0;
+  for (int k = 0; k < nchunk; ++k) {
+    const int n = cnt[c * nchunk + k];
+    total += n;
+    if (k < ch) before += n;
+  }
+  if (total == 0) {                                       // class absent: classes='present' skips it
+    const int r0 = ch * LV_CHUNK, r1 = min(P, r0 + LV_CHUNK);
+    for (int r = r0 + tid; r < r1; r += 256) grad[(size_t)c * P + (vals[(size_t)c * P + r] >> 1)] = 0.f;
+    if (tid == 0) part[c * nchunk + ch] = 0.0;
+    return;
+  }
+  const float gts = (float)total;
+  constexpr int PER = LV_CHUNK / 256;                     // contiguous ranks per thread
+  const int r0 = ch * LV_CHUNK + tid * PER, r1 = min(P, r0 + PER);
+  float run = 0.f;
+  for (int r = r0; r < r1; ++r) run += (float)(vals[(size_t)c * P + r] & 1u);
+  float scan = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float v = __shfl_up(scan, o, 64);
+    if (lane >= o) scan += v;
+  }
+  if (lane == 63) wsum[wv] = scan;
+  __syncthreads();
+  float cum = (float)before + scan - run;                 // foreground before this thread's run
+  for (int k = 0; k < wv; ++k) cum += wsum[k];
+  float jprev = 0.f;
+  if (r0 > 0 && r0 < P) {
+    const float inter = gts - cum, uni = gts + ((float)r0 - cum);
+    jprev = 1.f - inter / uni;
+  }
+  double acc = 0.0;
+  for (int r = r0; r < r1; ++r) {
+    const uint32_t v = vals[(size_t)c * P + r];
+    const float fg = (float)(v & 1u);
+    cum += fg;
+    const float inter = gts - cum, uni = gts + ((float)(r + 1) - cum);
+    const float jac = 1.f - inter / uni;
+    const float jd = r == 0 ? jac : jac - jprev;
+    jprev = jac;
+    const float e = keys[(size_t)c * P + r];
+    acc += (double)(e * jd);
+    const float sgn = e == 0.f ? 0.f : (fg != 0.f ? -1.f : 1.f);
+    grad[(size_t)c * P + (v >> 1)] = jd * sgn;
+  }
+  acc = c3d_wave_sum_d(acc);
+  if (lane == 0) dsum[wv] = acc;
+  __syncthreads();
+  if (tid == 0) part[c * nchunk + ch] = dsum[0] + dsum[1] + dsum[2] + dsum[3];
+}
+
+__global__ void lovasz_large_finish_kernel(const double* __restrict__ part, const int32_t* __restrict__ cnt, int nchunk, int C,
+                                           float* __restrict__ loss_c, float* __restrict__ present, float* __restrict__ out) {
+  float s = 0.f, n = 0.f;
+  for (int c = 0; c < C; ++c) {
+    double l = 0.0;
+    int total = 0;
+    for (int k = 0; k < nchunk; ++k) {
+      l += part[c * nchunk + k];
+      total += cnt[c * nchunk + k];
+    }
+    loss_c[c] = total > 0 ? (float)l : 0.f;
+    present[c] = total > 0 ? 1.f : 0.f;
+    s += loss_c[c] * present[c];
+    n += present[c];
+  }
+  out[0] = n > 0.f ? s / n : 0.f;
+  out[1] = n;
+}
+
+struct LovaszWs {
+  float *k_in, *k_out;
+  uint32_t *v_in, *v_out;
+  int32_t *offsets, *cnt;
+  double* part;
+  void* tmp;
+  size_t tmp_bytes;
+};
+size_t lovasz_align(size_t b) { return (b + 255) / 256 * 256; }
+size_t lovasz_sort_tmp(int C, int64_t n) {
+  size_t t = 0;
+  (void)rocprim::segmented_radix_sort_pairs_desc(nullptr, t, (const float*)nullptr, (float*)nullptr, (const uint32_t*)nullptr,
+                                                 (uint32_t*)nullptr, (unsigned)n, (unsigned)C, (const int32_t*)nullptr,
+                                                 (const int32_t*)nullptr, 0, 32, (hipStream_t)0);
+  return t;
+}
+size_t lovasz_carve(LovaszWs& w, char* base, int C, int P) {
+  const size_t n = (size_t)C * P;
+  const int nchunk = (P + LV_CHUNK - 1) / LV_CHUNK;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += lovasz_align(bytes);
+    return p;
+  };
+  w.k_in = (float*)take(n * 4);
+  w.k_out = (float*)take(n * 4);
+  w.v_in = (uint32_t*)take(n * 4);
+  w.v_out = (uint32_t*)take(n * 4);
+  w.offsets = (int32_t*)take((size_t)(C + 1) * 4);
+  w.cnt = (int32_t*)take((size_t)C * nchunk * 4);
+  w.part = (double*)take((size_t)C * nchunk * 8);
+  w.tmp_bytes = lovasz_sort_tmp(C, (int64_t)n);
+  w.tmp = take(w.tmp_bytes);
+  return off;
+}
+__global__ void lovasz_offsets_kernel(int32_t* offsets, int C, int P) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c <= C) offsets[c] = c * P;
+}
+}  // namespace
+
+extern "C" int64_t c3d_lovasz_workspace_bytes(int C, int P) {
+  if (C < 1 || P < 1) return 0;
+  LovaszWs w;
+  return (int64_t)lovasz_carve(w, nullptr, C, P);
+}
+
+extern "C" int c3d_lovasz_forward_large(const float* prob, int C, int cstride, const int64_t* labels, const int64_t* idx, int P,
+                                        float* loss_c, float* present, float* grad, float* out, void* workspace,
+                                        int64_t workspace_bytes, c3d_stream stream) {
+  C3D_REQUIRE(C >= 1 && C <= 64 && P >= 1, "lovasz_large: 1..64 classes, at least one labelled pixel");
+  C3D_REQUIRE((int64_t)C * P < (1ll << 31), "lovasz_large: C * P must stay below 2^31");
+  C3D_REQUIRE(workspace != nullptr && workspace_bytes >= c3d_lovasz_workspace_bytes(C, P), "lovasz_large: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  LovaszWs w;
+  (void)lovasz_carve(w, (char*)workspace, C, P);
+  const int nchunk = (P + LV_CHUNK - 1) / LV_CHUNK;
+  hipLaunchKernelGGL(lovasz_offsets_kernel, dim3((C + 64) / 64), dim3(64), 0, st, w.offsets, C, P);
+  C3D_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lovasz_fill_kernel, dim3(blocks_for((int64_t)P * C)), dim3(256), 0, st, prob, cstride, labels, idx, P, C, w.k_in,
+                     w.v_in);
+  C3D_CHECK_LAUNCH();
+  size_t tb = w.tmp_bytes;
+  C3D_REQUIRE(rocprim::segmented_radix_sort_pairs_desc(w.tmp, tb, w.k_in, w.k_out, w.v_in, w.v_out, (unsigned)((size_t)C * P),
+                                                       (unsigned)C, w.offsets, w.offsets + 1, 0, 32, st) == hipSuccess,
+              "lovasz_large: segmented sort failed");
+  hipLaunchKernelGGL(lovasz_count_kernel, dim3(nchunk, C), dim3(256), 0, st, w.v_out, P, nchunk, w.cnt);
+  C3D_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lovasz_chunk_kernel, dim3(nchunk, C), dim3(256), 0, st, w.k_out, w.v_out, P, nchunk, w.cnt, grad, w.part);
+  C3D_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lovasz_large_finish_kernel, dim3(1), dim3(1), 0, st, w.part, w.cnt, nchunk, C, loss_c, present, out);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -46,7 +46,9 @@ class _LossHeadFn(torch.autograd.Function):
 
 
 def fused_available(n_labelled):
-    return n_labelled <= ops.lovasz_max_pixels()
+    """The fused head handles any number of labelled pixels: up to ``ops.lovasz_max_pixels()`` the per-class sort runs in
+    LDS, beyond it as a device-wide segmented sort (as long as classes x pixels stays below 2^31)."""
+    return n_labelled < (1 << 31) // 64
 
 
 def loss_head(pred, target, mask, alpha, gamma, idx, want_focal=True, want_lovasz=True, count=None):

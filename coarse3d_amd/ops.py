@@ -823,6 +823,13 @@ def lovasz_forward(prob, labels, idx):
     present = torch.empty(c, device=p.device, dtype=torch.float32)
     grad = torch.empty(c, max(n_idx, 1), device=p.device, dtype=torch.float32)
     out = torch.empty(2, device=p.device, dtype=torch.float32)
+    if n_idx > lovasz_max_pixels():
+        # beyond the LDS sort: device-wide segmented sort per class (fully supervised batches)
+        nbytes = L.lib().c3d_lovasz_workspace_bytes(c, n_idx)
+        ws = torch.empty(nbytes, device=p.device, dtype=torch.uint8)
+        _call("c3d_lovasz_forward_large", _dp(p), c, cs, _dp(labels), _dp(idx), n_idx, _dp(loss_c), _dp(present), _dp(grad),
+              _dp(out), _dp(ws), nbytes, _stream())
+        return out, grad
     _call("c3d_lovasz_forward", _dp(p), c, cs, _dp(labels), _dp(idx), n_idx, _dp(loss_c), _dp(present), _dp(grad),
           _dp(out), _stream())
     return out, grad

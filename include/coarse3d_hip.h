@@ -395,6 +395,14 @@ int c3d_lovasz_forward(const float* prob, int C, int cstride, const int64_t* lab
 /* dprob[idx[p]][c] += (*gscale) / out[1] * grad[c][p]                                          */
 int c3d_lovasz_backward(const float* grad, const int64_t* idx, int P, int C, const float* stats,
                         const float* gscale, float* dprob, int dstride, c3d_stream stream);
+/* Lovasz beyond c3d_lovasz_max_pixels() labelled pixels (fully supervised batches; the reference sorts any number,
+ * lovasz_softmax.py:56-68,140-160): same outputs as c3d_lovasz_forward, the per-class sort is a device-wide segmented
+ * radix sort.  workspace >= c3d_lovasz_workspace_bytes(C, P) bytes; C * P < 2^31.  The backward is
+ * c3d_lovasz_backward (it has no capacity).                                                            */
+int64_t c3d_lovasz_workspace_bytes(int C, int P);
+int c3d_lovasz_forward_large(const float* prob, int C, int cstride, const int64_t* labels,
+                             const int64_t* idx, int P, float* loss_c, float* present, float* grad,
+                             float* out, void* workspace, int64_t workspace_bytes, c3d_stream stream);
 /* The same with the number of labelled pixels read from DEVICE memory (*P_dev, clamped to P_cap <=
  * c3d_lovasz_max_pixels()): idx holds P_cap entries of which the first *P_dev are used, grad is [C][P_cap].  The
  * launches are shape-static: the training step can be captured in a hipGraph and replayed on batches with

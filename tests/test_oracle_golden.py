@@ -347,3 +347,22 @@ def test_squeezeseg_oracle_vs_reference_golden(tag, b, h, w, ncls):
             n = k.split("/", 2)[2]
             if not n.endswith(SS_CANCELLED):
                 assert rel(got[n], d[k]) < 2e-2, n
+
+
+def test_oracle_losses_on_a_densely_labelled_batch_vs_reference_golden():
+    """Round 3: ~56 000 labelled pixels (more than the fused loss head sorts in LDS).  The oracle's focal / Lovasz against
+    the reference's own values and gradients (tests/golden/lovasz_large.npz, inputs regenerated from the seed)."""
+    from make_golden_round3 import lovasz_large_inputs
+    g = np.load(os.path.join(GOLD, "lovasz_large.npz"))
+    prob, lab, alpha = lovasz_large_inputs()
+    assert int((lab > 0).sum()) == int(g["n_labelled"])
+    pr = prob.clone().requires_grad_(True)
+    lf = oc.focal_loss(pr, lab, lab > 0, alpha, 2)
+    ll = oc.lovasz_loss(pr, lab)
+    gf, = torch.autograd.grad(lf, pr, retain_graph=True)
+    gl, = torch.autograd.grad(ll, pr)
+    assert abs(float(lf) - float(g["focal"])) < 1e-5 * float(g["focal"])
+    assert abs(float(ll) - float(g["lovasz"])) < 1e-5 * float(g["lovasz"])
+    sub = (slice(None), slice(None), slice(None, None, 7), slice(None, None, 13))
+    assert float((gf[sub] - torch.from_numpy(g["grad_focal_sub"])).abs().max()) < 1e-5 * float(g["grad_focal_absmax"])
+    assert float((gl[sub] - torch.from_numpy(g["grad_lovasz_sub"])).abs().max()) < 1e-5 * float(g["grad_lovasz_absmax"])
