@@ -246,6 +246,110 @@ class Backbone:
         self.tape[f"{name}.head"] = (xin, skip, up_b, m1, m2, direct)
         return a4
 
+    # ------------------------------------------------------------------ projector.proj.0 without the 704-channel concat
+    def _split_projector(self):
+        """ProjectionV1's first layer is a 1x1 conv over cat(resample(skip_i)) (salsanext_proto.py:466-483,
+        projector.py:18).  Bilinear resampling is linear, so conv1x1(resample(x)) == resample(conv1x1(x)) per skip: the
+        skips that get UPSAMPLED (256 channels at 1/4 and 1/16 of the embedding's pixels) are multiplied with their
+        slice of the weight at their own resolution -- 60 % fewer MFMAs in forward, input gradient and weight gradient
+        of the step's largest layer -- an identity-resampled skip is read in place, and the 704-channel concatenation
+        never exists.  The arithmetic is reassociated (sum over channels before instead of after the interpolation:
+        rounding-level differences, inside every golden's 1e-4).  fp32 tensors only; C3D_SPLIT_PROJECTOR=0 keeps the
+        concatenation."""
+        return (os.environ.get("C3D_SPLIT_PROJECTOR", "1") != "0" and len(self.skips) == 4
+                and all(s.t.dtype == torch.float32 and s.scale is None for s in self.skips))
+
+    def _proj0_forward(self, hh, wh, defer_bn):
+        name, bn = "projector.proj.0", "projector.proj.1"
+        w = self.P[f"{name}.weight"]
+        cout = w.shape[0]
+        b = self.skips[0].t.shape[0]
+        hi, lo, off = [], [], 0          # (Act at the embedding resolution | skip kept at its own, channel offset, channels)
+        for sk in self.skips:
+            c = sk.t.shape[3]
+            hs, ws = sk.t.shape[1], sk.t.shape[2]
+            if hs * ws < hh * wh:
+                lo.append((sk, off, c))
+            elif (hs, ws) == (hh, wh):
+                hi.append((sk, off, c, None))                       # identity resample: the skip itself is the source
+            else:
+                r = Act(ops.bilinear(sk.t, hh, wh))
+                hi.append((r, off, c, sk))                          # downsampled copy (gradient goes back through it)
+            off += c
+        assert len(lo) in (1, 2) and hi
+        taps = [(0, 0)]
+        # low-resolution shares, then their interpolated sum as the initial value of z
+        ts = []
+        for sk, o, c in lo:
+            t, _ = ops.conv_forward([sk.src()], self.packs.get(w, 0, c_off=o, c_cnt=c), None, cout, taps)
+            ts.append(t)
+        if len(ts) == 2:
+            z = ops.bilinear_sum2(ts[0], ts[1], hh, wh)
+        else:
+            z = ops.bilinear(ts[0], hh, wh)
+        # the high-resolution sources are contiguous in the weight's input channels: ONE multi-source launch, which
+        # accumulates into z and takes the BatchNorm statistics of the final values in its epilogue
+        h_off, h_cnt = hi[0][1], sum(h[2] for h in hi)
+        assert all(h[1] == h_off + sum(g[2] for g in hi[:i]) for i, h in enumerate(hi))
+        need_stats = self.train
+        _, partial = ops.conv_forward([h[0].src() for h in hi], self.packs.get(w, 0, c_off=h_off, c_cnt=h_cnt),
+                                      self.P.get(f"{name}.bias"), cout, taps, stats=need_stats, out=z, accumulate=True)
+        rec = _ConvRec()
+        rec.name, rec.srcs, rec.src_lrelu, rec.taps, rec.cout = name, [], False, taps, cout
+        rec.slope, rec.weight, rec.dweight, rec.mode = 0.0, None, None, 1
+        rec.bn = None
+        rec.out = Act(z)
+        defer_bn.append((rec, bn, partial, b * hh * wh, BN_MOMENTUM))
+        self.tape[name] = rec
+        self.tape["proj0.split"] = (hi, lo)
+        return rec.out
+
+    def _proj0_backward(self, dy, k):
+        """Backward of ``_proj0_forward``: BatchNorm backward at the embedding resolution, then per source the weight
+        gradient and the input gradient at the SOURCE's resolution (the output gradient goes down through the adjoint
+        of the interpolation once per low-resolution skip).  Initialises the gradients of all four skips."""
+        name = "projector.proj.0"
+        rec = self.tape[name]
+        hi, lo = self.tape["proj0.split"]
+        G = self.grads
+        w = self.P[f"{name}.weight"]
+        cout = rec.cout
+        dz, pz = self._bn_backward(rec.bn, dy, rec.out.t, cout, 1, 0.0, k)
+        if self.capture is not None:
+            # test hook: the layer as the reference sees it -- ONE 1x1 conv over the resampled, concatenated skips
+            hh, wh = dz.shape[1], dz.shape[2]
+            ordered = sorted([(o, src) for src, o, c, _ in hi] + [(o, Act(ops.bilinear(sk.t, hh, wh))) for sk, o, c in lo],
+                             key=lambda t: t[0])
+            rec.srcs = [a for _, a in ordered]
+            self.capture[name] = (rec, dy.clone(), dz.clone())
+        dzs = []
+        for sk, o, c in lo:
+            d = torch.empty(sk.t.shape[0], sk.t.shape[1], sk.t.shape[2], cout, device=dz.device, dtype=torch.float32)
+            dzs.append(ops.bilinear_bwd(d, dz))
+        dw = G[f"{name}.weight"]
+        with self._fork(dz, pz, *dzs):
+            db = G.get(f"{name}.bias")
+            for src, o, c, _ in hi:
+                ops.conv_wgrad(src.src(), dz, dw, rec.taps, cin_off=o, bias_partial=pz if db is not None else None, dbias=db)
+                db = None
+            for (sk, o, c), d in zip(lo, dzs):
+                ops.conv_wgrad(sk.src(), d, dw, rec.taps, cin_off=o)
+        kp = (cout + 15) // 16 * 16
+        for src, o, c, orig in hi:
+            wd = self.packs.get(w, 1, c_off=o, c_cnt=c, kpad=kp)
+            g = torch.empty_like(src.t)
+            ops.conv_forward([ops.Source(dz)], wd, None, c, rec.taps, out=g, grad=True)
+            if orig is None:
+                src.grad = g                                        # the skip itself
+            else:
+                orig.grad = torch.empty_like(orig.t)
+                ops.bilinear_bwd(orig.grad, g)
+        for (sk, o, c), d in zip(lo, dzs):
+            wd = self.packs.get(w, 1, c_off=o, c_cnt=c, kpad=kp)
+            sk.grad = torch.empty_like(sk.t)
+            ops.conv_forward([ops.Source(d)], wd, None, c, rec.taps, out=sk.grad, grad=True)
+        rec.out.grad = None
+
     # ------------------------------------------------------------------ forward
     def forward(self, x, train=True, dropout_masks=None, return_feat=True, update_running=True):
         """x [B,Cin,H,W] fp32 (NCHW, as the reference feeds it).  Returns dict with NHWC tensors:
@@ -276,17 +380,21 @@ class Backbone:
             # embedding branch, first half (salsanext_proto.py:466-483 + projector.proj.0): it only needs
             # the encoder skips, so its 704-wide GEMM is issued here and its BatchNorm statistics
             # share ONE exchange with upBlock1.bn1 (SyncBN: one all-reduce less per step)
-            b = x.shape[0]
             hh, wh = ho // 2, wo // 2
-            feat = torch.empty(b, hh, wh, sum(s.t.shape[3] for s in self.skips), device=x.device,
-                               dtype=self.skips[0].t.dtype)
-            off = 0
-            for s in self.skips:
-                ops.bilinear(s.t, hh, wh, dst=feat, dcoff=off, c=s.t.shape[3])
-                off += s.t.shape[3]
-            feat_a = Act(feat)
             group = []
-            z0 = self._conv("projector.proj.0", [feat_a], 1, 1, 0, lrelu=False, bn="projector.proj.1", defer_bn=group)
+            if self._split_projector():
+                z0 = self._proj0_forward(hh, wh, group)
+                feat_a = None
+            else:
+                b = x.shape[0]
+                feat = torch.empty(b, hh, wh, sum(s.t.shape[3] for s in self.skips), device=x.device,
+                                   dtype=self.skips[0].t.dtype)
+                off = 0
+                for s in self.skips:
+                    ops.bilinear(s.t, hh, wh, dst=feat, dcoff=off, c=s.t.shape[3])
+                    off += s.t.shape[3]
+                feat_a = Act(feat)
+                z0 = self._conv("projector.proj.0", [feat_a], 1, 1, 0, lrelu=False, bn="projector.proj.1", defer_bn=group)
         u4 = self._up_block("upBlock1", d5c, d3b, bn_group=group)
         u3 = self._up_block("upBlock2", u4, d2b)
         u2 = self._up_block("upBlock3", u3, d1b)
@@ -527,7 +635,10 @@ class Backbone:
         # ---- the two BatchNorm backwards that are ready now share one statistics exchange
         ks = self._bn_backward_group(([("projector.proj.0", z0.grad)] if embed else []) + [("upBlock4.conv4", a4.grad)])
         # ---- rest of the embedding branch: it initialises the skip gradients (gather-form transposes)
-        if embed:
+        if embed and "proj0.split" in self.tape:
+            self._proj0_backward(z0.grad, ks.get("projector.proj.0"))
+            z0.grad = None
+        elif embed:
             self._conv_backward("projector.proj.0", z0.grad, ks.get("projector.proj.0"))
             z0.grad = None
             off = 0

@@ -550,6 +550,56 @@ __global__ __launch_bounds__(256) void bilinear_kernel(BlArgs p, int chunks_per_
   }
 }
 
+// dst = bilinear(src) + bilinear(src2): two sources of different sizes, the same channel count, fp32, added in
+// one pass (the projector's 1x1 conv commutes with the resampling of its inputs: the shares of the two low-resolution
+// skips are multiplied at THEIR resolution and meet the full-resolution result here; coarse3d_amd/backbone.py).
+// Same work decomposition as bilinear_kernel.
+struct Bl2Args {
+  BlArgs a;              // src / Hs / Ws / scs, dst geometry, ratios of source 1
+  const float* src2; int Hs2, Ws2, scs2;
+  float ry2, rx2;
+};
+__global__ __launch_bounds__(256) void bilinear_sum2_kernel(Bl2Args q, int chunks_per_row, int q_shift) {
+  constexpr int V = 4;
+  const BlArgs& p = q.a;
+  const int Q = p.C / V;
+  const int row_elems = p.Wd * Q;
+  const int item = c3d_xcd_remap(blockIdx.x, gridDim.x);
+  const int row = item / chunks_per_row, chunk = item - row * chunks_per_row;
+  const int b = row / p.Hd, yd = row - b * p.Hd;
+  int y0, y1, u0, u1;
+  float ly, lu;
+  bl_coords(yd, p.ry, p.Hs, y0, y1, ly);
+  bl_coords(yd, q.ry2, q.Hs2, u0, u1, lu);
+  const size_t s0 = ((size_t)b * p.Hs + y0) * p.Ws * p.scs, s1 = ((size_t)b * p.Hs + y1) * p.Ws * p.scs;
+  const size_t t0 = ((size_t)b * q.Hs2 + u0) * q.Ws2 * q.scs2, t1 = ((size_t)b * q.Hs2 + u1) * q.Ws2 * q.scs2;
+  const size_t d0 = ((size_t)b * p.Hd + yd) * p.Wd * p.dcs;
+#pragma unroll 4
+  for (int k = 0; k < BL_IT; ++k) {
+    const int e = (chunk * BL_IT + k) * 256 + threadIdx.x;
+    if (e < row_elems) {
+      const int xd = q_shift >= 0 ? e >> q_shift : e / Q;
+      const int c = (e - xd * Q) * V;
+      int x0, x1, w0, w1;
+      float lx, lw;
+      bl_coords(xd, p.rx, p.Ws, x0, x1, lx);
+      bl_coords(xd, q.rx2, q.Ws2, w0, w1, lw);
+      const c3d_vec<V> a00 = c3d_vldf<V>(p.src, s0 + (size_t)(x0 * p.scs + c)), a01 = c3d_vldf<V>(p.src, s0 + (size_t)(x1 * p.scs + c));
+      const c3d_vec<V> a10 = c3d_vldf<V>(p.src, s1 + (size_t)(x0 * p.scs + c)), a11 = c3d_vldf<V>(p.src, s1 + (size_t)(x1 * p.scs + c));
+      const c3d_vec<V> b00 = c3d_vldf<V>(q.src2, t0 + (size_t)(w0 * q.scs2 + c)), b01 = c3d_vldf<V>(q.src2, t0 + (size_t)(w1 * q.scs2 + c));
+      const c3d_vec<V> b10 = c3d_vldf<V>(q.src2, t1 + (size_t)(w0 * q.scs2 + c)), b11 = c3d_vldf<V>(q.src2, t1 + (size_t)(w1 * q.scs2 + c));
+      c3d_vec<V> o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float atop = a00.v[j] * (1.f - lx) + a01.v[j] * lx, abot = a10.v[j] * (1.f - lx) + a11.v[j] * lx;
+        const float btop = b00.v[j] * (1.f - lw) + b01.v[j] * lw, bbot = b10.v[j] * (1.f - lw) + b11.v[j] * lw;
+        o.v[j] = (atop * (1.f - ly) + abot * ly) + (btop * (1.f - lu) + bbot * lu);
+      }
+      c3d_vst<V>(p.dst, d0 + (size_t)(xd * p.dcs + c), false, o);
+    }
+  }
+}
+
 // Range of destination indices d whose interpolation touches source index s:
 // floor(ratio*d) in {s-1, s}  <=>  (s-1)/ratio <= d < (s+1)/ratio   (+-1 slack, exact test inside)
 __device__ __forceinline__ void bl_dst_range(int s, float ratio, int nd, int& lo, int& hi) {
@@ -885,6 +935,22 @@ extern "C" int c3d_bilinear(const float* src, int Hs, int Ws, int scs, int scoff
     hipLaunchKernelGGL(bilinear_kernel<8>, dim3(grid), dim3(256), 0, ST, p, chunks, bl_shift(C / 8));
   else
     hipLaunchKernelGGL(bilinear_kernel<4>, dim3(grid), dim3(256), 0, ST, p, chunks, bl_shift(C / 4));
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_bilinear_sum2(const float* src1, int Hs1, int Ws1, const float* src2, int Hs2, int Ws2, float* dst, int Hd,
+                                 int Wd, int B, int C, c3d_stream stream) {
+  C3D_REQUIRE(src1 && src2 && dst && C % 4 == 0, "bilinear_sum2: two sources and C % 4 == 0 required");
+  Bl2Args q;
+  q.a = bl_args(src1, Hs1, Ws1, C, 0, dst, Hd, Wd, C, 0, B, C);
+  q.src2 = src2; q.Hs2 = Hs2; q.Ws2 = Ws2; q.scs2 = C;
+  q.ry2 = Hd > 1 ? (float)(Hs2 - 1) / (float)(Hd - 1) : 0.f;
+  q.rx2 = Wd > 1 ? (float)(Ws2 - 1) / (float)(Wd - 1) : 0.f;
+  C3D_REQUIRE((int64_t)Wd * C < (1ll << 31), "bilinear_sum2: a row exceeds 2^31 elements");
+  const int chunks = bl_chunks(Wd * (C / 4), BL_IT);
+  C3D_REQUIRE((int64_t)B * Hd * chunks < (1ll << 31), "bilinear_sum2: grid too large");
+  hipLaunchKernelGGL(bilinear_sum2_kernel, dim3(B * Hd * chunks), dim3(256), 0, ST, q, chunks, bl_shift(C / 4));
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -584,6 +584,16 @@ def bilinear(src, hd, wd, dst=None, dcoff=0, c=None, scoff=0, out_dtype=None):
     return dst
 
 
+def bilinear_sum2(src1, src2, hd, wd):
+    """bilinear(src1 -> hd x wd) + bilinear(src2 -> hd x wd), NHWC fp32 tensors with the same channel count."""
+    b, h1, w1, c = src1.shape
+    _, h2, w2, c2 = src2.shape
+    assert c == c2 and src1.dtype == src2.dtype == torch.float32 and src1.is_contiguous() and src2.is_contiguous()
+    dst = torch.empty(b, hd, wd, c, device=src1.device, dtype=torch.float32)
+    _call("c3d_bilinear_sum2", _dp(src1), h1, w1, _dp(src2), h2, w2, _dp(dst), hd, wd, b, c, _stream())
+    return dst
+
+
 def bilinear_bwd(dsrc, ddst, dcoff=0, c=None, scoff=0, accumulate=False, rowmask=None):
     """rowmask: int32 bitmap over the pixels of ddst (scatter_add_rows writes it); clear bit = known zeros, not read."""
     b, hs, ws, scs = dsrc.shape
