@@ -25,7 +25,8 @@ class ConvDesc(C.Structure):
                 ("wpack", C.c_void_p), ("bias", C.c_void_p), ("epi_lrelu", C.c_int32),
                 ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
                 ("accumulate", C.c_int32), ("stat_partial", C.c_void_p), ("lrelu_slope", C.c_float),
-                ("mfma_bf16", C.c_int32), ("out_bf16", C.c_int32), ("wpack_planes", C.c_int32)]
+                ("mfma_bf16", C.c_int32), ("out_bf16", C.c_int32), ("wpack_planes", C.c_int32),
+                ("stat_mul", C.c_void_p), ("stat_mul_cstride", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class WgradDesc(C.Structure):

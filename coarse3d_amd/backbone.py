@@ -26,17 +26,23 @@ from . import contrast, ops
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+# BatchNorm-backward sums in the epilogue of the last input-gradient conv (see _conv_backward); C3D_FUSE_BN_REDUCE=0: always
+# the separate reduce pass
+FUSE_BN_REDUCE = os.environ.get("C3D_FUSE_BN_REDUCE", "1") != "0"
 
 
 class Act:
     """An activation tensor as consumers see it: raw NHWC tensor + optional affine of its BN."""
-    __slots__ = ("t", "scale", "shift", "grad", "mask", "no_grad")
+    __slots__ = ("t", "scale", "shift", "grad", "mask", "no_grad", "producer", "first_consumer", "bwd_partial")
 
     def __init__(self, t, scale=None, shift=None, mask=None):
         self.t, self.scale, self.shift = t, scale, shift
         self.grad = None      # gradient w.r.t. the affine-transformed value (NHWC, same shape)
         self.mask = mask      # Dropout2d multiplier [B,C] applied by the consumer (UpBlock out)
         self.no_grad = False  # True: nothing upstream needs d(loss)/d(this) (network input, detached skips)
+        self.producer = None        # the conv record whose output this is
+        self.first_consumer = None  # name of the first conv (forward order) that reads it = the LAST one to add to its gradient
+        self.bwd_partial = None     # (sum dy, sum dy*a) partials taken in the epilogue of that last input-gradient launch
 
     def src(self, lrelu=False):
         return ops.Source(self.t, self.scale, self.shift, lrelu=lrelu)
@@ -168,6 +174,9 @@ class Backbone:
         rec.name, rec.srcs, rec.src_lrelu, rec.taps, rec.cout = name, srcs, src_lrelu, taps, cout
         rec.slope, rec.weight, rec.dweight = slope, weight, dweight
         rec.mode = 0 if (lrelu and bn) else (2 if lrelu else (1 if bn else 3))
+        for s_ in srcs:
+            if s_.first_consumer is None:
+                s_.first_consumer = name
         if bn is not None and defer_bn is not None:
             rec.bn = None
             rec.out = Act(y)
@@ -175,6 +184,7 @@ class Backbone:
         else:
             rec.bn = self._bn_forward(bn, partial, cout, b * h * wd, bn_momentum) if bn is not None else None
             rec.out = Act(y, rec.bn.scale if rec.bn else None, rec.bn.shift if rec.bn else None)
+        rec.out.producer = rec
         self.tape[name] = rec
         return rec.out
 
@@ -232,6 +242,8 @@ class Backbone:
         # remap on load; C3D_DIRECT_SKIP=0 restores the copy)
         direct = (m2 is None and skip.scale is None and skip.t.dtype == xin.t.dtype
                   and os.environ.get("C3D_DIRECT_SKIP", "1") != "0")
+        if xin.first_consumer is None:
+            xin.first_consumer = "glue"      # PixelShuffle reads BN(x): its gradient arrives through a glue kernel
         up_b = Act(ops.pixshuf_cat(xin.t, xin.scale, xin.shift, xin.mask, m1, m2, None if direct else skip.t))
         c1_srcs = [up_b, skip] if direct else [up_b]
         if bn_group is not None:
@@ -421,14 +433,15 @@ class Backbone:
         else:
             ops.axpy(g, act.grad)
 
-    def _bn_backward(self, bn, dy, a, c, mode, slope=0.0, k=None):
+    def _bn_backward(self, bn, dy, a, c, mode, slope=0.0, k=None, part=None):
         """dy: gradient w.r.t. BN(a) [mode 0] or LeakyReLU(BN(a)) [mode 1] -> (dz = d/da, partial with
         sum(dz)); writes the BatchNorm parameter gradients.  SyncBN: the fp64 sums are all-reduced
         (``k``: coefficients already computed by ``_bn_backward_group``)."""
         G = self.grads
         pre_s, pre_h = (bn.scale, bn.shift) if mode == 1 else (None, None)
         if k is None:
-            part = ops.bn_bwd_reduce(dy, a, c, mode, pre_s, pre_h, slope=slope)
+            if part is None:      # (else: taken in the epilogue of the last input-gradient conv, _conv_backward)
+                part = ops.bn_bwd_reduce(dy, a, c, mode, pre_s, pre_h, slope=slope)
             if self.reduce_fn is None:
                 k = ops.bn_bwd_coeffs_partials(part, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
                                                G[f"{bn.name}.weight"], G[f"{bn.name}.bias"])
@@ -454,7 +467,9 @@ class Backbone:
         off = 0
         for r, (_, dy) in zip(recs, items):
             pre_s, pre_h = (r.bn.scale, r.bn.shift) if r.mode == 1 else (None, None)
-            part = ops.bn_bwd_reduce(dy, r.out.t, r.cout, r.mode, pre_s, pre_h, slope=r.slope)
+            part, r.out.bwd_partial = r.out.bwd_partial, None
+            if part is None:
+                part = ops.bn_bwd_reduce(dy, r.out.t, r.cout, r.mode, pre_s, pre_h, slope=r.slope)
             ops.stat_reduce(part, r.cout, sums=buf[off:off + r.cout])
             off += r.cout
         local = buf.clone()
@@ -500,7 +515,8 @@ class Backbone:
         cpad = a.shape[3]
         G = self.grads
         if rec.mode == 0 or rec.mode == 1:
-            dz, pz = self._bn_backward(rec.bn, dy, a, c, rec.mode, rec.slope, k)
+            dz, pz = self._bn_backward(rec.bn, dy, a, c, rec.mode, rec.slope, k, rec.out.bwd_partial)
+            rec.out.bwd_partial = None
         elif rec.mode == 2:
             dz, pz = ops.bn_bwd_apply(dy, a, c, 2, slope=rec.slope)
         else:
@@ -530,7 +546,18 @@ class Backbone:
                     acc = False
                 else:
                     acc = True
-                ops.conv_forward([ops.Source(dz)], wd, None, cs, ntaps, out=s.grad, accumulate=acc, grad=True)
+                # This layer is the FIRST reader of s in forward order, i.e. the LAST one to add to its gradient: the
+                # launch's epilogue sees the final dy(s).  If s is the output of a conv -> LeakyReLU -> BatchNorm layer, take
+                # that BatchNorm's backward sums (sum dy, sum dy * a) there and spare its c3d_bn_bwd_reduce pass (two
+                # tensor reads per layer; 31 of the 43 BatchNorm layers end this way).  bf16x3 engine, fp32 tensors.
+                part = None
+                p_ = s.producer
+                if (FUSE_BN_REDUCE and ops.MFMA_MODE == 2 and self.train and p_ is not None and p_.mode == 0 and p_.bn is not None
+                        and s.first_consumer == name and s.t.dtype == torch.float32 and s.t.shape[3] == cs):
+                    part = torch.empty(cs, 2, ops.num_mtiles(*s.t.shape[:3]), device=s.t.device, dtype=torch.float32)
+                ops.conv_forward([ops.Source(dz)], wd, None, cs, ntaps, out=s.grad, accumulate=acc, grad=True,
+                                 stat_partial=part, stat_mul=s.t if part is not None else None)
+                s.bwd_partial = part
             off += cs
         rec.out.grad = None
 

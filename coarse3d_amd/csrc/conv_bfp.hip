@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
     c0 = c2;
     kbase = kb2;
   }
-  conv_epilogue<TR, NT, WM, WN, NP == 1>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
+  conv_epilogue<TR, NT, WM, WN, NP == 1, false, 256, false, NP == 3>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
+                                                                     tile_pix);
 }
 
 template <int TR, int NT, int CK, int HALO, int TT, int NP>

@@ -23,6 +23,8 @@ struct ConvArgs {
   float slope;               // LeakyReLU slope of the on-load and epilogue activations
   int out_bf16;              // out is bf16 (conv_bfp NP = 1 only)
   int six;                   // bf16x3: six plane products instead of eight (input-gradient convs, mfma_bf16 == 3)
+  const float* stat_mul;     // NULL, or the tensor whose product with the stored values replaces v*v in stat_partial
+  int stat_mul_cs;
 };
 
 // 64-cout tiles (two 32-wide sub-tiles per workgroup) unless the grid would then cover too few CUs -- the 8 x 256 and
@@ -58,7 +60,10 @@ struct c3d_type_tag {
 // NTHR: threads of the workgroup.  SUBFAST: the straight-line path is chosen per 32-wide cout
 // sub-tile (a ragged last cout tile keeps it for its live sub-tiles); otherwise per workgroup tile
 // (fewer code paths -- the 4-wave kernels sit at their register limits).
-template <int TR, int NT, int WM, int WN, bool BF16_OUT = false, bool ILV = false, int NTHR = 256, bool SUBFAST = false>
+// STATMUL: the kernel honours ConvArgs::stat_mul (BatchNorm-backward sums in the epilogue).  Only the bf16x3 engine's
+// kernels compile it in: the 16 extra registers of the multiplier tile spill in the register-capped fp32 / bf16 kernels.
+template <int TR, int NT, int WM, int WN, bool BF16_OUT = false, bool ILV = false, int NTHR = 256, bool SUBFAST = false,
+          bool STATMUL = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TR / WM][NT / WN], float* smem, int tid,
                                               int lane, int half, int l31, int wm, int wn, int b, int x0, int y0,
                                               int n0, int mt, int ntile, size_t tile_pix) {
@@ -70,6 +75,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
   const int ocs = a.out_cstride;
   const size_t obase_i = tile_pix * a.out_cstride + a.out_coff + n0 + l31;   // element index, + per-lane cout
   const bool obf = BF16_OUT && a.out_bf16 != 0;      // engines that never store bf16 compile that path out
+  const float* mulp = (STATMUL && a.stat_partial) ? a.stat_mul : nullptr;
   // one 32-wide cout sub-tile, any position: per-element predicates
   auto slow_sub = [&](int j) {
     const int co = n0 + (ILV ? j * WN + wn : wn * NPW + j) * 32 + l31;
@@ -90,7 +96,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
           if (a.accumulate) v += c3d_ld1(a.out, o, obf);
           c3d_st1(a.out, o, obf, v);
           s1[j] += v;
-          s2v[j] += v * v;
+          s2v[j] += v * (mulp ? mulp[((size_t)(b * a.H + gy) * a.W + gx) * a.stat_mul_cs + co] : v);
         }
       }
     }
@@ -127,6 +133,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 #pragma unroll
           for (int r = 0; r < 16; ++r) old[r] = (float)orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs];
         }
+        // BatchNorm-backward sums (stat_mul): the multiplier tile is requested with the old values, one round trip
+        float mul[STATMUL ? 16 : 1];
+        if constexpr (STATMUL) if (mulp) {
+          const float* mrow = mulp + (tile_pix + (size_t)((wm + i * WM) * a.W + 4 * half)) * a.stat_mul_cs + n0 + cl + l31;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mul[r] = mrow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * a.stat_mul_cs];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = acc[i][j][r] + bias;
@@ -137,7 +150,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
           if constexpr (!ACC) __builtin_nontemporal_store((OT)v, &orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs]);
           else orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs] = (OT)v;
           s1[j] += v;
-          s2v[j] += v * v;
+          if constexpr (STATMUL) s2v[j] += v * (mulp ? mul[r] : v);
+          else s2v[j] += v * v;
         }
       }
     }

@@ -295,6 +295,10 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   a.stat_partial = d->stat_partial;
   a.slope = c3d_slope_or_default(d->lrelu_slope);
   a.out_bf16 = d->out_bf16;
+  a.stat_mul = d->stat_mul;
+  a.stat_mul_cs = d->stat_mul_cstride;
+  C3D_REQUIRE(!d->stat_mul || (d->stat_partial && !d->out_bf16 && d->stat_mul_cstride >= d->Cout && d->mfma_bf16 >= 2),
+              "conv: stat_mul needs stat_partial, fp32 output, a channel stride >= Cout and the bf16x3 engine (mfma_bf16 >= 2)");
   {
     bool any_bf = d->out_bf16 != 0;
     for (int s = 0; s < d->nsrc; ++s) any_bf = any_bf || d->src[s].bf16 != 0;

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
     else if (nj == 1) mfma_chunk(cur, std::integral_constant<int, 1>{});
     __syncthreads();                       // the other buffer is complete, this one is free again
   }
-  conv_epilogue<TR, NT, WM, WN, NP == 1, true, 512, true>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
+  conv_epilogue<TR, NT, WM, WN, NP == 1, true, 512, true, NP == 3>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
                                                   tile_pix);
 }
 
@@ -550,8 +550,8 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void conv_pw3f_kernel(Co
   else if (NPW > 2 && nj == 2) k_loop(std::integral_constant<int, (NPW > 2 ? 2 : 1)>{});
   else if (nj == 1) k_loop(std::integral_constant<int, 1>{});
   else k_loop(std::integral_constant<int, 0>{});
-  conv_epilogue<TR, NT, WM, WN, false, true, NTHR, true>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
-                                                         tile_pix);
+  conv_epilogue<TR, NT, WM, WN, false, true, NTHR, true, true>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
+                                                               tile_pix);
 }
 
 template <int NT, int WN>

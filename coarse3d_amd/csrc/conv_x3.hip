@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs a) {
     c0 = c2;
     kbase = kb2;
   }
-  conv_epilogue<TR, NT, WM, WN>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
+  conv_epilogue<TR, NT, WM, WN, false, false, 256, false, true>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   };
   if (NPW == 1 || nj >= NPW) k_loop(std::integral_constant<int, NPW>{});
   else k_loop(std::integral_constant<int, 1>{});
-  conv_epilogue<TR, NT, WM, WN>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
+  conv_epilogue<TR, NT, WM, WN, false, false, 256, false, true>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
 }
 
 template <int NT, int HALO, int TT, bool SIX>

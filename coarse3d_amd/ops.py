@@ -254,7 +254,7 @@ def _pw3_kernel_name(nt, k, cout):
 
 
 def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=None, out_coff=0,
-                 accumulate=False, stat_partial=None, slope=0.0, grad=False):
+                 accumulate=False, stat_partial=None, slope=0.0, grad=False, stat_mul=None):
     """y = [LeakyReLU](conv(cat(transformed srcs)) + bias); optional per-tile channel stats.
     ``grad``: this launch is an input-gradient convolution (transposed weights, negated taps): the
     bf16x3 engine then accumulates six plane products instead of eight (c3d_conv_desc.mfma_bf16 = 3)."""
@@ -281,6 +281,10 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     if stats and stat_partial is None:
         stat_partial = torch.empty(cout, 2, num_mtiles(b, h, w), device=wpack.device, dtype=torch.float32)
     d.stat_partial = stat_partial.data_ptr() if stat_partial is not None else None
+    if stat_mul is not None:      # (sum v, sum v * stat_mul) instead of (sum v, sum v^2): BatchNorm-backward sums, bf16x3 engine
+        if stat_partial is None or MFMA_MODE != 2 or tuple(stat_mul.shape[:3]) != (b, h, w) or stat_mul.dtype != torch.float32:
+            raise ValueError("conv_forward: stat_mul needs statistics, the bf16x3 engine and an fp32 tensor of the output's shape")
+        d.stat_mul, d.stat_mul_cstride = stat_mul.data_ptr(), stat_mul.shape[3]
     tr = min((8, 4, 2), key=lambda t: ((h + t - 1) // t * t, -t))       # c3d_tile_rows() in csrc/conv_mfma.hip
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
     nt_ = len(taps)

@@ -96,6 +96,15 @@ typedef struct {
   int32_t wpack_planes;     /* 1: wpack came from c3d_pack_weights(mode | 2): the three bf16 planes of the
                                weights follow the fp32 image.  Required by the multi-tap bf16x3 kernels;
                                1x1 convs with Cout > 64 then take the wide kernel of conv_pw3.hip       */
+  const float* stat_mul;    /* NULL: stat_partial holds (sum v, sum v*v) of the stored values v.  Else an NHWC tensor of the
+                               output's shape (channel stride stat_mul_cstride, first channel 0): stat_partial holds
+                               (sum v, sum v * stat_mul) -- the two sums a BatchNorm BACKWARD needs when `out` is the
+                               gradient at a BatchNorm's output and stat_mul that BatchNorm's input: the LAST
+                               input-gradient launch that contributes to such a gradient (accumulate = 1 included:
+                               v is the final value) takes them in its epilogue and spares c3d_bn_bwd_reduce's two
+                               tensor reads                                                                        */
+  int32_t stat_mul_cstride;
+  int32_t reserved2;
 } c3d_conv_desc;
 
 /* y = epilogue(conv(transform(cat(src)))) as an implicit GEMM on fp32 MFMA.
