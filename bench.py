@@ -350,6 +350,12 @@ def main():
     # steps then bracket only the launches of that dominant instance (bracketing all ~300 launches
     # per step costs ~2 % of the step, which would distort `value`).
     survey = None
+    # Three extra untimed steps ahead of the W warm-up steps: on 2 of 5 fresh boxes of round 3 the FIRST bench process
+    # averaged 56-71 ms over its 20 timed steps (34.3 ms in the next process on the same box) -- one-time costs that W = 5
+    # steps do not always cover (first-touch of the ~25 GB the step allocates, lazily paged-in libraries).  They change
+    # nothing about what is timed: exactly K steps, bracketed by barrier + synchronize.
+    for s in range(3):
+        ts.step(*batches[s % total_steps], epoch=10)
     for s in range(args.warmup):
         # (captured step: the events can only bracket launches of an EAGER step -- the second warm-up step)
         last = s == (1 if ts.graph else args.warmup - 1) and not args.no_kernel_events
