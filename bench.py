@@ -250,6 +250,8 @@ def main():
                     help="replay the step as ONE hipGraph (TrainStep(graph=True): two eager steps, capture, replay).  The "
                          "default is launch-by-launch, which keeps live HIP events around the dominant kernel inside the "
                          "timed region; the default run reports the captured step under `engines.graph_replay`")
+    ap.add_argument("--prewarm", type=int, default=3,
+                    help="untimed steps ahead of the W warm-up steps (one-time costs of a fresh box; profiling runs pass 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--kernel-table", default=None, help="write a per-(kernel, layer shape) timing table (JSON) here")
@@ -354,11 +356,21 @@ def main():
     # averaged 56-71 ms over its 20 timed steps (34.3 ms in the next process on the same box) -- one-time costs that W = 5
     # steps do not always cover (first-touch of the ~25 GB the step allocates, lazily paged-in libraries).  They change
     # nothing about what is timed: exactly K steps, bracketed by barrier + synchronize.
-    for s in range(3):
+    if ts.graph:
+        args.prewarm = max(args.prewarm, 3)
+    for s in range(args.prewarm):
+        # (captured step: HIP events can only bracket launches of an EAGER step -- the second pre-warm step; the third
+        #  one is the capture)
+        probe = ts.graph and s == 1 and not args.no_kernel_events
+        if probe:
+            ops.KERNEL_EVENTS = []
         ts.step(*batches[s % total_steps], epoch=10)
+        if probe:
+            torch.cuda.synchronize()
+            survey = summarise(ops.KERNEL_EVENTS, 1)
+            ops.KERNEL_EVENTS = None
     for s in range(args.warmup):
-        # (captured step: the events can only bracket launches of an EAGER step -- the second warm-up step)
-        last = s == (1 if ts.graph else args.warmup - 1) and not args.no_kernel_events
+        last = s == args.warmup - 1 and not args.no_kernel_events and not ts.graph
         if last:
             ops.KERNEL_EVENTS = []
         ts.step(*batches[s], epoch=10)
