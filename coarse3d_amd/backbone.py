@@ -363,7 +363,7 @@ class Backbone:
         rec.out.grad = None
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, train=True, dropout_masks=None, return_feat=True, update_running=True):
+    def forward(self, x, train=True, dropout_masks=None, return_feat=True, update_running=True, lazy_feat=False):
         """x [B,Cin,H,W] fp32 (NCHW, as the reference feeds it).  Returns dict with NHWC tensors:
         prob [B,Ho,Wo,C], logits [B,H,W,32], feat [B,Ho,Wo,256] (if return_feat)."""
         self.train, self.masks, self.update_running = train, dropout_masks, update_running
@@ -418,9 +418,14 @@ class Backbone:
         if return_feat:
             emb = self._conv("projector.proj.3", [z0], 1, 1, 0, lrelu=False, src_lrelu=True)
             embn, norm = ops.l2norm(emb.t, 1e-12)
-            feat2d = ops.bilinear(embn, ho, wo, out_dtype=torch.float32)   # the embedding leaves the backbone in fp32
             self.tape["embed"] = (feat_a, z0, emb, embn, norm)
-            out["feat"] = feat2d
+            self.lazy_feat = lazy_feat
+            if lazy_feat:
+                # the caller interpolates the rows it reads (contrast.LowResFeat); backward() then receives the gradient
+                # of THIS tensor
+                out["feat_low"] = embn
+            else:
+                out["feat"] = ops.bilinear(embn, ho, wo, out_dtype=torch.float32)   # the embedding leaves the backbone in fp32
         if train and update_running:
             torch._foreach_add_([self.P[f"{n}.num_batches_tracked"] for n in self.bn_seen], 1)
         return out
@@ -649,10 +654,15 @@ class Backbone:
         # ---- both heads down to their first BatchNorm: projector.proj.3 and cls_head
         if embed:
             feat_a, z0, emb, embn, norm = self.tape["embed"]
-            d_embn = torch.empty_like(embn)
-            d_feat = d_feat.contiguous()
-            # the contrast loss marks the ~10^3 pixel rows of its dense gradient that are not zero (contrast.take_row_hint)
-            ops.bilinear_bwd(d_embn, d_feat, rowmask=contrast.take_row_hint(d_feat))
+            if self.lazy_feat:
+                d_embn = d_feat.contiguous()
+                if d_embn.shape != embn.shape or d_embn.dtype != embn.dtype:
+                    raise ValueError("backward: lazy_feat forward expects the gradient of out['feat_low']")
+            else:
+                d_embn = torch.empty_like(embn)
+                d_feat = d_feat.contiguous()
+                # the contrast loss marks the ~10^3 pixel rows of its dense gradient that are not zero (contrast.take_row_hint)
+                ops.bilinear_bwd(d_embn, d_feat, rowmask=contrast.take_row_hint(d_feat))
             d_emb = ops.l2norm_bwd(embn, norm, d_embn, 1e-12)
             self._conv_backward("projector.proj.3", d_emb)
         logits = self.tape["cls_head"].out

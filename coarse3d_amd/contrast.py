@@ -67,6 +67,63 @@ def take_row_hint(t):
     return rowmask
 
 
+# ---- the embedding without its last F.interpolate
+# salsanext_proto.py:485-490 l2-normalises the projector's output at half resolution and upsamples it to the label
+# resolution: ``feat_2d``, 1.07 GB at 8x256x64x2048.  Inside the training step only ROWS of it are read -- the sampled
+# anchors of the contrast loss (contrast_pixel_loss.py) and the labelled pixels of prototype_learning -- and its
+# gradient has ~10^3 non-zero pixel rows.  A LowResFeat carries the half-resolution tensor (autograd-connected) and the
+# target size; consumers that understand it interpolate the rows they need (ops.bilinear_rows: bit-identical to the
+# rows of the dense map) and send the gradient back in compact form (ops.scatter_rows_compact +
+# ops.bilinear_bwd_rows: bit-identical to the dense adjoint); everybody else calls ``dense()`` and gets the
+# reference's tensor.  C3D_LAZY_FEAT=0 makes the model hand out the dense tensor again.
+LAZY_FEAT_ON = os.environ.get("C3D_LAZY_FEAT", "1") != "0"
+
+
+class _UpsampleFn(torch.autograd.Function):
+    """F.interpolate(low, size, mode="bilinear", align_corners=True) of a channels-last [B,D,h,w] view, in fp32."""
+
+    @staticmethod
+    def forward(ctx, low, hd, wd):
+        ctx.low_meta = (tuple(low.shape), low.dtype)
+        return ops.bilinear(_nhwc_rows(low.detach()), hd, wd, out_dtype=torch.float32).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        (b, d, h, w), dtype = ctx.low_meta
+        d_low = torch.empty(b, h, w, d, device=g.device, dtype=dtype)
+        gn = g.permute(0, 2, 3, 1)
+        hint = take_row_hint(gn if gn.is_contiguous() else None)
+        ops.bilinear_bwd(d_low, gn.contiguous().float(), rowmask=hint)
+        return d_low.permute(0, 3, 1, 2), None, None
+
+
+class LowResFeat:
+    def __init__(self, low, size):
+        self.low = low                       # [B, D, h, w]-shaped view of channels-last memory, requires grad in training
+        self.size = (int(size[0]), int(size[1]))
+        self._dense = None
+
+    @property
+    def shape(self):                          # of the tensor it stands for
+        return torch.Size((self.low.shape[0], self.low.shape[1]) + self.size)
+
+    @property
+    def device(self):
+        return self.low.device
+
+    def low_nhwc(self):
+        return _nhwc_rows(self.low.detach())
+
+    def dense(self):
+        """The reference's ``feat_2d`` [B, D, H, W] (fp32, autograd-connected); computed once."""
+        if self._dense is None:
+            self._dense = _UpsampleFn.apply(self.low, *self.size)
+        return self._dense
+
+    def detach(self):
+        return self.dense().detach()
+
+
 class _ContrastFn(torch.autograd.Function):
     """loss = InfoNCE(anchors sampled from feats, prototype queue); d(loss)/d(feats) is a sparse
     scatter-add of at most B*(C-1)*A rows (the reference zero-fills a dense [B,HW,D] tensor per
@@ -80,17 +137,24 @@ class _ContrastFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         st = ctx.state
-        feat = st["feat"]
-        b, h, w, d = feat.shape
+        b, h, w, d = st["bhwd"]
         n = h * w
         tmax, a = st["tmax"], st["a"]
         # d(anchor rows, normalised) = dlogits x queue ; then through the l2 normalisation
         da = ops.gemm_rows(st["dlogits"], st["wq_t"], d)
         dx = ops.l2norm_bwd(st["anchors"], st["norm"], da)
-        dfeat = torch.zeros(b, h, w, d, device=feat.device, dtype=torch.float32)
         gs = g.reshape(1).to(torch.float32).contiguous()
+        if st["low"] is not None:
+            # gradient of the half-resolution embedding straight from the anchor rows: owner sums in a compact buffer,
+            # then the same gather-form adjoint the dense path runs over a zero-filled [B,H,W,D] tensor
+            low = st["low"]
+            drows, cmap, rowmask = ops.scatter_rows_compact(dx, st["img"], st["idx"], st["T"], tmax, a, n, b, gs)
+            d_low = torch.empty(b, low.shape[2], low.shape[3], d, device=dx.device, dtype=low.dtype)
+            ops.bilinear_bwd_rows(d_low, drows, cmap, rowmask, h, w)
+            return d_low.permute(0, 3, 1, 2), None
+        dfeat = torch.zeros(b, h, w, d, device=dx.device, dtype=torch.float32)
         # one bit per pixel that received a row: a hint for whoever consumes this (dense, complete) gradient next
-        rowmask = torch.zeros((b * n + 31) // 32, device=feat.device, dtype=torch.int32) if SPARSE_HINT_ON else None
+        rowmask = torch.zeros((b * n + 31) // 32, device=dx.device, dtype=torch.int32) if SPARSE_HINT_ON else None
         ops.scatter_add_rows(dx, st["img"], st["idx"], st["T"], tmax, a, n, dfeat, gs, rowmask=rowmask)
         if rowmask is not None:
             _publish_row_hint(dfeat, rowmask)
@@ -99,7 +163,7 @@ class _ContrastFn(torch.autograd.Function):
 
 def contrast_mem_loss(feats, prob, labels, keep_mask, proto_queue, temperature=0.1, base_temperature=0.07,
                       num_anchor=50, ignore_label=0, uniforms=None, perms=None, return_debug=False):
-    """feats [B,D,H,W]-shaped (channels-last memory preferred), prob [B,C,H,W]-shaped, labels
+    """feats [B,D,H,W]-shaped (channels-last memory preferred) or a LowResFeat, prob [B,C,H,W]-shaped, labels
     [B,H,W] int64, keep_mask [B,H,W] bool or None, proto_queue [C,M,D].
 
     uniforms: float64 [B*C, A] draws (row t feeds the t-th present (image,class) pair, exactly
@@ -109,7 +173,8 @@ def contrast_mem_loss(feats, prob, labels, keep_mask, proto_queue, temperature=0
     c = prob.shape[1]
     n = h * w
     dev = feats.device
-    feat = _nhwc_rows(feats.detach())
+    lazy = isinstance(feats, LowResFeat)
+    feat = None if lazy else _nhwc_rows(feats.detach())
     p = _nhwc_rows(prob.detach())
     w_anchor, _, _ = ops.entropy_stats(p, want_pl=False, want_amax=False)
     lab = labels.reshape(b, n).contiguous()
@@ -124,7 +189,10 @@ def contrast_mem_loss(feats, prob, labels, keep_mask, proto_queue, temperature=0
         u[: uniforms.shape[0]] = uniforms.to(dev)
         uniforms = u
     a_idx, a_img, a_cls, t = ops.anchor_sample(w_anchor, counts, idx, uniforms, b, n, c, a, ignore_label)
-    anchors, norm = ops.gather_rows_l2(feat, a_img, a_idx, t, tmax, a, n)
+    if lazy:
+        anchors, norm = ops.bilinear_rows(feats.low_nhwc(), h, w, a_idx, img=a_img, a=a, count=t, l2=True)
+    else:
+        anchors, norm = ops.gather_rows_l2(feat, a_img, a_idx, t, tmax, a, n)
     # queue: classes 1..C-1, rows permuted, l2-normalised, padded to a multiple of 16 rows
     m = proto_queue.shape[1]
     q = proto_queue.detach()[1:]
@@ -142,9 +210,9 @@ def contrast_mem_loss(feats, prob, labels, keep_mask, proto_queue, temperature=0
     w_q = qpad.view(ld, d, 1, 1)
     logits = ops.gemm_rows(anchors, ops.pack_weights(w_q, 0), ld)          # [tmax*a, ld] cosine
     loss, row_loss = ops.infonce_rows(logits, a_cls, t, tmax, a, m, ncols, temperature, base_temperature)
-    state = dict(feat=feat, anchors=anchors, norm=norm, dlogits=logits, wq_t=ops.pack_weights(w_q, 1),
-                 img=a_img, idx=a_idx, T=t, tmax=tmax, a=a, loss=loss)
-    out = _ContrastFn.apply(feats, state)
+    state = dict(bhwd=(b, h, w, d), low=feats.low if lazy else None, anchors=anchors, norm=norm, dlogits=logits,
+                 wq_t=ops.pack_weights(w_q, 1), img=a_img, idx=a_idx, T=t, tmax=tmax, a=a, loss=loss)
+    out = _ContrastFn.apply(feats.low if lazy else feats, state)
     if return_debug:
         return out, dict(idx=a_idx, img=a_img, cls=a_cls, T=t, row_loss=row_loss, weights=w_anchor, counts=counts,
                          candidates=idx, uniforms=uniforms)

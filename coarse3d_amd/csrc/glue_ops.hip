@@ -500,6 +500,21 @@ __device__ __forceinline__ void bl_coords(int d, float ratio, int n, int& i0, in
   l1 = fminf(fmaxf(r - (float)i0, 0.f), 1.f);
 }
 
+// the four-tap mix of one output element; bilinear_kernel and bilinear_rows_kernel share it so that a row gathered
+// straight from the source equals the row of the materialised map bit for bit
+template <int V>
+__device__ __forceinline__ c3d_vec<V> bl_mix(const c3d_vec<V>& v00, const c3d_vec<V>& v01, const c3d_vec<V>& v10,
+                                             const c3d_vec<V>& v11, float lx, float ly) {
+  c3d_vec<V> o;
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    const float top = v00.v[q] * (1.f - lx) + v01.v[q] * lx;
+    const float bot = v10.v[q] * (1.f - lx) + v11.v[q] * lx;
+    o.v[q] = top * (1.f - ly) + bot * ly;
+  }
+  return o;
+}
+
 // Work item of a workgroup = 2048 consecutive (pixel, channel-group) elements of ONE destination row: the row's
 // image, y coordinates and base addresses are workgroup-uniform (scalar unit), a lane only divides its element index
 // by the channel groups per pixel (a shift when that is a power of two).  (First version: a flat grid-stride loop with
@@ -537,15 +552,74 @@ __global__ __launch_bounds__(256) void bilinear_kernel(BlArgs p, int chunks_per_
         const c3d_vec<V> v01 = c3d_vld<V>(p.src, s0 + (size_t)(x1 * p.scs + c), p.bf & 1);
         const c3d_vec<V> v10 = c3d_vld<V>(p.src, s1 + (size_t)(x0 * p.scs + c), p.bf & 1);
         const c3d_vec<V> v11 = c3d_vld<V>(p.src, s1 + (size_t)(x1 * p.scs + c), p.bf & 1);
-        c3d_vec<V> o;
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-          const float top = v00.v[q] * (1.f - lx) + v01.v[q] * lx;
-          const float bot = v10.v[q] * (1.f - lx) + v11.v[q] * lx;
-          o.v[q] = top * (1.f - ly) + bot * ly;
-        }
+        const c3d_vec<V> o = bl_mix<V>(v00, v01, v10, v11, lx, ly);
         c3d_vst_nt<V>(p.dst, d0 + (size_t)(xd * p.dcs + c), p.bf & 2, o);
       }
+    }
+  }
+}
+
+// out[r][:] = bilinear(src)[pixel of row r][:] for a LIST of destination pixels -- the rows a consumer needs of a map that
+// is never materialised (the 64x2048 embedding, 1.07 GB at bs=8: only ~10^3 anchor rows and <= 8192 labelled rows of
+// it are ever read inside the training step; salsanext_proto.py:488-490 followed by contrast_pixel_loss.py's and
+// prototype_learning's row selections).  Row r is destination pixel idx[r] of image img[r / A] (img != null) or the flat
+// pixel idx[r] = b * Hd * Wd + pixel (img == null).  Rows with r / A >= *count are zero.  l2: rows leave l2-normalised,
+// norm[r] = their length (rows past count: 1) -- the arithmetic of gather_l2_kernel.  One wave per row.
+template <class IDX>
+__global__ __launch_bounds__(256) void bilinear_rows_kernel(BlArgs p, const int32_t* __restrict__ img,
+                                                            const IDX* __restrict__ idx, int A,
+                                                            const int32_t* __restrict__ count, int R, int l2, float eps,
+                                                            float* __restrict__ out, float* __restrict__ norm) {
+  constexpr int V = 4;
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+  const int live = count ? *count : R;
+  const int n = p.Hd * p.Wd;
+  for (size_t r = wave; r < (size_t)R; r += nw) {
+    if ((int)(r / A) >= live) {
+      for (int c = lane * V; c < p.C; c += 64 * V) c3d_vst<V>(out, r * p.C + c, false, c3d_vzero<V>());
+      if (norm && lane == 0) norm[r] = 1.f;
+      continue;
+    }
+    int b, pix;
+    if (img) {
+      b = img[r / A];
+      pix = (int)idx[r];
+    } else {
+      const long long flat = (long long)idx[r];
+      b = (int)(flat / n);
+      pix = (int)(flat - (long long)b * n);
+    }
+    const int yd = pix / p.Wd, xd = pix - yd * p.Wd;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bl_coords(yd, p.ry, p.Hs, y0, y1, ly);
+    bl_coords(xd, p.rx, p.Ws, x0, x1, lx);
+    const size_t s0 = ((size_t)b * p.Hs + y0) * p.Ws * p.scs + p.scoff;
+    const size_t s1 = ((size_t)b * p.Hs + y1) * p.Ws * p.scs + p.scoff;
+    auto row_quad = [&](int c) {
+      const c3d_vec<V> v00 = c3d_vld<V>(p.src, s0 + (size_t)(x0 * p.scs + c), p.bf & 1);
+      const c3d_vec<V> v01 = c3d_vld<V>(p.src, s0 + (size_t)(x1 * p.scs + c), p.bf & 1);
+      const c3d_vec<V> v10 = c3d_vld<V>(p.src, s1 + (size_t)(x0 * p.scs + c), p.bf & 1);
+      const c3d_vec<V> v11 = c3d_vld<V>(p.src, s1 + (size_t)(x1 * p.scs + c), p.bf & 1);
+      return bl_mix<V>(v00, v01, v10, v11, lx, ly);
+    };
+    float inv = 1.f;
+    if (l2) {
+      float s = 0.f;
+      for (int c = lane * V; c < p.C; c += 64 * V) {
+        const c3d_vec<V> v = row_quad(c);
+        s += v.v[0] * v.v[0] + v.v[1] * v.v[1] + v.v[2] * v.v[2] + v.v[3] * v.v[3];
+      }
+      const float nr = sqrtf(c3d_wave_sum(s));
+      inv = 1.f / fmaxf(nr, eps);
+      if (norm && lane == 0) norm[r] = nr;
+    }
+    for (int c = lane * V; c < p.C; c += 64 * V) {
+      c3d_vec<V> v = row_quad(c);
+      if (l2) v *= inv;
+      c3d_vst<V>(out, r * p.C + c, false, v);
     }
   }
 }
@@ -633,7 +707,8 @@ __device__ __forceinline__ float bl_weight(int d, int s, float ratio, int n) {
 constexpr int BL_NX = 8;
 template <int V>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(BlArgs p, int accumulate, int chunks_per_row, int q_shift,
-                                                           const uint32_t* __restrict__ rowmask) {
+                                                           const uint32_t* __restrict__ rowmask,
+                                                           const int32_t* __restrict__ cmap) {
   const int Q = p.C / V;
   const int row_elems = p.Ws * Q;
   float* dsrc = const_cast<float*>(p.src);
@@ -665,7 +740,9 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(BlArgs p, int accumul
 #pragma unroll
           for (int j = 0; j < BL_NX; ++j) {
             if (wxr[j] != 0.f && (!rowmask || ((rowmask[(m0 + xlo + j) >> 5] >> ((m0 + xlo + j) & 31)) & 1u))) {
-              c3d_vec<V> g = c3d_vld<V>(p.dst, g0 + (size_t)((xlo + j) * p.dcs + c), p.bf & 2);
+              // (compact d_dst: row cmap[pixel] of a [rows][C] buffer stands for the pixel's row of the dense map)
+              c3d_vec<V> g = cmap ? c3d_vld<V>(p.dst, (size_t)cmap[m0 + xlo + j] * p.dcs + c, false)
+                                  : c3d_vld<V>(p.dst, g0 + (size_t)((xlo + j) * p.dcs + c), p.bf & 2);
               g *= (wy * wxr[j]);
               acc += g;
             }
@@ -674,7 +751,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(BlArgs p, int accumul
             const float wx = bl_weight(xd, xs, p.rx, p.Ws);
             if (wx == 0.f) continue;
             if (rowmask && !((rowmask[(m0 + xd) >> 5] >> ((m0 + xd) & 31)) & 1u)) continue;
-            c3d_vec<V> g = c3d_vld<V>(p.dst, g0 + (size_t)(xd * p.dcs + c), p.bf & 2);
+            c3d_vec<V> g = cmap ? c3d_vld<V>(p.dst, (size_t)cmap[m0 + xd] * p.dcs + c, false)
+                                : c3d_vld<V>(p.dst, g0 + (size_t)(xd * p.dcs + c), p.bf & 2);
             g *= (wy * wx);
             acc += g;
           }
@@ -969,9 +1047,47 @@ extern "C" int c3d_bilinear_bwd(float* dsrc, int Hs, int Ws, int scs, int scoff,
   C3D_REQUIRE(!ddst_rowmask || (int64_t)B * Hd * Wd < (1ll << 32), "bilinear_bwd: row mask needs < 2^32 destination pixels");
   const int grid = B * Hs * chunks;
   if (V == 8)
-    hipLaunchKernelGGL(bilinear_bwd_kernel<8>, dim3(grid), dim3(256), 0, ST, p, accumulate, chunks, bl_shift(C / 8), ddst_rowmask);
+    hipLaunchKernelGGL(bilinear_bwd_kernel<8>, dim3(grid), dim3(256), 0, ST, p, accumulate, chunks, bl_shift(C / 8), ddst_rowmask,
+                       (const int32_t*)nullptr);
   else
-    hipLaunchKernelGGL(bilinear_bwd_kernel<4>, dim3(grid), dim3(256), 0, ST, p, accumulate, chunks, bl_shift(C / 4), ddst_rowmask);
+    hipLaunchKernelGGL(bilinear_bwd_kernel<4>, dim3(grid), dim3(256), 0, ST, p, accumulate, chunks, bl_shift(C / 4), ddst_rowmask,
+                       (const int32_t*)nullptr);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_bilinear_bwd_rows(float* dsrc, int Hs, int Ws, int scs, int scoff, const float* drows, const int32_t* cmap,
+                                     const uint32_t* rowmask, int Hd, int Wd, int B, int C, int accumulate, int dsrc_bf16,
+                                     c3d_stream stream) {
+  C3D_REQUIRE(drows && cmap && rowmask, "bilinear_bwd_rows: drows, cmap and rowmask are required");
+  C3D_REQUIRE(C % 4 == 0 && scs % 4 == 0 && scoff % 4 == 0, "bilinear_bwd_rows: channel counts/strides must be multiples of 4");
+  BlArgs p = bl_args(dsrc, Hs, Ws, scs, scoff, const_cast<float*>(drows), Hd, Wd, C, 0, B, C);
+  p.bf = dsrc_bf16 ? 1 : 0;
+  C3D_REQUIRE((int64_t)Ws * scs < (1ll << 31) && (int64_t)B * Hd * Wd < (1ll << 31), "bilinear_bwd_rows: sizes exceed 2^31");
+  const int chunks = bl_chunks(Ws * (C / 4), BL_IT_BWD);
+  C3D_REQUIRE((int64_t)B * Hs * chunks < (1ll << 31), "bilinear_bwd_rows: grid too large");
+  hipLaunchKernelGGL(bilinear_bwd_kernel<4>, dim3(B * Hs * chunks), dim3(256), 0, ST, p, accumulate, chunks, bl_shift(C / 4),
+                     rowmask, cmap);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_bilinear_rows(const float* src, int Hs, int Ws, int scs, int scoff, int src_bf16, int Hd, int Wd, int B,
+                                 int C, const int32_t* img, const void* idx, int idx64, int A, const int32_t* count, int R,
+                                 int l2, float eps, float* out, float* norm, c3d_stream stream) {
+  C3D_REQUIRE(src && idx && out && C % 4 == 0 && scs % 4 == 0 && scoff % 4 == 0 && A >= 1,
+              "bilinear_rows: src, idx, out required; channel counts/strides multiples of 4; A >= 1");
+  C3D_REQUIRE(!(img && idx64), "bilinear_rows: (img, idx) pairs use int32 indices");
+  if (R <= 0) return 0;
+  BlArgs p = bl_args(src, Hs, Ws, scs, scoff, nullptr, Hd, Wd, C, 0, B, C);
+  p.bf = src_bf16 ? 1 : 0;
+  const int grid = nblocks((size_t)R, 4);
+  if (idx64)
+    hipLaunchKernelGGL(bilinear_rows_kernel<int64_t>, dim3(grid), dim3(256), 0, ST, p, img, (const int64_t*)idx, A, count, R, l2,
+                       eps, out, norm);
+  else
+    hipLaunchKernelGGL(bilinear_rows_kernel<int32_t>, dim3(grid), dim3(256), 0, ST, p, img, (const int32_t*)idx, A, count, R, l2,
+                       eps, out, norm);
   C3D_CHECK_LAUNCH();
   return 0;
 }

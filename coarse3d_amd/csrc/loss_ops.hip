@@ -353,7 +353,8 @@ __global__ __launch_bounds__(256) void gather_l2_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ dx, const int32_t* __restrict__ img,
                                                            const int32_t* __restrict__ idx, const int32_t* __restrict__ T,
                                                            int Tmax, int A, int n, int D, const float* __restrict__ gscale,
-                                                           float* __restrict__ dfeat, uint32_t* __restrict__ rowmask) {
+                                                           float* __restrict__ dfeat, uint32_t* __restrict__ rowmask,
+                                                           int32_t* __restrict__ cmap) {
   const int lane = threadIdx.x & 63;
   const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -419,12 +420,19 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
       }
     }
     if (d < D) {
-      float* dst = dfeat + ((size_t)img[t] * n + mine) * D + d;
-      *dst += g * acc;
+      if (cmap) {
+        // compact form: the owner's own row slot holds the pixel's sum (what a zero-filled dense gradient would hold
+        // there: 0 + g * acc), cmap[pixel] says which slot; pixels without a set rowmask bit have no cmap entry
+        dfeat[r * D + d] = 0.f + g * acc;
+      } else {
+        float* dst = dfeat + ((size_t)img[t] * n + mine) * D + d;
+        *dst += g * acc;
+      }
     }
-    if (rowmask && d == 0) {                 // one lane per written row (an OR: order-free)
+    if (d == 0 && (rowmask || cmap)) {       // one lane per written row (an OR: order-free)
       const size_t pix = (size_t)img[t] * n + mine;
-      atomicOr(&rowmask[pix >> 5], 1u << (pix & 31));
+      if (cmap) cmap[pix] = (int32_t)r;
+      if (rowmask) atomicOr(&rowmask[pix >> 5], 1u << (pix & 31));
     }
   }
 }
@@ -601,7 +609,17 @@ extern "C" int c3d_gather_rows_l2(const float* feat, const int32_t* img, const i
 extern "C" int c3d_scatter_add_rows(const float* dx, const int32_t* img, const int32_t* idx, const int32_t* T, int Tmax,
                                     int A, int n, int D, const float* gscale, float* dfeat, uint32_t* rowmask, c3d_stream stream) {
   hipLaunchKernelGGL(scatter_rows_kernel, dim3(nb_for((size_t)Tmax * A, 4)), dim3(256), 0, ST, dx, img, idx, T, Tmax, A,
-                     n, D, gscale, dfeat, rowmask);
+                     n, D, gscale, dfeat, rowmask, (int32_t*)nullptr);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_scatter_rows_compact(const float* dx, const int32_t* img, const int32_t* idx, const int32_t* T, int Tmax,
+                                        int A, int n, int D, const float* gscale, float* drows, int32_t* cmap,
+                                        uint32_t* rowmask, c3d_stream stream) {
+  C3D_REQUIRE(drows && cmap && rowmask, "scatter_rows_compact: drows, cmap and rowmask are required");
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(nb_for((size_t)Tmax * A, 4)), dim3(256), 0, ST, dx, img, idx, T, Tmax, A,
+                     n, D, gscale, drows, rowmask, cmap);
   C3D_CHECK_LAUNCH();
   return 0;
 }

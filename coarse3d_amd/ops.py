@@ -610,6 +610,34 @@ def bilinear_bwd(dsrc, ddst, dcoff=0, c=None, scoff=0, accumulate=False, rowmask
     return dsrc
 
 
+def bilinear_bwd_rows(dsrc, drows, cmap, rowmask, hd, wd, accumulate=False):
+    """bilinear_bwd for a destination gradient in compact form (scatter_rows_compact): bit-identical to the dense call."""
+    b, hs, ws, scs = dsrc.shape
+    if drows.dtype != torch.float32 or cmap.dtype != torch.int32 or rowmask.dtype != torch.int32:
+        raise ValueError("bilinear_bwd_rows: drows fp32, cmap / rowmask int32")
+    if cmap.numel() < b * hd * wd or rowmask.numel() * 32 < b * hd * wd or drows.shape[-1] != scs:
+        raise ValueError("bilinear_bwd_rows: cmap / rowmask must cover every destination pixel, rows must have C channels")
+    _call("c3d_bilinear_bwd_rows", _dp(dsrc), hs, ws, scs, 0, _dp(drows), _dp(cmap), _dp(rowmask), hd, wd, b, scs,
+          int(accumulate), int(dsrc.dtype == torch.bfloat16), _stream())
+    return dsrc
+
+
+def bilinear_rows(src, hd, wd, idx, img=None, a=1, count=None, l2=False, eps=1e-12):
+    """Rows of bilinear(src -> hd x wd) (align_corners=True) at listed destination pixels, without the map.
+    idx: int64 flat pixels b*hd*wd + p (img None) or int32 pixels of image img[r // a]; rows with r // a >= count[0]
+    (int32 device scalar) are zero.  l2: rows l2-normalised, returns (rows, norms).  Rows are padded to a multiple of 32."""
+    b, hs, ws, c = src.shape
+    r = idx.numel()
+    rpad = (r + 31) // 32 * 32            # the GEMM engine wants a multiple of 32 rows
+    out = (torch.empty if rpad == r else torch.zeros)(rpad, c, device=src.device, dtype=torch.float32)
+    norm = torch.ones(rpad, device=src.device, dtype=torch.float32) if l2 else None
+    if idx.dtype not in (torch.int32, torch.int64) or (img is not None and idx.dtype != torch.int32):
+        raise ValueError("bilinear_rows: idx int64 (flat) or int32 with img")
+    _call("c3d_bilinear_rows", _dp(src), hs, ws, c, 0, int(src.dtype == torch.bfloat16), hd, wd, b, c, _dp(img), _dp(idx),
+          int(idx.dtype == torch.int64), a, _dp(count), r, int(l2), eps, _dp(out), _dp(norm), _stream())
+    return (out, norm) if l2 else out
+
+
 def l2norm(x, eps=1e-12, want_norm=True):
     c = x.shape[-1]
     n = x.numel() // c
@@ -738,6 +766,17 @@ def scatter_add_rows(dx, img, idx, t, tmax, a, n, dfeat, gscale=None, rowmask=No
     _call("c3d_scatter_add_rows", _dp(dx), _dp(img), _dp(idx), _dp(t), tmax, a, n, d, _dp(gscale), _dp(dfeat),
           _dp(rowmask), _stream())
     return dfeat
+
+
+def scatter_rows_compact(dx, img, idx, t, tmax, a, n, b, gscale=None):
+    """scatter_add_rows without the dense target: (drows [tmax*a, D], cmap int32 [b*n], rowmask int32 bitmap)."""
+    d = dx.shape[-1]
+    drows = torch.empty(tmax * a, d, device=dx.device, dtype=torch.float32)
+    cmap = torch.empty(b * n, device=dx.device, dtype=torch.int32)
+    rowmask = torch.zeros((b * n + 31) // 32, device=dx.device, dtype=torch.int32)
+    _call("c3d_scatter_rows_compact", _dp(dx), _dp(img), _dp(idx), _dp(t), tmax, a, n, d, _dp(gscale), _dp(drows),
+          _dp(cmap), _dp(rowmask), _stream())
+    return drows, cmap, rowmask
 
 
 def infonce_rows(logits, row_cls, t, tmax, a, m, ncols, temperature, base_temperature=0.07):

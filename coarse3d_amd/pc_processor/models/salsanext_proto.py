@@ -18,6 +18,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from ... import contrast
 from ... import ops as ops_mod
 from ... import proto as proto_ops
 from ...backbone import Backbone
@@ -84,11 +85,16 @@ class _BackboneFn(torch.autograd.Function):
     def forward(ctx, model, x, masks, return_feat, names, *tensors):
         bb = model._make_backbone(model._tensor_dict())
         bb.on_block_done = model._block_done
-        out = bb.forward(x.detach().float(), model.training, masks, return_feat)
+        # (training mode only: a captured eval forward -- serving.GraphedInference -- hands out the tensors of its graph)
+        lazy = bool(return_feat) and model._lazy_feat()
+        out = (bb.forward(x.detach().float(), model.training, masks, return_feat, lazy_feat=True) if lazy
+               else bb.forward(x.detach().float(), model.training, masks, return_feat))
         ctx.bb, ctx.names, ctx.model = bb, names, model
         ctx.return_feat = return_feat
         pred = out["prob"].permute(0, 3, 1, 2)
-        feat = out["feat"].permute(0, 3, 1, 2) if return_feat else x.new_zeros(())
+        # lazy: the l2-normalised embedding BEFORE its last interpolation (half resolution); SalsaNextProto.forward
+        # wraps it in a contrast.LowResFeat and ``feat_2d`` becomes an on-demand entry of the output
+        feat = out["feat_low" if lazy else "feat"].permute(0, 3, 1, 2) if return_feat else x.new_zeros(())
         ctx.mark_non_differentiable(*([] if return_feat else [feat]))
         return pred, feat
 
@@ -318,6 +324,11 @@ class SalsaNextProto(nn.Module):
             off += b * c
         return masks
 
+    def _lazy_feat(self):
+        """Whether ``feat_2d`` is an on-demand entry of the output (contrast.LowResFeat): this class' backbone, in
+        training mode, unless C3D_LAZY_FEAT=0."""
+        return contrast.LAZY_FEAT_ON and self.training and type(self) is SalsaNextProto
+
     # ------------------------------------------------------------------ forward
     def forward(self, x, label=None, eval_mask=None, return_feat=True, proto_loss=False, proto_pl=None):
         b, c, h, w = x.shape
@@ -329,13 +340,20 @@ class SalsaNextProto(nn.Module):
         labelled, self._labelled_hint = self._labelled_hint, None
         if not return_feat:
             return out
-        out["feat_2d"] = feat
+        if self._lazy_feat():
+            # ``feat`` is the embedding before its last interpolation: ``feat_2d`` (1.07 GB at 8x64x2048) is computed
+            # when somebody reads it; the consumers of the training step read rows through ``out.feat_rows``
+            out.feat_rows = contrast.LowResFeat(feat, (h, w))
+            out.lazy["feat_2d"] = out.feat_rows.dense
+        else:
+            out.feat_rows = None
+            out["feat_2d"] = feat
         if self.use_prototype and label is not None and eval_mask is not None:
             with torch.no_grad():
                 P = {"prototypes": self.prototypes.data, "feat_norm.weight": self.feat_norm.weight.data,
                      "feat_norm.bias": self.feat_norm.bias.data, "mask_norm.weight": self.mask_norm.weight.data,
                      "mask_norm.bias": self.mask_norm.bias.data}
-                feat_nhwc = feat.detach().permute(0, 2, 3, 1).contiguous()
+                feat_nhwc = out.feat_rows if out.feat_rows is not None else feat.detach().permute(0, 2, 3, 1).contiguous()
                 res = proto_ops.prototype_step(
                     feat_nhwc, P, label.reshape(-1).long() if proto_loss else None, proto_loss,
                     noise=self.gumbel_noise, momentum=self.proto_mom, ignore_label=self.ignore_label,

@@ -97,17 +97,27 @@ def prototype_step(feat_nhwc, P, label, proto_loss, noise=None, momentum=0.999, 
         # the similarity map is unobservable in this mode (the reference computes and drops it);
         # the only side effect is the in-place renormalisation of the bank
         return {"bank_l2": bank_l2, "nearest": None, "pred": None}
+    handle = feat_nhwc if hasattr(feat_nhwc, "low_nhwc") else None        # contrast.LowResFeat: rows on demand
     b = feat_nhwc.shape[0]
-    n = feat_nhwc.numel() // d
+    n = feat_nhwc.shape.numel() // d
     sparse = learn and labelled is not None and not want_nearest
-    full_sim = lambda: similarity(feat_nhwc, bank_l2, P["feat_norm.weight"], P["feat_norm.bias"])[1]   # noqa: E731
+    if handle is not None:
+        dense = lambda: handle.dense().detach().permute(0, 2, 3, 1).contiguous()   # noqa: E731
+        if not sparse:
+            feat_nhwc = dense()
+    else:
+        dense = lambda: feat_nhwc   # noqa: E731
+    full_sim = lambda: similarity(dense(), bank_l2, P["feat_norm.weight"], P["feat_norm.bias"])[1]   # noqa: E731
     cmap = None
     if sparse:
         idx, cnt = labelled
         cap = idx.numel()
         ar = torch.arange(cap, device=idx.device)
         ok = ar < cnt
-        g = feat_nhwc.view(n, d).index_select(0, torch.where(ok, idx, torch.zeros_like(idx)))       # [cap, D]
+        if handle is not None:
+            g = ops.bilinear_rows(handle.low_nhwc(), handle.size[0], handle.size[1], idx, count=cnt)[:cap]   # [cap, D]
+        else:
+            g = feat_nhwc.view(n, d).index_select(0, torch.where(ok, idx, torch.zeros_like(idx)))       # [cap, D]
         rows = ops.rownorm_ln_l2(g, P["feat_norm.weight"], P["feat_norm.bias"])
         w_oihw = bank_l2.permute(1, 0, 2).reshape(m * c, d, 1, 1).contiguous()
         cpad = (cap + 31) // 32 * 32

@@ -189,8 +189,11 @@ class TrainStep:
                 lab_c, mask_c = train_label, wss_mask
             res["labels_contra"], res["mask_contra"] = lab_c, mask_c
             queue = net.prototypes.detach().unsqueeze(0)
-            res["contrast"] = self.contrast(feats=out["feat_2d"], output=pred, labels=lab_c, keep_mask=mask_c,
-                                            proto_queue=queue)
+            # (the embedding as rows-on-demand where the model offers it: the anchors are interpolated from the
+            #  half-resolution tensor and ``feat_2d`` is never materialised; contrast.LowResFeat)
+            feats = getattr(out, "feat_rows", None)
+            res["contrast"] = self.contrast(feats=feats if feats is not None else out["feat_2d"], output=pred,
+                                            labels=lab_c, keep_mask=mask_c, proto_queue=queue)
             total = total + self.w_con * res["contrast"]
         self.optimizer.zero_grad(set_to_none=True)
         total.backward()

@@ -281,6 +281,22 @@ int c3d_bilinear_sum2(const float* src1, int Hs1, int Ws1, const float* src2, in
  * zeros and are not read (the contrast loss' gradient touches ~10^3 of 10^6 pixels: c3d_scatter_add_rows writes the mask) */
 int c3d_bilinear_bwd(float* dsrc, int Hs, int Ws, int scs, int scoff, const float* ddst, int Hd,
                      int Wd, int dcs, int dcoff, int B, int C, int accumulate, int bf16_mask, const uint32_t* ddst_rowmask, c3d_stream stream);
+/* The same adjoint for a destination gradient kept in COMPACT form: drows [rows][C] fp32 + cmap[pixel] = row of that
+ * pixel (valid where the rowmask bit is set; c3d_scatter_rows_compact writes all three).  Same summation order as
+ * c3d_bilinear_bwd over the equivalent dense, zero-filled ddst: bit-identical result, without the dense tensor
+ * (1.07 GB for the 8x64x2048x256 embedding of salsanext_proto.py:488-490).                                        */
+int c3d_bilinear_bwd_rows(float* dsrc, int Hs, int Ws, int scs, int scoff, const float* drows, const int32_t* cmap,
+                          const uint32_t* rowmask, int Hd, int Wd, int B, int C, int accumulate, int dsrc_bf16,
+                          c3d_stream stream);
+/* out[r][0..C) = row of F.interpolate(src, (Hd, Wd), bilinear, align_corners=True) at ONE destination pixel per r --
+ * the rows contrast_pixel_loss.py (anchors) and prototype_learning (labelled pixels, salsanext_proto.py:494-527) read
+ * of the upsampled embedding, without materialising it; bit-identical to the rows of c3d_bilinear's output.
+ * Pixel of row r: image img[r / A], pixel idx[r] (img != NULL, int32 idx) or flat b*Hd*Wd + pixel = idx[r]
+ * (img == NULL; idx64 != 0: int64 idx).  Rows with r / A >= *count (count may be NULL) are zero.  l2 != 0: rows are
+ * l2-normalised like c3d_gather_rows_l2 and norm[r] (may be NULL) receives their length.                          */
+int c3d_bilinear_rows(const float* src, int Hs, int Ws, int scs, int scoff, int src_bf16, int Hd, int Wd, int B,
+                      int C, const int32_t* img, const void* idx, int idx64, int A, const int32_t* count, int R,
+                      int l2, float eps, float* out, float* norm, c3d_stream stream);
 /* F.normalize(p=2) over rows of [n][C] (:485; eps 1e-12); norm may be NULL                  */
 int c3d_l2norm(const float* x, int64_t n, int C, float eps, float* y, float* norm, int bf16_mask,
                c3d_stream stream);
@@ -362,6 +378,12 @@ int c3d_gather_rows_l2(const float* feat, const int32_t* img, const int32_t* idx
 int c3d_scatter_add_rows(const float* dx, const int32_t* img, const int32_t* idx,
                          const int32_t* T, int Tmax, int A, int n, int D, const float* gscale,
                          float* dfeat, uint32_t* rowmask, c3d_stream stream);
+/* c3d_scatter_add_rows into a compact gradient: drows[t*A+s] (the slot of the FIRST occurrence s of a pixel in its
+ * pair) = (*gscale) * sum of the pixel's rows, cmap[img*n + pixel] = that slot, rowmask bit set (pre-zeroed by the
+ * caller; cmap needs no initialisation: it is only read where the bit is set).  Feeds c3d_bilinear_bwd_rows.      */
+int c3d_scatter_rows_compact(const float* dx, const int32_t* img, const int32_t* idx, const int32_t* T, int Tmax,
+                             int A, int n, int D, const float* gscale, float* drows, int32_t* cmap,
+                             uint32_t* rowmask, c3d_stream stream);
 /* InfoNCE over cosine logits [Tmax*A][ld] (first ncols=(C-1)*M columns valid, column class
  * 1 + j/M): replaces logits by d(mean loss)/d(logits) in place, row_loss per row, *loss.     */
 int c3d_infonce_rows(float* logits, int ld, const int32_t* row_cls, const int32_t* T, int Tmax,

@@ -525,12 +525,14 @@ def test_prototype_sums_exchange_mode():
     assert float((banks["fused"][1] - l2).abs().max()) > 1e-6
 
 
-def test_fast_paths_of_the_training_step_change_nothing():
-    """Four shortcuts of TrainStep on a plain model -- param.grad bound to one persistent buffer instead of going through
+def test_fast_paths_of_the_training_step_change_nothing(monkeypatch):
+    """Five shortcuts of TrainStep on a plain model -- param.grad bound to one persistent buffer instead of going through
     AccumulateGrad, the contrast loss' row bitmap letting the bilinear adjoint skip known-zero rows of the dense
-    embedding gradient, AdamW stepping all parameters as one flat buffer (coarse3d_amd/optim.py), and the prototype
-    similarity computed for the labelled pixels only (coarse3d_amd/proto.py) -- against the same steps with
-    all of them off and torch's per-parameter fused AdamW: identical losses, gradients, parameters and prototype bank."""
+    embedding gradient, AdamW stepping all parameters as one flat buffer (coarse3d_amd/optim.py), the prototype
+    similarity computed for the labelled pixels only (coarse3d_amd/proto.py), and -- third variant -- the
+    upsampled embedding ``feat_2d`` never materialised (contrast.LowResFeat: anchor / labelled rows interpolated on
+    demand, gradient sent back in compact form) -- against the same steps with all of them off and torch's
+    per-parameter fused AdamW: identical losses, gradients, parameters and prototype bank, bit for bit."""
     from coarse3d_amd import contrast, ops
     from coarse3d_amd.pc_processor.models import SalsaNextProto
     from coarse3d_amd.trainer import TrainStep
@@ -539,7 +541,8 @@ def test_fast_paths_of_the_training_step_change_nothing():
     masks = {k: v.to(DEV) for k, v in W.dropout_masks_for(None, b, 6).items()}
     results, taken = [], []
     orig_take = contrast.take_row_hint
-    for fast in (False, True):
+    for variant in ("slow", "dense", "lazy"):
+        fast = variant != "slow"
         torch.manual_seed(3)
         m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True)
         m.load_state_dict(W.closed_form_state(nclasses=ncls))
@@ -554,6 +557,7 @@ def test_fast_paths_of_the_training_step_change_nothing():
         assert (type(ts.optimizer).__name__ == "FlatAdamW") == fast
         m._bind_grads = fast
         contrast.SPARSE_HINT_ON = fast
+        monkeypatch.setattr(contrast, "LAZY_FEAT_ON", variant == "lazy")
         ts.sparse_proto = fast             # prototype similarity at the labelled pixels only vs the full [N, C*M] map
 
         def spy(t):
@@ -574,12 +578,16 @@ def test_fast_paths_of_the_training_step_change_nothing():
             torch.manual_seed(12 + extra)
             res2 = ts.step(x.to(DEV), tr.to(DEV), ev.to(DEV), epoch=10)
         results.append((float(res["loss"]), float(res["contrast"].detach()), grads,
-                        {k: p.detach().clone() for k, p in m.named_parameters()}, float(res2["loss"])))
-    assert taken == [False, True], taken               # the hint reaches the backbone through autograd, and only when on
-    assert results[0][1] > 0 and results[0][0] == results[1][0]
-    assert results[0][2].keys() == results[1][2].keys()
-    for k in results[0][2]:
-        assert torch.equal(results[0][2][k], results[1][2][k]), k
-    for k in results[0][3]:
-        assert torch.equal(results[0][3][k], results[1][3][k]), k         # parameters after three updates
-    assert results[0][4] == results[1][4]
+                        {k: p.detach().clone() for k, p in m.named_parameters()}, float(res2["loss"]),
+                        m.prototypes.detach().clone()))
+    # the hint reaches the backbone through autograd, and only when on; the lazy variant has no dense gradient to hint at
+    assert taken == [False, True], taken
+    for other in (1, 2):
+        assert results[0][1] > 0 and results[0][0] == results[other][0] and results[0][1] == results[other][1]
+        assert results[0][2].keys() == results[other][2].keys()
+        for k in results[0][2]:
+            assert torch.equal(results[0][2][k], results[other][2][k]), (other, k)
+        for k in results[0][3]:
+            assert torch.equal(results[0][3][k], results[other][3][k]), (other, k)     # parameters after three updates
+        assert results[0][4] == results[other][4]
+        assert torch.equal(results[0][5], results[other][5])                            # the prototype bank
