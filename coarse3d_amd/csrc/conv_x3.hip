@@ -498,14 +498,15 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
 
   // one tap row (G taps) of the current chunk out of slab buffer `wb`, with the weight atoms of the next pair
   // (into the other buffer) and input atoms [IA0, IA1) of the next chunk dealt between the products
-  auto group = [&](auto g_tag, int wb, auto nj_tag) {
+  auto group = [&](auto g_tag, int wb, auto nj_tag, auto last_tag) {
     constexpr int g = decltype(g_tag)::value;
     constexpr int NJ = decltype(nj_tag)::value;
+    constexpr bool LAST = decltype(last_tag)::value;  // last chunk: there is no next chunk to load and convert
     // atoms of this tap row, in issue order: [LOAD (first tap row only)] [weights of the next pair] [CONV share]
-    constexpr int NL = g == 0 ? LOAD_ATOMS : 0;
+    constexpr int NL = (g == 0 && !LAST) ? LOAD_ATOMS : 0;
     constexpr int CG = NG - 1;                        // tap rows that convert: all but the first
-    constexpr int CA0 = g == 0 ? 0 : ((g - 1) * CONV_ATOMS) / CG;
-    constexpr int CA1 = g == 0 ? 0 : (g * CONV_ATOMS) / CG;
+    constexpr int CA0 = (g == 0 || LAST) ? 0 : ((g - 1) * CONV_ATOMS) / CG;
+    constexpr int CA1 = (g == 0 || LAST) ? 0 : (g * CONV_ATOMS) / CG;
     constexpr int NA = NL + W_ATOMS + (CA1 - CA0);
     constexpr int NS = G * NQ;                        // slots = products
     const unsigned short* s_w = s_w0 + wb * WBUF;
@@ -583,19 +584,25 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
 
   auto k_loop = [&](auto nj_tag) {
     int wb = 0;
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = 0; c + 1 < nchunks; ++c) {
       c3d_x3_static_for<0, NG>([&](auto g_tag) {
-        group(g_tag, wb, nj_tag);      // multiplies tap row g of chunk c; stores pair +1 into the other slab buffer and
-        ++wq;                          // requests pair +2; first row: requests chunk c+1, later rows: convert it
+        group(g_tag, wb, nj_tag, std::false_type{});   // multiplies tap row g of chunk c; stores pair +1 into the other slab
+        ++wq;                          // buffer and requests pair +2; first row: requests chunk c+1, later rows: convert it
         wb ^= 1;
         __syncthreads();               // the other slab buffer is complete; everyone is done with this one
       });
-      if (c + 1 < nchunks) {
-        store_in();                    // chunk c+1's planes (the barrier above: every wave is done reading chunk c)
-        advance();
-        __syncthreads();
-      }
+      store_in();                      // chunk c+1's planes (the barrier above: every wave is done reading chunk c)
+      advance();
+      __syncthreads();
     }
+    // last chunk: weight atoms only (round 3: its input atoms used to re-load and re-convert the last chunk -- half of
+    // all staging work of a 32-channel layer)
+    c3d_x3_static_for<0, NG>([&](auto g_tag) {
+      group(g_tag, wb, nj_tag, std::true_type{});
+      ++wq;
+      wb ^= 1;
+      __syncthreads();
+    });
   };
   if (NPW == 1 || nj >= NPW) k_loop(std::integral_constant<int, NPW>{});
   else k_loop(std::integral_constant<int, 1>{});

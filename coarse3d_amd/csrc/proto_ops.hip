@@ -220,6 +220,7 @@ struct LearnArgs {
   float momentum;
   float* fsum;           // NULL, or [C][M][D+1]: write the masked feature sums + counts, skip the EMA
   const int32_t* cmap;   // NULL, or [N]: row of a (labelled) pixel in COMPACT sim / feat
+  int noise_by_row;      // noise is [rows][M], indexed like sim / feat (compact rows) instead of by pixel
 };
 
 // EMA of the class's prototypes with the l2-normalised feature sums, then the final l2
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(LEARN_THREADS) void proto_learn_kernel(LearnArgs a)
       const float colsum = group32_sum(e);
       const float qq = m < M ? e / colsum : -INFINITY;
       const int best = group32_argmax(qq, m);
-      const float hh = m < M ? (qq - logf(a.noise[(size_t)r * M + m])) / 0.5f : -INFINITY;
+      const float hh = m < M ? (qq - logf(a.noise[(size_t)(a.noise_by_row ? cr : r) * M + m])) / 0.5f : -INFINITY;
       const int hot = group32_argmax(hh, m);
       int pred_r;
       if (a.pred) {
@@ -468,12 +469,13 @@ extern "C" int c3d_proto_learn(const float* sim, const float* feat, const int32_
                                const float* ln_b, float ln_eps, const int32_t* counts,
                                const int32_t* idx, int32_t* rows, const float* noise, const float* protos,
                                float* protos_out, float* target, int32_t* assign, int B, int n, int M, int C, int D,
-                               int ignore_label, float momentum, float* fsum, const int32_t* cmap, c3d_stream stream) {
+                               int ignore_label, float momentum, float* fsum, const int32_t* cmap, int noise_by_row,
+                               c3d_stream stream) {
   C3D_REQUIRE(M <= 32, "proto_learn: at most 32 sub-prototypes per class");
   C3D_REQUIRE(cmap == nullptr || pred == nullptr, "proto_learn: a precomputed argmax map is indexed by pixel; not with compact rows");
   const int N = B * n;
   LearnArgs a{sim, feat, pred, ln_w, ln_b, ln_eps, counts, idx, rows, B, n, noise, protos, protos_out, target, assign, N, M, C, D,
-              ignore_label, momentum, fsum, cmap};
+              ignore_label, momentum, fsum, cmap, noise_by_row};
   const size_t lds = (2 * LEARN_SUBS * 32 + 32 + 512 + (size_t)M * D + M) * sizeof(float);
   hipLaunchKernelGGL(proto_learn_kernel, dim3(C), dim3(LEARN_THREADS), lds, ST, a);
   C3D_CHECK_LAUNCH();

@@ -689,7 +689,7 @@ def label_hist(labels, ncls):
 
 
 def proto_learn(sim, feat, pred, counts, idx, noise, protos, m, c, ignore_label, momentum, ln_w=None, ln_b=None,
-                ln_eps=1e-5, sums_reduce=None, cmap=None):
+                ln_eps=1e-5, sums_reduce=None, cmap=None, noise_by_row=False):
     """counts [B, C], idx [B, C, n]: per-image ordered pixel lists of each class.
     ``sums_reduce`` (data parallel, optional): in-place all-reduce applied to the per-class
     feature sums + counts [C, M, D+1] before the EMA ("per-class prototype sums" exchange).
@@ -706,7 +706,7 @@ def proto_learn(sim, feat, pred, counts, idx, noise, protos, m, c, ignore_label,
     _call("c3d_proto_learn", _dp(sim), _dp(feat), _dp(pred), _dp(ln_w), _dp(ln_b), ln_eps, _dp(counts), _dp(idx),
           _dp(rows), _dp(noise),
           _dp(protos), _dp(protos_out), _dp(target), _dp(assign), b, n, m, c, d, ignore_label, momentum, _dp(fsum),
-          _dp(cmap), _stream())
+          _dp(cmap), int(noise_by_row), _stream())
     if fsum is not None:
         sums_reduce(fsum)
         _call("c3d_proto_ema", _dp(fsum), _dp(protos), _dp(protos_out), m, c, d, ignore_label, momentum, _stream())

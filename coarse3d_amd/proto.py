@@ -139,12 +139,14 @@ def prototype_step(feat_nhwc, P, label, proto_loss, noise=None, momentum=0.999, 
     if learn:
         lab = label.reshape(b, n // b).contiguous()
         counts, idx_lists = ops.group_compact(lab, c)
+        by_row = noise is None and cmap is not None
         if noise is None:
-            noise = torch.empty(n, m, device=rows.device, dtype=torch.float32).exponential_()
+            # (compact rows: variates for those rows only -- the kernel reads noise at labelled pixels and nowhere else)
+            noise = torch.empty(rows.shape[0] if by_row else n, m, device=rows.device, dtype=torch.float32).exponential_()
         base = bank_l2 if ema_base is None else ema_base.contiguous()   # proto_pl replaces the bank (:515-518)
         new_bank, target = ops.proto_learn(sim, rows, pred, counts, idx_lists, noise.contiguous(),
                                            base, m, c, ignore_label, momentum, P["mask_norm.weight"],
-                                           P["mask_norm.bias"], sums_reduce=sums_reduce, cmap=cmap)
+                                           P["mask_norm.bias"], sums_reduce=sums_reduce, cmap=cmap, noise_by_row=by_row)
         if world_mean is not None and sums_reduce is None:
             # data parallel, reference semantics: mean over ranks of the per-rank updated banks
             # (salsanext_proto.py:397-400); with ``sums_reduce`` the ranks already agree

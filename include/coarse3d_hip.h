@@ -335,12 +335,14 @@ int c3d_label_hist(const int64_t* labels, int groups, int n, int ncls, int32_t* 
  * "per-class prototype sums" exchange).
  * cmap = NULL: sim / feat hold one row per pixel.  cmap = [B*n] int32: sim / feat are COMPACT -- only the
  * labelled pixels were normalised and multiplied with the bank (their rows in any order) -- and cmap[pixel] is
- * the pixel's row in them (read at labelled pixels only); target / noise stay indexed by pixel.       */
+ * the pixel's row in them (read at labelled pixels only); target stays indexed by pixel, noise too unless
+ * noise_by_row != 0: then noise is [rows][M], indexed like sim / feat (the caller drew variates for the compact rows
+ * only: 0.6 MB instead of 84 MB at 8x64x2048).                                                          */
 int c3d_proto_learn(const float* sim, const float* feat, const int32_t* pred, const float* ln_w,
                     const float* ln_b, float ln_eps, const int32_t* counts, const int32_t* idx, int32_t* rows, const float* noise,
                     const float* protos, float* protos_out, float* target, int32_t* assign,
                     int B, int n, int M, int C, int D, int ignore_label, float momentum,
-                    float* fsum, const int32_t* cmap, c3d_stream stream);
+                    float* fsum, const int32_t* cmap, int noise_by_row, c3d_stream stream);
 /* EMA with the l2-normalised sums + final l2 normalisation (salsanext_proto.py:376-395, :402)  */
 int c3d_proto_ema(const float* fsum, const float* protos, float* protos_out, int M, int C, int D,
                   int ignore_label, float momentum, c3d_stream stream);
