@@ -296,3 +296,42 @@ def test_row_mask_hint_scatter_and_bilinear_adjoint():
     contrast._publish_row_hint(dfeat, mask)
     dfeat.mul_(2.0)
     assert contrast.take_row_hint(dfeat) is None
+
+
+@pytest.mark.parametrize("src_dtype", [torch.float32, torch.bfloat16])
+def test_rows_of_the_upsampled_embedding_without_the_map(src_dtype):
+    """contrast.LowResFeat's three kernels against the dense path they replace (salsanext_proto.py:488-490 followed by
+    the row selections of contrast_pixel_loss.py / prototype_learning), bit for bit: rows interpolated on demand
+    (c3d_bilinear_rows, both index forms, with and without the l2 normalisation, rows past the count zero) equal the
+    rows of the materialised map; the compact gradient (c3d_scatter_rows_compact + c3d_bilinear_bwd_rows) equals the
+    adjoint over the zero-filled dense gradient, repeated anchors included."""
+    from coarse3d_amd import ops
+    g = torch.Generator().manual_seed(5)
+    b, hs, ws, d, H, W = 2, 16, 64, 256, 32, 128
+    n = H * W
+    low = torch.randn(b, hs, ws, d, generator=g).to(DEV).to(src_dtype)
+    dense = ops.bilinear(low, H, W, out_dtype=torch.float32)
+    # flat int64 pixels + a device count (the labelled pixels of prototype_learning)
+    idx = torch.randint(0, b * n, (1000,), generator=g).to(DEV)
+    rows = ops.bilinear_rows(low, H, W, idx, count=torch.tensor([900], device=DEV, dtype=torch.int32))
+    assert rows.shape == (1024, d) and torch.equal(rows[:900], dense.view(b * n, d)[idx[:900]])
+    assert float(rows[900:].abs().max()) == 0.0
+    # (image, pixel) pairs, l2-normalised (the anchors of the contrast loss); pixel sets of different pairs are disjoint
+    A, tmax, tn = 50, 12, 9
+    img = (torch.arange(tmax) % b).to(torch.int32).to(DEV)
+    aidx = torch.stack([torch.randint(p * 100, p * 100 + 40, (A,), generator=g) for p in range(tmax)]).to(torch.int32).to(DEV)
+    t = torch.tensor([tn], device=DEV, dtype=torch.int32)
+    o1, n1 = ops.bilinear_rows(low, H, W, aidx, img=img, a=A, count=t, l2=True)
+    o2, n2 = ops.gather_rows_l2(dense, img, aidx, t, tmax, A, n)
+    assert torch.equal(o1, o2) and torch.equal(n1, n2) and float(o1[: tn * A].abs().max()) > 0
+    # gradient: dense scatter + adjoint (with and without the row bitmap) vs compact scatter + adjoint
+    dx = torch.randn(tmax * A, d, generator=g).to(DEV)
+    gs = torch.tensor([0.37], device=DEV)
+    dfeat = torch.zeros(b, H, W, d, device=DEV)
+    rm = torch.zeros((b * n + 31) // 32, device=DEV, dtype=torch.int32)
+    ops.scatter_add_rows(dx, img, aidx, t, tmax, A, n, dfeat, gs, rowmask=rm)
+    want = ops.bilinear_bwd(torch.empty_like(low), dfeat)
+    drows, cmap, rm2 = ops.scatter_rows_compact(dx, img, aidx, t, tmax, A, n, b, gs)
+    got = ops.bilinear_bwd_rows(torch.empty_like(low), drows, cmap, rm2, H, W)
+    assert torch.equal(rm, rm2) and torch.equal(want, got) and float(got.float().abs().max()) > 0
+    assert torch.equal(want, ops.bilinear_bwd(torch.empty_like(low), dfeat, rowmask=rm))
