@@ -606,6 +606,19 @@ __global__ __launch_bounds__(256) void bilinear_rows_kernel(BlArgs p, const int3
       return bl_mix<V>(v00, v01, v10, v11, lx, ly);
     };
     float inv = 1.f;
+    if (p.C <= 64 * V) {
+      // one quad per lane (the 256-channel embedding): interpolate once, keep it for the norm and the store
+      const int c = lane * V;
+      c3d_vec<V> v = c < p.C ? row_quad(c) : c3d_vzero<V>();
+      if (l2) {
+        const float nr = sqrtf(c3d_wave_sum(v.v[0] * v.v[0] + v.v[1] * v.v[1] + v.v[2] * v.v[2] + v.v[3] * v.v[3]));
+        inv = 1.f / fmaxf(nr, eps);
+        if (norm && lane == 0) norm[r] = nr;
+        v *= inv;
+      }
+      if (c < p.C) c3d_vst<V>(out, r * p.C + c, false, v);
+      continue;
+    }
     if (l2) {
       float s = 0.f;
       for (int c = lane * V; c < p.C; c += 64 * V) {
@@ -707,8 +720,7 @@ __device__ __forceinline__ float bl_weight(int d, int s, float ratio, int n) {
 constexpr int BL_NX = 8;
 template <int V>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(BlArgs p, int accumulate, int chunks_per_row, int q_shift,
-                                                           const uint32_t* __restrict__ rowmask,
-                                                           const int32_t* __restrict__ cmap) {
+                                                           const uint32_t* __restrict__ rowmask) {
   const int Q = p.C / V;
   const int row_elems = p.Ws * Q;
   float* dsrc = const_cast<float*>(p.src);
@@ -740,9 +752,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(BlArgs p, int accumul
 #pragma unroll
           for (int j = 0; j < BL_NX; ++j) {
             if (wxr[j] != 0.f && (!rowmask || ((rowmask[(m0 + xlo + j) >> 5] >> ((m0 + xlo + j) & 31)) & 1u))) {
-              // (compact d_dst: row cmap[pixel] of a [rows][C] buffer stands for the pixel's row of the dense map)
-              c3d_vec<V> g = cmap ? c3d_vld<V>(p.dst, (size_t)cmap[m0 + xlo + j] * p.dcs + c, false)
-                                  : c3d_vld<V>(p.dst, g0 + (size_t)((xlo + j) * p.dcs + c), p.bf & 2);
+              c3d_vec<V> g = c3d_vld<V>(p.dst, g0 + (size_t)((xlo + j) * p.dcs + c), p.bf & 2);
               g *= (wy * wxr[j]);
               acc += g;
             }
@@ -751,8 +761,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(BlArgs p, int accumul
             const float wx = bl_weight(xd, xs, p.rx, p.Ws);
             if (wx == 0.f) continue;
             if (rowmask && !((rowmask[(m0 + xd) >> 5] >> ((m0 + xd) & 31)) & 1u)) continue;
-            c3d_vec<V> g = cmap ? c3d_vld<V>(p.dst, (size_t)cmap[m0 + xd] * p.dcs + c, false)
-                                : c3d_vld<V>(p.dst, g0 + (size_t)(xd * p.dcs + c), p.bf & 2);
+            c3d_vec<V> g = c3d_vld<V>(p.dst, g0 + (size_t)(xd * p.dcs + c), p.bf & 2);
             g *= (wy * wx);
             acc += g;
           }
@@ -761,6 +770,71 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(BlArgs p, int accumul
         if (accumulate) acc += c3d_vld<V>(dsrc, o, p.bf & 1);
         c3d_vst<V>(dsrc, o, p.bf & 1, acc);
       }
+    }
+  }
+}
+
+// The same adjoint for a destination gradient in COMPACT form (drows / cmap / rowmask of c3d_scatter_rows_compact):
+// ~10^4 of 10^6 destination pixels carry a row.  One WAVE per source pixel, so everything that decides which
+// destination pixels are read is wave-uniform: the lanes test one candidate destination pixel each (bitmap bit, both
+// weights, cmap slot -- all loads in flight together), a ballot gives the contributing ones, and the wave walks them in
+// order; the common case -- nothing in the support -- is one round of loads and a zero store.  (Scalar loads of the
+// bitmap words row by row, each waited for in turn: 136 us.)
+// Summation order and arithmetic as in bilinear_bwd_kernel over the equivalent zero-filled dense gradient (rows outer,
+// columns inner, ascending; g * (wy * wx) added): bit-identical.  (The generic kernel with the bitmap as a filter, one
+// lane per (pixel, channel quad) each testing its own bits: 228 us for the 8x32x1024x256 embedding gradient.)
+__global__ __launch_bounds__(256) void bilinear_bwd_rows_kernel(BlArgs p, int accumulate, const uint32_t* __restrict__ rowmask,
+                                                                const int32_t* __restrict__ cmap, int nsrc) {
+  constexpr int V = 4;
+  const int lane = threadIdx.x & 63;
+  float* dsrc = const_cast<float*>(p.src);
+  const int wv = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  if (wv >= nsrc) return;
+  const int xs = wv % p.Ws;
+  const int rowi = wv / p.Ws;
+  const int b = rowi / p.Hs, ys = rowi - b * p.Hs;
+  int ylo, yhi, xlo, xhi;
+  bl_dst_range(ys, p.ry, p.Hd, ylo, yhi);
+  bl_dst_range(xs, p.rx, p.Wd, xlo, xhi);
+  const size_t o0 = (((size_t)b * p.Hs + ys) * p.Ws + xs) * p.scs + p.scoff;
+  // candidate destination pixels (row-major over [ylo, yhi] x [xlo, xhi]: the dense kernel's summation order), 64 per
+  // round, one per lane: bit test, weights and the cmap lookup of all of them are in flight together
+  const int nx = xhi - xlo + 1, nc = (yhi - ylo + 1) * nx;
+  for (int c0 = 0; c0 < p.C; c0 += 64 * V) {
+    const int c = c0 + lane * V;
+    c3d_vec<V> acc = c3d_vzero<V>();
+    for (int base = 0; base < nc; base += 64) {
+      const int cand = base + lane;
+      const int yd = ylo + cand / nx, xd = xlo + cand % nx;
+      float w = 0.f;
+      int slot = 0;
+      bool live = false;
+      if (cand < nc) {
+        const float wy = bl_weight(yd, ys, p.ry, p.Hs), wx = bl_weight(xd, xs, p.rx, p.Ws);
+        const unsigned pix = (unsigned)((b * p.Hd + yd) * p.Wd + xd);
+        live = wy != 0.f && wx != 0.f && ((rowmask[pix >> 5] >> (pix & 31)) & 1u);
+        if (live) {
+          slot = cmap[pix];
+          w = wy * wx;
+        }
+      }
+      unsigned long long m = __ballot(live);
+      while (m) {
+        const int j = __builtin_ctzll(m);
+        m &= m - 1;
+        const int sj = __builtin_amdgcn_readlane(slot, j);
+        const float wj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), j));
+        if (c < p.C) {
+          c3d_vec<V> g = c3d_vld<V>(p.dst, (size_t)sj * p.dcs + c, false);
+          g *= wj;
+          acc += g;
+        }
+      }
+    }
+    if (c < p.C) {
+      const size_t o = o0 + c;
+      if (accumulate) acc += c3d_vld<V>(dsrc, o, p.bf & 1);
+      c3d_vst<V>(dsrc, o, p.bf & 1, acc);
     }
   }
 }
@@ -1047,11 +1121,9 @@ extern "C" int c3d_bilinear_bwd(float* dsrc, int Hs, int Ws, int scs, int scoff,
   C3D_REQUIRE(!ddst_rowmask || (int64_t)B * Hd * Wd < (1ll << 32), "bilinear_bwd: row mask needs < 2^32 destination pixels");
   const int grid = B * Hs * chunks;
   if (V == 8)
-    hipLaunchKernelGGL(bilinear_bwd_kernel<8>, dim3(grid), dim3(256), 0, ST, p, accumulate, chunks, bl_shift(C / 8), ddst_rowmask,
-                       (const int32_t*)nullptr);
+    hipLaunchKernelGGL(bilinear_bwd_kernel<8>, dim3(grid), dim3(256), 0, ST, p, accumulate, chunks, bl_shift(C / 8), ddst_rowmask);
   else
-    hipLaunchKernelGGL(bilinear_bwd_kernel<4>, dim3(grid), dim3(256), 0, ST, p, accumulate, chunks, bl_shift(C / 4), ddst_rowmask,
-                       (const int32_t*)nullptr);
+    hipLaunchKernelGGL(bilinear_bwd_kernel<4>, dim3(grid), dim3(256), 0, ST, p, accumulate, chunks, bl_shift(C / 4), ddst_rowmask);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -1064,10 +1136,10 @@ extern "C" int c3d_bilinear_bwd_rows(float* dsrc, int Hs, int Ws, int scs, int s
   BlArgs p = bl_args(dsrc, Hs, Ws, scs, scoff, const_cast<float*>(drows), Hd, Wd, C, 0, B, C);
   p.bf = dsrc_bf16 ? 1 : 0;
   C3D_REQUIRE((int64_t)Ws * scs < (1ll << 31) && (int64_t)B * Hd * Wd < (1ll << 31), "bilinear_bwd_rows: sizes exceed 2^31");
-  const int chunks = bl_chunks(Ws * (C / 4), BL_IT_BWD);
-  C3D_REQUIRE((int64_t)B * Hs * chunks < (1ll << 31), "bilinear_bwd_rows: grid too large");
-  hipLaunchKernelGGL(bilinear_bwd_kernel<4>, dim3(B * Hs * chunks), dim3(256), 0, ST, p, accumulate, chunks, bl_shift(C / 4),
-                     rowmask, cmap);
+  const int64_t nsrc = (int64_t)B * Hs * Ws;
+  C3D_REQUIRE(nsrc < (1ll << 31) && (nsrc + 3) / 4 < (1ll << 31), "bilinear_bwd_rows: grid too large");
+  hipLaunchKernelGGL(bilinear_bwd_rows_kernel, dim3((unsigned)((nsrc + 3) / 4)), dim3(256), 0, ST, p, accumulate, rowmask, cmap,
+                     (int)nsrc);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -347,9 +347,11 @@ __global__ __launch_bounds__(256) void gather_l2_kernel(const float* __restrict_
 // of different (image, class) pairs are disjoint.  One wave per row; the wave of the FIRST occurrence of a pixel in its
 // pair sums all of that pixel's rows in ascending s and does one plain read-modify-write -- no atomics, and the
 // result does not depend on the order in which waves run (bit-reproducible d feat).
-// Work item = (row, 64-channel chunk) per wave.  With weak labels a pair has a handful of labelled pixels and hundreds
+// Work item = (row, chunk of 64 * VW channels) per wave (VW = 4 when D % 4 == 0: the ownership test, the expensive part,
+// runs once per 256 channels; with VW = 1 -- 64 channels per item -- the compact scatter took 139 us at the headline shape).  With weak labels a pair has a handful of labelled pixels and hundreds
 // of anchors, so an owner sums ~A/pixels rows: their loads are issued eight at a time (independent), the adds stay in
 // row order.  (One wave per whole row with one load in flight per duplicate: 425 us at the headline shape.)
+template <int VW>
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ dx, const int32_t* __restrict__ img,
                                                            const int32_t* __restrict__ idx, const int32_t* __restrict__ T,
                                                            int Tmax, int A, int n, int D, const float* __restrict__ gscale,
@@ -360,15 +362,16 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
   const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
   const int Tn = *T;
   const float g = gscale ? *gscale : 1.f;
-  const int DC = (D + 63) / 64;
+  typedef float vecw __attribute__((ext_vector_type(VW)));
+  const int DC = (D + 64 * VW - 1) / (64 * VW);
   for (size_t wi = wave; wi < (size_t)Tn * A * DC; wi += nw) {
     const size_t r = wi / DC;
-    const int d = (int)(wi - r * DC) * 64 + lane;
+    const int d = ((int)(wi - r * DC) * 64 + lane) * VW;
     const int t = r / A, s = (int)(r - (size_t)t * A);
     const int32_t* grp = idx + (size_t)t * A;
     const int mine = grp[s];
     const float* src = dx + (size_t)t * A * D + d;
-    float acc = 0.f;
+    vecw acc = 0.f;
     // sum the rows q[0..8) (ascending, -1 = none): loads first, adds in row order
     auto add_rows = [&](unsigned long long& m, int base) {
       int q[8];
@@ -377,9 +380,9 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
         q[k] = m ? base + __builtin_ctzll(m) : -1;
         m &= m - 1;          // 0 stays 0
       }
-      float x[8];
+      vecw x[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) x[k] = (q[k] >= 0 && d < D) ? src[(size_t)q[k] * D] : 0.f;
+      for (int k = 0; k < 8; ++k) x[k] = (q[k] >= 0 && d < D) ? *reinterpret_cast<const vecw*>(src + (size_t)q[k] * D) : vecw(0.f);
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc += x[k];      // absent rows add 0
     };
@@ -423,9 +426,9 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
       if (cmap) {
         // compact form: the owner's own row slot holds the pixel's sum (what a zero-filled dense gradient would hold
         // there: 0 + g * acc), cmap[pixel] says which slot; pixels without a set rowmask bit have no cmap entry
-        dfeat[r * D + d] = 0.f + g * acc;
+        *reinterpret_cast<vecw*>(dfeat + r * D + d) = vecw(0.f) + g * acc;
       } else {
-        float* dst = dfeat + ((size_t)img[t] * n + mine) * D + d;
+        vecw* dst = reinterpret_cast<vecw*>(dfeat + ((size_t)img[t] * n + mine) * D + d);
         *dst += g * acc;
       }
     }
@@ -608,8 +611,12 @@ extern "C" int c3d_gather_rows_l2(const float* feat, const int32_t* img, const i
 
 extern "C" int c3d_scatter_add_rows(const float* dx, const int32_t* img, const int32_t* idx, const int32_t* T, int Tmax,
                                     int A, int n, int D, const float* gscale, float* dfeat, uint32_t* rowmask, c3d_stream stream) {
-  hipLaunchKernelGGL(scatter_rows_kernel, dim3(nb_for((size_t)Tmax * A, 4)), dim3(256), 0, ST, dx, img, idx, T, Tmax, A,
-                     n, D, gscale, dfeat, rowmask, (int32_t*)nullptr);
+  if (D % 4 == 0)
+    hipLaunchKernelGGL(scatter_rows_kernel<4>, dim3(nb_for((size_t)Tmax * A, 4)), dim3(256), 0, ST, dx, img, idx, T, Tmax, A,
+                       n, D, gscale, dfeat, rowmask, (int32_t*)nullptr);
+  else
+    hipLaunchKernelGGL(scatter_rows_kernel<1>, dim3(nb_for((size_t)Tmax * A, 4)), dim3(256), 0, ST, dx, img, idx, T, Tmax, A,
+                       n, D, gscale, dfeat, rowmask, (int32_t*)nullptr);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -618,8 +625,12 @@ extern "C" int c3d_scatter_rows_compact(const float* dx, const int32_t* img, con
                                         int A, int n, int D, const float* gscale, float* drows, int32_t* cmap,
                                         uint32_t* rowmask, c3d_stream stream) {
   C3D_REQUIRE(drows && cmap && rowmask, "scatter_rows_compact: drows, cmap and rowmask are required");
-  hipLaunchKernelGGL(scatter_rows_kernel, dim3(nb_for((size_t)Tmax * A, 4)), dim3(256), 0, ST, dx, img, idx, T, Tmax, A,
-                     n, D, gscale, drows, rowmask, cmap);
+  if (D % 4 == 0)
+    hipLaunchKernelGGL(scatter_rows_kernel<4>, dim3(nb_for((size_t)Tmax * A, 4)), dim3(256), 0, ST, dx, img, idx, T, Tmax, A,
+                       n, D, gscale, drows, rowmask, cmap);
+  else
+    hipLaunchKernelGGL(scatter_rows_kernel<1>, dim3(nb_for((size_t)Tmax * A, 4)), dim3(256), 0, ST, dx, img, idx, T, Tmax, A,
+                       n, D, gscale, drows, rowmask, cmap);
   C3D_CHECK_LAUNCH();
   return 0;
 }
