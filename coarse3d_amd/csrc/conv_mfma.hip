@@ -235,19 +235,16 @@ int launch_taps(ConvArgs& a, int halo, hipStream_t st) {
 
 }  // namespace
 
-// Tile rows: the candidate (8, 4, 2) that pads H the least, larger tiles on ties (H = 12 -> 4,
-// not 8: the SemanticPOSS pyramid 48/24/12/6/3 would otherwise waste 25 % of the rows at two
-// levels).  A function of the image height only, so that every conv over the same [B,H,W]
-// produces the same number of statistic partials.
+// Tile rows: 8 wherever that pads H by at most a third, else the candidate (4, 2) that pads H the least, larger tiles on
+// ties.  Round 3: the fused bf16x3 kernels (conv_x3f, conv_pw3f) exist for 8-row tiles only and run 1.5-5x faster per
+// pixel than the narrow-tile kernels (the 256-channel 1x1 convs of the SemanticPOSS pyramid's 12-row level took 169 us on
+// 4-row tiles -- 34 TF), which buys back 33 % padded rows at H = 12 and H = 6 many times over (rounds 1-2 picked 4 / 2
+// there to save the padding).  A function of the image height only, so that every conv over the same [B,H,W] produces
+// the same number of statistic partials.
 static int c3d_tile_rows(int H) {
-  int best = 8, best_pad = (H + 7) / 8 * 8;
-  for (int tr = 4; tr >= 2; tr /= 2) {
-    const int pad = (H + tr - 1) / tr * tr;
-    if (pad < best_pad) {
-      best = tr;
-      best_pad = pad;
-    }
-  }
+  if (((H + 7) / 8 * 8) * 3 <= H * 4) return 8;
+  int best = 4, best_pad = (H + 3) / 4 * 4;
+  if ((H + 1) / 2 * 2 < best_pad) best = 2;
   return best;
 }
 

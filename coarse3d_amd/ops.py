@@ -213,6 +213,13 @@ class PackCache:
         self.fresh = True
 
 
+def _tile_rows(h):
+    """c3d_tile_rows() in csrc/conv_mfma.hip (for the kernel-name mirror of the event timer only)."""
+    if ((h + 7) // 8 * 8) * 3 <= h * 4:
+        return 8
+    return 2 if (h + 1) // 2 * 2 < (h + 3) // 4 * 4 else 4
+
+
 def num_mtiles(b, h, w):
     return L.lib().c3d_conv_num_mtiles(b, h, w)
 
@@ -285,7 +292,7 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         if stat_partial is None or MFMA_MODE != 2 or tuple(stat_mul.shape[:3]) != (b, h, w) or stat_mul.dtype != torch.float32:
             raise ValueError("conv_forward: stat_mul needs statistics, the bf16x3 engine and an fp32 tensor of the output's shape")
         d.stat_mul, d.stat_mul_cstride = stat_mul.data_ptr(), stat_mul.shape[3]
-    tr = min((8, 4, 2), key=lambda t: ((h + t - 1) // t * t, -t))       # c3d_tile_rows() in csrc/conv_mfma.hip
+    tr = _tile_rows(h)
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
     nt_ = len(taps)
     hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
