@@ -1,6 +1,7 @@
 // Shared by the weight-gradient kernels (wgrad_mfma.hip: fp32 MFMA; wgrad_tr.hip: bf16 planes read
 // through ds_read_b64_tr_b16): launch arguments, tile configurations and the partial-sum layout.
 #pragma once
+#include <cstdlib>
 #include "common.h"
 #include "../../include/coarse3d_hip.h"
 
@@ -27,7 +28,7 @@ struct WgCfg {
 
 // planes = 0: fp32 MFMA kernels; 1 / 3: bf16-plane kernels (smaller pixel tiles: three planes of a
 // tile must leave room for two workgroups per CU)
-inline WgCfg c3d_wgrad_cfg(int T, int Cin, int Cout, int planes) {
+inline WgCfg c3d_wgrad_cfg(int T, int Cin, int Cout, int planes, int halo = 1) {
   const bool tr = planes != 0;
   if (T == 1) {
     if (Cin >= 96 && Cout >= 192) return {0, 128, 256, 1};
@@ -37,6 +38,10 @@ inline WgCfg c3d_wgrad_cfg(int T, int Cin, int Cout, int planes) {
   }
   // (one plane: a tile costs a third of the LDS and next to no matrix time; the kernel is then bound by
   //  the per-tile synchronisation, so it takes 4-row tiles everywhere)
+  // (three planes, >= 64 input channels: two consumer waves split a 64-channel cin slice -- twice the MFMAs per staged
+  //  dz element of the 32-channel slice, which left the 2x2 weight gradients at 125-133 TF against 195-210 for the 3x3)
+  //  (halo <= 1: with a two-pixel halo the two tile buffers of that slice exceed the 160 KB of LDS)
+  if (T <= 4 && planes == 3 && Cout > 32 && Cin % 64 == 0 && halo <= 1 && !getenv("C3D_WGRAD_T4_NARROW")) return WgCfg{8, 64, 64, 2};
   if (T <= 4) return Cout > 32 ? WgCfg{4, 32, 64, planes == 3 ? 2 : 4} : WgCfg{5, 32, 32, 4};
   return Cout > 32 ? WgCfg{6, 32, 64, planes == 1 ? 4 : 2} : WgCfg{7, 32, 32, 4};
 }

@@ -352,7 +352,12 @@ int planes_for(const c3d_wgrad_desc* d) {
 }
 
 void plan(const c3d_wgrad_desc* d, WgradArgs& a, WgCfg& c) {
-  c = c3d_wgrad_cfg(d->ntaps, d->x.C, d->Cout, planes_for(d));
+  int halo = 0;
+  for (int t = 0; t < d->ntaps && t < 9; ++t) {
+    const int m = abs(d->tap_dy[t]) > abs(d->tap_dx[t]) ? abs(d->tap_dy[t]) : abs(d->tap_dx[t]);
+    if (m > halo) halo = m;
+  }
+  c = c3d_wgrad_cfg(d->ntaps, d->x.C, d->Cout, planes_for(d), halo);
   a.tiles_x = (d->W + 31) / 32;
   a.tiles_y = (d->H + c.TRW - 1) / c.TRW;
   a.ntiles = d->B * a.tiles_x * a.tiles_y;

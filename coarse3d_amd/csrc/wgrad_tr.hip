@@ -556,6 +556,9 @@ int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
     case 3: return launch_tr<NP, 1, 1, 1, 1, 1, 4, 0>(a, st);
     case 4: return halo <= 1 ? launch_tr<NP, 4, 1, 2, 1, 1, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 4, 1, 2, 1, 1, (NP == 1 ? 4 : 2), 2>(a, st);
     case 5: return halo <= 1 ? launch_tr<NP, 4, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 4, 1, 1, 1, 1, 4, 2>(a, st);
+    case 8:
+      if constexpr (NP == 3) return halo <= 1 ? launch_tr<NP, 4, 1, 2, 2, 1, 2, 1>(a, st) : launch_tr<NP, 4, 1, 2, 2, 1, 2, 2>(a, st);
+      else return -1;
     case 6: return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 2>(a, st);
     default: return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, 4, 2>(a, st);
   }

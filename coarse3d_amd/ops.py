@@ -337,7 +337,10 @@ def _wgrad_kernel_name(ci, co, nt, halo):
         cfg = ("1, 2, 4, 2, 2, 1, 0" if (ci >= 96 and co >= 192) else "1, 2, 2, 2, 2, 1, 0" if (ci >= 96 and co >= 96)
                else f"1, 2, 2, 1, 1, {2 if tr else 4}, 0" if co > 32 else "1, 1, 1, 1, 1, 4, 0")
     elif nt == 4:
-        cfg = f"4, 1, 2, 1, 1, {2 if x3 else 4}, {hl}" if co > 32 else f"4, 1, 1, 1, 1, 4, {hl}"
+        if x3 and co > 32 and ci % 64 == 0 and halo <= 1 and not os.environ.get("C3D_WGRAD_T4_NARROW"):
+            cfg = f"4, 1, 2, 2, 1, 2, {hl}"
+        else:
+            cfg = f"4, 1, 2, 1, 1, {2 if x3 else 4}, {hl}" if co > 32 else f"4, 1, 1, 1, 1, 4, {hl}"
     else:
         cfg = f"9, 1, 1, 1, 2, {4 if (tr and not x3) else 2}, {hl}" if co > 32 else f"9, 1, 1, 1, 1, 4, {hl}"
     if tr:

@@ -12,7 +12,8 @@ dev = "cuda"
 shapes = [(8, 32, 1024, 704, 704, 1, 1, 0), (8, 32, 1024, 704, 256, 1, 1, 0), (8, 64, 2048, 64, 64, 3, 2, 2),
           (8, 64, 2048, 64, 64, 3, 1, 1), (8, 64, 2048, 64, 64, 2, 2, 1), (8, 64, 2048, 32, 32, 3, 1, 1),
           (8, 64, 2048, 32, 32, 3, 2, 2), (8, 64, 2048, 64, 64, 1, 1, 0), (8, 32, 1024, 128, 128, 1, 1, 0),
-          (8, 64, 2048, 32, 32, 1, 1, 0), (8, 32, 1024, 128, 128, 3, 2, 2), (8, 16, 512, 256, 256, 3, 1, 1)]
+          (8, 64, 2048, 32, 32, 1, 1, 0), (8, 32, 1024, 128, 128, 3, 2, 2), (8, 16, 512, 256, 256, 3, 1, 1),
+          (8, 32, 1024, 128, 128, 2, 2, 1), (8, 16, 512, 256, 256, 2, 2, 1), (8, 8, 256, 256, 256, 2, 2, 1)]
 for (B, H, W, Ci, Co, k, dil, pad) in shapes:
     torch.manual_seed(Ci * 7 + Co + k)
     x = torch.randn(B, H, W, Ci, device=dev)
