@@ -230,3 +230,18 @@ def test_flat_adamw_checkpoints_are_torch_adamw_checkpoints():
     named2[0][1].data = named2[0][1].data.clone()
     with pytest.raises(RuntimeError):
         opt2.step()
+
+
+def test_tile_row_rule_of_the_host_mirror_matches_the_library():
+    """ops._tile_rows (used to name the kernel a conv launch will run, for the bench's per-kernel timers) restates
+    c3d_tile_rows of csrc/conv_mfma.hip, which decides the number of BatchNorm-statistic partials of every conv over an
+    image (c3d_conv_num_mtiles, a host call): the two must agree for every height, and 8-row tiles -- the only ones the
+    fused bf16x3 kernels exist for -- are chosen wherever they pad the image by at most a third."""
+    from coarse3d_amd import ops
+    for h in range(1, 200):
+        tr = ops._tile_rows(h)
+        assert tr in (8, 4, 2)
+        assert ops.num_mtiles(3, h, 70) == 3 * ((h + tr - 1) // tr) * 3, h
+        if ((h + 7) // 8 * 8) * 3 <= h * 4:
+            assert tr == 8, h
+    assert [ops._tile_rows(h) for h in (64, 48, 32, 24, 16, 12, 8, 6, 4, 3, 2)] == [8, 8, 8, 8, 8, 8, 8, 8, 4, 4, 2]
