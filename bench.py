@@ -10,10 +10,16 @@ A step = input normalisation -> SalsaNextProto forward (return_feat, use_prototy
 GPU, fp32 (BASELINE.json configs[1]; BASELINE.md section 3 input recipe).  Inputs are resident in
 HBM before the timed region.  Rank 0 prints ONE JSON line.
 
-`roofline`: the dominant kernel is the fp32-MFMA implicit-GEMM convolution; every launch of it is
-bracketed by HIP events on the launch stream during the timed steps, and `achieved` = algorithmic
-FLOPs of those launches / their summed duration, for the template instance with the largest
-total time (name in roofline.kernel; the rocprofv3 summary in profiles/ lists the same name).
+Two passes on one GPU (``--graph auto``, the default): W + K steps launched kernel by kernel, then the same W + K steps
+each replayed as ONE hipGraph (``TrainStep(graph=True)``, bit-identical to the first pass: tests/test_gpu_step.py).
+`value` / `ms_per_step` are the K timed steps of the captured pass -- the launch mode that does not depend on how busy
+the host is (launch by launch the host needs ~20 ms per step; the same run's `launch_by_launch` reports that pass).
+More than one rank: launch by launch (the data-parallel exchanges stay eager).
+
+`roofline`: every launch of the dominant kernel (the template instance with the largest total time; name in
+roofline.kernel, the rocprofv3 summary in profiles/ lists the same name) is bracketed by HIP events on the launch stream
+during the timed steps of the kernel-by-kernel pass (events cannot bracket launches inside a replayed graph), and
+`achieved` = algorithmic FLOPs of those launches / their summed duration.
 `cpu_baseline`: the CPU oracle (a port: oracle/coarse3d_oracle.py) timed on this host.
 """
 import argparse
@@ -246,10 +252,13 @@ def main():
     ap.add_argument("--storage", choices=("bf16", "f32"), default="bf16",
                     help="activation storage of --matrix-dtype bf16 (BASELINE configs[2]): bf16 tensors in HBM "
                          "(default) or fp32 tensors with bf16 MFMA operands only")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step as ONE hipGraph (TrainStep(graph=True): two eager steps, capture, replay).  The "
-                         "default is launch-by-launch, which keeps live HIP events around the dominant kernel inside the "
-                         "timed region; the default run reports the captured step under `engines.graph_replay`")
+    ap.add_argument("--graph", nargs="?", const="on", default="auto", choices=("auto", "on", "off"),
+                    help="how the step is launched.  auto (default; one GPU, SalsaNext): TWO passes of W + K steps over the same "
+                         "batches -- launch by launch, with live HIP events around the dominant kernel inside its timed region "
+                         "(`roofline`, `launch_by_launch`), then replayed as ONE hipGraph per step (TrainStep(graph=True), "
+                         "bit-identical: tests/test_gpu_step.py), whose K timed steps give `value` (the host needs ~20 ms per "
+                         "step launch by launch; on a box whose host is busy that, not the GPU, bounds the step).  on: only the "
+                         "captured step (per-kernel figures from its eager warm-up step).  off: launch by launch only")
     ap.add_argument("--prewarm", type=int, default=3,
                     help="untimed steps ahead of the W warm-up steps (one-time costs of a fresh box; profiling runs pass 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -320,7 +329,7 @@ def main():
     wrapped = D.DataParallel(model) if (world > 1 or single_rank_group or os.environ.get("C3D_FORCE_DP")) else model
     ts = TrainStep(wrapped, args.classes, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512,
                    loss_w_ce_2d=1.0, loss_w_lov_2d=1.0, loss_w_contrast=0.1, feature_mean=FEATURE_MEAN,
-                   feature_std=FEATURE_STD, proto_loss=True, graph=args.graph and world == 1 and not single_rank_group,
+                   feature_std=FEATURE_STD, proto_loss=True, graph=args.graph == "on" and world == 1 and not single_rank_group,
                    inputs_resident=True)      # the batches below are generated and synchronised before the timed region
     if ts.graph and args.warmup < 3:
         args.warmup = 3                       # two eager steps + the capture
@@ -540,15 +549,17 @@ def main():
                        "collectives_per_step": collectives},
             "roofline": roofline,
         }
-        if world == 1 and args.matrix_dtype == "bf16x3" and not args.no_second_engine:
-            # the same step on the fp32-MFMA engine (v_mfma_f32_32x32x2_f32), timed the same way, for comparison
+        auto_graph = (args.graph == "auto" and world == 1 and not single_rank_group and args.net == "salsanext"
+                      and os.environ.get("C3D_WGRAD_STREAM", "0") != "1")
+        second = world == 1 and args.matrix_dtype == "bf16x3" and not args.no_second_engine
+        if auto_graph or second:
             del ts, wrapped, model, res
             torch.cuda.empty_cache()
             k2 = min(args.steps, 10)
 
-            def quick_run(dtype, wgrad_stream, graph=False):
+            def quick_run(dtype, wgrad_stream, graph=False, k2=k2, storage=None):
                 """value / ms_per_step of k2 steps of the same workload on another engine configuration"""
-                ops.set_matrix_precision(dtype)
+                ops.set_matrix_precision(dtype, storage=storage)
                 prev = os.environ.get("C3D_WGRAD_STREAM")
                 os.environ["C3D_WGRAD_STREAM"] = wgrad_stream        # read when the backbone is built
                 try:
@@ -561,8 +572,8 @@ def main():
                     ts2 = TrainStep(m2, args.classes, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512, loss_w_ce_2d=1.0,
                                     loss_w_lov_2d=1.0, loss_w_contrast=0.1, feature_mean=FEATURE_MEAN, feature_std=FEATURE_STD,
                                     proto_loss=True, inputs_resident=True, graph=graph)
-                    for s_ in range(3 if graph else (min(args.warmup, 2) or 1)):
-                        ts2.step(*batches[s_], epoch=10)
+                    for s_ in range((3 + min(args.warmup, 2)) if graph else (min(args.warmup, 2) or 1)):   # graph: 2 eager + capture
+                        ts2.step(*batches[s_ % total_steps], epoch=10)
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
                     for s_ in range(k2):
@@ -578,6 +589,21 @@ def main():
                 torch.cuda.empty_cache()
                 return {"value": round(args.batch * k2 / e2, 3), "ms_per_step": round(e2 / k2 * 1e3, 3), "steps": k2}
 
+        if auto_graph:
+            # second pass: the same K steps (same batches), each replayed as ONE hipGraph -- the launch mode `value` is quoted on
+            eager = {"value": out["value"], "ms_per_step": out["ms_per_step"], "steps": args.steps,
+                     "note": "the first pass of this run: the same K steps launched one kernel at a time (python bench.py --graph off); "
+                             "`roofline` holds the HIP-event kernel times of THIS pass' timed region"}
+            cap = quick_run(args.matrix_dtype, "0", graph=True, k2=args.steps,
+                            storage=args.storage if args.matrix_dtype == "bf16" else None)
+            out["value"], out["ms_per_step"] = cap["value"], cap["ms_per_step"]
+            out["launch_by_launch"] = eager
+            out["config"]["launch"] = ("one hipGraph replay per step (TrainStep(graph=True): two eager steps, capture, replay; "
+                                       "bit-identical to the launch-by-launch step; `launch_by_launch` = the same K steps issued "
+                                       "kernel by kernel in the same process, where the host's ~20 ms per step can be the bound)")
+            ops.set_matrix_precision(args.matrix_dtype, storage=args.storage if args.matrix_dtype == "bf16" else None)
+        if second:
+            # the same step on the fp32-MFMA engine (v_mfma_f32_32x32x2_f32), timed the same way, for comparison
             f32_run = quick_run("f32", os.environ.get("C3D_WGRAD_STREAM", "auto"))
             f32_run["dtype"] = "f32 (v_mfma_f32_32x32x2_f32 everywhere)"
             overlap_run = quick_run("bf16x3", "1")
@@ -585,14 +611,10 @@ def main():
                                    "(C3D_WGRAD_STREAM=1; what data-parallel runs use): weight gradients then execute under the "
                                    "BatchNorm-backward / elementwise kernels of the main chain.  Off by default on one GPU because the "
                                    "kernels of the two streams share the CUs and every per-kernel duration of `roofline` would inflate")
-            graph_run = quick_run("bf16x3", "0", graph=True)
-            graph_run["note"] = ("the headline step captured in ONE hipGraph and replayed (python bench.py --graph; "
-                                 "TrainStep(graph=True): bit-identical to the launch-by-launch step, tests/test_gpu_step.py).  "
-                                 "Launch by launch the host needs ~24 ms per step, so this matters where the GPU needs less "
-                                 "(32x1024 bs=16, the bf16 mode); at 64x2048 bs=8 the GPU is the bound either way")
-            out["engines"] = {"f32_mfma": f32_run, "bf16x3_wgrad_on_second_stream": overlap_run, "graph_replay": graph_run,
-                              "note": "`value` is the bf16x3 engine's on one stream; these are the same step on the fp32-MFMA engine "
-                                      "(python bench.py --matrix-dtype f32 gives its full roofline object) and with the second stream on"}
+            out["engines"] = {"f32_mfma": f32_run, "bf16x3_wgrad_on_second_stream": overlap_run,
+                              "note": "`value` is the bf16x3 engine's on one stream; these are the same step, launched kernel by kernel, "
+                                      "on the fp32-MFMA engine (python bench.py --matrix-dtype f32 gives its full roofline object) and "
+                                      "with the second stream on"}
             ops.set_matrix_precision(args.matrix_dtype)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = (cpu_baseline(args.classes, args.height, args.width) if args.net == "salsanext"

@@ -13,5 +13,5 @@ tools/profile_round.sh round3_poss_bf16x3 --height 40 --width 1800 --classes 14 
 export TMPDIR=/tmp
 ROOT=$(pwd)
 rm -rf /tmp/p_busy; mkdir -p /tmp/p_busy
-(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_busy -o b -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-second-engine --prewarm 0 > $ROOT/gpurun_out/prof/round3_busy.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_busy -o b -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-second-engine --prewarm 0 --graph off > $ROOT/gpurun_out/prof/round3_busy.log 2>&1)
 python3 tools/pmc_step_summary.py $(find /tmp/p_busy -name '*counter_collection.csv' | head -1) 3 > gpurun_out/prof/round3_kitti_bf16x3_mfma_busy.md
