@@ -293,35 +293,43 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
             raise ValueError("conv_forward: stat_mul needs statistics, the bf16x3 engine and an fp32 tensor of the output's shape")
         d.stat_mul, d.stat_mul_cstride = stat_mul.data_ptr(), stat_mul.shape[3]
     tr = _tile_rows(h)
-    halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
     nt_ = len(taps)
-    hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
-    k32 = tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs)
-    if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
-        # nine taps: the fused kernel (round 3), four taps: the phased one; C3D_X3_FUSED=0 forces the phased one
-        fused_ = nt_ == 9 and os.environ.get("C3D_X3_FUSED", "1")[:1] != "0"
-        name = (f"conv_x3{'f' if fused_ else ''}_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, {nt_}, "
-                f"{'true' if grad else 'false'}>")
-    elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
-        name = _pw3_kernel_name(_pw3_tile(b, h, w, cout), sum(s.C for s in srcs), cout)
-    elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
-        np_ = 3 if MFMA_MODE == 2 else 1
-        wide_ = _wide_cout_tiles(b, h, w, cout, tr)
-        name = (f"conv_bfp_kernel<8, {2 if wide_ else 1}, 32, 0, 1, {np_}>" if k32 else
-                f"conv_bfp_kernel<{tr}, {2 if (wide_ or tr == 2) else 1}, 16, {hh}, {nt_}, {np_}>")
-    elif k32:         # mirrors c3d_conv_forward / launch_taps() in csrc/conv_mfma.hip
-        wide = cout > 64 and (cout + 127) // 128 * 128 <= (cout + 63) // 64 * 64
-        name = f"conv_mfma_kernel<8, {4 if wide else (2 if cout > 32 else 1)}, 32, 0, 1>"
-    else:
-        name = f"conv_mfma_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}>"
+    timed = KERNEL_EVENTS is not None        # the kernel-name mirror below only serves the per-kernel event timers
+
+    def kernel_name():
+        halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
+        hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
+        k32 = tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs)
+        if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
+            # nine taps: the fused kernel (round 3), four taps: the phased one; C3D_X3_FUSED=0 forces the phased one
+            fused_ = nt_ == 9 and os.environ.get("C3D_X3_FUSED", "1")[:1] != "0"
+            name = (f"conv_x3{'f' if fused_ else ''}_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, {nt_}, "
+                    f"{'true' if grad else 'false'}>")
+        elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
+            name = _pw3_kernel_name(_pw3_tile(b, h, w, cout), sum(s.C for s in srcs), cout)
+        elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
+            np_ = 3 if MFMA_MODE == 2 else 1
+            wide_ = _wide_cout_tiles(b, h, w, cout, tr)
+            name = (f"conv_bfp_kernel<8, {2 if wide_ else 1}, 32, 0, 1, {np_}>" if k32 else
+                    f"conv_bfp_kernel<{tr}, {2 if (wide_ or tr == 2) else 1}, 16, {hh}, {nt_}, {np_}>")
+        elif k32:         # mirrors c3d_conv_forward / launch_taps() in csrc/conv_mfma.hip
+            wide = cout > 64 and (cout + 127) // 128 * 128 <= (cout + 63) // 64 * 64
+            name = f"conv_mfma_kernel<8, {4 if wide else (2 if cout > 32 else 1)}, 32, 0, 1>"
+        else:
+            name = f"conv_mfma_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}>"
+        return name, halo
     # six plane products: every input gradient, and forward multi-tap convs whose BatchNorm population is large
     # (SIX_FWD_MIN_PIXELS).  conv_pw3 runs six in every launch (the flag is ignored there).
     # (C3D_SIX=0: eight products everywhere -- the probe switch behind DESIGN.md's "where the plane products matter")
     six = (MFMA_MODE == 2 and (grad or (nt_ > 1 and tr == 8 and b * h * w >= SIX_FWD_MIN_PIXELS))
            and os.environ.get("C3D_SIX", "1") != "0")
+    d.mfma_bf16 = 3 if six else MFMA_MODE
+    if not timed:
+        L.check(L.lib().c3d_conv_forward(C.byref(d), _stream()), "c3d_conv_forward")
+        return out, stat_partial
+    name, halo = kernel_name()
     if six and not grad:
         name = name.replace(", false>", ", true>")
-    d.mfma_bf16 = 3 if six else MFMA_MODE
     with _Timed(name, 2.0 * b * h * w * cout * len(taps) * sum(s.C for s in srcs),
                 (h, w, sum(s.C for s in srcs), cout, nt_, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_forward(C.byref(d), _stream()), "c3d_conv_forward")
@@ -372,6 +380,9 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_p
         if dbias is None or dbias.shape[0] != dw.shape[0] or bias_partial.shape[0] < dw.shape[0]:
             raise ValueError("conv_wgrad: bias_partial needs a dbias of Cout entries")
         d.bias_partial, d.dbias, d.bias_n = bias_partial.data_ptr(), dbias.data_ptr(), bias_partial.shape[2]
+    if KERNEL_EVENTS is None:        # (the kernel-name mirror only serves the per-kernel event timers)
+        L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
+        return dw
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
     co, ci, nt = dw.shape[0], src.C, len(taps)
     name = _wgrad_kernel_name(ci, co, nt, halo)
