@@ -11,8 +11,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define C3D_MAX_SRC 3
 #define C3D_MAX_TAPS 9
 
-__device__ __forceinline__ float c3d_lrelu(float v) { return v > 0.f ? v : C3D_LRELU_SLOPE * v; }
-__device__ __forceinline__ float c3d_lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
+// LeakyReLU as max(v, slope * v): the same value as v > 0 ? v : slope * v for every slope in [0, 1] (the entry points
+// refuse others), two VALU instructions instead of three (compare, multiply, select) in every staging loop
+__device__ __forceinline__ float c3d_lrelu(float v) { return __builtin_fmaxf(v, C3D_LRELU_SLOPE * v); }
+__device__ __forceinline__ float c3d_lrelu(float v, float slope) { return __builtin_fmaxf(v, slope * v); }
 // descriptors carry the slope as a float where 0 means the SalsaNext default (0.01)
 inline float c3d_slope_or_default(float s) { return s > 0.f ? s : C3D_LRELU_SLOPE; }
 

@@ -291,6 +291,7 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   a.accumulate = d->accumulate;
   a.stat_partial = d->stat_partial;
   a.slope = c3d_slope_or_default(d->lrelu_slope);
+  C3D_REQUIRE(a.slope <= 1.f, "conv: LeakyReLU slopes above 1 are not supported (the kernels evaluate max(v, slope * v))");
   a.out_bf16 = d->out_bf16;
   a.stat_mul = d->stat_mul;
   a.stat_mul_cs = d->stat_mul_cstride;

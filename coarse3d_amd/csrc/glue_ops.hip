@@ -931,6 +931,7 @@ extern "C" int c3d_conv_in5_wgrad(const float* x_nchw, const float* dz, int B, i
 
 extern "C" int c3d_affine_add(const float* x, const float* a, const float* scale, const float* shift, int64_t npix,
                               int C, float lrelu_slope, float* out, int bf16_mask, c3d_stream stream) {
+  C3D_REQUIRE(lrelu_slope <= 1.f, "affine_add: LeakyReLU slopes above 1 are not supported (max(v, slope * v))");
   C3D_REQUIRE(C % 4 == 0, "affine_add: C must be a multiple of 4");
   if (bf16_mask && C % 8 == 0)
     hipLaunchKernelGGL(affine_add_kernel<8>, dim3(nblocks((size_t)npix * C / 8)), dim3(256), 0, ST, x, a, scale, shift,

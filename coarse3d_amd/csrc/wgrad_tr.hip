@@ -270,7 +270,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
 #pragma unroll
       for (int i = 0; i < D_PT; ++i) {
         const int off = dt + (((i * DSTEP) / 32) * a.W + (i * DSTEP) % 32) * a.dz_cstride + (int)doff0;
-        sg.pd[i] = c3d_ld4u<DBF>(a.dz, dimg, ((dmask >> i) & 1u) ? (unsigned)off : 0u);
+        if constexpr (DBF) {
+          // bf16 gradient, one plane: the four values go to LDS as they are -- the raw 8 bytes travel in the first two
+          // lanes of the register set (no widening here, no rounding back in store_tile: 8 of the ~10 VALU instructions
+          // a dz unit cost the producer waves, which bound this mode)
+          const char* bp = c3d_uniform_ptr(reinterpret_cast<const unsigned short*>(a.dz) + dimg);
+          const unsigned o2 = ((dmask >> i) & 1u) ? (unsigned)off : 0u;
+          const c3d_u32x2 r = *(const __attribute__((address_space(1))) c3d_u32x2*)(bp + (size_t)(o2 * 2u));
+          sg.pd[i] = f32x4{__uint_as_float(r[0]), __uint_as_float(r[1]), 0.f, 0.f};
+        } else {
+          sg.pd[i] = c3d_ld4u<DBF>(a.dz, dimg, ((dmask >> i) & 1u) ? (unsigned)off : 0u);
+        }
       }
     };
     if (NP == 1 && a.x.bf16) load_x(std::true_type{});
@@ -304,7 +314,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
       const int u = tid + i * 256;
       if (u < D_UNITS) {
         u32x2 pl[NP];
-        split_planes<NP>(((sg.dmask >> i) & 1u) ? sg.pd[i] : f32x4{0.f, 0.f, 0.f, 0.f}, pl);
+        if (NP == 1 && a.dz_bf16) {       // raw bf16 (load_dz)
+          const bool in = (sg.dmask >> i) & 1u;
+          pl[0] = u32x2{in ? __float_as_uint(sg.pd[i][0]) : 0u, in ? __float_as_uint(sg.pd[i][1]) : 0u};
+        } else {
+          split_planes<NP>(((sg.dmask >> i) & 1u) ? sg.pd[i] : f32x4{0.f, 0.f, 0.f, 0.f}, pl);
+        }
         const int o = tr_swz<NSD>(u / (CO / 4), (u % (CO / 4)) * 4);
 #pragma unroll
         for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_dz + p * DROWS * CO + o) = pl[p];
