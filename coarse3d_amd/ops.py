@@ -79,7 +79,16 @@ def _bf(*tensors):
     return m
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_dev = torch.cuda.current_device
+
+
 def _stream():
+    """The current HIP stream of the current device as the C ABI wants it.  (torch.cuda.current_stream() builds a
+    Stream object through four Python layers: 9 us per call, ~450 calls per training step = 4 ms of the step's 9.5 ms
+    of host work; the raw query is 0.3 us.)"""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(_cur_dev()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

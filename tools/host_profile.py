@@ -19,7 +19,8 @@ model = SalsaNextProto(5, 20, 20, 0, use_prototype=True).to(dev).train()
 ts = trainer.TrainStep(model, 20, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512, loss_w_ce_2d=1.0, loss_w_lov_2d=1.0,
                        loss_w_contrast=0.1, feature_mean=bench.FEATURE_MEAN, feature_std=bench.FEATURE_STD, proto_loss=True,
                        inputs_resident=True)
-batches = [bench.synth_batch(8, 64, 2048, 20, 1000 + s, dev, 1e-3) for s in range(4)]
+HH, WW = (int(os.environ.get("HP_H", "64")), int(os.environ.get("HP_W", "2048")))
+batches = [bench.synth_batch(8, HH, WW, 20, 1000 + s, dev, 1e-3) for s in range(4)]
 for s in range(4):
     ts.step(*batches[s], epoch=10)
 torch.cuda.synchronize()
