@@ -457,11 +457,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
     constexpr int k = decltype(k_tag)::value;
     constexpr int i = k / 8, r = k % 8;
     if constexpr (r < 2) {
-      const bool in = (inb >> i) & 1u;
+      // zero padding AFTER the transform, as a bit mask: written as `in ? f(v) : 0.f` the compiler built a branch per pair
+      // of elements (s_and_saveexec / s_xor / s_andn2_saveexec / s_or around three VALU instructions each) in the
+      // middle of the MFMA stream
+      const unsigned keep = 0u - ((inb >> i) & 1u);
 #pragma unroll
       for (int q = 2 * r; q < 2 * r + 2; ++q) {
         const float v = __builtin_fmaf(pin[i][q], psc[q], psh[q]);
-        sv[q] = in ? __builtin_fmaxf(v, v * pslope) : 0.f;     // zero padding AFTER the transform
+        sv[q] = __uint_as_float(__float_as_uint(__builtin_fmaxf(v, v * pslope)) & keep);
       }
     } else {
       constexpr int p = (r - 2) / 2, e = (r - 2) % 2;
