@@ -225,3 +225,32 @@ def test_every_backbone_reports_all_gradient_blocks_under_a_process_group(net):
     coll = line["config"]["collectives_per_step"]
     assert coll["gradient_buckets"] >= 1 and coll["syncbn"] >= 2, coll
     assert line["n_gpus"] == 1 and line["value"] > 0
+
+
+def test_bench_line_carries_the_contract_fields_and_both_launch_modes():
+    """One GPU, default flags: the JSON line (LAST stdout line) has the contract's keys; `value` is the pass whose steps
+    are one hipGraph replay each, `launch_by_launch` the kernel-by-kernel pass of the same run (whose timed region the
+    live HIP events of `roofline` bracket); `--graph off` prints the kernel-by-kernel line alone."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "2", "--height", "32",
+            "--width", "256", "--no-cpu-baseline", "--no-second-engine"]
+    r = subprocess.run(base, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "launch_by_launch"):
+        assert k in line, k
+    assert line["steps"] == 3 and line["n_gpus"] == 1 and line["value"] > 0 and line["launch_by_launch"]["value"] > 0
+    assert "hipGraph" in line["config"]["launch"] and "workload" in line["config"]
+    roof = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in roof, k
+    assert roof["bound"] == "mfma" and 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    off = subprocess.run(base + ["--graph", "off"], capture_output=True, text=True, timeout=900)
+    assert off.returncode == 0, off.stderr[-3000:]
+    line_off = json.loads(off.stdout.strip().splitlines()[-1])
+    assert "launch_by_launch" not in line_off and "launch" not in line_off["config"] and line_off["value"] > 0
+    assert line_off["config"]["final_loss"] == line["config"]["final_loss"]       # the same first pass
