@@ -434,6 +434,7 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   }
   C3D_REQUIRE(halo <= 2, "wgrad: tap offsets beyond +-2 are not supported");
   C3D_REQUIRE(d->ntaps != 1 || halo == 0, "wgrad: a single tap must have zero offset");
+  a.xmajor = getenv("C3D_WGRAD_XMAJOR") != nullptr;
   a.partial = d->partial;
   a.slope = c3d_slope_or_default(d->lrelu_slope);
   C3D_REQUIRE(a.slope <= 1.f, "wgrad: LeakyReLU slopes above 1 are not supported (the kernels evaluate max(v, slope * v))");

@@ -212,14 +212,32 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
 
   // coordinates of the next tile to load (producer state, advanced by load_tile)
   int ltx = 0, lty = 0, lb = 0;
+  // Tiles are walked DOWN the image first (tile index = (image, column of tiles, row)): with a halo the next tile of a
+  // strip re-reads 2 * HALO of its TRW + 2 * HALO input rows, and they are the rows the workgroup fetched a tile ago (L2
+  // hits); walking along x the vertical neighbour came tiles_x tiles later, from HBM again.  (The order of the tiles only
+  // changes the order of the fp32 pixel sums; C3D_WGRAD_XMAJOR=1 via a.xmajor restores the round-2 order for A/B.)
+  const bool ymajor = HALO > 0 && !a.xmajor;
   auto seek_tile = [&](int mt) {
-    ltx = mt % a.tiles_x;
-    lty = (mt / a.tiles_x) % a.tiles_y;
+    if (ymajor) {
+      lty = mt % a.tiles_y;
+      ltx = (mt / a.tiles_y) % a.tiles_x;
+    } else {
+      ltx = mt % a.tiles_x;
+      lty = (mt / a.tiles_x) % a.tiles_y;
+    }
     lb = mt / (a.tiles_x * a.tiles_y);
   };
   auto load_tile = [&](Stage& sg) {
     const int x0 = ltx * 32, y0 = lty * TRW, b = lb;
-    if (++ltx == a.tiles_x) {
+    if (ymajor) {
+      if (++lty == a.tiles_y) {
+        lty = 0;
+        if (++ltx == a.tiles_x) {
+          ltx = 0;
+          ++lb;
+        }
+      }
+    } else if (++ltx == a.tiles_x) {
       ltx = 0;
       if (++lty == a.tiles_y) {
         lty = 0;
