@@ -449,7 +449,12 @@ def main():
                     "peak_note": ("fp32-equivalent ceiling of the exact-split engine: dense bf16 MFMA peak 2500 / 8 plane "
                                   "products (forward convs; the gradient kernels run six products: 416.7)")
                                  if peak_tf == PEAK_BF16_MFMA_TFLOPS / 8.0 else
-                                 "fp32-equivalent ceiling of the exact-split engine with six plane products: 2500 / 6"
+                                 "fp32-equivalent ceiling of the exact-split engine with six plane products: 2500 / 6 -- the "
+                                 "NOMINAL dense bf16 peak.  On operands that toggle the chip runs these launches at its power "
+                                 "budget (1.9-2.0 GHz): the same launches on zero-filled tensors are 32-35 % faster "
+                                 "(profiles/round3_dvfs_zero_inputs.txt; 1.23-1.41 PF on random data vs 1.67-1.86 zero-filled, "
+                                 "MI355X_MICROARCH.md's own attention kernel: 1.25 / 1.48), so frac ~0.5-0.56 is the sustained "
+                                 "rate of the matrix pipe on real data, not slack in the schedule"
                                  if peak_tf == PEAK_BF16_MFMA_TFLOPS / 6.0 else
                                  "fp32 MFMA peak (MI355X_MICROARCH.md)",
                     "traffic": traffic,
