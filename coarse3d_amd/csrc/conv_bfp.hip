@@ -23,10 +23,28 @@
 namespace {
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 // 4 floats -> NP x (4 bf16 packed in 2 dwords)
+// EXPERIMENT (NP == 2, "f16x2"): two fp16 planes, x = H + L to 2^-24 |x|, three products H*H' + H*L' + L*H'
 template <int NP>
 __device__ __forceinline__ void split4(f32x4 v, u32x2 (&out)[NP]) {
+  if constexpr (NP == 2) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    f32x4 r = v;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      f16x4 h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h[q] = (_Float16)r[q];
+      out[p] = __builtin_bit_cast(u32x2, h);
+      if (p == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] -= (float)h[q];
+      }
+    }
+    return;
+  }
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   f32x4 r = v;
 #pragma unroll
@@ -234,7 +252,13 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
 #define C3D_PLANE(PA, PB)                                                                          \
   _Pragma("unroll") for (int i = 0; i < RPW; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)  \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA][i], bp[PB][j], acc[i][j], 0, 0, 0);
-          if constexpr (NP == 3) {
+#define C3D_PLANE_H(PA, PB)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < RPW; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)  \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ap[PA][i]),   \
+                                                          __builtin_bit_cast(f16x8_t, bp[PB][j]), acc[i][j], 0, 0, 0);
+          if constexpr (NP == 2) {
+            C3D_PLANE_H(1, 0) C3D_PLANE_H(0, 1) C3D_PLANE_H(0, 0)
+          } else if constexpr (NP == 3) {
             // eight of the nine plane products, smallest first; only l*l (< 2^-32 |a||b|) is dropped:
             // every a*b is then exact to 2^-32, i.e. the result carries fp32 ACCUMULATION rounding only
             C3D_PLANE(2, 1) C3D_PLANE(1, 2) C3D_PLANE(2, 0) C3D_PLANE(0, 2) C3D_PLANE(1, 1) C3D_PLANE(1, 0) C3D_PLANE(0, 1)
@@ -243,6 +267,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
             C3D_PLANE(0, 0)
           }
 #undef C3D_PLANE
+#undef C3D_PLANE_H
         }
       }
     };
@@ -254,7 +279,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
     c0 = c2;
     kbase = kb2;
   }
-  conv_epilogue<TR, NT, WM, WN, NP == 1, false, 256, false, NP == 3>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
+  conv_epilogue<TR, NT, WM, WN, NP == 1, false, 256, false, NP >= 2>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
                                                                      tile_pix);
 }
 
@@ -298,5 +323,6 @@ int dispatch_bfp(ConvArgs& a, int tr, int halo, bool k32, hipStream_t st) {
 
 // called by c3d_conv_forward (conv_mfma.hip) for mfma_bf16 = 1 (planes = 1) or 2 (planes = 3)
 int c3d_conv_forward_bfp(ConvArgs& a, int planes, int tr, int halo, bool k32, hipStream_t st) {
+  if (planes == 3 && getenv("C3D_F16X2")) return dispatch_bfp<2>(a, tr, halo, k32, st);     // EXPERIMENT
   return planes == 3 ? dispatch_bfp<3>(a, tr, halo, k32, st) : dispatch_bfp<1>(a, tr, halo, k32, st);
 }

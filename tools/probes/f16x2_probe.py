@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""EXPERIMENT for round 4: two fp16 planes / three products (C3D_F16X2=1, conv_bfp only) against the exact three-bf16-plane
+split with eight products in the same phased kernel: time and error vs float64.  3x3 256->256 on 4-row tiles (the shape
+class conv_bfp serves in the bf16x3 mode).  Operands are pre-scaled by exact powers of two (fp16's range)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import torch.nn.functional as F
+from coarse3d_amd import ops
+
+ops.set_matrix_precision("bf16x3")
+dev = "cuda"
+
+
+def timeit(fn, n=20):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+B, H, W, Ci, Co = 64, 4, 512, 256, 256
+g = torch.Generator().manual_seed(0)
+x = torch.randn(B, H, W, Ci, generator=g).to(dev)
+w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.02).to(dev)
+taps = ops.conv_taps(3, 3, 1, 1)
+ref = F.conv2d(x[:2].double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
+fl = 2.0 * B * H * W * Ci * Co * 9
+for label, env, xs, ws in (("bf16x3, 8 products", None, 0, 0), ("f16x2, 3 products, unscaled", "1", 0, 0),
+                           ("f16x2, 3 products, x * 2^6, w * 2^10", "1", 6, 10)):
+    if env:
+        os.environ["C3D_F16X2"] = env
+    else:
+        os.environ.pop("C3D_F16X2", None)
+    xi, wi = x * 2.0 ** xs, w * 2.0 ** ws
+    wp = ops.pack_weights(wi, 0)
+    out = torch.empty(B, H, W, Co, device=dev)
+    f = lambda: ops.conv_forward([ops.Source(xi)], wp, None, Co, taps, out=out)
+    ms = timeit(f)
+    y = out[:2].double() * 2.0 ** -(xs + ws)
+    err = (y - ref).abs()
+    print(f"{label:40s} {ms * 1e3:7.1f} us  {fl / ms / 1e9:6.1f} TF-equivalent   max err / max|y| {float(err.max() / ref.abs().max()):.2e}   "
+          f"rms err / rms y {float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()):.2e}", flush=True)
+# fp32 reference error for scale: torch fp32 conv on the GPU
+y32 = F.conv2d(x[:2].permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1).double()
+e32 = (y32 - ref).abs()
+print(f"{'torch fp32 conv (MIOpen)':40s}                                  max err / max|y| {float(e32.max() / ref.abs().max()):.2e}   "
+      f"rms err / rms y {float(e32.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()):.2e}")
