@@ -54,3 +54,28 @@ y32 = F.conv2d(x[:2].permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1).doub
 e32 = (y32 - ref).abs()
 print(f"{'torch fp32 conv (MIOpen)':40s}                                  max err / max|y| {float(e32.max() / ref.abs().max()):.2e}   "
       f"rms err / rms y {float(e32.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()):.2e}")
+
+# gradient-like operand: wide dynamic range (log-normal magnitudes around 1e-6), per-tensor exponent from its maximum
+print("-- gradient-like activations: randn * exp(2 randn) * 1e-6, weights as above")
+xg = (torch.randn(B, H, W, Ci, generator=g) * torch.exp(2.0 * torch.randn(B, H, W, Ci, generator=g)) * 1e-6).to(dev)
+refg = F.conv2d(xg[:2].double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
+import math
+kx = 14 - math.ceil(math.log2(float(xg.abs().max())))
+for label, env, xs, ws in (("bf16x3, 8 products", None, 0, 0), ("f16x2, 3 products, unscaled", "1", 0, 0),
+                           (f"f16x2, 3 products, x * 2^{kx} (max -> 2^14), w * 2^10", "1", kx, 10)):
+    if env:
+        os.environ["C3D_F16X2"] = env
+    else:
+        os.environ.pop("C3D_F16X2", None)
+    xi, wi = xg * 2.0 ** xs, w * 2.0 ** ws
+    wp = ops.pack_weights(wi, 0)
+    out = torch.empty(B, H, W, Co, device=dev)
+    ops.conv_forward([ops.Source(xi)], wp, None, Co, taps, out=out)
+    y = out[:2].double() * 2.0 ** -(xs + ws)
+    err = (y - refg).abs()
+    print(f"{label:56s} max err / max|y| {float(err.max() / refg.abs().max()):.2e}   rms err / rms y "
+          f"{float(err.pow(2).mean().sqrt() / refg.pow(2).mean().sqrt()):.2e}", flush=True)
+y32 = F.conv2d(xg[:2].permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1).double()
+e32 = (y32 - refg).abs()
+print(f"{'torch fp32 conv (MIOpen)':56s} max err / max|y| {float(e32.max() / refg.abs().max()):.2e}   rms err / rms y "
+      f"{float(e32.pow(2).mean().sqrt() / refg.pow(2).mean().sqrt()):.2e}")
