@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
             for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q], a.slope);
           }
         }
+        if constexpr (NP == 2) v = v * 64.f;            // f16x2: keep the low plane out of fp16's subnormals (exact)
         u32x2 pl[NP];
         split4<NP>(v, pl);
 #pragma unroll
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
         const int r = u / TN;
         const int kq = r % CQ, t = r / CQ;
         u32x2 pl[NP];
-        split4<NP>(pw[i], pl);
+        split4<NP>(NP == 2 ? pw[i] * 1024.f : pw[i], pl);
 #pragma unroll
         for (int p = 0; p < NP; ++p)
           *reinterpret_cast<u32x2*>(s_w + (p * W_ROWS + t * TN + n) * CSB + kq * 4) = pl[p];
@@ -323,6 +324,9 @@ int dispatch_bfp(ConvArgs& a, int tr, int halo, bool k32, hipStream_t st) {
 
 // called by c3d_conv_forward (conv_mfma.hip) for mfma_bf16 = 1 (planes = 1) or 2 (planes = 3)
 int c3d_conv_forward_bfp(ConvArgs& a, int planes, int tr, int halo, bool k32, hipStream_t st) {
-  if (planes == 3 && getenv("C3D_F16X2")) return dispatch_bfp<2>(a, tr, halo, k32, st);     // EXPERIMENT
+  if (planes == 2 || (planes == 3 && getenv("C3D_F16X2"))) {     // EXPERIMENT (mfma_bf16 == 4 / the probe's switch)
+    a.acc_scale = 1.f / 65536.f;                                   // operands are staged times 2^6 and 2^10
+    return dispatch_bfp<2>(a, tr, halo, k32, st);
+  }
   return planes == 3 ? dispatch_bfp<3>(a, tr, halo, k32, st) : dispatch_bfp<1>(a, tr, halo, k32, st);
 }

@@ -25,6 +25,8 @@ struct ConvArgs {
   int six;                   // bf16x3: six plane products instead of eight (input-gradient convs, mfma_bf16 == 3)
   const float* stat_mul;     // NULL, or the tensor whose product with the stored values replaces v*v in stat_partial
   int stat_mul_cs;
+  float acc_scale = 1.f;   // the accumulators are multiplied by this before bias / activation (1: fma(acc, 1, bias) == acc + bias);
+                           // the f16x2 experiment stages its operands times 2^6 / 2^10 and hands 2^-16 back here
 };
 
 // 64-cout tiles (two 32-wide sub-tiles per workgroup) unless the grid would then cover too few CUs -- the 8 x 256 and
@@ -89,7 +91,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = acc[i][j][r] + bias;
+        float v = __builtin_fmaf(acc[i][j][r], a.acc_scale, bias);
         if (a.epi_lrelu) v = c3d_lrelu(v, a.slope);
         if (cok && gy < a.H && gx < a.W) {
           const size_t o = ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co;
@@ -142,7 +144,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r] + bias;
+          float v = __builtin_fmaf(acc[i][j][r], a.acc_scale, bias);
           if (a.epi_lrelu) v = c3d_lrelu(v, a.slope);
           if constexpr (ACC) v += old[r];
           // fresh outputs leave with the nontemporal hint: the tile's halo / weight re-reads live on L2 hits and the

@@ -310,7 +310,12 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   a.ntn = 1;
   hipStream_t st = (hipStream_t)stream;
   if (d->mfma_bf16) {      // opt-in precision modes on the bf16 matrix pipe (conv_bfp.hip)
-    C3D_REQUIRE(d->mfma_bf16 >= 1 && d->mfma_bf16 <= 3, "conv: mfma_bf16 must be 0, 1, 2 or 3");
+    C3D_REQUIRE(d->mfma_bf16 >= 1 && d->mfma_bf16 <= 4, "conv: mfma_bf16 must be 0, 1, 2, 3 or 4");
+    if (d->mfma_bf16 == 4) {     // EXPERIMENT: two fp16 planes, three products, generic kernel (forward convs; DESIGN.md round-4 list)
+      bool k32f = tr == 8 && d->ntaps == 1;
+      for (int s = 0; s < d->nsrc; ++s) k32f = k32f && (d->src[s].C % 32 == 0);
+      return c3d_conv_forward_bfp(a, 2, tr, halo, k32f, st);
+    }
     bool k32 = true;
     for (int s = 0; s < d->nsrc; ++s) k32 = k32 && (d->src[s].C % 32 == 0);
     const bool x3 = d->mfma_bf16 >= 2;      // 3 = the exact-split engine with six plane products (input gradients)

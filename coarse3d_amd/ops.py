@@ -79,6 +79,7 @@ def _bf(*tensors):
     return m
 
 
+F16X2_FWD = os.environ.get("C3D_F16X2_FWD", "0") == "1"
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _cur_dev = torch.cuda.current_device
 
@@ -333,6 +334,10 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     six = (MFMA_MODE == 2 and (grad or (nt_ > 1 and tr == 8 and b * h * w >= SIX_FWD_MIN_PIXELS))
            and os.environ.get("C3D_SIX", "1") != "0")
     d.mfma_bf16 = 3 if six else MFMA_MODE
+    if F16X2_FWD and MFMA_MODE == 2 and not grad and b * h * w >= SIX_FWD_MIN_PIXELS:
+        # EXPERIMENT (C3D_F16X2_FWD=1; DESIGN.md round-4 list): forward convs over large BatchNorm populations -- where the
+        # exact split already runs six products -- on two fp16 planes / three products, generic kernel
+        d.mfma_bf16 = 4
     if not timed:
         L.check(L.lib().c3d_conv_forward(C.byref(d), _stream()), "c3d_conv_forward")
         return out, stat_partial

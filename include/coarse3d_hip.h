@@ -90,7 +90,10 @@ typedef struct {
                                3: as 2 with SIX plane products (l*m and m*l dropped too) -- for INPUT-GRADIENT
                                convolutions (transposed weights, negated taps): measured to leave every
                                gradient's error against float64 unchanged, while on the forward activations
-                               six products cost 4-5x the fp32 engine's noise (csrc/conv_x3.hip)          */
+                               six products cost 4-5x the fp32 engine's noise (csrc/conv_x3.hip).
+                               4 (EXPERIMENT, round 3): two fp16 planes (x = H + L to 2^-24 |x|), three products
+                               H*H' + H*L' + L*H', operands staged times 2^6 / 2^10 against fp16's range, generic
+                               kernel; forward convolutions only (profiles/round3_f16x2_probe.txt)            */
   int32_t out_bf16;         /* 1: `out` is bf16 (values rounded RNE on store, accumulate reads bf16);
                                the statistics partials are taken from the fp32 values; mfma_bf16 == 1 only */
   int32_t wpack_planes;     /* 1: wpack came from c3d_pack_weights(mode | 2): the three bf16 planes of the
