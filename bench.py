@@ -623,7 +623,17 @@ def main():
                                    "(C3D_WGRAD_STREAM=1; what data-parallel runs use): weight gradients then execute under the "
                                    "BatchNorm-backward / elementwise kernels of the main chain.  Off by default on one GPU because the "
                                    "kernels of the two streams share the CUs and every per-kernel duration of `roofline` would inflate")
-            out["engines"] = {"f32_mfma": f32_run, "bf16x3_wgrad_on_second_stream": overlap_run,
+            ops.F16X2_FWD = True
+            try:
+                f16_run = quick_run("bf16x3", "0")
+            finally:
+                ops.F16X2_FWD = False
+            f16_run["note"] = ("EXPERIMENT, off by default (C3D_F16X2_FWD=1): the headline engine with the FORWARD convolutions over >= 32768 "
+                               "pixels on two fp16 planes (x = H + L to 2^-24 |x|, operands staged times 2^6 / 2^10) and three products "
+                               "instead of six -- fused nine-tap kernel conv_x3f_kernel<..., 2>, generic kernel elsewhere; gradients "
+                               "unchanged.  The whole GPU parity suite passes with it; error vs float64 equals the exact split's "
+                               "(profiles/round3_f16x2_probe.txt); launched kernel by kernel")
+            out["engines"] = {"f32_mfma": f32_run, "bf16x3_wgrad_on_second_stream": overlap_run, "bf16x3_f16x2_forward": f16_run,
                               "note": "`value` is the bf16x3 engine's on one stream; these are the same step, launched kernel by kernel, "
                                       "on the fp32-MFMA engine (python bench.py --matrix-dtype f32 gives its full roofline object) and "
                                       "with the second stream on"}

@@ -25,6 +25,7 @@ struct ConvArgs {
   int six;                   // bf16x3: six plane products instead of eight (input-gradient convs, mfma_bf16 == 3)
   const float* stat_mul;     // NULL, or the tensor whose product with the stored values replaces v*v in stat_partial
   int stat_mul_cs;
+  bool f16x2 = false;      // EXPERIMENT (mfma_bf16 == 4): two fp16 planes / three products where a kernel has the variant
   float acc_scale = 1.f;   // the accumulators are multiplied by this before bias / activation (1: fma(acc, 1, bias) == acc + bias);
                            // the f16x2 experiment stages its operands times 2^6 / 2^10 and hands 2^-16 back here
 };

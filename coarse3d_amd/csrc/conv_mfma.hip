@@ -314,6 +314,10 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
     if (d->mfma_bf16 == 4) {     // EXPERIMENT: two fp16 planes, three products, generic kernel (forward convs; DESIGN.md round-4 list)
       bool k32f = tr == 8 && d->ntaps == 1;
       for (int s = 0; s < d->nsrc; ++s) k32f = k32f && (d->src[s].C % 32 == 0);
+      if (tr == 8 && d->ntaps == 9 && d->wpack_planes && !getenv("C3D_F16X2_GENERIC")) {     // the fused nine-tap kernel has the variant
+        a.f16x2 = true;
+        return c3d_conv_forward_x3(a, halo, st);
+      }
       return c3d_conv_forward_bfp(a, 2, tr, halo, k32f, st);
     }
     bool k32 = true;

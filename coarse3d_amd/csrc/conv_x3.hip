@@ -296,8 +296,20 @@ struct c3d_x3_products {
   static constexpr int last_b(int p) { int l = -1; for (int q = 0; q < N; ++q) if (pb(q) == p) l = q; return l; }
 };
 
-template <int NT, int HALO, int TT, bool SIX>
+// EXPERIMENT (NPL = 2, "f16x2"): two fp16 planes per operand, three products -- L*H', H*H', H*L' (no plane both opens and
+// closes a tap); DESIGN.md round-4 list, profiles/round3_f16x2_probe.txt
+struct c3d_x3_products_f16 {
+  static constexpr int N = 3;
+  static constexpr int pa(int q) { constexpr int t[3] = {1, 0, 0}; return t[q]; }
+  static constexpr int pb(int q) { constexpr int t[3] = {0, 0, 1}; return t[q]; }
+  static constexpr int last_a(int p) { int l = -1; for (int q = 0; q < N; ++q) if (pa(q) == p) l = q; return l; }
+  static constexpr int last_b(int p) { int l = -1; for (int q = 0; q < N; ++q) if (pb(q) == p) l = q; return l; }
+};
+
+template <int NT, int HALO, int TT, bool SIX, int NPL = 3>
 __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
+  constexpr bool F16 = NPL == 2;
+  typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
   constexpr int TR = 8, CQ = 4;                    // 16 channels per K chunk
   constexpr int TWh = 32 + 2 * HALO, THh = TR + 2 * HALO;
   constexpr int TN = 32 * NT;
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   constexpr int WG_ROWS = G * TN;
   constexpr int W_UNITS = WG_ROWS * CQ;
   constexpr int W_PT = (W_UNITS + 255) / 256;
-  using PR = c3d_x3_products<SIX>;
+  using PR = std::conditional_t<F16, c3d_x3_products_f16, c3d_x3_products<SIX>>;
   constexpr int NQ = PR::N;
 
   // LDS rows are padded to whole staging units (64 rows per unit index): unit i of a thread is row tid/4 + 64 i,
@@ -318,9 +330,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   // nobody reads, so the staging needs no predicates, no clamps and no per-unit address registers
   constexpr int IN_ROWS_P = IN_PT * 64, WG_ROWS_P = W_PT * 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  unsigned short* s_in = reinterpret_cast<unsigned short*>(smem);   // [3][IN_ROWS_P][16]
-  unsigned short* s_w0 = s_in + 3 * IN_ROWS_P * 16;                 // 2 x [3][WG_ROWS_P][16]
-  constexpr int WBUF = 3 * WG_ROWS_P * 16;
+  unsigned short* s_in = reinterpret_cast<unsigned short*>(smem);   // [NPL][IN_ROWS_P][16]
+  unsigned short* s_w0 = s_in + NPL * IN_ROWS_P * 16;               // 2 x [NPL][WG_ROWS_P][16]
+  constexpr int WBUF = NPL * WG_ROWS_P * 16;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -359,8 +371,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
     if (p < IN_ROWS && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H) inb |= 1u << i;
   }
   const unsigned wplane_b = (unsigned)a.T * a.Kq * a.Cout * 8;                  // bytes per bf16 weight plane
+  // (F16: the fp32 image at the head of the pack, 16 bytes per unit, split in the kernel -- no fp16 planes in the pack yet)
+  constexpr unsigned WU = F16 ? 16u : 8u;                                       // bytes per weight unit in global memory
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.wpack) + (size_t)a.T * a.Kq * a.Cout * 4, 0, 3 * wplane_b, 0x00020000);
+      const_cast<float*>(a.wpack) + (F16 ? (size_t)0 : (size_t)a.T * a.Kq * a.Cout * 4), 0, F16 ? 2 * wplane_b : 3 * wplane_b,
+      0x00020000);
   // weight unit i: u = tid + 256 i -> cout n = u % TN, row r = u / TN = kq + 4 * tap-in-row; slab row tg * TN + n
   unsigned vw[W_PT];
 #pragma unroll
@@ -369,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
     const int n = u % TN;
     const int r = u / TN;
     const int kq = r % CQ, tg = r / CQ;
-    vw[i] = (u < W_UNITS && n0 + n < a.Cout) ? (unsigned)(((tg * a.Kq + kq) * a.Cout + n0 + n) * 8) : OOB;
+    vw[i] = (u < W_UNITS && n0 + n < a.Cout) ? (unsigned)(((tg * a.Kq + kq) * a.Cout + n0 + n) * WU) : OOB;
   }
   // LDS byte offsets of unit 0 (plane 0): input row r0, weight row (tid / TN / 4) * TN + tid % TN; unit i adds a constant
   const int wR0 = (tid / TN / CQ) * TN + tid % TN, wkq0 = (tid / TN) % CQ;
@@ -418,8 +433,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
 
   // ---- registers in flight
   f32x4 pin[IN_PT];                        // raw input of the chunk after next (after its atoms ran: of the one after)
-  u32x2 npl[IN_PT][3];                     // the next chunk's planes, waiting for the store phase
-  u32x2 pw[W_PT][3];
+  u32x2 npl[IN_PT][NPL];                   // the next chunk's planes, waiting for the store phase
+  u32x2 pw[W_PT][NPL];
+  f32x4 pwf[F16 ? W_PT : 1];               // F16: the raw fp32 weight units in flight
   f32x4 psc, psh;
   float pslope;
   auto load_in = [&](int i) { pin[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vin[i], lc0 * 4, 0)); };
@@ -427,14 +443,22 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
     const int so = (lstep >> 6) * lc0 * 4;
     psc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_sc, vaff, so, 0));
     psh = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_sh, vaff, so, 0));
+    if constexpr (F16) {                   // activations staged times 2^6 (LeakyReLU is positively homogeneous: exact)
+      psc = psc * 64.f;
+      psh = psh * 64.f;
+    }
     pslope = lslope;
   };
   auto load_w = [&](int i) {               // weight unit i of pair wq (clamped to the last pair)
     const int q = min(wq, nwq - 1);
     const int chunk = q / NG, g = q % NG;
-    const int so = (g * G * a.Kq + chunk * 4) * a.Cout * 8;
+    const int so = (g * G * a.Kq + chunk * 4) * a.Cout * WU;
+    if constexpr (F16) {
+      pwf[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, vw[i], so, 0));
+    } else {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) pw[i][p] = __builtin_amdgcn_raw_buffer_load_b64(rs_w, vw[i], so + p * wplane_b, 0);
+      for (int p = 0; p < NPL; ++p) pw[i][p] = __builtin_amdgcn_raw_buffer_load_b64(rs_w, vw[i], so + p * wplane_b, 0);
+    }
   };
 
   // ---- atoms of the NEXT chunk's input, two lists: LOAD (the units' raw values + scale / shift, issued early in the
@@ -446,8 +470,20 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   static_assert(NG > 1, "the fused schedule needs more than one tap row per chunk");
   f32x4 sv;
   constexpr int LOAD_ATOMS = IN_PT + 1;            // + scale / shift
-  constexpr int CONV_ATOMS = IN_PT * 8;
-  constexpr int W_ATOMS = W_PT * 4;
+  constexpr int CA_U = 2 + 2 * NPL;                // atoms per input unit: XF e0, XF e1, then two SPLIT halves per plane
+  constexpr int CONV_ATOMS = IN_PT * CA_U;
+  constexpr int WA_U = NPL + 1;                    // atoms per weight unit: one store per plane, then the next load
+  constexpr int W_ATOMS = W_PT * WA_U;
+  // two fp16 planes of two floats: H = RNE11(x), L = RNE11(x - H)
+  auto split_f16 = [](float x0, float x1, float& r0, float& r1) {
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    f16x2_t h;
+    h[0] = (_Float16)x0;
+    h[1] = (_Float16)x1;
+    r0 = x0 - (float)h[0];
+    r1 = x1 - (float)h[1];
+    return __builtin_bit_cast(unsigned, h);
+  };
   auto load_atom = [&](auto k_tag) {
     constexpr int k = decltype(k_tag)::value;
     if constexpr (k == IN_PT) load_aff();
@@ -455,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   };
   auto conv_atom = [&](auto k_tag) {
     constexpr int k = decltype(k_tag)::value;
-    constexpr int i = k / 8, r = k % 8;
+    constexpr int i = k / CA_U, r = k % CA_U;
     if constexpr (r < 2) {
       // zero padding AFTER the transform, as a bit mask: written as `in ? f(v) : 0.f` the compiler built a branch per pair
       // of elements (s_and_saveexec / s_xor / s_andn2_saveexec / s_or around three VALU instructions each) in the
@@ -468,6 +504,15 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
       }
     } else {
       constexpr int p = (r - 2) / 2, e = (r - 2) % 2;
+      if constexpr (F16) {
+        float r0, r1;
+        npl[i][p][e] = split_f16(sv[2 * e], sv[2 * e + 1], r0, r1);
+        if constexpr (p == 0) {
+          sv[2 * e] = r0;
+          sv[2 * e + 1] = r1;
+        }
+        return;
+      }
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       bf16x2 h;
       h[0] = (__bf16)sv[2 * e];
@@ -482,8 +527,16 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   };
   auto w_atom = [&](auto k_tag, unsigned short* s_w) {
     constexpr int k = decltype(k_tag)::value;
-    constexpr int i = k / 4, r = k % 4;
-    if constexpr (r < 3) {
+    constexpr int i = k / WA_U, r = k % WA_U;
+    if constexpr (r < NPL) {
+      if constexpr (F16 && r == 0) {           // weights staged times 2^10, split here (the pack carries bf16 planes only)
+        const f32x4 wv = pwf[i] * 1024.f;
+        float r0, r1, r2, r3, d0, d1;
+        pw[i][0][0] = split_f16(wv[0], wv[1], r0, r1);
+        pw[i][0][1] = split_f16(wv[2], wv[3], r2, r3);
+        pw[i][1][0] = split_f16(r0, r1, d0, d1);
+        pw[i][1][1] = split_f16(r2, r3, d0, d1);
+      }
       *reinterpret_cast<u32x2*>(s_w + (r * WG_ROWS_P + wR0 + i * W_ROW_STEP) * 16 + swz_quad(wR0, wkq0)) = pw[i][r];
     } else {
       load_w(i);
@@ -493,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < IN_PT; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NPL; ++p)
         *reinterpret_cast<u32x2*>(s_in + (p * IN_ROWS_P + r0 + 64 * i) * 16 + swz_quad(r0, c4)) = npl[i][p];
   };
 
@@ -514,8 +567,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
     constexpr int NS = G * NQ;                        // slots = products
     const unsigned short* s_w = s_w0 + wb * WBUF;
     unsigned short* d_w = s_w0 + (wb ^ 1) * WBUF;
-    bf16x8 ap[3][RPW];
-    bf16x8 bq[3][NJ];
+    bf16x8 ap[NPL][RPW];
+    bf16x8 bq[NPL][NJ];
     // (no plane both closes a tap and opens the next one -- static_assert below -- so one register set per plane)
     static_assert(PR::last_a(PR::pa(0)) != NQ - 1 && PR::last_b(PR::pb(0)) != NQ - 1, "a tap must not open with the plane it closed with");
     // (`fresh` is zero, but opaque to the compiler and redefined per tap row: the 2 x 9 fragment row addresses are then
@@ -557,7 +610,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < RPW; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA][i], bq[PB][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) {
+          if constexpr (F16)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ap[PA][i]), __builtin_bit_cast(f16x8_t, bq[PB][j]),
+                                                               acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA][i], bq[PB][j], acc[i][j], 0, 0, 0);
+        }
       // fragments of the next tap: each plane right after its last product of this tap
       if constexpr (tg + 1 < G) {
         if constexpr (PR::last_a(PA) == q) read_a(tg + 1, PA);
@@ -612,22 +671,23 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   conv_epilogue<TR, NT, WM, WN, false, false, 256, false, true>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
 }
 
-template <int NT, int HALO, int TT, bool SIX>
+template <int NT, int HALO, int TT, bool SIX, int NPL = 3>
 int launch_x3f_s(ConvArgs& a, hipStream_t st) {
   constexpr int G = (TT == 9) ? 3 : TT;
   constexpr int IN_PT = ((8 + 2 * HALO) * (32 + 2 * HALO) * 4 + 255) / 256, W_PT = (G * 32 * NT * 4 + 255) / 256;
-  size_t lds = (size_t)3 * (IN_PT * 64 + 2 * W_PT * 64) * 16 * 2;      // rows padded to whole staging units
+  size_t lds = (size_t)NPL * (IN_PT * 64 + 2 * W_PT * 64) * 16 * 2;      // rows padded to whole staging units
   const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
   if (lds < red) lds = red;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3f_kernel<NT, HALO, TT, SIX>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3f_kernel<NT, HALO, TT, SIX, NPL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
-  hipLaunchKernelGGL((conv_x3f_kernel<NT, HALO, TT, SIX>), grid, dim3(256), lds, st, a);
+  if (NPL == 2) a.acc_scale = 1.f / 65536.f;           // operands staged times 2^6 and 2^10
+  hipLaunchKernelGGL((conv_x3f_kernel<NT, HALO, TT, SIX, NPL>), grid, dim3(256), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -657,6 +717,7 @@ int launch_x3(ConvArgs& a, hipStream_t st) {
     // the fused kernel; C3D_X3_FUSED=0: round 2's phased kernel (same-box A/B and the bit-identity test; read per
     // launch on purpose)
     const char* e = getenv("C3D_X3_FUSED");
+    if (a.f16x2) return launch_x3f_s<NT, HALO, TT, true, 2>(a, st);           // EXPERIMENT: two fp16 planes, three products
     if (!(e && e[0] == '0')) return a.six ? launch_x3f_s<NT, HALO, TT, true>(a, st) : launch_x3f_s<NT, HALO, TT, false>(a, st);
   }
   return a.six ? launch_x3_s<NT, HALO, TT, true>(a, st) : launch_x3_s<NT, HALO, TT, false>(a, st);
