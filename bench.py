@@ -629,7 +629,7 @@ def main():
             finally:
                 ops.F16X2_FWD = False
             f16_run["note"] = ("EXPERIMENT, off by default (C3D_F16X2_FWD=1): the headline engine with the FORWARD convolutions over >= 32768 "
-                               "pixels on two fp16 planes (x = H + L to 2^-24 |x|, operands staged times 2^6 / 2^10) and three products "
+                               "pixels on two fp16 planes (x = H + L to 2^-22 |x| worst case -- a 22-bit operand, NOT the exact split --, staged times 2^6 / 2^10) and three products "
                                "instead of six -- fused nine-tap kernel conv_x3f_kernel<..., 2>, generic kernel elsewhere; gradients "
                                "unchanged.  The whole GPU parity suite passes with it; error vs float64 equals the exact split's "
                                "(profiles/round3_f16x2_probe.txt); launched kernel by kernel")

@@ -26,7 +26,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 // 4 floats -> NP x (4 bf16 packed in 2 dwords)
-// EXPERIMENT (NP == 2, "f16x2"): two fp16 planes, x = H + L to 2^-24 |x|, three products H*H' + H*L' + L*H'
+// EXPERIMENT (NP == 2, "f16x2"): two fp16 planes, x = H + L to 2^-22 |x| (worst case), three products H*H' + H*L' + L*H'
 template <int NP>
 __device__ __forceinline__ void split4(f32x4 v, u32x2 (&out)[NP]) {
   if constexpr (NP == 2) {

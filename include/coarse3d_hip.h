@@ -91,7 +91,7 @@ typedef struct {
                                convolutions (transposed weights, negated taps): measured to leave every
                                gradient's error against float64 unchanged, while on the forward activations
                                six products cost 4-5x the fp32 engine's noise (csrc/conv_x3.hip).
-                               4 (EXPERIMENT, round 3): two fp16 planes (x = H + L to 2^-24 |x|), three products
+                               4 (EXPERIMENT, round 3): two fp16 planes (x = H + L to 2^-22 |x| worst case), three products
                                H*H' + H*L' + L*H', operands staged times 2^6 / 2^10 against fp16's range, generic
                                kernel; forward convolutions only (profiles/round3_f16x2_probe.txt)            */
   int32_t out_bf16;         /* 1: `out` is bf16 (values rounded RNE on store, accumulate reads bf16);
