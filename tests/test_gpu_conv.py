@@ -451,3 +451,45 @@ def test_fused_multitap_kernel_is_bit_identical_to_the_phased_one():
         else:
             os.environ["C3D_X3_FUSED"] = saved
         ops.set_matrix_precision(*prev)
+
+
+@pytest.mark.parametrize("k,dil,pad,cin,cout", [(3, 1, 1, 64, 64), (3, 2, 2, 32, 32), (3, 1, 1, 80, 32), (1, 1, 0, 96, 128), (2, 2, 1, 64, 64)])
+def test_f16x2_forward_experiment_against_float64(k, dil, pad, cin, cout, monkeypatch):
+    """The round-3 experiment behind C3D_F16X2_FWD=1 (c3d_conv_desc.mfma_bf16 = 4): forward convolutions over >= 32768
+    pixels on two fp16 planes / three products -- the two-plane instantiation of the fused nine-tap kernel for 3x3, the
+    generic kernel otherwise -- with the BatchNorm affine + LeakyReLU on load, bias, the epilogue's statistics and
+    operands staged times 2^6 / 2^10.  Against float64: the bar of the exact split (1e-4 of max|ref| is the suite's;
+    measured here ~1e-6), and the statistics partials sum to the output's sums.  Populations below the threshold keep the
+    exact split (same call, bit-identical to the switch being off)."""
+    from coarse3d_amd import ops
+    dev = "cuda"
+    g = torch.Generator().manual_seed(100 * k + dil)
+    B, H, W = 2, 64, 512                                    # 65536 pixels
+    x = torch.randn(B, H, W, cin, generator=g).to(dev)
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.05).to(dev)
+    bias = torch.randn(cout, generator=g).to(dev)
+    sc, sh = (torch.rand(cin, generator=g) + 0.5).to(dev), (torch.randn(cin, generator=g) * 0.1).to(dev)
+    taps = ops.conv_taps(k, k, dil, pad)
+    _PREV.append(ops.matrix_precision_state())
+    ops.set_matrix_precision("bf16x3")
+    try:
+        wp = ops.pack_weights(w, 0)
+        exact, _ = ops.conv_forward([ops.Source(x, sc, sh, lrelu=True)], wp, bias, cout, taps, lrelu=True, stats=True)
+        monkeypatch.setattr(ops, "F16X2_FWD", True)
+        got, part = ops.conv_forward([ops.Source(x, sc, sh, lrelu=True)], wp, bias, cout, taps, lrelu=True, stats=True)
+        small = x[:, :8].contiguous()                       # 2 x 8 x 512 = 8192 pixels: below the threshold
+        on_small, _ = ops.conv_forward([ops.Source(small, sc, sh, lrelu=True)], wp, bias, cout, taps, lrelu=True)
+        monkeypatch.setattr(ops, "F16X2_FWD", False)
+        off_small, _ = ops.conv_forward([ops.Source(small, sc, sh, lrelu=True)], wp, bias, cout, taps, lrelu=True)
+    finally:
+        ops.set_matrix_precision(*_PREV.pop())
+    xin = F.leaky_relu(x.double() * sc.double() + sh.double(), 0.01).permute(0, 3, 1, 2)
+    ref = F.leaky_relu(F.conv2d(xin, w.double(), bias.double(), padding=pad, dilation=dil), 0.01).permute(0, 2, 3, 1)
+    ref = ref[:, :H, :W]
+    e_got = float((got.double() - ref).abs().max() / ref.abs().max())
+    e_exact = float((exact.double() - ref).abs().max() / ref.abs().max())
+    assert e_got < 1e-5 and e_got < 8 * e_exact + 1e-7, (e_got, e_exact)
+    assert not torch.equal(got, exact)                      # the switch did take the other arithmetic
+    s1 = part[:, 0].double().sum(1)
+    assert float((s1 - got.double().sum((0, 1, 2))).abs().max() / got.double().abs().sum((0, 1, 2)).max()) < 1e-6
+    assert torch.equal(on_small, off_small)
