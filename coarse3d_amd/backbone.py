@@ -438,7 +438,7 @@ class Backbone:
         else:
             ops.axpy(g, act.grad)
 
-    def _bn_backward(self, bn, dy, a, c, mode, slope=0.0, k=None, part=None):
+    def _bn_backward(self, bn, dy, a, c, mode, slope=0.0, k=None, part=None, gmax=None):
         """dy: gradient w.r.t. BN(a) [mode 0] or LeakyReLU(BN(a)) [mode 1] -> (dz = d/da, partial with
         sum(dz)); writes the BatchNorm parameter gradients.  SyncBN: the fp64 sums are all-reduced
         (``k``: coefficients already computed by ``_bn_backward_group``)."""
@@ -456,7 +456,7 @@ class Backbone:
                 self.reduce_fn(sums)
                 k = ops.bn_bwd_coeffs(sums, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
                                       G[f"{bn.name}.weight"], G[f"{bn.name}.bias"], local)
-        return ops.bn_bwd_apply(dy, a, c, mode, k, pre_s, pre_h, slope=slope)
+        return ops.bn_bwd_apply(dy, a, c, mode, k, pre_s, pre_h, slope=slope, gmax=gmax)
 
     def _bn_backward_group(self, items):
         """SyncBN backward of layers whose output gradients are all available: the (sum dy, sum dy*a)
@@ -505,6 +505,12 @@ class Backbone:
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
 
+    def _zeros(self, c, device):
+        z = getattr(self, "_zero_cache", None)
+        if z is None or z.numel() < c or z.device != device:
+            z = self._zero_cache = torch.zeros(max(c, 1024), device=device, dtype=torch.float32)
+        return z[:c]
+
     def _conv_backward(self, name, dy, k=None):
         """dy: gradient w.r.t. the layer's consumer-visible output (BN output if it has BN).
         k: BatchNorm-backward coefficients from ``_bn_backward_group`` (else computed here).
@@ -519,11 +525,22 @@ class Backbone:
         c = rec.cout
         cpad = a.shape[3]
         G = self.grads
+        # EXPERIMENT (C3D_F16X2_BWD=1): multi-tap input gradients over large populations on two fp16 planes -- dz is then read
+        # through a per-tensor exponent; the apply pass folds max |dz| into one word on the way (no reduction launch)
+        gmax = None
+        if (ops.F16X2_BWD and ops.MFMA_MODE == 2 and len(rec.taps) > 1 and rec.mode in (0, 1, 2) and a.dtype == torch.float32
+                and a.shape[0] * a.shape[1] * a.shape[2] >= ops.SIX_FWD_MIN_PIXELS):
+            pool = getattr(self, "_gmax_pool", None)
+            if pool is None or self._gmax_next >= pool.numel():
+                pool = self._gmax_pool = torch.zeros(256, device=a.device, dtype=torch.int32)
+                self._gmax_next = 0
+            gmax = pool[self._gmax_next:self._gmax_next + 1]
+            self._gmax_next += 1
         if rec.mode == 0 or rec.mode == 1:
-            dz, pz = self._bn_backward(rec.bn, dy, a, c, rec.mode, rec.slope, k, rec.out.bwd_partial)
+            dz, pz = self._bn_backward(rec.bn, dy, a, c, rec.mode, rec.slope, k, rec.out.bwd_partial, gmax=gmax)
             rec.out.bwd_partial = None
         elif rec.mode == 2:
-            dz, pz = ops.bn_bwd_apply(dy, a, c, 2, slope=rec.slope)
+            dz, pz = ops.bn_bwd_apply(dy, a, c, 2, slope=rec.slope, gmax=gmax)
         else:
             dz, pz = ops.bn_bwd_apply(dy, dy, cpad, 3, dz=dy)
         if self.capture is not None:
@@ -540,6 +557,10 @@ class Backbone:
                 off += s.t.shape[3]
         ntaps = ops.negate_taps(rec.taps)
         off = 0
+        gsrc, ginv = ops.Source(dz), None
+        if gmax is not None:
+            gscale, ginv = ops.grad_exponent_max(gmax, dz.shape[3])
+            gsrc = ops.Source(dz, gscale, self._zeros(dz.shape[3], dz.device))
         for s in rec.srcs:
             cs = s.t.shape[3]
             if not getattr(s, "no_grad", False):
@@ -560,8 +581,8 @@ class Backbone:
                 if (FUSE_BN_REDUCE and ops.MFMA_MODE == 2 and self.train and p_ is not None and p_.mode == 0 and p_.bn is not None
                         and s.first_consumer == name and s.t.dtype == torch.float32 and s.t.shape[3] == cs):
                     part = torch.empty(cs, 2, ops.num_mtiles(*s.t.shape[:3]), device=s.t.device, dtype=torch.float32)
-                ops.conv_forward([ops.Source(dz)], wd, None, cs, ntaps, out=s.grad, accumulate=acc, grad=True,
-                                 stat_partial=part, stat_mul=s.t if part is not None else None)
+                ops.conv_forward([gsrc], wd, None, cs, ntaps, out=s.grad, accumulate=acc, grad=True,
+                                 stat_partial=part, stat_mul=s.t if part is not None else None, f16x2_inv=ginv)
                 s.bwd_partial = part
             off += cs
         rec.out.grad = None

@@ -156,6 +156,7 @@ struct BwdArgs {
   int pix_per_block;
   float slope;
   int bf;                    // bit 0: dy, bit 1: a, bit 2: dz are bf16
+  unsigned* gmax = nullptr;  // apply: atomicMax of the bits of max |dz| over the whole tensor (order-free, exact)
 };
 
 // thread = (pixel lane, channel quad); block walks a contiguous pixel chunk
@@ -212,6 +213,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
         }
         c3d_vst<V>(p.dz, (size_t)i * p.dz_cs + c, p.bf & 4, dz);
         s1 += dz;
+#pragma unroll
+        for (int q = 0; q < V; ++q) s2.v[q] = fmaxf(s2.v[q], fabsf(dz.v[q]));     // row 1 of the apply partials: max |dz|
       }
     };
     int i = p0 + pl;
@@ -238,11 +241,13 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
     float t1 = 0.f, t2 = 0.f;
     for (int k = 0; k < PL; ++k) {
       t1 += red[(k * p.C + ch) * 2 + 0];
-      t2 += red[(k * p.C + ch) * 2 + 1];
+      if (APPLY) t2 = fmaxf(t2, red[(k * p.C + ch) * 2 + 1]);      // (max |dz|: c3d_grad_exponent reads it)
+      else t2 += red[(k * p.C + ch) * 2 + 1];
     }
     float* o = p.partial + (size_t)ch * 2 * gridDim.x + blockIdx.x;   // [C][2][nblk]
     o[0] = t1;
     o[gridDim.x] = t2;
+    if (APPLY && p.gmax && t2 > 0.f) atomicMax(p.gmax, __float_as_uint(t2));     // positive floats order like their bits
   }
 }
 
@@ -315,7 +320,8 @@ extern "C" int c3d_bn_bwd_num_blocks(int npix) {
 
 static int bn_bwd_launch(bool apply, const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C, int mode,
                          const float* pre_scale, const float* pre_shift, const float* k1, const float* k2,
-                         const float* k3, float* dz, int dz_cs, float* partial, float slope, int bf, hipStream_t st) {
+                         const float* k3, float* dz, int dz_cs, float* partial, float slope, int bf, hipStream_t st,
+                         unsigned* gmax = nullptr) {
   C3D_REQUIRE(C % 4 == 0 && C <= 1024, "bn_bwd: C must be a multiple of 4 and <= 1024");
   C3D_REQUIRE(dy_cs % 4 == 0 && a_cs % 4 == 0 && (!apply || dz_cs % 4 == 0), "bn_bwd: strides must be multiples of 4");
   BwdArgs p;
@@ -324,6 +330,7 @@ static int bn_bwd_launch(bool apply, const float* dy, int dy_cs, const float* a,
   p.dz = dz; p.dz_cs = dz_cs; p.partial = partial;
   p.slope = c3d_slope_or_default(slope);
   p.bf = bf;
+  p.gmax = gmax;
   const int nb = c3d_bn_bwd_num_blocks(npix);
   p.pix_per_block = (npix + nb - 1) / nb;
   // 8 channels per lane when any tensor is bf16 (16-byte accesses), 4 otherwise (the fp32 path as before)
@@ -365,6 +372,78 @@ extern "C" int c3d_bn_bwd_apply(const float* dy, int dy_cs, const float* a, int 
                                 c3d_stream stream) {
   return bn_bwd_launch(true, dy, dy_cs, a, a_cs, npix, C, mode, pre_scale, pre_shift, k1, k2, k3, dz, dz_cs, partial,
                        lrelu_slope, bf16_mask, (hipStream_t)stream);
+}
+
+// scale_out[0 .. scale_len) = 2^s, *inv_out = 2^-s with s = target_log2 - ceil(log2(max |dz|)), the maximum taken from row 1
+// of c3d_bn_bwd_apply's partials ([C][2][n]); an all-zero gradient gives s = 0.  One workgroup.
+__global__ __launch_bounds__(256) void grad_exponent_kernel(const float* __restrict__ partial, int n, int C, int target_log2,
+                                                            float* __restrict__ scale_out, int scale_len,
+                                                            float* __restrict__ inv_out) {
+  __shared__ float red[256];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < C * n; i += 256) {
+    const int c = i / n, k = i - c * n;
+    m = fmaxf(m, partial[((size_t)c * 2 + 1) * n + k]);
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  m = red[0];
+  int s = 0;
+  if (m > 0.f && m < INFINITY) {
+    int e;
+    const float f = frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1): ceil(log2 m) = e, or e - 1 for m = 2^(e-1)
+    s = target_log2 - (f == 0.5f ? e - 1 : e);
+  }
+  const float up = ldexpf(1.f, s), down = ldexpf(1.f, -s);
+  for (int i = threadIdx.x; i < scale_len; i += 256) scale_out[i] = up;
+  if (threadIdx.x == 0) *inv_out = down;
+}
+
+extern "C" int c3d_grad_exponent(const float* partial, int n, int C, int target_log2, float* scale_out, int scale_len,
+                                 float* inv_out, c3d_stream stream) {
+  C3D_REQUIRE(partial && scale_out && inv_out && n > 0 && C > 0 && scale_len > 0, "grad_exponent: null pointer or empty size");
+  hipLaunchKernelGGL(grad_exponent_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, C, target_log2, scale_out,
+                     scale_len, inv_out);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+// c3d_bn_bwd_apply that also folds max |dz| of the whole tensor into *gmax (bits of a non-negative float, pre-zeroed by the
+// caller, atomicMax: exact and order-free) -- the per-tensor exponent of the f16x2 gradient experiment without a reduction
+// launch of its own
+extern "C" int c3d_bn_bwd_apply_gmax(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C, int mode,
+                                     const float* pre_scale, const float* pre_shift, const float* k1, const float* k2,
+                                     const float* k3, float* dz, int dz_cs, float* partial, float lrelu_slope, int bf16_mask,
+                                     uint32_t* gmax, c3d_stream stream) {
+  return bn_bwd_launch(true, dy, dy_cs, a, a_cs, npix, C, mode, pre_scale, pre_shift, k1, k2, k3, dz, dz_cs, partial,
+                       lrelu_slope, bf16_mask, (hipStream_t)stream, gmax);
+}
+
+__global__ void grad_exponent_max_kernel(const unsigned* __restrict__ gmax, int target_log2, float* __restrict__ scale_out,
+                                         int scale_len, float* __restrict__ inv_out) {
+  const float m = __uint_as_float(*gmax);
+  int s = 0;
+  if (m > 0.f && m < INFINITY) {
+    int e;
+    const float f = frexpf(m, &e);
+    s = target_log2 - (f == 0.5f ? e - 1 : e);
+  }
+  const float up = ldexpf(1.f, s), down = ldexpf(1.f, -s);
+  for (int i = threadIdx.x; i < scale_len; i += 256) scale_out[i] = up;
+  if (threadIdx.x == 0) *inv_out = down;
+}
+
+extern "C" int c3d_grad_exponent_max(const uint32_t* gmax, int target_log2, float* scale_out, int scale_len, float* inv_out,
+                                     c3d_stream stream) {
+  C3D_REQUIRE(gmax && scale_out && inv_out && scale_len > 0, "grad_exponent_max: null pointer or empty size");
+  hipLaunchKernelGGL(grad_exponent_max_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gmax, target_log2, scale_out,
+                     scale_len, inv_out);
+  C3D_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int c3d_sums_to_f32(const double* sums, int C, int col, float* out, int accumulate, c3d_stream stream) {

@@ -26,6 +26,7 @@ struct ConvArgs {
   const float* stat_mul;     // NULL, or the tensor whose product with the stored values replaces v*v in stat_partial
   int stat_mul_cs;
   bool f16x2 = false;      // EXPERIMENT (mfma_bf16 == 4): two fp16 planes / three products where a kernel has the variant
+  const float* acc_scale_dev = nullptr;   // times this device scalar, if any (per-tensor gradient exponent)
   float acc_scale = 1.f;   // the accumulators are multiplied by this before bias / activation (1: fma(acc, 1, bias) == acc + bias);
                            // the f16x2 experiment stages its operands times 2^6 / 2^10 and hands 2^-16 back here
 };
@@ -79,6 +80,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
   const size_t obase_i = tile_pix * a.out_cstride + a.out_coff + n0 + l31;   // element index, + per-lane cout
   const bool obf = BF16_OUT && a.out_bf16 != 0;      // engines that never store bf16 compile that path out
   const float* mulp = (STATMUL && a.stat_partial) ? a.stat_mul : nullptr;
+  const float asc = a.acc_scale_dev ? a.acc_scale * *a.acc_scale_dev : a.acc_scale;
   // one 32-wide cout sub-tile, any position: per-element predicates
   auto slow_sub = [&](int j) {
     const int co = n0 + (ILV ? j * WN + wn : wn * NPW + j) * 32 + l31;
@@ -92,7 +94,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gx = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = __builtin_fmaf(acc[i][j][r], a.acc_scale, bias);
+        float v = __builtin_fmaf(acc[i][j][r], asc, bias);
         if (a.epi_lrelu) v = c3d_lrelu(v, a.slope);
         if (cok && gy < a.H && gx < a.W) {
           const size_t o = ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co;
@@ -145,7 +147,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float v = __builtin_fmaf(acc[i][j][r], a.acc_scale, bias);
+          float v = __builtin_fmaf(acc[i][j][r], asc, bias);
           if (a.epi_lrelu) v = c3d_lrelu(v, a.slope);
           if constexpr (ACC) v += old[r];
           // fresh outputs leave with the nontemporal hint: the tile's halo / weight re-reads live on L2 hits and the

@@ -295,6 +295,8 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   a.out_bf16 = d->out_bf16;
   a.stat_mul = d->stat_mul;
   a.stat_mul_cs = d->stat_mul_cstride;
+  a.acc_scale_dev = d->acc_scale_dev;
+  C3D_REQUIRE(!d->acc_scale_dev || d->mfma_bf16 == 4, "conv: acc_scale_dev belongs to the f16x2 experiment (mfma_bf16 == 4)");
   C3D_REQUIRE(!d->stat_mul || (d->stat_partial && !d->out_bf16 && d->stat_mul_cstride >= d->Cout && d->mfma_bf16 >= 2),
               "conv: stat_mul needs stat_partial, fp32 output, a channel stride >= Cout and the bf16x3 engine (mfma_bf16 >= 2)");
   {

@@ -80,6 +80,7 @@ def _bf(*tensors):
 
 
 F16X2_FWD = os.environ.get("C3D_F16X2_FWD", "0") == "1"
+F16X2_BWD = os.environ.get("C3D_F16X2_BWD", "0") == "1"     # EXPERIMENT: multi-tap input gradients too (per-tensor exponent)
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _cur_dev = torch.cuda.current_device
 
@@ -271,7 +272,7 @@ def _pw3_kernel_name(nt, k, cout):
 
 
 def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=None, out_coff=0,
-                 accumulate=False, stat_partial=None, slope=0.0, grad=False, stat_mul=None):
+                 accumulate=False, stat_partial=None, slope=0.0, grad=False, stat_mul=None, f16x2_inv=None):
     """y = [LeakyReLU](conv(cat(transformed srcs)) + bias); optional per-tile channel stats.
     ``grad``: this launch is an input-gradient convolution (transposed weights, negated taps): the
     bf16x3 engine then accumulates six plane products instead of eight (c3d_conv_desc.mfma_bf16 = 3)."""
@@ -334,7 +335,12 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     six = (MFMA_MODE == 2 and (grad or (nt_ > 1 and tr == 8 and b * h * w >= SIX_FWD_MIN_PIXELS))
            and os.environ.get("C3D_SIX", "1") != "0")
     d.mfma_bf16 = 3 if six else MFMA_MODE
-    if F16X2_FWD and MFMA_MODE == 2 and not grad and b * h * w >= SIX_FWD_MIN_PIXELS:
+    if f16x2_inv is not None:
+        # EXPERIMENT (C3D_F16X2_BWD=1): an input gradient on two fp16 planes; the source carries 2^s in its scale array
+        # (grad_exponent), this device scalar 2^-s goes to the epilogue
+        d.mfma_bf16 = 4
+        d.acc_scale_dev = f16x2_inv.data_ptr()
+    elif F16X2_FWD and MFMA_MODE == 2 and not grad and b * h * w >= SIX_FWD_MIN_PIXELS:
         # EXPERIMENT (C3D_F16X2_FWD=1; DESIGN.md round-4 list): forward convs over large BatchNorm populations -- where the
         # exact split already runs six products -- on two fp16 planes / three products, generic kernel
         d.mfma_bf16 = 4
@@ -482,6 +488,24 @@ def bn_bwd_reduce(dy, a, c, mode=0, pre_scale=None, pre_shift=None, slope=0.0):
     return part
 
 
+def grad_exponent(apply_partial, c, target_log2=8):
+    """(scale [c] = 2^s, inv [1] = 2^-s) from the max |dz| row of bn_bwd_apply's partials: the per-tensor exponent that
+    brings a gradient tensor into fp16's range (times the kernel's own 2^6: its maximum lands at 2^14)."""
+    n = apply_partial.shape[2]
+    scale = torch.empty(c, device=apply_partial.device, dtype=torch.float32)
+    inv = torch.empty(1, device=apply_partial.device, dtype=torch.float32)
+    _call("c3d_grad_exponent", _dp(apply_partial), n, min(c, apply_partial.shape[0]), target_log2, _dp(scale), c, _dp(inv), _stream())
+    return scale, inv
+
+
+def grad_exponent_max(gmax, c, target_log2=8):
+    """grad_exponent from the word bn_bwd_apply(gmax=...) filled."""
+    scale = torch.empty(c, device=gmax.device, dtype=torch.float32)
+    inv = torch.empty(1, device=gmax.device, dtype=torch.float32)
+    _call("c3d_grad_exponent_max", _dp(gmax), target_log2, _dp(scale), c, _dp(inv), _stream())
+    return scale, inv
+
+
 def bn_bwd_coeffs(sums, count, mean, invstd, gamma, dgamma, dbeta, sums_param=None):
     c = gamma.shape[0]
     k = torch.empty(3, c, device=gamma.device, dtype=torch.float32)
@@ -490,8 +514,9 @@ def bn_bwd_coeffs(sums, count, mean, invstd, gamma, dgamma, dbeta, sums_param=No
     return k
 
 
-def bn_bwd_apply(dy, a, c, mode, k=None, pre_scale=None, pre_shift=None, dz=None, slope=0.0):
-    """dz = act'(.) * (k1*dy + k2*a + k3); returns (dz, partial [C,2,nblk] with sum(dz) in row 0)."""
+def bn_bwd_apply(dy, a, c, mode, k=None, pre_scale=None, pre_shift=None, dz=None, slope=0.0, gmax=None):
+    """dz = act'(.) * (k1*dy + k2*a + k3); returns (dz, partial [C,2,nblk] with sum(dz) in row 0, max |dz| in row 1).
+    gmax: optional zeroed int32 [1]; receives the bits of max |dz| over the tensor (the f16x2 gradient experiment)."""
     npix = dy.numel() // dy.shape[-1]
     if dz is None:
         dz = torch.empty(dy.shape[:-1] + (c,), device=dy.device, dtype=a.dtype)
@@ -499,6 +524,11 @@ def bn_bwd_apply(dy, a, c, mode, k=None, pre_scale=None, pre_shift=None, dz=None
     k1, k2, k3 = (k[0], k[1], k[2]) if k is not None else (None, None, None)
     for c0 in range(0, c, _BN_BWD_MAX_C):
         cc = min(_BN_BWD_MAX_C, c - c0)
+        if gmax is not None:
+            _call("c3d_bn_bwd_apply_gmax", _off(dy, c0), dy.shape[-1], _off(a, c0), a.shape[-1], npix, cc, mode, _off(pre_scale, c0),
+                  _off(pre_shift, c0), _off(k1, c0), _off(k2, c0), _off(k3, c0), _off(dz, c0), dz.shape[-1],
+                  _dp(part[c0:c0 + cc]), float(slope), _bf(dy, a, dz), _dp(gmax), _stream())
+            continue
         _call("c3d_bn_bwd_apply", _off(dy, c0), dy.shape[-1], _off(a, c0), a.shape[-1], npix, cc, mode, _off(pre_scale, c0),
               _off(pre_shift, c0), _off(k1, c0), _off(k2, c0), _off(k3, c0), _off(dz, c0), dz.shape[-1],
               _dp(part[c0:c0 + cc]), float(slope), _bf(dy, a, dz), _stream())

@@ -108,6 +108,9 @@ typedef struct {
                                tensor reads                                                                        */
   int32_t stat_mul_cstride;
   int32_t reserved2;
+  const float* acc_scale_dev; /* EXPERIMENT (mfma_bf16 == 4): NULL, or a device scalar the accumulators are multiplied
+                               with before bias / activation -- the inverse of a per-tensor gradient exponent
+                               (c3d_grad_exponent)                                                            */
 } c3d_conv_desc;
 
 /* y = epilogue(conv(transform(cat(src)))) as an implicit GEMM on fp32 MFMA.
@@ -346,6 +349,20 @@ int c3d_proto_learn(const float* sim, const float* feat, const int32_t* pred, co
                     const float* protos, float* protos_out, float* target, int32_t* assign,
                     int B, int n, int M, int C, int D, int ignore_label, float momentum,
                     float* fsum, const int32_t* cmap, int noise_by_row, c3d_stream stream);
+/* EXPERIMENT (f16x2 gradients): per-tensor power-of-two scale of a gradient tensor from the maxima c3d_bn_bwd_apply
+ * leaves in row 1 of its partials [C][2][n]: scale_out[0 .. scale_len) = 2^s (a per-channel `scale` array for c3d_src),
+ * *inv_out = 2^-s (c3d_conv_desc.acc_scale_dev), s = target_log2 - ceil(log2 max|dz|).                              */
+int c3d_grad_exponent(const float* partial, int n, int C, int target_log2, float* scale_out, int scale_len,
+                      float* inv_out, c3d_stream stream);
+/* The same without a reduction launch: c3d_bn_bwd_apply_gmax is c3d_bn_bwd_apply that also folds max |dz| into *gmax (the
+ * bits of a non-negative float, zeroed by the caller; atomicMax: exact, order-free), c3d_grad_exponent_max turns that word
+ * into the scale array and its inverse.                                                                              */
+int c3d_bn_bwd_apply_gmax(const float* dy, int dy_cs, const float* a, int a_cs, int npix, int C, int mode,
+                          const float* pre_scale, const float* pre_shift, const float* k1, const float* k2,
+                          const float* k3, float* dz, int dz_cs, float* partial, float lrelu_slope, int bf16_mask,
+                          uint32_t* gmax, c3d_stream stream);
+int c3d_grad_exponent_max(const uint32_t* gmax, int target_log2, float* scale_out, int scale_len, float* inv_out,
+                          c3d_stream stream);
 /* EMA with the l2-normalised sums + final l2 normalisation (salsanext_proto.py:376-395, :402)  */
 int c3d_proto_ema(const float* fsum, const float* protos, float* protos_out, int M, int C, int D,
                   int ignore_label, float momentum, c3d_stream stream);
