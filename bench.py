@@ -626,8 +626,13 @@ def main():
             ops.F16X2_FWD = True
             try:
                 f16_run = quick_run("bf16x3", "0")
+                ops.F16X2_BWD = True
+                f16_run["with_input_gradients"] = dict(quick_run("bf16x3", "0"),
+                                                       note="C3D_F16X2_BWD=1 on top: the multi-tap input gradients on the same arithmetic, "
+                                                            "read through a per-tensor exponent (c3d_bn_bwd_apply_gmax)")
             finally:
                 ops.F16X2_FWD = False
+                ops.F16X2_BWD = False
             f16_run["note"] = ("EXPERIMENT, off by default (C3D_F16X2_FWD=1): the headline engine with the FORWARD convolutions over >= 32768 "
                                "pixels on two fp16 planes (x = H + L to 2^-22 |x| worst case -- a 22-bit operand, NOT the exact split --, staged times 2^6 / 2^10) and three products "
                                "instead of six -- fused nine-tap kernel conv_x3f_kernel<..., 2>, generic kernel elsewhere; gradients "
