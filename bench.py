@@ -628,7 +628,7 @@ def main():
                 f16_run = quick_run("bf16x3", "0")
                 ops.F16X2_BWD = True
                 f16_run["with_input_gradients"] = dict(quick_run("bf16x3", "0"),
-                                                       note="C3D_F16X2_BWD=1 on top: the multi-tap input gradients on the same arithmetic, "
+                                                       note="C3D_F16X2_BWD=1 on top: the multi-tap input AND weight gradients on the same arithmetic, "
                                                             "read through a per-tensor exponent (c3d_bn_bwd_apply_gmax)")
             finally:
                 ops.F16X2_FWD = False

@@ -29,6 +29,7 @@ BN_MOMENTUM = 0.1
 # BatchNorm-backward sums in the epilogue of the last input-gradient conv (see _conv_backward); C3D_FUSE_BN_REDUCE=0: always
 # the separate reduce pass
 FUSE_BN_REDUCE = os.environ.get("C3D_FUSE_BN_REDUCE", "1") != "0"
+F16X2_WGRAD = os.environ.get("C3D_F16X2_WGRAD", "1") != "0"      # (with C3D_F16X2_BWD=1: the weight gradients of those layers too)
 
 
 class Act:
@@ -547,19 +548,22 @@ class Backbone:
             self.capture[name] = (rec, None if dy is dz else dy.clone(), dz.clone())
         w = self.P[f"{name}.weight"] if rec.weight is None else rec.weight
         dw = G[f"{name}.weight"] if rec.dweight is None else rec.dweight
-        with self._fork(dz, pz):
+        gscale = ginv = None
+        if gmax is not None:
+            gscale, ginv = ops.grad_exponent_max(gmax, dz.shape[3])
+        wg16 = (gscale, ginv) if (gmax is not None and F16X2_WGRAD and all(s.t.dtype == torch.float32 for s in rec.srcs)) else None
+        with self._fork(dz, pz, *([gscale, ginv] if gmax is not None else [])):
             db = G.get(f"{name}.bias")       # folded by the first weight-gradient launch of the layer
             off = 0
             for s in rec.srcs:
                 ops.conv_wgrad(s.src(rec.src_lrelu), dz, dw, rec.taps, cin_off=off, slope=rec.slope,
-                               bias_partial=pz if db is not None else None, dbias=db)
+                               bias_partial=pz if db is not None else None, dbias=db, f16x2=wg16)
                 db = None
                 off += s.t.shape[3]
         ntaps = ops.negate_taps(rec.taps)
         off = 0
-        gsrc, ginv = ops.Source(dz), None
+        gsrc = ops.Source(dz)
         if gmax is not None:
-            gscale, ginv = ops.grad_exponent_max(gmax, dz.shape[3])
             gsrc = ops.Source(dz, gscale, self._zeros(dz.shape[3], dz.device))
         for s in rec.srcs:
             cs = s.t.shape[3]

@@ -16,6 +16,7 @@ struct WgradArgs {
   int dx[C3D_MAX_TAPS];
   float* partial;
   int tiles_x, tiles_y, ntiles, strips, tiles_per_strip;
+  const float* dz_scale = nullptr;   // f16x2 experiment: per-cout scale of dz on load
   int xmajor = 0;        // wgrad_tr: walk the tiles along x (round-2 order) instead of down the image
   int ci_slices, co_slices;
   float slope;

@@ -285,8 +285,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            int co_slices, int Cin_src, int Cout, int Cin_total,
                                                            int cin_off, int accumulate, int main_blocks,
                                                            const float* __restrict__ bias_partial, int bias_n,
-                                                           float* __restrict__ dbias) {
+                                                           float* __restrict__ dbias, float out_scale,
+                                                           const float* __restrict__ out_scale_dev) {
   __shared__ double red[8][32];
+  const double osc = out_scale_dev ? (double)out_scale * (double)*out_scale_dev : (double)out_scale;   // powers of two: exact
   if ((int)blockIdx.x >= main_blocks) {
     const int c = blockIdx.x - main_blocks;
     const float* p = bias_partial + (size_t)c * 2 * bias_n;
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       double v = 0.0;
 #pragma unroll
       for (int k = 0; k < 8; ++k) v += red[k][o];
+      v *= osc;
       float* d = dw + ((size_t)co * Cin_total + cin_off + ci) * T + t;
       *d = accumulate ? (*d + (float)v) : (float)v;
     }
@@ -348,6 +351,7 @@ int planes_for(const c3d_wgrad_desc* d) {
     return (e && e[0] == '0') ? 0 : 1;
   }();
   if (!tr_on || d->mfma_bf16 == 0) return 0;
+  if (d->mfma_bf16 == 4) return 2;        // EXPERIMENT: two fp16 planes
   return d->mfma_bf16 == 2 ? 3 : 1;
 }
 
@@ -357,7 +361,7 @@ void plan(const c3d_wgrad_desc* d, WgradArgs& a, WgCfg& c) {
     const int m = abs(d->tap_dy[t]) > abs(d->tap_dx[t]) ? abs(d->tap_dy[t]) : abs(d->tap_dx[t]);
     if (m > halo) halo = m;
   }
-  c = c3d_wgrad_cfg(d->ntaps, d->x.C, d->Cout, planes_for(d), halo);
+  c = c3d_wgrad_cfg(d->ntaps, d->x.C, d->Cout, planes_for(d) == 2 ? 3 : planes_for(d), halo);     // (two fp16 planes: the tiles of three)
   a.tiles_x = (d->W + 31) / 32;
   a.tiles_y = (d->H + c.TRW - 1) / c.TRW;
   a.ntiles = d->B * a.tiles_x * a.tiles_y;
@@ -435,6 +439,9 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   C3D_REQUIRE(halo <= 2, "wgrad: tap offsets beyond +-2 are not supported");
   C3D_REQUIRE(d->ntaps != 1 || halo == 0, "wgrad: a single tap must have zero offset");
   a.xmajor = getenv("C3D_WGRAD_XMAJOR") != nullptr;
+  a.dz_scale = d->dz_scale;
+  C3D_REQUIRE(d->mfma_bf16 != 4 || (d->dz_scale && d->out_scale_dev && !d->dz_bf16 && !d->x.bf16 && d->ntaps > 1),
+              "wgrad: mfma_bf16 == 4 (f16x2 experiment) needs dz_scale, out_scale_dev, fp32 tensors and more than one tap");
   a.partial = d->partial;
   a.slope = c3d_slope_or_default(d->lrelu_slope);
   C3D_REQUIRE(a.slope <= 1.f, "wgrad: LeakyReLU slopes above 1 are not supported (the kernels evaluate max(v, slope * v))");
@@ -452,7 +459,8 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   C3D_REQUIRE(!bias || (d->dbias != nullptr && d->bias_n > 0), "wgrad: bias_partial needs dbias and bias_n");
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks + (bias ? d->Cout : 0)), dim3(256), 0, st, a.partial, d->dw, a.strips,
                      d->ntaps, c.CI, c.CO, a.ci_slices, a.co_slices, d->x.C, d->Cout, d->Cin_total, d->cin_off, d->accumulate,
-                     blocks, d->bias_partial, d->bias_n, d->dbias);
+                     blocks, d->bias_partial, d->bias_n, d->dbias, d->mfma_bf16 == 4 ? 1.f / 64.f : 1.f,
+                     d->mfma_bf16 == 4 ? d->out_scale_dev : nullptr);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -50,9 +50,27 @@ namespace {
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
+// EXPERIMENT (NP == 2): two fp16 planes, H = RNE11(x), L = RNE11(x - H); three products (DESIGN.md round-4 list)
 template <int NP>
 __device__ __forceinline__ void split_planes(f32x4 v, u32x2 (&out)[NP]) {
+  if constexpr (NP == 2) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    f32x4 r = v;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      f16x4 h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h[q] = (_Float16)r[q];
+      out[p] = __builtin_bit_cast(u32x2, h);
+      if (p == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] -= (float)h[q];
+      }
+    }
+    return;
+  }
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   f32x4 r = v;
 #pragma unroll
@@ -183,7 +201,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     psc = *reinterpret_cast<const f32x4*>(a.x.scale + xc);
     psh = *reinterpret_cast<const f32x4*>(a.x.shift + xc);
   }
-  const bool aff = a.x.scale != nullptr, lr = a.x.lrelu != 0;
+  bool aff = a.x.scale != nullptr;
+  const bool lr = a.x.lrelu != 0;
+  f32x4 dsc = {1.f, 1.f, 1.f, 1.f};          // NP == 2: the gradient's per-tensor exponent, applied while dz is staged
+  if constexpr (NP == 2) {
+    psc = psc * 64.f;                          // x staged times 2^6 (LeakyReLU is positively homogeneous: exact)
+    psh = psh * 64.f;
+    aff = true;
+  }
 
   // Per-thread constant element offsets of every staged unit relative to the tile's first (halo)
   // pixel: interior tiles (the vast majority) load with a uniform base + these offsets, no
@@ -197,6 +222,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   static_assert(DSTEP % 32 == 0 || 32 % DSTEP == 0, "pass size must tile the 32-pixel rows");
   const int dc = co0 + dc4 * 4;
   const bool dc_ok = dc + 3 < a.dz_cstride;
+  if constexpr (NP == 2) {
+    if (a.dz_scale && dc + 3 < a.Cout) dsc = *reinterpret_cast<const f32x4*>(a.dz_scale + dc);
+  }
   unsigned xoff[HALO > 0 ? X_PT : 1];
   if constexpr (HALO > 0) {
 #pragma unroll
@@ -336,7 +364,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
           const bool in = (sg.dmask >> i) & 1u;
           pl[0] = u32x2{in ? __float_as_uint(sg.pd[i][0]) : 0u, in ? __float_as_uint(sg.pd[i][1]) : 0u};
         } else {
-          split_planes<NP>(((sg.dmask >> i) & 1u) ? sg.pd[i] : f32x4{0.f, 0.f, 0.f, 0.f}, pl);
+          split_planes<NP>(((sg.dmask >> i) & 1u) ? (NP == 2 ? sg.pd[i] * dsc : sg.pd[i]) : f32x4{0.f, 0.f, 0.f, 0.f}, pl);
         }
         const int o = tr_swz<NSD>(u / (CO / 4), (u % (CO / 4)) * 4);
 #pragma unroll
@@ -447,8 +475,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     constexpr int NSTAGE = KPW * NJ0 * NT0;
     // plane products in issue order (A plane, B plane): NP = 3: six of nine, smallest class first (m*m, l*h, h*l:
     // 2^-16; m*h, h*m: 2^-8; h*h); NP = 1: the one product
-    constexpr int NQ = NP == 3 ? 6 : 1;
-    constexpr int PA[6] = {NP == 3 ? 1 : 0, 2, 0, 1, 0, 0}, PB[6] = {NP == 3 ? 1 : 0, 0, 2, 0, 1, 0};
+    constexpr int NQ = NP == 3 ? 6 : (NP == 2 ? 3 : 1);
+    // (NP == 2: L*H', H*H', H*L' -- no plane both closes a stage and opens the next)
+    constexpr int PA[6] = {NP >= 2 ? 1 : 0, NP == 3 ? 2 : 0, 0, 1, 0, 0}, PB[6] = {NP == 3 ? 1 : 0, 0, NP == 3 ? 2 : 1, 0, 1, 0};
     auto last_use = [](const int (&pl)[6], int plane) constexpr {
       int l = -1;
       for (int q = 0; q < NQ; ++q)
@@ -503,7 +532,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
 #pragma unroll
           for (int jg = 0; jg < JG; ++jg)
             acc[t0 + tg][i][j0 + jg] =
-                __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[tg][i][PA[q]], bp[jg][PB[q]], acc[t0 + tg][i][j0 + jg], 0, 0, 0);
+                NP == 2 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ap[tg][i][PA[q]]),
+                                                                 __builtin_bit_cast(f16x8_t, bp[jg][PB[q]]), acc[t0 + tg][i][j0 + jg], 0, 0, 0)
+                        : __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[tg][i][PA[q]], bp[jg][PB[q]], acc[t0 + tg][i][j0 + jg], 0, 0, 0);
       if constexpr (st + 1 < NSTAGE) {
         constexpr int n = st + 1;
         // A changes with the tap group or the K step, B with the cout group or the K step
@@ -590,7 +621,7 @@ int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
     case 4: return halo <= 1 ? launch_tr<NP, 4, 1, 2, 1, 1, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 4, 1, 2, 1, 1, (NP == 1 ? 4 : 2), 2>(a, st);
     case 5: return halo <= 1 ? launch_tr<NP, 4, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 4, 1, 1, 1, 1, 4, 2>(a, st);
     case 8:
-      if constexpr (NP == 3) return halo <= 1 ? launch_tr<NP, 4, 1, 2, 2, 1, 2, 1>(a, st) : launch_tr<NP, 4, 1, 2, 2, 1, 2, 2>(a, st);
+      if constexpr (NP >= 2) return halo <= 1 ? launch_tr<NP, 4, 1, 2, 2, 1, 2, 1>(a, st) : launch_tr<NP, 4, 1, 2, 2, 1, 2, 2>(a, st);
       else return -1;
     case 6: return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 2>(a, st);
     default: return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, 4, 2>(a, st);
@@ -600,5 +631,6 @@ int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
 }  // namespace
 
 int c3d_wgrad_launch_tr(int planes, int id, int halo, const WgradArgs& a, hipStream_t st) {
+  if (planes == 2) return launch_tr_id<2>(id, halo, a, st);      // EXPERIMENT
   return planes == 3 ? launch_tr_id<3>(id, halo, a, st) : launch_tr_id<1>(id, halo, a, st);
 }

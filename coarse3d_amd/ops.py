@@ -376,7 +376,7 @@ def _wgrad_kernel_name(ci, co, nt, halo):
     return f"wgrad_mfma_kernel<{cfg}, {'true' if MFMA_MODE == 1 else 'false'}>"
 
 
-def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_partial=None, dbias=None):
+def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_partial=None, dbias=None, f16x2=None):
     """dw[:, cin_off:cin_off+src.C] (+)= sum_p dz[p] (x) transformed src[p + tap].
     bias_partial [>=Cout, 2, n] + dbias [Cout]: the launch that folds the weight-gradient strips folds the layer's
     bias-gradient partials too (instead of a separate bias_from_partials launch)."""
@@ -393,6 +393,9 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_p
     d.dw, d.accumulate = dw.data_ptr(), int(accumulate)
     d.lrelu_slope = slope
     d.mfma_bf16 = MFMA_MODE           # the tiling (and with it the partial-sum size) depends on the engine
+    if f16x2 is not None:      # EXPERIMENT (C3D_F16X2_BWD=1): (scale [Cout] = 2^s, inv [1] = 2^-s) of grad_exponent_max
+        d.mfma_bf16 = 4
+        d.dz_scale, d.out_scale_dev = f16x2[0].data_ptr(), f16x2[1].data_ptr()
     n = L.lib().c3d_wgrad_partial_floats(C.byref(d))
     part = torch.empty(n, device=dz.device, dtype=torch.float32)
     d.partial = part.data_ptr()

@@ -170,6 +170,10 @@ typedef struct {
   float* dbias;
   int32_t bias_n;
   int32_t reserved2;
+  /* EXPERIMENT (mfma_bf16 == 4, two fp16 planes / three products): dz is multiplied with dz_scale[cout] (2^s,
+   * c3d_grad_exponent_max) while it is staged, x with 2^6; the fold multiplies 2^-6 * *out_scale_dev (2^-s) back */
+  const float* dz_scale;
+  const float* out_scale_dev;
 } c3d_wgrad_desc;
 int64_t c3d_wgrad_partial_floats(const c3d_wgrad_desc* d);
 int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream);
