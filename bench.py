@@ -10,11 +10,15 @@ A step = input normalisation -> SalsaNextProto forward (return_feat, use_prototy
 GPU, fp32 (BASELINE.json configs[1]; BASELINE.md section 3 input recipe).  Inputs are resident in
 HBM before the timed region.  Rank 0 prints ONE JSON line.
 
-Two passes on one GPU (``--graph auto``, the default): W + K steps launched kernel by kernel, then the same W + K steps
-each replayed as ONE hipGraph (``TrainStep(graph=True)``, bit-identical to the first pass: tests/test_gpu_step.py).
+Two passes (``--graph auto``, the default): W + K steps launched kernel by kernel, then the same W + K steps each
+replayed as ONE hipGraph (``TrainStep(graph=True)``, bit-identical to the eager shape-static step: tests/test_gpu_step.py).
 `value` / `ms_per_step` are the K timed steps of the captured pass -- the launch mode that does not depend on how busy
 the host is (launch by launch the host needs ~20 ms per step; the same run's `launch_by_launch` reports that pass).
-More than one rank: launch by launch (the data-parallel exchanges stay eager).
+More than one rank (RCCL): the same two passes under coarse3d_amd.dist.DataParallel -- the captured step contains the
+exchanges (SyncBatchNorm sums, gradient buckets, prototype bank) as graph nodes; `config.collectives_per_step` carries
+the counts and, from the launch-by-launch pass, the exposed communication time.  The default one-GPU line also carries
+`engines.dp_single_rank_rccl` (the data-parallel step in a 1-rank RCCL group: the exchange code live on every run) and
+`configs` (short passes of BASELINE.json configs[2..4] with their own roofline objects).
 
 `roofline`: every launch of the dominant kernel (the template instance with the largest total time; name in
 roofline.kernel, the rocprofv3 summary in profiles/ lists the same name) is bracketed by HIP events on the launch stream
@@ -38,22 +42,9 @@ FEATURE_MEAN = [12.12, 10.88, 0.23, -1.04, 0.21]     # config_semantic_kitti.yam
 FEATURE_STD = [12.32, 11.47, 6.91, 0.86, 0.16]       # config_semantic_kitti.yaml:148-153
 PEAK_FP32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md chip-level parameters
 PEAK_BF16_MFMA_TFLOPS = 2500.0                       # dense bf16 (no sparsity), same guide
-# committed per-kernel HBM-traffic captures (tools/profile_round.sh <tag> <bench args>): one per (workload, engine)
-PMC_FILE = "round3_{tag}_hbm.json"
-
-
-def pmc_tag(args):
-    """Tag of the committed rocprofv3 capture that matches this command line (workload + matrix engine), or None."""
-    if args.net != "salsanext":
-        return None
-    key = (args.height, args.width, args.classes, args.dataset, args.batch)
-    wl = {(64, 2048, 20, "SemanticKitti", 8): "kitti", (32, 1024, 17, "SemanticKitti", 16): "nuscenes",
-          (32, 1024, 17, "nuScenes", 16): "nuscenes", (40, 1800, 14, "SemanticPOSS", 8): "poss"}.get(key)
-    if wl is None:
-        return None
-    if args.matrix_dtype == "bf16" and args.storage != "bf16":
-        return None
-    return f"{wl}_{args.matrix_dtype}"
+# committed per-kernel HBM-traffic captures (tools/profile_round.sh <tag> <bench args>): profiles/round<N>_<workload>_<engine>_hbm.json,
+# newest round first
+PMC_ROUNDS = (4, 3)
 
 
 def synth_batch(b, h, w, ncls, seed, device, label_rate=1e-3):
@@ -225,8 +216,353 @@ def launch_ranks(n):
     return 0
 
 
-def default_shape_for_step(args):
-    return (args.net, args.height, args.width, args.classes, args.dataset) == ("salsanext", 64, 2048, 20, "SemanticKitti")
+# ---------------------------------------------------------------------------------------------- workloads
+# BASELINE.json configs on one MI355X (configs[0] is the reference's CPU case = `cpu_baseline`); the default run measures
+# configs[1] in full (`value`, `roofline`, both launch modes) and appends short passes of the others under `configs`
+BASELINE_CONFIGS = {
+    "configs[2]": dict(height=64, width=2048, classes=20, dataset="SemanticKitti", batch=8, matrix_dtype="bf16", storage="bf16",
+                       note="SemanticKITTI 64x2048 bf16 (bf16 activations in HBM + bf16 MFMA operands, f32 accumulate / statistics / "
+                            "master weights), bs=8"),
+    "configs[3]": dict(height=32, width=1024, classes=17, dataset="SemanticKitti", batch=16, matrix_dtype="bf16x3", storage=None,
+                       note="nuScenes 32x1024 range image, 16 classes + ignore, bs=16 (small-H path)"),
+    "configs[4]": dict(height=40, width=1800, classes=14, dataset="SemanticPOSS", batch=8, matrix_dtype="bf16x3", storage=None,
+                       note="SemanticPOSS 40x1800 (+8 pad), 0.01 % weak labels, entropy anchor sampling on (sparse-anchor path)"),
+}
+
+
+def pmc_tag(wl):
+    """Tag of the committed rocprofv3 capture that matches a workload (shape + matrix engine), or None."""
+    if wl["net"] != "salsanext":
+        return None
+    key = (wl["height"], wl["width"], wl["classes"], wl["dataset"], wl["batch"])
+    name = {(64, 2048, 20, "SemanticKitti", 8): "kitti", (32, 1024, 17, "SemanticKitti", 16): "nuscenes",
+            (32, 1024, 17, "nuScenes", 16): "nuscenes", (40, 1800, 14, "SemanticPOSS", 8): "poss"}.get(key)
+    if name is None or (wl["matrix_dtype"] == "bf16" and wl["storage"] != "bf16"):
+        return None
+    return f"{name}_{wl['matrix_dtype']}"
+
+
+def load_pmc(wl):
+    """(tag, file name, {kernel: row}) of the newest committed PMC capture of this workload, or (tag, None, None)."""
+    tag = pmc_tag(wl)
+    if tag is None:
+        return None, None, None
+    for rnd in PMC_ROUNDS:
+        name = f"round{rnd}_{tag}_hbm.json"
+        try:
+            return tag, name, json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+    return tag, None, None
+
+
+def peak_for(kernel_name):
+    """Matrix-pipe ceiling (TFLOP/s, fp32-equivalent) of one kernel instance: the dense bf16 peak divided by the plane
+    products the instance runs per fp32 multiply-add; fp32 MFMA kernels against the fp32 MFMA peak."""
+    if kernel_name.startswith("conv_pw3f_kernel"):       # <NT, WN>: the fused bf16x3 kernel, six plane products
+        return PEAK_BF16_MFMA_TFLOPS / 6.0
+    if kernel_name.startswith("conv_pw3_kernel"):        # <NT, NP>; NP = 3 runs six plane products
+        return PEAK_BF16_MFMA_TFLOPS / 6.0 if kernel_name.endswith(", 3>") else PEAK_BF16_MFMA_TFLOPS
+    if kernel_name.startswith(("conv_x3_kernel", "conv_x3f_kernel")):   # <NT, HALO, TT, SIX>
+        return PEAK_BF16_MFMA_TFLOPS / (6.0 if kernel_name.endswith("true>") else 8.0)
+    if kernel_name.startswith("conv_bfp_kernel"):
+        return PEAK_BF16_MFMA_TFLOPS / 8.0 if kernel_name.rstrip(">").endswith("3") else PEAK_BF16_MFMA_TFLOPS
+    if kernel_name.startswith("wgrad_mfma_kernel") and kernel_name.endswith("true>"):
+        return PEAK_BF16_MFMA_TFLOPS
+    if kernel_name.startswith("wgrad_tr_kernel"):
+        return PEAK_BF16_MFMA_TFLOPS / 6.0 if kernel_name.startswith("wgrad_tr_kernel<3") else PEAK_BF16_MFMA_TFLOPS
+    return PEAK_FP32_MFMA_TFLOPS
+
+
+HBM_KERNELS = ("bn_bwd_kernel", "bilinear_kernel", "bilinear_bwd_kernel", "bilinear_sum2_kernel", "affine_add_kernel",
+               "maskpool_kernel", "maskpool_bwd_kernel", "catskip_kernel", "catskip_bwd_kernel", "pixshuf_kernel",
+               "pixshuf_bwd_kernel", "l2norm_kernel", "l2norm_bwd_kernel", "rownorm_kernel", "softmax_kernel", "softmax_bwd_kernel",
+               "bn_bwd_reduce_kernel", "axpy_kernel")
+MATRIX_KERNELS = ("conv_", "wgrad_")
+
+
+class Bench:
+    """One workload on the current process' GPU: model + TrainStep construction, the timed passes, the roofline object."""
+
+    def __init__(self, wl, dev, rank, world, dp):
+        self.wl, self.dev, self.rank, self.world, self.dp = wl, dev, rank, world, dp
+
+    def build(self, graph, wgrad_stream=None):
+        import torch
+        from coarse3d_amd import dist as D
+        from coarse3d_amd import ops
+        from coarse3d_amd.pc_processor.models import RangeNetProto, SalsaNextProto, SqueezeSegV3Proto
+        from coarse3d_amd.trainer import TrainStep
+        wl = self.wl
+        ops.set_matrix_precision(wl["matrix_dtype"], storage=wl["storage"] if wl["matrix_dtype"] == "bf16" else None)
+        torch.manual_seed(1)
+        net = wl["net"]
+        if net == "salsanext":
+            model = SalsaNextProto(5, wl["classes"], 20, 0, use_prototype=True, dataset=wl["dataset"])
+        elif net.startswith("rangenet"):
+            model = RangeNetProto(layers=int(net[-2:]), nclasses=wl["classes"], dataset=wl["dataset"], use_prototype=True)
+        else:
+            model = SqueezeSegV3Proto(nclasses=wl["classes"], layers=int(net[-2:]), dataset=wl["dataset"], use_prototype=True)
+        model = model.to(self.dev).train()
+        prev = os.environ.get("C3D_WGRAD_STREAM")
+        if wgrad_stream is not None:
+            os.environ["C3D_WGRAD_STREAM"] = wgrad_stream      # read whenever a backbone pass is built
+        self._restore_env = (prev, wgrad_stream is not None)
+        wrapped = D.DataParallel(model) if self.dp else model
+        ts = TrainStep(wrapped, wl["classes"], lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512, loss_w_ce_2d=1.0,
+                       loss_w_lov_2d=1.0, loss_w_contrast=0.1, feature_mean=FEATURE_MEAN, feature_std=FEATURE_STD,
+                       proto_loss=True, graph=graph, inputs_resident=True)   # batches are generated and synchronised before the timed region
+        return model, ts
+
+    def done(self):
+        prev, touched = self._restore_env
+        if touched:
+            if prev is None:
+                os.environ.pop("C3D_WGRAD_STREAM", None)
+            else:
+                os.environ["C3D_WGRAD_STREAM"] = prev
+
+    def batches(self, n):
+        import torch
+        wl = self.wl
+        rate = 1e-4 if wl["dataset"] == "SemanticPOSS" else 1e-3
+        out = [synth_batch(wl["batch"], wl["height"], wl["width"], wl["classes"], 1000 + s + 7919 * self.rank, self.dev, rate)
+               for s in range(n)]
+        torch.cuda.synchronize()               # inputs resident in HBM before the first step touches them
+        return out
+
+    def barrier(self):
+        import torch
+        import torch.distributed as dist
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    @staticmethod
+    def summarise(events):
+        """{kernel instance: [flops, seconds, launches]} and the per-(instance, layer shape) table."""
+        per, table = {}, {}
+        for name, flops, e0, e1, detail in events:
+            sec_ = e0.elapsed_time(e1) * 1e-3
+            for dd, key in ((per, name), (table, (name, detail))):
+                d = dd.setdefault(key, [0.0, 0.0, 0])
+                d[0] += flops
+                d[1] += sec_
+                d[2] += 1
+        return per, table
+
+    def run(self, graph, steps, warmup, prewarm, events, wgrad_stream=None, exposed=False):
+        """W untimed warm-up steps (after ``prewarm`` extra ones: one-time costs of a fresh box), then EXACTLY ``steps``
+        timed steps between barrier + synchronize on both sides; max over ranks.  ``events``: bracket every MFMA launch of
+        the last eager warm-up step with HIP events on the launch stream (survey: picks the dominant kernel instance) and,
+        launch by launch, the dominant instance's launches inside the timed region.  Returns a dict."""
+        import torch
+        import torch.distributed as dist
+        from coarse3d_amd import dist as D
+        from coarse3d_amd import ops
+        model, ts = self.build(graph, wgrad_stream)
+        try:
+            if graph:
+                warmup = max(warmup, 3)            # two eager steps + the capture
+                if events:
+                    prewarm = max(prewarm, 3)      # the survey step must be an eager one ahead of the capture
+            total = warmup + steps
+            batches = self.batches(total)
+            survey = None
+            for s in range(prewarm):
+                # captured pass: HIP events can only bracket launches of an EAGER step (the second pre-warm step; the third is the capture)
+                probe = graph and s == 1 and events
+                if probe:
+                    ops.KERNEL_EVENTS = []
+                ts.step(*batches[s % total], epoch=10)
+                if probe:
+                    torch.cuda.synchronize()
+                    survey = self.summarise(ops.KERNEL_EVENTS)
+                    ops.KERNEL_EVENTS = None
+            for s in range(warmup):
+                last = s == warmup - 1 and events and not graph
+                if last:
+                    ops.KERNEL_EVENTS = []
+                ts.step(*batches[s], epoch=10)
+                if last:
+                    torch.cuda.synchronize()
+                    survey = self.summarise(ops.KERNEL_EVENTS)
+                    ops.KERNEL_EVENTS = None
+            # RCCL prints a version banner through C stdio on first use; push it out now so that the JSON line is the
+            # last thing this process writes to stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+            if events and not graph:
+                ops.KERNEL_EVENTS = []
+                if survey is not None:
+                    ops.KERNEL_EVENT_FILTER = max(survey[0].items(), key=lambda kv: kv[1][1])[0]
+            counts0 = dict(D.COUNTS)
+            if exposed and not graph:
+                D.EXPOSED = []                   # event-time what the main stream waits for each blocking exchange
+            self.barrier()
+            t0 = time.perf_counter()
+            for s in range(warmup, total):
+                res = ts.step(*batches[s], epoch=10)
+            self.barrier()
+            elapsed = time.perf_counter() - t0
+            loss = float(res["loss"])
+            if self.world > 1:
+                t = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t)
+            timed = None
+            if ops.KERNEL_EVENTS:
+                timed = self.summarise(ops.KERNEL_EVENTS)
+            ops.KERNEL_EVENTS = None
+            ops.KERNEL_EVENT_FILTER = None
+            out = {"elapsed": elapsed, "loss": loss, "steps": steps, "warmup": warmup, "survey": survey, "timed": timed,
+                   "graph": bool(graph), "type": type(model).__name__}
+            n_ranks = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+            if self.dp:
+                coll = {k: round((D.COUNTS[k] - counts0[k]) / steps, 2) for k in D.COUNTS}
+                coll["total"] = round(sum(coll.values()), 2)
+                if D.EXPOSED is not None:
+                    ex = D.exposed_ms(D.EXPOSED)
+                    D.EXPOSED = None
+                    coll["comm_exposed_ms"] = {k: round(v / steps, 3) for k, v in ex.items()}
+                    coll["comm_exposed_ms"]["total"] = round(sum(ex.values()) / steps, 3)
+                out["collectives"] = coll
+            out["n_ranks"] = n_ranks
+            out["value"] = round(self.wl["batch"] * n_ranks * steps / elapsed, 3)
+            out["ms_per_step"] = round(elapsed / steps * 1e3, 3)
+            return out
+        finally:
+            D.EXPOSED = None
+            ops.KERNEL_EVENTS = None
+            ops.KERNEL_EVENT_FILTER = None
+            self.done()
+            del ts, model
+            torch.cuda.empty_cache()
+
+    def roofline(self, run, kernel_table=None):
+        """The `roofline` object from a pass that carried HIP events (see ``run``)."""
+        survey, timed = run["survey"], run["timed"]
+        if survey is None and timed is None:
+            return None
+        per = timed[0] if timed is not None else survey[0]
+        if survey is None:                   # no warm-up step: everything was bracketed in the timed region
+            survey, all_steps = timed, run["steps"]
+        else:
+            all_steps = 1
+        name, (fl, sec, n) = max(per.items(), key=lambda kv: kv[1][1])
+        timed_steps = run["steps"] if timed is not None else 1
+        all_fl = sum(v[0] for v in survey[0].values())
+        all_sec = sum(v[1] for v in survey[0].values())
+        all_ideal = sum(v[0] / (peak_for(k) * 1e12) for k, v in survey[0].items())    # seconds at each kernel's own peak
+        peak_tf = peak_for(name)
+        if kernel_table and self.rank == 0:
+            rows = [{"kernel": k[0], "h_w_cin_cout_taps_halo_acc": k[1], "launches_per_step": v[2] / all_steps,
+                     "ms_per_step": round(v[1] / all_steps * 1e3, 4), "tflops": round(v[0] / v[1] / 1e12, 2)}
+                    for k, v in sorted(survey[1].items(), key=lambda kv: -kv[1][1])]
+            json.dump(rows, open(kernel_table, "w"), indent=0)
+        # HBM traffic of the same kernel from the PMC passes kept under profiles/ (2*FETCH_SIZE + WRITE_SIZE, separate
+        # rocprofv3 --pmc runs of this bench; tools/profile_round.sh, tools/hbm_report.py)
+        tag, pmc_name, pmc = load_pmc(self.wl)
+        traffic = None
+        if pmc is not None and name in pmc:
+            traffic = round(pmc[name]["hbm_bytes_per_launch"])
+        if peak_tf == PEAK_BF16_MFMA_TFLOPS / 8.0:
+            note = ("fp32-equivalent ceiling of the exact-split engine: dense bf16 MFMA peak 2500 / 8 plane products (forward convs "
+                    "over small BatchNorm populations; everything else runs six: 416.7)")
+        elif peak_tf == PEAK_BF16_MFMA_TFLOPS / 6.0:
+            note = ("fp32-equivalent ceiling of the exact-split engine with six plane products: 2500 / 6 -- the NOMINAL dense bf16 "
+                    "peak.  On operands that toggle the chip runs these launches at its power budget (1.9-2.0 GHz): the same launches "
+                    "on zero-filled tensors are 32-35 % faster (profiles/round3_dvfs_zero_inputs.txt; 1.23-1.41 PF on random data vs "
+                    "1.67-1.86 zero-filled, MI355X_MICROARCH.md's own attention kernel: 1.25 / 1.48), so frac ~0.5-0.56 is the "
+                    "sustained rate of the matrix pipe on real data, not slack in the schedule")
+        elif peak_tf == PEAK_BF16_MFMA_TFLOPS:
+            note = "dense bf16 MFMA peak (MI355X_MICROARCH.md)"
+        else:
+            note = "fp32 MFMA peak (MI355X_MICROARCH.md)"
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2), "peak": round(peak_tf, 1), "unit": "TFLOP/s",
+                "frac": round(fl / sec / 1e12 / peak_tf, 4), "peak_note": note, "traffic": traffic,
+                "traffic_source": (f"committed PMC pass profiles/{pmc_name} (2*FETCH_SIZE + WRITE_SIZE per launch of this kernel, "
+                                   "separate rocprofv3 --pmc runs of this bench); not re-measured in this run") if traffic is not None else None,
+                "launches_per_step": n // timed_steps, "avg_launch_us": round(sec / n * 1e6, 2),
+                "gflop_per_launch": round(fl / n / 1e9, 3),
+                "dominant_kernel_is": "the MFMA kernel instance with the largest total time (HIP events on the launch stream); see "
+                                      "`largest_kernel` for the largest kernel of the step whatever its bound",
+                "all_mfma_kernels": {"achieved": round(all_fl / all_sec / 1e12, 2), "frac": round(all_ideal / all_sec, 4),
+                                     "frac_note": "time at each kernel's own matrix-pipe peak / measured time",
+                                     "achieved_vs_fp32_mfma_peak": round(all_fl / all_sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                     "ms_per_step": round(all_sec / all_steps * 1e3, 2),
+                                     "executed_TFLOP_per_step": round(all_fl / all_steps / 1e12, 3),
+                                     "measured_in": "last eager warm-up step" if all_steps == 1 else "timed steps"},
+                "dominant_kernel_measured_in": ("the eager warm-up step before the capture (HIP events cannot bracket launches inside "
+                                                "a replayed graph)") if timed is None else "timed steps"}
+        if pmc is not None:
+            # the HBM-bound kernels of the conv blocks (north star: "achieved HBM GB/s for the conv blocks"): bytes =
+            # 2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes over this same bench command (same workload, same
+            # matrix engine), time = that capture's kernel-trace average
+            rows, tot_ms, tot_bytes = {}, 0.0, 0.0
+            for k, v in pmc.items():
+                if k.split("<")[0] in HBM_KERNELS:
+                    rows[k] = {"GBps": round(v["gbps"]), "frac_of_8TBps": round(v["gbps"] / 8000.0, 3),
+                               "ms_per_step": round(v["ms_per_step"], 3)}
+                    tot_ms += v["ms_per_step"]
+                    tot_bytes += v["hbm_bytes_per_launch"] * v["launches_per_step"]
+            roof["hbm_kernels"] = {"source": f"profiles/{pmc_name} (committed rocprofv3 PMC passes of this workload and engine, not "
+                                             "re-measured in this run)",
+                                   "peak_GBps": 8000, "ms_per_step": round(tot_ms, 3),
+                                   "achieved_GBps": round(tot_bytes / (tot_ms * 1e-3) / 1e9) if tot_ms else None,
+                                   "frac_of_8TBps": round(tot_bytes / (tot_ms * 1e-3) / 8e12, 3) if tot_ms else None,
+                                   "kernels": rows}
+            step_bytes = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in pmc.values())
+            roof["step_hbm_traffic_GB"] = round(step_bytes / 1e9, 2)
+            # the largest kernel of the step by total time, whatever bounds it (round 3's line never showed that an
+            # HBM-bound kernel led the list)
+            # (FillFunctor / __amd_rocclr rows are one-time allocations and uploads that the capture divides by its steps)
+            k, v = max(((k, v) for k, v in pmc.items() if "FillFunctor" not in k and not k.startswith("__amd_rocclr")),
+                       key=lambda kv: kv[1]["ms_per_step"])
+            is_matrix = k.startswith(MATRIX_KERNELS)
+            entry = {"kernel": k, "ms_per_step": round(v["ms_per_step"], 3), "launches_per_step": v["launches_per_step"],
+                     "bound": "mfma" if is_matrix else "hbm", "hbm_GBps": round(v["gbps"]),
+                     "frac_of_8TBps": round(v["gbps"] / 8000.0, 3), "source": f"profiles/{pmc_name}"}
+            if is_matrix and k in survey[0]:
+                f_, s_, _ = survey[0][k]
+                entry["achieved_TFLOPs"] = round(f_ / s_ / 1e12, 2)
+                entry["frac_of_matrix_peak"] = round(f_ / s_ / 1e12 / peak_for(k), 4)
+            roof["largest_kernel"] = entry
+        return roof
+
+
+def whole_step(roof, value_img_s):
+    """Whole-step view with SURVEY 8d's normative work per 64x2048 image (533.5 GFLOP, 10.96 GB fp32) -- the REFERENCE's
+    arithmetic -- beside the work the step actually executes (rounds 2-3 removed work: similarity on the labelled rows only,
+    the projector's first conv commuted with the resampling): 'reference-work-equivalent' throughput is not utilisation."""
+    sec_img = 1.0 / value_img_s
+    out = {"reference_work_equivalent_TFLOPs": round(533.5e9 / sec_img / 1e12, 2),
+           "reference_work_equivalent_vs_fp32_mfma_peak": round(533.5e9 / sec_img / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+           "note": "533.5 GFLOP / image is the normative work of the reference's step (SURVEY 8d); this is throughput in units of the "
+                   "reference's work, NOT utilisation of the matrix pipe -- see executed_* and roofline.all_mfma_kernels.frac",
+           "algorithmic_GBps": round(10.96e9 / sec_img / 1e9, 1), "frac_of_hbm_peak": round(10.96e9 / sec_img / 8e12, 4)}
+    ex = roof["all_mfma_kernels"].get("executed_TFLOP_per_step") if roof else None
+    if ex:
+        out["normative_TFLOP_per_step"] = round(533.5e9 * 8 / 1e12, 3)
+        out["executed_matrix_TFLOP_per_step"] = ex
+        out["executed_over_normative"] = round(ex / (533.5e9 * 8 / 1e12), 3)
+    return out
+
+
+DTYPE_NOTE = {
+    "f32": "f32 (v_mfma_f32_32x32x2_f32 everywhere)",
+    "bf16": "bf16 activations in HBM + bf16 MFMA operands, f32 accumulate / statistics / master weights",
+    "bf16_f32storage": "bf16 MFMA operands, f32 accumulate/storage",
+    "bf16x3": "f32 via 3xbf16 exact split on the bf16 matrix pipe (the library's default engine), f32 accumulate; 6 of 9 plane "
+              "products (8 of 9 in forward 3x3 / 2x2 convs whose output has fewer than 32768 pixels, where a small BatchNorm "
+              "population amplifies the difference); f32 storage everywhere.  Parity as measured on MI355X "
+              "(profiles/round4_parity_measured.json): forward / logits / prototypes <= 1e-4 of the reference on every golden; "
+              "pseudo-label maps identical; anchor selection bit-exact on identical weights; END TO END against the reference's "
+              "golden steps: {anchor_rate}; whole-network gradient error vs the reference golden: median 1.1e-2 (fp32-MFMA engine "
+              "6.1e-3; per-layer float64 check 7e-7 on both)",
+}
+ANCHOR_RATE = ("2303 of 2304 draws identical at 2x64x128 / 64 anchors (one draw lies 6.7 fp32 ulps from its bin edge and lands on the "
+               "neighbouring candidate; strict fp32-MFMA engine: 2304 of 2304)")
 
 
 def main():
@@ -243,22 +579,23 @@ def main():
                     help="backbone (default: SalsaNextProto, the BASELINE workload; rangenet* / squeezeseg*: SURVEY 8f N3)")
     ap.add_argument("--matrix-dtype", choices=("f32", "bf16", "bf16x3"), default="bf16x3",
                     help="matrix engine of conv / input-gradient kernels.  bf16x3 (default): every fp32 operand split "
-                         "EXACTLY into three bf16 planes, eight of the nine plane products accumulated in fp32 on the "
-                         "bf16 MFMA pipe -- fp32-class results (the whole -m gpu parity suite passes in this "
-                         "mode: tests/test_gpu_configs.py::test_whole_gpu_suite_passes_on_the_exact_split_bf16_engine); "
+                         "EXACTLY into three bf16 planes, six or eight of the nine plane products accumulated in fp32 on the "
+                         "bf16 MFMA pipe -- fp32-class results (the library default: the whole -m gpu parity suite runs on it); "
                          "f32: the fp32-MFMA engine (also timed, reported under `engines`); bf16: opt-in mixed "
-                         "precision (operands rounded to bf16, fp32 accumulate and storage; BASELINE configs[2])")
-    ap.add_argument("--no-second-engine", action="store_true", help="skip the fp32-MFMA engine's comparison run")
+                         "precision (operands rounded to bf16, fp32 accumulate; BASELINE configs[2])")
+    ap.add_argument("--no-second-engine", action="store_true", help="skip the comparison passes under `engines`")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short passes of BASELINE configs[2..4] under `configs`")
     ap.add_argument("--storage", choices=("bf16", "f32"), default="bf16",
                     help="activation storage of --matrix-dtype bf16 (BASELINE configs[2]): bf16 tensors in HBM "
                          "(default) or fp32 tensors with bf16 MFMA operands only")
     ap.add_argument("--graph", nargs="?", const="on", default="auto", choices=("auto", "on", "off"),
-                    help="how the step is launched.  auto (default; one GPU, SalsaNext): TWO passes of W + K steps over the same "
-                         "batches -- launch by launch, with live HIP events around the dominant kernel inside its timed region "
-                         "(`roofline`, `launch_by_launch`), then replayed as ONE hipGraph per step (TrainStep(graph=True), "
-                         "bit-identical: tests/test_gpu_step.py), whose K timed steps give `value` (the host needs ~20 ms per "
-                         "step launch by launch; on a box whose host is busy that, not the GPU, bounds the step).  on: only the "
-                         "captured step (per-kernel figures from its eager warm-up step).  off: launch by launch only")
+                    help="how the step is launched.  auto (default): TWO passes of W + K steps over the same batches -- launch by "
+                         "launch, with live HIP events around the dominant kernel inside its timed region (`roofline`, "
+                         "`launch_by_launch`; data parallel: `comm_exposed_ms`), then replayed as ONE hipGraph per step "
+                         "(TrainStep(graph=True), bit-identical: tests/test_gpu_step.py, tests/test_gpu_dp.py), whose K timed steps "
+                         "give `value` (the host needs ~20 ms per step launch by launch; on a box whose host is busy that, not "
+                         "the GPU, bounds the step).  on: only the captured step (per-kernel figures from its eager warm-up step).  "
+                         "off: launch by launch only.  More than one rank: the captured step contains the RCCL exchanges")
     ap.add_argument("--prewarm", type=int, default=3,
                     help="untimed steps ahead of the W warm-up steps (one-time costs of a fresh box; profiling runs pass 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -284,365 +621,120 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     single_rank_group = world == 1 and bool(os.environ.get("C3D_SINGLE_RANK_COLLECTIVES"))   # RCCL smoke test
+    backend = os.environ.get("C3D_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; gloo lets two ranks share one GPU for testing
     if world > 1 or single_rank_group:
-        # "nccl" is RCCL on ROCm; C3D_DIST_BACKEND=gloo lets two ranks share one GPU for testing
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        backend = os.environ.get("C3D_DIST_BACKEND", "nccl")
         dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
+    dp = world > 1 or single_rank_group
 
-    from coarse3d_amd import dist as D
     from coarse3d_amd import ops
-    from coarse3d_amd.pc_processor.models import RangeNetProto, SalsaNextProto, SqueezeSegV3Proto
-    from coarse3d_amd.trainer import TrainStep
 
-    ops.set_matrix_precision(args.matrix_dtype, storage=args.storage if args.matrix_dtype == "bf16" else None)
-    # bf16x3: EIGHT bf16 MFMAs (32x32x16) do the work of eight fp32 MFMAs' worth of K... i.e. per fp32 product
-    # eight plane products: the fp32-equivalent ceiling of that engine is the dense bf16 peak / 8
-    peak_tf = {"f32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS,
-               "bf16x3": PEAK_BF16_MFMA_TFLOPS / 8.0}[args.matrix_dtype]
-
-    def peak_for(kernel_name):
-        """Matrix-pipe ceiling of one kernel instance: conv_bfp / conv_x3 / wgrad_tr instances run on the bf16
-        pipe (eight plane products per fp32 product in the "<3" instances); the rest on fp32 MFMA."""
-        if kernel_name.startswith("conv_pw3f_kernel"):       # <NT, WN>: the fused bf16x3 kernel, six plane products
-            return PEAK_BF16_MFMA_TFLOPS / 6.0
-        if kernel_name.startswith("conv_pw3_kernel"):        # <NT, NP>; NP = 3 runs six plane products
-            return PEAK_BF16_MFMA_TFLOPS / 6.0 if kernel_name.endswith(", 3>") else PEAK_BF16_MFMA_TFLOPS
-        if kernel_name.startswith(("conv_x3_kernel", "conv_x3f_kernel")):   # <NT, HALO, TT, SIX>
-            return PEAK_BF16_MFMA_TFLOPS / (6.0 if kernel_name.endswith("true>") else 8.0)
-        if kernel_name.startswith("conv_bfp_kernel"):
-            return PEAK_BF16_MFMA_TFLOPS / 8.0 if kernel_name.rstrip(">").endswith("3") else PEAK_BF16_MFMA_TFLOPS
-        if kernel_name.startswith("wgrad_mfma_kernel") and kernel_name.endswith("true>"):
-            return PEAK_BF16_MFMA_TFLOPS
-        if kernel_name.startswith("wgrad_tr_kernel"):
-            return PEAK_BF16_MFMA_TFLOPS / 6.0 if kernel_name.startswith("wgrad_tr_kernel<3") else PEAK_BF16_MFMA_TFLOPS   # six plane products
-        return PEAK_FP32_MFMA_TFLOPS
-    torch.manual_seed(1)
-    if args.net == "salsanext":
-        model = SalsaNextProto(5, args.classes, 20, 0, use_prototype=True, dataset=args.dataset)
-    elif args.net.startswith("rangenet"):
-        model = RangeNetProto(layers=int(args.net[-2:]), nclasses=args.classes, dataset=args.dataset, use_prototype=True)
-    else:
-        model = SqueezeSegV3Proto(nclasses=args.classes, layers=int(args.net[-2:]), dataset=args.dataset, use_prototype=True)
-    model = model.to(dev).train()
-    wrapped = D.DataParallel(model) if (world > 1 or single_rank_group or os.environ.get("C3D_FORCE_DP")) else model
-    ts = TrainStep(wrapped, args.classes, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512,
-                   loss_w_ce_2d=1.0, loss_w_lov_2d=1.0, loss_w_contrast=0.1, feature_mean=FEATURE_MEAN,
-                   feature_std=FEATURE_STD, proto_loss=True, graph=args.graph == "on" and world == 1 and not single_rank_group,
-                   inputs_resident=True)      # the batches below are generated and synchronised before the timed region
-    if ts.graph and args.warmup < 3:
-        args.warmup = 3                       # two eager steps + the capture
-    rate = 1e-4 if args.dataset == "SemanticPOSS" else 1e-3
-    total_steps = args.warmup + args.steps
-    batches = [synth_batch(args.batch, args.height, args.width, args.classes, 1000 + s + 7919 * rank, dev, rate)
-               for s in range(total_steps)]
-    torch.cuda.synchronize()               # inputs resident in HBM before the first step touches them
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def summarise(events, nsteps):
-        """{kernel instance: [flops, seconds, launches]} and the per-(instance, layer shape) table."""
-        per, table = {}, {}
-        for name, flops, e0, e1, detail in events:
-            sec_ = e0.elapsed_time(e1) * 1e-3
-            for dd, key in ((per, name), (table, (name, detail))):
-                d = dd.setdefault(key, [0.0, 0.0, 0])
-                d[0] += flops
-                d[1] += sec_
-                d[2] += 1
-        return per, table
-
-    # Warm-up.  The LAST warm-up step brackets EVERY MFMA launch with HIP events on the launch
-    # stream: that picks the dominant kernel instance and gives the all-kernel summary.  The timed
-    # steps then bracket only the launches of that dominant instance (bracketing all ~300 launches
-    # per step costs ~2 % of the step, which would distort `value`).
-    survey = None
-    # Three extra untimed steps ahead of the W warm-up steps: on 2 of 5 fresh boxes of round 3 the FIRST bench process
-    # averaged 56-71 ms over its 20 timed steps (34.3 ms in the next process on the same box) -- one-time costs that W = 5
-    # steps do not always cover (first-touch of the ~25 GB the step allocates, lazily paged-in libraries).  They change
-    # nothing about what is timed: exactly K steps, bracketed by barrier + synchronize.
-    if ts.graph:
-        args.prewarm = max(args.prewarm, 3)
-    for s in range(args.prewarm):
-        # (captured step: HIP events can only bracket launches of an EAGER step -- the second pre-warm step; the third
-        #  one is the capture)
-        probe = ts.graph and s == 1 and not args.no_kernel_events
-        if probe:
-            ops.KERNEL_EVENTS = []
-        ts.step(*batches[s % total_steps], epoch=10)
-        if probe:
-            torch.cuda.synchronize()
-            survey = summarise(ops.KERNEL_EVENTS, 1)
-            ops.KERNEL_EVENTS = None
-    for s in range(args.warmup):
-        last = s == args.warmup - 1 and not args.no_kernel_events and not ts.graph
-        if last:
-            ops.KERNEL_EVENTS = []
-        ts.step(*batches[s], epoch=10)
-        if last:
-            torch.cuda.synchronize()
-            survey = summarise(ops.KERNEL_EVENTS, 1)
-            ops.KERNEL_EVENTS = None
-    # RCCL prints a version banner through C stdio on first use; push it out now so that the
-    # JSON line below is the last thing this process writes to stdout
-    import ctypes
-    ctypes.CDLL(None).fflush(None)
-    if not args.no_kernel_events and not ts.graph:
-        ops.KERNEL_EVENTS = []
-        if survey is not None:
-            ops.KERNEL_EVENT_FILTER = max(survey[0].items(), key=lambda kv: kv[1][1])[0]
-    counts0 = dict(D.COUNTS)
-    if world > 1 or single_rank_group:
-        D.EXPOSED = []                   # event-time what the main stream waits for each blocking exchange
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(args.warmup, total_steps):
-        res = ts.step(*batches[s], epoch=10)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    loss = float(res["loss"])
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-
-    roofline = None
-    pmc_all = None
-    tag = None
-    if ts.graph and survey is not None:     # per-kernel figures of a captured run: from its eager warm-up step
-        ops.KERNEL_EVENTS = [None]
-    if ops.KERNEL_EVENTS:
-        per, table = (summarise(ops.KERNEL_EVENTS, args.steps) if not ts.graph else survey)
-        name, (fl, sec, n) = max(per.items(), key=lambda kv: kv[1][1])
-        if survey is None:                   # no warm-up step: everything was bracketed in the timed region
-            survey, all_steps = (per, table), args.steps
-        else:
-            all_steps = 1
-        timed_steps = 1 if ts.graph else args.steps    # captured run: the launches of ONE eager step were timed
-        all_fl = sum(v[0] for v in survey[0].values())
-        all_sec = sum(v[1] for v in survey[0].values())
-        all_ideal = sum(v[0] / (peak_for(k) * 1e12) for k, v in survey[0].items())    # seconds at each kernel's own peak
-        peak_tf = peak_for(name)
-        if args.kernel_table and rank == 0:
-            rows = [{"kernel": k[0], "h_w_cin_cout_taps_halo_acc": k[1], "launches_per_step": v[2] / all_steps,
-                     "ms_per_step": round(v[1] / all_steps * 1e3, 4), "tflops": round(v[0] / v[1] / 1e12, 2)}
-                    for k, v in sorted(survey[1].items(), key=lambda kv: -kv[1][1])]
-            json.dump(rows, open(args.kernel_table, "w"), indent=0)
-        # HBM traffic of the same kernel from the PMC passes kept under profiles/ (2*FETCH_SIZE +
-        # WRITE_SIZE, separate rocprofv3 --pmc runs of this bench; tools/profile_round.sh, tools/hbm_report.py)
-        traffic = None
-        tag = pmc_tag(args)
-        pmc_all = None
+    wl = dict(net=args.net, height=args.height, width=args.width, classes=args.classes, dataset=args.dataset, batch=args.batch,
+              matrix_dtype=args.matrix_dtype, storage=args.storage if args.matrix_dtype == "bf16" else None)
+    b = Bench(wl, dev, rank, world, dp)
+    events = not args.no_kernel_events
+    can_capture = not (dp and backend != "nccl")             # only RCCL collectives are capturable
+    want_eager = args.graph in ("auto", "off") or not can_capture
+    want_graph = args.graph in ("auto", "on") and can_capture
+    eager = cap = None
+    launch_note = None
+    if want_eager:
+        eager = b.run(False, args.steps, args.warmup, args.prewarm, events, exposed=dp)
+    if want_graph:
         try:
-            if tag is None:
-                raise KeyError("no PMC capture for this workload / engine")
-            pmc_all = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE.format(tag=tag))))
-            traffic = round(pmc_all[name]["hbm_bytes_per_launch"])
-        except (OSError, KeyError, ValueError):
-            pass
-        roofline = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2),
-                    "peak": round(peak_tf, 1), "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak_tf, 4),
-                    "peak_note": ("fp32-equivalent ceiling of the exact-split engine: dense bf16 MFMA peak 2500 / 8 plane "
-                                  "products (forward convs; the gradient kernels run six products: 416.7)")
-                                 if peak_tf == PEAK_BF16_MFMA_TFLOPS / 8.0 else
-                                 "fp32-equivalent ceiling of the exact-split engine with six plane products: 2500 / 6 -- the "
-                                 "NOMINAL dense bf16 peak.  On operands that toggle the chip runs these launches at its power "
-                                 "budget (1.9-2.0 GHz): the same launches on zero-filled tensors are 32-35 % faster "
-                                 "(profiles/round3_dvfs_zero_inputs.txt; 1.23-1.41 PF on random data vs 1.67-1.86 zero-filled, "
-                                 "MI355X_MICROARCH.md's own attention kernel: 1.25 / 1.48), so frac ~0.5-0.56 is the sustained "
-                                 "rate of the matrix pipe on real data, not slack in the schedule"
-                                 if peak_tf == PEAK_BF16_MFMA_TFLOPS / 6.0 else
-                                 "fp32 MFMA peak (MI355X_MICROARCH.md)",
-                    "traffic": traffic,
-                    "traffic_source": (f"committed PMC pass profiles/{PMC_FILE.format(tag=tag or '')} (2*FETCH_SIZE + WRITE_SIZE "
-                                       "per launch of this kernel, separate rocprofv3 --pmc runs of this bench); not "
-                                       "re-measured in this run") if traffic is not None else None,
-                    "launches_per_step": n // timed_steps,
-                    "avg_launch_us": round(sec / n * 1e6, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
-                    "all_mfma_kernels": {"achieved": round(all_fl / all_sec / 1e12, 2),
-                                         "frac": round(all_ideal / all_sec, 4),
-                                         "frac_note": "time at each kernel's own matrix-pipe peak / measured time",
-                                         "achieved_vs_fp32_mfma_peak": round(all_fl / all_sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                                         "achieved_vs_fp32_mfma_peak_note": "the same fp32-class TFLOP/s against the 157.3 TFLOP/s "
-                                                                            "ceiling of the fp32 MFMA instructions the reference "
-                                                                            "arithmetic would run on (round 1's yardstick)",
-                                         "ms_per_step": round(all_sec / all_steps * 1e3, 2),
-                                         "measured_in": "last warm-up step" if all_steps == 1 else "timed steps"},
-                    "dominant_kernel_measured_in": ("the eager warm-up step before the capture (HIP events cannot bracket "
-                                                    "launches inside a replayed graph)") if ts.graph else "timed steps"}
-    ops.KERNEL_EVENTS = None
-    ops.KERNEL_EVENT_FILTER = None
-    if roofline is not None and pmc_all is not None:
-        # the HBM-bound kernels of the conv blocks (north star: "achieved HBM GB/s for the conv blocks"):
-        # bytes = 2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes over this same bench command (same workload,
-        # same matrix engine), time = that capture's kernel-trace average
-        rows = {}
-        wanted = ("bn_bwd_kernel", "bilinear_kernel", "bilinear_bwd_kernel", "affine_add_kernel", "maskpool_kernel",
-                  "maskpool_bwd_kernel", "catskip_kernel", "catskip_bwd_kernel", "pixshuf_kernel", "pixshuf_bwd_kernel",
-                  "l2norm_bwd_kernel", "rownorm_kernel", "softmax_kernel", "softmax_bwd_kernel")
-        tot_ms = tot_bytes = 0.0
-        for k, v in pmc_all.items():
-            if k.split("<")[0] in wanted:
-                rows[k] = {"GBps": round(v["gbps"]), "frac_of_8TBps": round(v["gbps"] / 8000.0, 3),
-                           "ms_per_step": round(v["ms_per_step"], 3)}
-                tot_ms += v["ms_per_step"]
-                tot_bytes += v["hbm_bytes_per_launch"] * v["launches_per_step"]
-        roofline["hbm_kernels"] = {"source": f"profiles/{PMC_FILE.format(tag=tag)} (committed rocprofv3 PMC passes of this workload "
-                                             "and engine, not re-measured in this run)",
-                                   "peak_GBps": 8000, "ms_per_step": round(tot_ms, 3),
-                                   "achieved_GBps": round(tot_bytes / (tot_ms * 1e-3) / 1e9) if tot_ms else None,
-                                   "frac_of_8TBps": round(tot_bytes / (tot_ms * 1e-3) / 8e12, 3) if tot_ms else None,
-                                   "kernels": rows}
-        step_bytes = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in pmc_all.values())
-        roofline["step_hbm_traffic_GB"] = round(step_bytes / 1e9, 2)
-    if roofline is not None and default_shape_for_step(args):
-        # whole-step view with SURVEY 8d's normative algorithmic work per 64x2048 image and step
-        # (533.5 GFLOP, 10.96 GB fp32): fraction of the fp32 matrix peak / of the 8 TB/s HBM peak
-        sec_img = elapsed / (args.batch * args.steps)
-        roofline["whole_step"] = {"algorithmic_TFLOPs": round(533.5e9 / sec_img / 1e12, 2),
-                                  "frac_of_mfma_peak": round(533.5e9 / sec_img / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                                  "mfma_peak_used": "fp32 MFMA 157.3 TFLOP/s (SURVEY 8d's ideal; same yardstick as round 1)",
-                                  "algorithmic_GBps": round(10.96e9 / sec_img / 1e9, 1),
-                                  "frac_of_hbm_peak": round(10.96e9 / sec_img / 8e12, 4)}
+            cap = b.run(True, args.steps, args.warmup, args.prewarm, events and eager is None)
+        except Exception as e:      # noqa: BLE001 -- a bench line with the first pass' numbers beats no line
+            if eager is None:
+                raise
+            launch_note = f"kernel by kernel (the captured pass failed: {type(e).__name__}: {e})"
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    head = cap if cap is not None else eager
+    roof_run = eager if eager is not None else cap
+    roofline = b.roofline(roof_run, args.kernel_table) if events else None
+    headline_shape = (args.net, args.height, args.width, args.classes, args.dataset, args.batch) == ("salsanext", 64, 2048, 20, "SemanticKitti", 8)
+    if roofline is not None and headline_shape:
+        roofline["whole_step"] = whole_step(roofline, head["value"] / head["n_ranks"])
 
-    # ranks as the process group reports them (RCCL / gloo), not as the command line claims
-    n_ranks = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    n_ranks = head["n_ranks"]
     collectives = None
-    if n_ranks > 1 or single_rank_group:
-        collectives = {k: round((D.COUNTS[k] - counts0[k]) / args.steps, 2) for k in D.COUNTS}
-        collectives["total"] = round(sum(collectives.values()), 2)
-        if D.EXPOSED is not None:
-            ex = D.exposed_ms(D.EXPOSED)
-            D.EXPOSED = None
-            collectives["comm_exposed_ms"] = {k: round(v / args.steps, 3) for k, v in ex.items()}
-            collectives["comm_exposed_ms"]["total"] = round(sum(ex.values()) / args.steps, 3)
-            collectives["comm_exposed_note"] = ("HIP-event time per step between the issue and the completion of every BLOCKING "
-                                                "exchange on the main stream (SyncBatchNorm sums, prototype bank) and of the final "
-                                                "wait for the asynchronous gradient buckets: the communication nothing hides")
-        collectives["note"] = ("syncbn: 43 forward + 43 backward BatchNorm layers, minus the exchanges batched with an "
-                               "independent layer's; the weight-gradient stream runs under them")
+    if dp:
+        collectives = dict((eager or cap)["collectives"])
+        collectives["note"] = ("syncbn: 43 forward + 43 backward BatchNorm layers, minus the exchanges batched with an independent "
+                               "layer's; the weight-gradient stream runs under them.  comm_exposed_ms (launch-by-launch pass): HIP-event "
+                               "time per step between the issue and the completion of every BLOCKING exchange on the main stream and of the "
+                               "final wait for the asynchronous gradient buckets: the communication nothing hides")
+        if cap is not None:
+            collectives["in_captured_step"] = cap["collectives"]["total"]
     if rank == 0:
-        images = args.batch * n_ranks * args.steps
+        dkey = args.matrix_dtype if not (args.matrix_dtype == "bf16" and args.storage != "bf16") else "bf16_f32storage"
+        cfg_idx = 2 if args.matrix_dtype == "bf16" else 1
         out = {
             "metric": f"range-images/sec training step, {args.height}x{args.width}x5, bs={args.batch}/GPU",
-            "value": round(images / elapsed, 3), "unit": "range-images/sec",
-            "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "value": head["value"], "unit": "range-images/sec",
+            "n_gpus": n_ranks, "steps": args.steps, "warmup": head["warmup"],
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16": ("bf16 activations in HBM + bf16 MFMA operands, f32 accumulate / statistics / master weights"
-                               if args.storage == "bf16" else "bf16 MFMA operands, f32 accumulate/storage"),
-                      "bf16x3": "f32 via 3xbf16 exact split on the bf16 matrix pipe (the library's default engine), f32 accumulate; "
-                                "6 of 9 plane products (8 of 9 in forward 3x3 / 2x2 convs whose output has fewer than 32768 "
-                                "pixels, where a small BatchNorm population amplifies the difference); f32 storage everywhere.  "
-                                "Parity as measured on MI355X (profiles/round3_parity_measured.json): forward / logits / "
-                                "prototypes <= 1e-4 of the reference on every golden; pseudo-label maps identical; anchor "
-                                "selection bit-exact on identical weights, and END TO END 2303 of 2304 anchor draws of the "
-                                "reference's golden step identical (one draw lies 6.7 fp32 ulps from its bin edge and lands "
-                                "on the neighbouring candidate; the strict fp32-MFMA engine, --matrix-dtype f32: 2304 of "
-                                "2304); whole-network gradient error vs the reference golden: median 1.1e-2 (fp32-MFMA engine "
-                                "6.1e-3; per-layer float64 check 7e-7 on both)"}[args.matrix_dtype],
+            "dtype": DTYPE_NOTE[dkey].replace("{anchor_rate}", ANCHOR_RATE),
             "data": "synthetic",
             "config": {"workload": f"{args.dataset} {args.height}x{args.width}x5 range image, C={args.classes}, "
-                                   f"bs={args.batch}/GPU, {type(model).__name__}{'' if args.net == 'salsanext' else args.net[-2:]} fwd+bwd + prototype bank + contrast "
-                                   f"loss + AdamW" + (f" (BASELINE.json configs[{2 if args.matrix_dtype == 'bf16' else 1}])"
-                                                      if args.net == "salsanext" else " (SURVEY 8f N3 backbone)"),
-                       "global_batch": args.batch * n_ranks, "parallelism": f"dp{n_ranks}", "final_loss": round(loss, 4),
+                                   f"bs={args.batch}/GPU, {head['type']}{'' if args.net == 'salsanext' else args.net[-2:]} fwd+bwd + prototype bank + contrast "
+                                   f"loss + AdamW" + (f" (BASELINE.json configs[{cfg_idx}])" if args.net == "salsanext" else " (SURVEY 8f N3 backbone)"),
+                       "global_batch": args.batch * n_ranks, "parallelism": f"dp{n_ranks}", "final_loss": round((eager or cap)["loss"], 4),
                        "collectives_per_step": collectives},
             "roofline": roofline,
         }
-        auto_graph = (args.graph == "auto" and world == 1 and not single_rank_group and args.net == "salsanext"
-                      and os.environ.get("C3D_WGRAD_STREAM", "0") != "1")
-        second = world == 1 and args.matrix_dtype == "bf16x3" and not args.no_second_engine
-        if auto_graph or second:
-            del ts, wrapped, model, res
-            torch.cuda.empty_cache()
+        if cap is not None:
+            out["config"]["launch"] = ("one hipGraph replay per step (TrainStep(graph=True): two eager steps, capture, replay; bit-identical "
+                                       "to the eager shape-static step" + (", RCCL exchanges inside the graph" if dp else "") + ")")
+            if eager is not None:
+                out["launch_by_launch"] = {"value": eager["value"], "ms_per_step": eager["ms_per_step"], "steps": eager["steps"],
+                                           "note": "the first pass of this run: the same K steps launched one kernel at a time (python bench.py "
+                                                   "--graph off); `roofline` holds the HIP-event kernel times of THIS pass' timed region"}
+        elif launch_note:
+            out["config"]["launch"] = launch_note
+
+        extra = world == 1 and not single_rank_group
+        if extra and args.matrix_dtype == "bf16x3" and not args.no_second_engine:
             k2 = min(args.steps, 10)
-
-            def quick_run(dtype, wgrad_stream, graph=False, k2=k2, storage=None):
-                """value / ms_per_step of k2 steps of the same workload on another engine configuration"""
-                ops.set_matrix_precision(dtype, storage=storage)
-                prev = os.environ.get("C3D_WGRAD_STREAM")
-                os.environ["C3D_WGRAD_STREAM"] = wgrad_stream        # read when the backbone is built
-                try:
-                    torch.manual_seed(1)
-                    m2 = (SalsaNextProto(5, args.classes, 20, 0, use_prototype=True, dataset=args.dataset) if args.net == "salsanext"
-                          else RangeNetProto(layers=int(args.net[-2:]), nclasses=args.classes, dataset=args.dataset, use_prototype=True)
-                          if args.net.startswith("rangenet")
-                          else SqueezeSegV3Proto(nclasses=args.classes, layers=int(args.net[-2:]), dataset=args.dataset, use_prototype=True))
-                    m2 = m2.to(dev).train()
-                    ts2 = TrainStep(m2, args.classes, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512, loss_w_ce_2d=1.0,
-                                    loss_w_lov_2d=1.0, loss_w_contrast=0.1, feature_mean=FEATURE_MEAN, feature_std=FEATURE_STD,
-                                    proto_loss=True, inputs_resident=True, graph=graph)
-                    for s_ in range((3 + min(args.warmup, 2)) if graph else (min(args.warmup, 2) or 1)):   # graph: 2 eager + capture
-                        ts2.step(*batches[s_ % total_steps], epoch=10)
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    for s_ in range(k2):
-                        ts2.step(*batches[(args.warmup + s_) % total_steps], epoch=10)
-                    torch.cuda.synchronize()
-                    e2 = time.perf_counter() - t1
-                finally:
-                    if prev is None:
-                        os.environ.pop("C3D_WGRAD_STREAM", None)
-                    else:
-                        os.environ["C3D_WGRAD_STREAM"] = prev
-                del ts2, m2
-                torch.cuda.empty_cache()
-                return {"value": round(args.batch * k2 / e2, 3), "ms_per_step": round(e2 / k2 * 1e3, 3), "steps": k2}
-
-        if auto_graph:
-            # second pass: the same K steps (same batches), each replayed as ONE hipGraph -- the launch mode `value` is quoted on
-            eager = {"value": out["value"], "ms_per_step": out["ms_per_step"], "steps": args.steps,
-                     "note": "the first pass of this run: the same K steps launched one kernel at a time (python bench.py --graph off); "
-                             "`roofline` holds the HIP-event kernel times of THIS pass' timed region"}
+            w2 = min(args.warmup, 2) or 1
+            engines = {}
+            # the same step on the fp32-MFMA engine (v_mfma_f32_32x32x2_f32), timed the same way, for comparison
+            r = Bench(dict(wl, matrix_dtype="f32"), dev, 0, 1, False).run(False, k2, w2, 0, False)
+            engines["f32_mfma"] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "steps": k2, "dtype": DTYPE_NOTE["f32"],
+                                   "launch": "kernel by kernel"}
+            r = b.run(False, k2, w2, 0, False, wgrad_stream="1")
+            engines["bf16x3_wgrad_on_second_stream"] = {
+                "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": k2, "launch": "kernel by kernel",
+                "note": "the headline engine with the weight-gradient chain of the backward pass on a second HIP stream (C3D_WGRAD_STREAM=1; what "
+                        "data-parallel runs use).  Off by default on one GPU because the kernels of the two streams share the CUs and every "
+                        "per-kernel duration of `roofline` would inflate"}
+            # the data-parallel step on this one GPU: a 1-rank RCCL group in which every exchange point issues its real collective
             try:
-                cap = quick_run(args.matrix_dtype, "0", graph=True, k2=args.steps,
-                                storage=args.storage if args.matrix_dtype == "bf16" else None)
-            except Exception as e:      # noqa: BLE001 -- a bench line with the first pass' numbers beats no line
-                cap = None
-                out["config"]["launch"] = f"kernel by kernel (the captured pass failed: {type(e).__name__}: {e})"
+                engines["dp_single_rank_rccl"] = dp_single_rank(wl, dev, k2, w2)
+            except Exception as e:      # noqa: BLE001
+                engines["dp_single_rank_rccl"] = {"error": f"{type(e).__name__}: {e}"}
                 torch.cuda.synchronize()
                 torch.cuda.empty_cache()
-            if cap is not None:
-                out["value"], out["ms_per_step"] = cap["value"], cap["ms_per_step"]
-                out["launch_by_launch"] = eager
-                out["config"]["launch"] = ("one hipGraph replay per step (TrainStep(graph=True): two eager steps, capture, replay; "
-                                           "bit-identical to the launch-by-launch step; `launch_by_launch` = the same K steps issued "
-                                           "kernel by kernel in the same process, where the host's ~20 ms per step can be the bound)")
-            ops.set_matrix_precision(args.matrix_dtype, storage=args.storage if args.matrix_dtype == "bf16" else None)
-        if second:
-            # the same step on the fp32-MFMA engine (v_mfma_f32_32x32x2_f32), timed the same way, for comparison
-            f32_run = quick_run("f32", os.environ.get("C3D_WGRAD_STREAM", "auto"))
-            f32_run["dtype"] = "f32 (v_mfma_f32_32x32x2_f32 everywhere)"
-            overlap_run = quick_run("bf16x3", "1")
-            overlap_run["note"] = ("the headline engine with the weight-gradient chain of the backward pass on a second HIP stream "
-                                   "(C3D_WGRAD_STREAM=1; what data-parallel runs use): weight gradients then execute under the "
-                                   "BatchNorm-backward / elementwise kernels of the main chain.  Off by default on one GPU because the "
-                                   "kernels of the two streams share the CUs and every per-kernel duration of `roofline` would inflate")
-            ops.F16X2_FWD = True
-            try:
-                f16_run = quick_run("bf16x3", "0")
-                ops.F16X2_BWD = True
-                f16_run["with_input_gradients"] = dict(quick_run("bf16x3", "0"),
-                                                       note="C3D_F16X2_BWD=1 on top: the multi-tap input AND weight gradients on the same arithmetic, "
-                                                            "read through a per-tensor exponent (c3d_bn_bwd_apply_gmax)")
-            finally:
-                ops.F16X2_FWD = False
-                ops.F16X2_BWD = False
-            f16_run["note"] = ("EXPERIMENT, off by default (C3D_F16X2_FWD=1): the headline engine with the FORWARD convolutions over >= 32768 "
-                               "pixels on two fp16 planes (x = H + L to 2^-22 |x| worst case -- a 22-bit operand, NOT the exact split --, staged times 2^6 / 2^10) and three products "
-                               "instead of six -- fused nine-tap kernel conv_x3f_kernel<..., 2>, generic kernel elsewhere; gradients "
-                               "unchanged.  The whole GPU parity suite passes with it; error vs float64 equals the exact split's "
-                               "(profiles/round3_f16x2_probe.txt); launched kernel by kernel")
-            out["engines"] = {"f32_mfma": f32_run, "bf16x3_wgrad_on_second_stream": overlap_run, "bf16x3_f16x2_forward": f16_run,
-                              "note": "`value` is the bf16x3 engine's on one stream; these are the same step, launched kernel by kernel, "
-                                      "on the fp32-MFMA engine (python bench.py --matrix-dtype f32 gives its full roofline object) and "
-                                      "with the second stream on"}
-            ops.set_matrix_precision(args.matrix_dtype)
+            engines["note"] = ("`value` is the bf16x3 engine's captured step on one stream; these are the same step on the fp32-MFMA engine "
+                               "(python bench.py --matrix-dtype f32 gives its full roofline object), with the second stream on, and under the "
+                               "data-parallel wrapper with the RCCL exchange code live")
+            out["engines"] = engines
+        if extra and headline_shape and args.matrix_dtype == "bf16x3" and not args.no_configs:
+            out["configs"] = {}
+            k3 = min(args.steps, 10)
+            for key, c in BASELINE_CONFIGS.items():
+                try:
+                    out["configs"][key] = short_config(dict(c), dev, k3, events)
+                except Exception as e:      # noqa: BLE001
+                    out["configs"][key] = {"error": f"{type(e).__name__}: {e}"}
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()
+            out["configs"]["note"] = ("the other BASELINE.json configs on ONE MI355X (their 8-GPU halves are the driver's to run): "
+                                      f"{k3} timed steps each, captured (`value`) and launch by launch (`roofline` from that pass' HIP events; "
+                                      "traffic and hbm_kernels from the committed PMC capture of the same workload)")
+        ops.set_matrix_precision(args.matrix_dtype, storage=args.storage if args.matrix_dtype == "bf16" else None)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = (cpu_baseline(args.classes, args.height, args.width) if args.net == "salsanext"
                                    else cpu_baseline_rangenet(args.classes, args.height, args.width, int(args.net[-2:]),
@@ -654,8 +746,58 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        import ctypes
         ctypes.CDLL(None).fflush(None)
         print(line, flush=True)
+
+
+def short_config(c, dev, steps, events):
+    """One of BASELINE_CONFIGS on this GPU: a launch-by-launch pass with HIP events (roofline) and a captured pass (value)."""
+    import torch
+    note = c.pop("note")
+    wl = dict(c, net="salsanext")
+    b = Bench(wl, dev, 0, 1, False)
+    eager = b.run(False, steps, 2, 1, events)
+    cap = b.run(True, steps, 3, 0, False)
+    roof = b.roofline(eager) if events else None
+    torch.cuda.empty_cache()
+    hbm_frac = None
+    if roof is not None and roof.get("step_hbm_traffic_GB"):
+        hbm_frac = round(roof["step_hbm_traffic_GB"] * 1e9 / (cap["ms_per_step"] * 1e-3) / 8e12, 3)
+    return {"workload": note, "value": cap["value"], "unit": "range-images/sec", "ms_per_step": cap["ms_per_step"], "steps": steps,
+            "launch": "one hipGraph replay per step", "launch_by_launch": {"value": eager["value"], "ms_per_step": eager["ms_per_step"]},
+            "dtype": DTYPE_NOTE[wl["matrix_dtype"]].split(";")[0] if wl["matrix_dtype"] == "bf16x3" else DTYPE_NOTE[wl["matrix_dtype"]],
+            "step_frac_of_hbm_peak": hbm_frac, "roofline": roof}
+
+
+def dp_single_rank(wl, dev, steps, warmup):
+    """The data-parallel step on one GPU: a 1-rank RCCL process group created inside this process,
+    C3D_SINGLE_RANK_COLLECTIVES=1 so that every exchange point (SyncBatchNorm sums, gradient buckets from the
+    weight-gradient stream, prototype bank) issues its real collective.  Launch by launch (comm_exposed_ms,
+    collectives_per_step) and captured (`value`: the RCCL calls are nodes of the step's hipGraph)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29519")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    prev = os.environ.get("C3D_SINGLE_RANK_COLLECTIVES")
+    os.environ["C3D_SINGLE_RANK_COLLECTIVES"] = "1"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        b = Bench(wl, dev, 0, 1, True)
+        eager = b.run(False, steps, warmup, 0, False, exposed=True)
+        cap = b.run(True, steps, 3, 0, False)
+    finally:
+        dist.destroy_process_group()
+        if prev is None:
+            os.environ.pop("C3D_SINGLE_RANK_COLLECTIVES", None)
+        else:
+            os.environ["C3D_SINGLE_RANK_COLLECTIVES"] = prev
+    return {"value": cap["value"], "ms_per_step": cap["ms_per_step"], "steps": steps,
+            "launch": "one hipGraph replay per step, RCCL exchanges inside the graph (coarse3d_amd.dist.DataParallel, weight gradients "
+                      "on the second stream)",
+            "collectives_per_step": eager["collectives"], "collectives_in_captured_step": cap["collectives"]["total"],
+            "launch_by_launch": {"value": eager["value"], "ms_per_step": eager["ms_per_step"]},
+            "note": "n_gpus = 1: what N > 1 adds on top is the latency / bandwidth of the collectives themselves"}
 
 
 if __name__ == "__main__":

@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
                 ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
                 ("accumulate", C.c_int32), ("stat_partial", C.c_void_p), ("lrelu_slope", C.c_float),
                 ("mfma_bf16", C.c_int32), ("out_bf16", C.c_int32), ("wpack_planes", C.c_int32),
-                ("stat_mul", C.c_void_p), ("stat_mul_cstride", C.c_int32), ("reserved2", C.c_int32),
+                ("stat_mul", C.c_void_p), ("stat_mul_cstride", C.c_int32), ("variant", C.c_int32),
                 ("acc_scale_dev", C.c_void_p)]
 
 

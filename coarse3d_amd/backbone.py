@@ -26,10 +26,9 @@ from . import contrast, ops
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
-# BatchNorm-backward sums in the epilogue of the last input-gradient conv (see _conv_backward); C3D_FUSE_BN_REDUCE=0: always
-# the separate reduce pass
-FUSE_BN_REDUCE = os.environ.get("C3D_FUSE_BN_REDUCE", "1") != "0"
-F16X2_WGRAD = os.environ.get("C3D_F16X2_WGRAD", "1") != "0"      # (with C3D_F16X2_BWD=1: the weight gradients of those layers too)
+# BatchNorm-backward sums in the epilogue of the last input-gradient conv (see _conv_backward); False: always the
+# separate reduce pass (module flag for tests / A-B runs)
+FUSE_BN_REDUCE = True
 
 
 class Act:
@@ -240,9 +239,8 @@ class Backbone:
         # cat(PixelShuffle(x), skip): without a Dropout2d mask on the concatenation (upBlock4 in training, every block
         # in eval mode) the skip tensor is NOT copied -- conv1 (and its weight gradient) read it as a second source
         # and the input-gradient conv writes its gradient straight into the skip's (the concat as an index
-        # remap on load; C3D_DIRECT_SKIP=0 restores the copy)
-        direct = (m2 is None and skip.scale is None and skip.t.dtype == xin.t.dtype
-                  and os.environ.get("C3D_DIRECT_SKIP", "1") != "0")
+        # remap on load)
+        direct = m2 is None and skip.scale is None and skip.t.dtype == xin.t.dtype
         if xin.first_consumer is None:
             xin.first_consumer = "glue"      # PixelShuffle reads BN(x): its gradient arrives through a glue kernel
         up_b = Act(ops.pixshuf_cat(xin.t, xin.scale, xin.shift, xin.mask, m1, m2, None if direct else skip.t))
@@ -267,9 +265,9 @@ class Backbone:
         slice of the weight at their own resolution -- 60 % fewer MFMAs in forward, input gradient and weight gradient
         of the step's largest layer -- an identity-resampled skip is read in place, and the 704-channel concatenation
         never exists.  The arithmetic is reassociated (sum over channels before instead of after the interpolation:
-        rounding-level differences, inside every golden's 1e-4).  fp32 tensors only; C3D_SPLIT_PROJECTOR=0 keeps the
-        concatenation."""
-        return (os.environ.get("C3D_SPLIT_PROJECTOR", "1") != "0" and len(self.skips) == 4
+        rounding-level differences, inside every golden's 1e-4).  fp32 tensors only (the bf16-storage mode keeps the
+        concatenation)."""
+        return (len(self.skips) == 4
                 and all(s.t.dtype == torch.float32 and s.scale is None for s in self.skips))
 
     def _proj0_forward(self, hh, wh, defer_bn):
@@ -551,7 +549,7 @@ class Backbone:
         gscale = ginv = None
         if gmax is not None:
             gscale, ginv = ops.grad_exponent_max(gmax, dz.shape[3])
-        wg16 = (gscale, ginv) if (gmax is not None and F16X2_WGRAD and all(s.t.dtype == torch.float32 for s in rec.srcs)) else None
+        wg16 = (gscale, ginv) if (gmax is not None and all(s.t.dtype == torch.float32 for s in rec.srcs)) else None
         with self._fork(dz, pz, *([gscale, ginv] if gmax is not None else [])):
             db = G.get(f"{name}.bias")       # folded by the first weight-gradient launch of the layer
             off = 0
@@ -676,6 +674,7 @@ class Backbone:
         if d_prob is None:
             raise ValueError("backward needs d_prob (the segmentation losses always produce it)")
         embed = d_feat is not None and self.return_feat
+        self.embed_ran = embed
         # ---- both heads down to their first BatchNorm: projector.proj.3 and cls_head
         if embed:
             feat_a, z0, emb, embn, norm = self.tape["embed"]

@@ -5,7 +5,6 @@ tasks/weak_segmentation/trainer.py:447-518 (``entropy_based_selection``).  Every
 shape-static and free of host synchronisation: absent (image, class) pairs are masked on the
 device instead of being skipped by Python loops."""
 import numpy as np
-import os
 import weakref
 
 import torch
@@ -20,6 +19,7 @@ def _nhwc_rows(t_nchw_like):
 
 def entropy_selection(prob_nhwc, train_label, eval_label, select_ratio, noise=None, ignore_cls=0):
     """prob [B,H,W,C]; labels [B,H,W] int64.  noise: Exp(1) [B,C,H*W] or None (drawn on device).
+    select_ratio: Python float or an fp32 device scalar (read by the kernel: nothing epoch-dependent in the launch).
     Returns (labels [B,H,W] int64, mask [B,H,W] bool)."""
     b, h, w, c = prob_nhwc.shape
     n = h * w
@@ -30,7 +30,7 @@ def entropy_selection(prob_nhwc, train_label, eval_label, select_ratio, noise=No
     if noise is None:
         noise = torch.empty(b, c, n, device=prob_nhwc.device, dtype=torch.float32).exponential_()
     labels, mask = ops.pl_select(w_pl, amax, ev, tl, noise.contiguous(), tl_counts, b, n, c, ignore_cls,
-                                 np.float32(select_ratio))
+                                 select_ratio if isinstance(select_ratio, torch.Tensor) else np.float32(select_ratio))
     return labels.view(b, h, w), mask.view(b, h, w)
 
 
@@ -40,8 +40,8 @@ def entropy_selection(prob_nhwc, train_label, eval_label, select_ratio, noise=No
 # wrote.  A consumer that receives THIS tensor object (a view whose base it is) may skip rows whose bit is clear --
 # the backbone's bilinear adjoint does (its 1 GB read drops to the marked rows).  One slot, consumed on first use, held
 # by weak reference: a gradient that autograd summed with another one, copied, or that comes from elsewhere never
-# matches.  C3D_SPARSE_DFEAT=0 switches it off.
-SPARSE_HINT_ON = os.environ.get("C3D_SPARSE_DFEAT", "1") != "0"
+# matches.  (Module flag: the tests switch it off to compare.)
+SPARSE_HINT_ON = True
 _row_hint = None
 
 
@@ -75,8 +75,8 @@ def take_row_hint(t):
 # target size; consumers that understand it interpolate the rows they need (ops.bilinear_rows: bit-identical to the
 # rows of the dense map) and send the gradient back in compact form (ops.scatter_rows_compact +
 # ops.bilinear_bwd_rows: bit-identical to the dense adjoint); everybody else calls ``dense()`` and gets the
-# reference's tensor.  C3D_LAZY_FEAT=0 makes the model hand out the dense tensor again.
-LAZY_FEAT_ON = os.environ.get("C3D_LAZY_FEAT", "1") != "0"
+# reference's tensor.  (Module flag: False makes the model hand out the dense tensor again; the tests compare both.)
+LAZY_FEAT_ON = True
 
 
 class _UpsampleFn(torch.autograd.Function):

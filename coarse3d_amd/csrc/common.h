@@ -7,6 +7,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Opt a kernel into more than 64 KB of dynamic LDS.  The attribute is PER DEVICE: once per (kernel instance, device),
+// lock-free (a race between two host threads only repeats the cheap, idempotent call).
+#include <atomic>
+template <auto Kernel>
+inline void c3d_opt_in_lds(int bytes = 160 * 1024) {
+  static std::atomic<uint64_t> seen{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(seen.load(std::memory_order_relaxed) & bit)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    seen.fetch_or(bit, std::memory_order_relaxed);
+  }
+}
+
 #define C3D_LRELU_SLOPE 0.01f
 #define C3D_MAX_SRC 3
 #define C3D_MAX_TAPS 9

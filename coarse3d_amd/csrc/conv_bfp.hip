@@ -290,12 +290,7 @@ int launch_bfp(ConvArgs& a, hipStream_t st) {
   size_t lds = (size_t)NP * ((size_t)(TR + 2 * HALO) * (32 + 2 * HALO) + (size_t)TT * 32 * NT) * CSB * 2;
   const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
   if (lds < red) lds = red;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bfp_kernel<TR, NT, CK, HALO, TT, NP>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  c3d_opt_in_lds<&conv_bfp_kernel<TR, NT, CK, HALO, TT, NP>>();
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
   hipLaunchKernelGGL((conv_bfp_kernel<TR, NT, CK, HALO, TT, NP>), grid, dim3(256), lds, st, a);
@@ -324,7 +319,7 @@ int dispatch_bfp(ConvArgs& a, int tr, int halo, bool k32, hipStream_t st) {
 
 // called by c3d_conv_forward (conv_mfma.hip) for mfma_bf16 = 1 (planes = 1) or 2 (planes = 3)
 int c3d_conv_forward_bfp(ConvArgs& a, int planes, int tr, int halo, bool k32, hipStream_t st) {
-  if (planes == 2 || (planes == 3 && getenv("C3D_F16X2"))) {     // EXPERIMENT (mfma_bf16 == 4 / the probe's switch)
+  if (planes == 2) {     // EXPERIMENT (mfma_bf16 == 4)
     a.acc_scale = 1.f / 65536.f;                                   // operands are staged times 2^6 and 2^10
     return dispatch_bfp<2>(a, tr, halo, k32, st);
   }

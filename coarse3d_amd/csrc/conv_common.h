@@ -25,6 +25,7 @@ struct ConvArgs {
   int six;                   // bf16x3: six plane products instead of eight (input-gradient convs, mfma_bf16 == 3)
   const float* stat_mul;     // NULL, or the tensor whose product with the stored values replaces v*v in stat_partial
   int stat_mul_cs;
+  int variant = 0;         // c3d_conv_desc.variant (schedule selector of the bit-identity tests)
   bool f16x2 = false;      // EXPERIMENT (mfma_bf16 == 4): two fp16 planes / three products where a kernel has the variant
   const float* acc_scale_dev = nullptr;   // times this device scalar, if any (per-tensor gradient exponent)
   float acc_scale = 1.f;   // the accumulators are multiplied by this before bias / activation (1: fma(acc, 1, bias) == acc + bias);
@@ -33,13 +34,10 @@ struct ConvArgs {
 
 // 64-cout tiles (two 32-wide sub-tiles per workgroup) unless the grid would then cover too few CUs -- the 8 x 256 and
 // 4 x 128 levels of the encoder have 64 / 32 pixel tiles per batch of 8 -- in which case 32-cout tiles double the
-// workgroups.  C3D_NARROW_MIN_WG overrides the threshold (tuning).  Mirrored by ops._wide_cout_tiles().
+// workgroups.  Mirrored by ops._wide_cout_tiles().
 inline bool c3d_wide_cout_tiles(const ConvArgs& a) {
   if (a.Cout <= 32) return false;
-  static const int min_wg = [] {
-    const char* e = getenv("C3D_NARROW_MIN_WG");
-    return e ? atoi(e) : 192;
-  }();
+  constexpr int min_wg = 192;
   return a.B * a.tiles_x * a.tiles_y * ((a.Cout + 63) / 64) >= min_wg;
 }
 

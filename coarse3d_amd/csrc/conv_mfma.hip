@@ -211,12 +211,7 @@ template <int TR, int NT, int CK, int HALO, int TT>
 int launch_cfg(ConvArgs& a, hipStream_t st) {
   constexpr int CS = CK + 4;
   const size_t lds = ((size_t)(TR + 2 * HALO) * (32 + 2 * HALO) + (size_t)TT * 32 * NT) * CS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TR, NT, CK, HALO, TT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  c3d_opt_in_lds<&conv_mfma_kernel<TR, NT, CK, HALO, TT>>();
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
   hipLaunchKernelGGL((conv_mfma_kernel<TR, NT, CK, HALO, TT>), grid, dim3(256), lds, st, a);
@@ -253,11 +248,8 @@ extern "C" int c3d_conv_num_mtiles(int B, int H, int W) {
   return B * ((H + tr - 1) / tr) * ((W + 31) / 32);
 }
 
-// smallest grid the wide pointwise kernel is launched with (see c3d_conv_forward); C3D_PW3_MIN_WG overrides (tuning)
-static int c3d_pw3_min_workgroups() {
-  const char* e = getenv("C3D_PW3_MIN_WG");
-  return e ? atoi(e) : 128;
-}
+// smallest grid the wide pointwise kernel is launched with (see c3d_conv_forward); mirrored by ops._pw3_tile()
+static int c3d_pw3_min_workgroups() { return 128; }
 
 extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   C3D_REQUIRE(d != nullptr, "conv: null descriptor");
@@ -296,6 +288,7 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   a.stat_mul = d->stat_mul;
   a.stat_mul_cs = d->stat_mul_cstride;
   a.acc_scale_dev = d->acc_scale_dev;
+  a.variant = d->variant;
   C3D_REQUIRE(!d->acc_scale_dev || d->mfma_bf16 == 4, "conv: acc_scale_dev belongs to the f16x2 experiment (mfma_bf16 == 4)");
   C3D_REQUIRE(!d->stat_mul || (d->stat_partial && !d->out_bf16 && d->stat_mul_cstride >= d->Cout && d->mfma_bf16 >= 2),
               "conv: stat_mul needs stat_partial, fp32 output, a channel stride >= Cout and the bf16x3 engine (mfma_bf16 >= 2)");
@@ -316,7 +309,7 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
     if (d->mfma_bf16 == 4) {     // EXPERIMENT: two fp16 planes, three products, generic kernel (forward convs; DESIGN.md round-4 list)
       bool k32f = tr == 8 && d->ntaps == 1;
       for (int s = 0; s < d->nsrc; ++s) k32f = k32f && (d->src[s].C % 32 == 0);
-      if (tr == 8 && d->ntaps == 9 && d->wpack_planes && !getenv("C3D_F16X2_GENERIC")) {     // the fused nine-tap kernel has the variant
+      if (tr == 8 && d->ntaps == 9 && d->wpack_planes) {     // the fused nine-tap kernel has the variant
         a.f16x2 = true;
         return c3d_conv_forward_x3(a, halo, st);
       }

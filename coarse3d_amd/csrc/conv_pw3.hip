@@ -560,12 +560,7 @@ int launch_pw3f(ConvArgs& a, hipStream_t st) {
   size_t lds = (size_t)2 * NP * (8 * 32 + 32 * NT) * 16 * 2;
   const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
   if (lds < red) lds = red;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw3f_kernel<NT, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    attr_set = true;
-  }
+  c3d_opt_in_lds<&conv_pw3f_kernel<NT, WN>>();
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
   hipLaunchKernelGGL((conv_pw3f_kernel<NT, WN>), grid, dim3(256 * WN), lds, st, a);
@@ -578,12 +573,7 @@ int launch_pw3(ConvArgs& a, hipStream_t st) {
   size_t lds = (size_t)2 * NP * (8 * 32 + 32 * NT) * 16 * 2;
   const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
   if (lds < red) lds = red;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw3_kernel<NT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    attr_set = true;
-  }
+  c3d_opt_in_lds<&conv_pw3_kernel<NT, NP>>();
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
   hipLaunchKernelGGL((conv_pw3_kernel<NT, NP>), grid, dim3(512), lds, st, a);
@@ -601,12 +591,11 @@ int c3d_conv_forward_pw3(ConvArgs& a, int planes, bool wide, hipStream_t st) {
     // with a short K (<= 256 channels: the prologue, the epilogue and the barrier bubbles are a large share of a
     // workgroup's life) and couts that tile by 128, four waves x 128 couts with TWO workgroups per CU, which run those
     // under each other's MFMAs (128 -> 384 at 8x32x1024: 0.181 -> 0.159 ms; 704 -> 704: 1.16 vs 1.22, so long K stays
-    // on eight waves).  C3D_PW3_FUSED = 0: round 2's phased kernel, 1 / 2: force eight / four waves (same-box A/B and
-    // the bit-identity test; read per launch on purpose).
-    const char* e = getenv("C3D_PW3_FUSED");
-    const char mode = e ? e[0] : 'a';
-    const bool four = mode == '2' || (mode != '1' && a.Kq * 4 <= 256 && a.Cout % 128 == 0);
-    if (mode != '0') {
+    // on eight waves).  c3d_conv_desc.variant & 3: 0 = this choice, 1 / 2 = force eight / four waves, 3 = round 2's
+    // phased kernel (the bit-identity tests compare all of them).
+    const int mode = a.variant & 3;
+    const bool four = mode == 2 || (mode != 1 && a.Kq * 4 <= 256 && a.Cout % 128 == 0);
+    if (mode != 3) {
       if (four) return launch_pw3f<4, 1>(a, st);
       return wide ? launch_pw3f<8, 2>(a, st) : launch_pw3f<4, 2>(a, st);
     }

@@ -678,12 +678,7 @@ int launch_x3f_s(ConvArgs& a, hipStream_t st) {
   size_t lds = (size_t)NPL * (IN_PT * 64 + 2 * W_PT * 64) * 16 * 2;      // rows padded to whole staging units
   const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
   if (lds < red) lds = red;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3f_kernel<NT, HALO, TT, SIX, NPL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  c3d_opt_in_lds<&conv_x3f_kernel<NT, HALO, TT, SIX, NPL>>();
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
   if (NPL == 2) a.acc_scale = 1.f / 65536.f;           // operands staged times 2^6 and 2^10
@@ -698,12 +693,7 @@ int launch_x3_s(ConvArgs& a, hipStream_t st) {
   size_t lds = (size_t)3 * ((size_t)(8 + 2 * HALO) * (32 + 2 * HALO) + (size_t)G * 32 * NT) * 16 * 2;
   const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
   if (lds < red) lds = red;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<NT, HALO, TT, SIX>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  c3d_opt_in_lds<&conv_x3_kernel<NT, HALO, TT, SIX>>();
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
   hipLaunchKernelGGL((conv_x3_kernel<NT, HALO, TT, SIX>), grid, dim3(256), lds, st, a);
@@ -714,11 +704,9 @@ int launch_x3_s(ConvArgs& a, hipStream_t st) {
 template <int NT, int HALO, int TT>
 int launch_x3(ConvArgs& a, hipStream_t st) {
   if constexpr (TT == 9) {
-    // the fused kernel; C3D_X3_FUSED=0: round 2's phased kernel (same-box A/B and the bit-identity test; read per
-    // launch on purpose)
-    const char* e = getenv("C3D_X3_FUSED");
+    // the fused kernel; c3d_conv_desc.variant & 4: round 2's phased kernel (the bit-identity test compares them)
     if (a.f16x2) return launch_x3f_s<NT, HALO, TT, true, 2>(a, st);           // EXPERIMENT: two fp16 planes, three products
-    if (!(e && e[0] == '0')) return a.six ? launch_x3f_s<NT, HALO, TT, true>(a, st) : launch_x3f_s<NT, HALO, TT, false>(a, st);
+    if (!(a.variant & 4)) return a.six ? launch_x3f_s<NT, HALO, TT, true>(a, st) : launch_x3f_s<NT, HALO, TT, false>(a, st);
   }
   return a.six ? launch_x3_s<NT, HALO, TT, true>(a, st) : launch_x3_s<NT, HALO, TT, false>(a, st);
 }

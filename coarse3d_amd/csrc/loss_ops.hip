@@ -84,6 +84,7 @@ struct PlArgs {
   const int32_t* tl_counts;    // [B][C] number of weak labels of class c in image b
   int n, C, ignore;
   float ratio;
+  const float* ratio_dev;      // NULL, or the ratio as a device scalar (a captured step must not bake the epoch in)
   int32_t* cnt;                // [B][C] members per pair
   int32_t* cursor;             // [B][C] fill cursor
   uint32_t* keys;              // [B][n] bucketed keys (bucket of (b,c) starts at offset[b][c])
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(PL_THREADS) void pl_select_kernel(PlArgs a) {
   const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int cnt = a.cnt[b * a.C + c];
   if (cnt == 0) return;
-  const int k = (int)((float)cnt * a.ratio);
+  const int k = (int)((float)cnt * (a.ratio_dev ? *a.ratio_dev : a.ratio));
   if (k < 1) return;
   int off = 0;
   for (int cc = 0; cc < c; ++cc) off += a.cnt[b * a.C + cc];
@@ -562,9 +563,9 @@ extern "C" int c3d_entropy_stats(const float* prob, int64_t n, int C, float* w_a
   return 0;
 }
 
-extern "C" int c3d_pl_select(const float* w_pl, const int32_t* amax, const int64_t* eval_label,
+static int pl_select_impl(const float* w_pl, const int32_t* amax, const int64_t* eval_label,
                              const int64_t* train_label, const float* noise, const int32_t* tl_counts, int B, int n,
-                             int C, int ignore_label, float ratio, int32_t* scratch, uint8_t* chosen,
+                             int C, int ignore_label, float ratio, const float* ratio_dev, int32_t* scratch, uint8_t* chosen,
                              int64_t* labels_out, uint8_t* mask_out, c3d_stream stream) {
   C3D_REQUIRE(C <= 64, "pl_select: at most 64 classes");
   // scratch: cnt [B*C] | cursor [B*C] | keys [B*n] | pix [B*n]
@@ -573,7 +574,7 @@ extern "C" int c3d_pl_select(const float* w_pl, const int32_t* amax, const int64
   uint32_t* keys = reinterpret_cast<uint32_t*>(scratch + (size_t)2 * B * C);
   int32_t* pix = scratch + (size_t)2 * B * C + (size_t)B * n;
   (void)hipMemsetAsync(scratch, 0, sizeof(int32_t) * 2 * B * C, ST);
-  PlArgs a{w_pl, amax, eval_label, noise, tl_counts, n, C, ignore_label, ratio, cnt, cursor, keys, pix, chosen};
+  PlArgs a{w_pl, amax, eval_label, noise, tl_counts, n, C, ignore_label, ratio, ratio_dev, cnt, cursor, keys, pix, chosen};
   int chunks = (n + 4095) / 4096;
   if (chunks < 1) chunks = 1;
   hipLaunchKernelGGL(pl_bucket_kernel<false>, dim3(chunks, B), dim3(256), 0, ST, a);
@@ -586,6 +587,23 @@ extern "C" int c3d_pl_select(const float* w_pl, const int32_t* amax, const int64
                      train_label, (size_t)B * n, ignore_label, labels_out, mask_out);
   C3D_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int c3d_pl_select(const float* w_pl, const int32_t* amax, const int64_t* eval_label,
+                             const int64_t* train_label, const float* noise, const int32_t* tl_counts, int B, int n,
+                             int C, int ignore_label, float ratio, int32_t* scratch, uint8_t* chosen,
+                             int64_t* labels_out, uint8_t* mask_out, c3d_stream stream) {
+  return pl_select_impl(w_pl, amax, eval_label, train_label, noise, tl_counts, B, n, C, ignore_label, ratio, nullptr,
+                        scratch, chosen, labels_out, mask_out, stream);
+}
+
+extern "C" int c3d_pl_select_dev(const float* w_pl, const int32_t* amax, const int64_t* eval_label,
+                                 const int64_t* train_label, const float* noise, const int32_t* tl_counts, int B, int n,
+                                 int C, int ignore_label, const float* ratio_dev, int32_t* scratch, uint8_t* chosen,
+                                 int64_t* labels_out, uint8_t* mask_out, c3d_stream stream) {
+  C3D_REQUIRE(ratio_dev != nullptr, "pl_select_dev: the ratio must be a device scalar");
+  return pl_select_impl(w_pl, amax, eval_label, train_label, noise, tl_counts, B, n, C, ignore_label, 0.f, ratio_dev,
+                        scratch, chosen, labels_out, mask_out, stream);
 }
 
 extern "C" int c3d_anchor_sample(const float* weights, const int32_t* counts, const int32_t* idx,

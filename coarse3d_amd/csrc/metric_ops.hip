@@ -339,12 +339,7 @@ static int lovasz_forward_impl(const float* prob, int C, int cstride, const int6
     (void)hipMemsetAsync(loss_c, 0, sizeof(float) * C, st);
     (void)hipMemsetAsync(present, 0, sizeof(float) * C, st);
   } else {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lovasz_class_kernel<8192>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8);
-      attr_set = true;
-    }
+    c3d_opt_in_lds<&lovasz_class_kernel<8192>>(8192 * 8);
     int npow = 1;
     while (npow < P) npow <<= 1;
     hipLaunchKernelGGL(lovasz_class_kernel<8192>, dim3(C), dim3(256), (size_t)npow * 8, st, prob, cstride, labels, idx, P, P_dev,

@@ -17,7 +17,6 @@ struct WgradArgs {
   float* partial;
   int tiles_x, tiles_y, ntiles, strips, tiles_per_strip;
   const float* dz_scale = nullptr;   // f16x2 experiment: per-cout scale of dz on load
-  int xmajor = 0;        // wgrad_tr: walk the tiles along x (round-2 order) instead of down the image
   int ci_slices, co_slices;
   float slope;
 };
@@ -43,7 +42,7 @@ inline WgCfg c3d_wgrad_cfg(int T, int Cin, int Cout, int planes, int halo = 1) {
   // (three planes, >= 64 input channels: two consumer waves split a 64-channel cin slice -- twice the MFMAs per staged
   //  dz element of the 32-channel slice, which left the 2x2 weight gradients at 125-133 TF against 195-210 for the 3x3)
   //  (halo <= 1: with a two-pixel halo the two tile buffers of that slice exceed the 160 KB of LDS)
-  if (T <= 4 && planes == 3 && Cout > 32 && Cin % 64 == 0 && halo <= 1 && !getenv("C3D_WGRAD_T4_NARROW")) return WgCfg{8, 64, 64, 2};
+  if (T <= 4 && planes == 3 && Cout > 32 && Cin % 64 == 0 && halo <= 1) return WgCfg{8, 64, 64, 2};
   if (T <= 4) return Cout > 32 ? WgCfg{4, 32, 64, planes == 3 ? 2 : 4} : WgCfg{5, 32, 32, 4};
   return Cout > 32 ? WgCfg{6, 32, 64, planes == 1 ? 4 : 2} : WgCfg{7, 32, 32, 4};
 }

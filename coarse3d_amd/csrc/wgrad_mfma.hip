@@ -344,13 +344,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // bf16 planes of the operands (wgrad_tr.hip) or 0 = the fp32-MFMA kernel of this file.
-// C3D_WGRAD_TR=0 keeps the kernels of this file for the bf16 modes too (A/B measurements).
 int planes_for(const c3d_wgrad_desc* d) {
-  static const int tr_on = [] {
-    const char* e = getenv("C3D_WGRAD_TR");
-    return (e && e[0] == '0') ? 0 : 1;
-  }();
-  if (!tr_on || d->mfma_bf16 == 0) return 0;
+  if (d->mfma_bf16 == 0) return 0;
   if (d->mfma_bf16 == 4) return 2;        // EXPERIMENT: two fp16 planes
   return d->mfma_bf16 == 2 ? 3 : 1;
 }
@@ -384,12 +379,7 @@ int launch_wg(const WgradArgs& a, hipStream_t st) {
   size_t lds = ((size_t)(TRW + 2 * HALO) * (32 + 2 * HALO) * CI + (size_t)TRW * 32 * CO) * sizeof(float);
   const size_t red = (size_t)(WK - 1) * WCI * WCO * CI_T * CO_T * 1024 * sizeof(float);
   if (red > lds) lds = red;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, BF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  c3d_opt_in_lds<&wgrad_mfma_kernel<TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, BF>>();
   dim3 grid(a.strips * a.ci_slices * a.co_slices);
   hipLaunchKernelGGL((wgrad_mfma_kernel<TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, BF>), grid, dim3(256), lds, st, a);
   C3D_CHECK_LAUNCH();
@@ -438,7 +428,6 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   }
   C3D_REQUIRE(halo <= 2, "wgrad: tap offsets beyond +-2 are not supported");
   C3D_REQUIRE(d->ntaps != 1 || halo == 0, "wgrad: a single tap must have zero offset");
-  a.xmajor = getenv("C3D_WGRAD_XMAJOR") != nullptr;
   a.dz_scale = d->dz_scale;
   C3D_REQUIRE(d->mfma_bf16 != 4 || (d->dz_scale && d->out_scale_dev && !d->dz_bf16 && !d->x.bf16 && d->ntaps > 1),
               "wgrad: mfma_bf16 == 4 (f16x2 experiment) needs dz_scale, out_scale_dev, fp32 tensors and more than one tap");

@@ -243,8 +243,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   // Tiles are walked DOWN the image first (tile index = (image, column of tiles, row)): with a halo the next tile of a
   // strip re-reads 2 * HALO of its TRW + 2 * HALO input rows, and they are the rows the workgroup fetched a tile ago (L2
   // hits); walking along x the vertical neighbour came tiles_x tiles later, from HBM again.  (The order of the tiles only
-  // changes the order of the fp32 pixel sums; C3D_WGRAD_XMAJOR=1 via a.xmajor restores the round-2 order for A/B.)
-  const bool ymajor = HALO > 0 && !a.xmajor;
+  // changes the order of the fp32 pixel sums.)
+  const bool ymajor = HALO > 0;
   auto seek_tile = [&](int mt) {
     if (ymajor) {
       lty = mt % a.tiles_y;
@@ -597,12 +597,7 @@ int launch_tr(const WgradArgs& a, hipStream_t st) {
   size_t lds = 2 * (size_t)NP * ((size_t)(TRW + 2 * HALO) * (32 + 2 * HALO) * CI + (size_t)TRW * 32 * CO) * 2;   // two tile buffers
   const size_t red = (size_t)(WK - 1) * WCI * WCO * CI_T * CO_T * 1024 * sizeof(float);
   if (red > lds) lds = red;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO>>();
   dim3 grid(a.strips * a.ci_slices * a.co_slices);
   hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO>), grid, dim3(512), lds, st, a);
   C3D_CHECK_LAUNCH();

@@ -251,5 +251,7 @@ class DataParallel(torch.nn.Module):
 
     def finish_gradients(self):
         self.flat.finish()
+        live = getattr(self.module, "_grads_live", True)
         for n, p in self.module._trainable():      # autograd may have cloned the views
-            p.grad = self.flat.views[n]
+            # (no embedding branch in this step -- contrast warm-up --: the projector has no gradient, on any rank)
+            p.grad = self.flat.views[n] if (live or not n.startswith("projector.")) else None

@@ -35,7 +35,7 @@ MFMA_MODE = _MODES[__import__("os").environ.get("C3D_MATRIX", DEFAULT_MATRIX)]
 # False = fp32 tensors, bf16 MFMA operands only (round 1).  Tensors carry their own dtype: every wrapper below
 # derives the library's bf16 flags from them, so the two layouts can meet (e.g. fp32 loss gradients entering a
 # bf16 backbone).
-STORAGE_BF16 = MFMA_MODE == 1 and __import__("os").environ.get("C3D_BF16_STORAGE", "1") != "0"
+STORAGE_BF16 = MFMA_MODE == 1
 
 
 # bf16x3 engine: forward 3x3 / 2x2 convolutions run six instead of eight plane products when their output has at
@@ -79,6 +79,10 @@ def _bf(*tensors):
     return m
 
 
+# Schedule selector of the bit-identity tests (c3d_conv_desc.variant): 0 = the library's choice; bits 0-1 for 1x1 convs
+# with Cout > 64 on the bf16x3 engine (1 = fused kernel with eight waves, 2 = with four, 3 = round 2's phased kernel);
+# bit 2 = round 2's phased kernel for nine-tap convs.  Same bits out of every variant (tests/test_gpu_conv.py).
+CONV_VARIANT = 0
 F16X2_FWD = os.environ.get("C3D_F16X2_FWD", "0") == "1"
 F16X2_BWD = os.environ.get("C3D_F16X2_BWD", "0") == "1"     # EXPERIMENT: multi-tap input gradients too (per-tensor exponent)
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -240,14 +244,14 @@ def _wide_cout_tiles(b, h, w, cout, tr):
     csrc/conv_common.h."""
     if cout <= 32:
         return False
-    min_wg = int(os.environ.get("C3D_NARROW_MIN_WG", "192"))
+    min_wg = 192
     return b * ((w + 31) // 32) * ((h + tr - 1) // tr) * ((cout + 63) // 64) >= min_wg
 
 
 def _pw3_tile(b, h, w, cout):
     """Cout sub-tiles (8 = 256 couts, 4 = 128) of the wide pointwise kernel for this launch, 0 = the grid would leave
     most CUs idle and conv_bfp's 64-wide workgroups run instead.  Mirrors c3d_conv_forward() in csrc/conv_mfma.hip."""
-    fill = int(os.environ.get("C3D_PW3_MIN_WG", "128"))
+    fill = 128
     px_tiles = b * ((w + 31) // 32) * ((h + 7) // 8)
     wide = cout > 128
     if wide and px_tiles * ((cout + 255) // 256) < fill:
@@ -263,10 +267,10 @@ def _pw3_kernel_name(nt, k, cout):
     (short K, couts a multiple of 128) -- the "bf16" mode round 2's conv_pw3_kernel<NT, 1>."""
     if MFMA_MODE != 2:
         return f"conv_pw3_kernel<{nt}, 1>"
-    mode = os.environ.get("C3D_PW3_FUSED", "a")[:1]
-    if mode == "0":
+    mode = CONV_VARIANT & 3
+    if mode == 3:
         return f"conv_pw3_kernel<{nt}, 3>"
-    if mode == "2" or (mode != "1" and k <= 256 and cout % 128 == 0):
+    if mode == 2 or (mode != 1 and k <= 256 and cout % 128 == 0):
         return "conv_pw3f_kernel<4, 1>"
     return f"conv_pw3f_kernel<{nt}, 2>"
 
@@ -296,6 +300,7 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         out = torch.empty(b, h, w, cout, device=wpack.device, dtype=srcs[0].t.dtype)
     d.out, d.out_cstride, d.out_coff, d.accumulate = out.data_ptr(), out.shape[3], out_coff, int(accumulate)
     d.out_bf16 = int(out.dtype == torch.bfloat16)
+    d.variant = CONV_VARIANT
     if stats and stat_partial is None:
         stat_partial = torch.empty(cout, 2, num_mtiles(b, h, w), device=wpack.device, dtype=torch.float32)
     d.stat_partial = stat_partial.data_ptr() if stat_partial is not None else None
@@ -312,8 +317,8 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
         k32 = tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs)
         if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
-            # nine taps: the fused kernel (round 3), four taps: the phased one; C3D_X3_FUSED=0 forces the phased one
-            fused_ = nt_ == 9 and os.environ.get("C3D_X3_FUSED", "1")[:1] != "0"
+            # nine taps: the fused kernel (round 3), four taps: the phased one; CONV_VARIANT & 4 forces the phased one
+            fused_ = nt_ == 9 and not (CONV_VARIANT & 4)
             name = (f"conv_x3{'f' if fused_ else ''}_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, {nt_}, "
                     f"{'true' if grad else 'false'}>")
         elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
@@ -331,9 +336,7 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         return name, halo
     # six plane products: every input gradient, and forward multi-tap convs whose BatchNorm population is large
     # (SIX_FWD_MIN_PIXELS).  conv_pw3 runs six in every launch (the flag is ignored there).
-    # (C3D_SIX=0: eight products everywhere -- the probe switch behind DESIGN.md's "where the plane products matter")
-    six = (MFMA_MODE == 2 and (grad or (nt_ > 1 and tr == 8 and b * h * w >= SIX_FWD_MIN_PIXELS))
-           and os.environ.get("C3D_SIX", "1") != "0")
+    six = MFMA_MODE == 2 and (grad or (nt_ > 1 and tr == 8 and b * h * w >= SIX_FWD_MIN_PIXELS))
     d.mfma_bf16 = 3 if six else MFMA_MODE
     if f16x2_inv is not None:
         # EXPERIMENT (C3D_F16X2_BWD=1): an input gradient on two fp16 planes; the source carries 2^s in its scale array
@@ -358,14 +361,14 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
 
 def _wgrad_kernel_name(ci, co, nt, halo):
     """Mirrors c3d_wgrad_cfg() (csrc/wgrad_common.h) and the launch tables of wgrad_mfma.hip / wgrad_tr.hip."""
-    tr = MFMA_MODE != 0 and os.environ.get("C3D_WGRAD_TR", "1") != "0"
+    tr = MFMA_MODE != 0
     hl = 1 if halo <= 1 else 2
     x3 = tr and MFMA_MODE == 2          # three planes: the smaller pixel tiles of c3d_wgrad_cfg
     if nt == 1:
         cfg = ("1, 2, 4, 2, 2, 1, 0" if (ci >= 96 and co >= 192) else "1, 2, 2, 2, 2, 1, 0" if (ci >= 96 and co >= 96)
                else f"1, 2, 2, 1, 1, {2 if tr else 4}, 0" if co > 32 else "1, 1, 1, 1, 1, 4, 0")
     elif nt == 4:
-        if x3 and co > 32 and ci % 64 == 0 and halo <= 1 and not os.environ.get("C3D_WGRAD_T4_NARROW"):
+        if x3 and co > 32 and ci % 64 == 0 and halo <= 1:
             cfg = f"4, 1, 2, 2, 1, 2, {hl}"
         else:
             cfg = f"4, 1, 2, 1, 1, {2 if x3 else 4}, {hl}" if co > 32 else f"4, 1, 1, 1, 1, 4, {hl}"
@@ -799,6 +802,12 @@ def pl_select(w_pl, amax, eval_label, train_label, noise, tl_counts, b, n, c, ig
     labels = torch.empty(b, n, device=dev, dtype=torch.int64)
     mask = torch.empty(b, n, device=dev, dtype=torch.uint8)
     scratch = torch.empty(2 * b * c + 2 * b * n, device=dev, dtype=torch.int32)
+    if isinstance(ratio, torch.Tensor):      # device scalar (fp32 [1]): the captured step reads the epoch's ratio from it
+        if ratio.dtype != torch.float32 or ratio.numel() != 1 or ratio.device != dev:
+            raise ValueError("pl_select: a tensor ratio must be one fp32 value on the labels' device")
+        _call("c3d_pl_select_dev", _dp(w_pl), _dp(amax), _dp(eval_label), _dp(train_label), _dp(noise), _dp(tl_counts), b, n,
+              c, ignore_label, _dp(ratio), _dp(scratch), _dp(chosen), _dp(labels), _dp(mask), _stream())
+        return labels, mask.bool()
     _call("c3d_pl_select", _dp(w_pl), _dp(amax), _dp(eval_label), _dp(train_label), _dp(noise), _dp(tl_counts), b, n,
           c, ignore_label, float(ratio), _dp(scratch), _dp(chosen), _dp(labels), _dp(mask), _stream())
     return labels, mask.bool()

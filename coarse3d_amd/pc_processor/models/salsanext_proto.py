@@ -109,6 +109,11 @@ class _BackboneFn(torch.autograd.Function):
         bound = model._bound_grad_views(ctx.names)
         grads = bb.backward(d_prob, d_f, grads=bound if bound is not None else model._grad_buffers(ctx.names))
         ctx.bb = None
+        # Without the embedding branch in the graph (contrast warm-up epochs: return_feat=False, trainer.py:625-630; or a
+        # loss that never read feat_2d) the reference's projector parameters get NO gradient (autograd leaves .grad at
+        # None and AdamW skips them: no weight decay, no step count).  Same here: their buffers hold zeros, .grad stays None.
+        live = getattr(bb, "embed_ran", True)
+        model._grads_live = live
         if model._grad_ready is not None:
             model._grad_ready()
         if bound is not None:
@@ -117,14 +122,16 @@ class _BackboneFn(torch.autograd.Function):
             # directly -- no 192 allocations at the start of every backward (the stream idled ~0.4 ms behind
             # them) and nothing for AccumulateGrad to do
             for n, p_ in model._cached()[0]:
-                p_.grad = bound[n]
+                if live or not n.startswith("projector."):
+                    p_.grad = bound[n]
             return (None,) * (5 + len(ctx.names))
         if model._flat_grads is not None:
             # coarse3d_amd.dist.DataParallel: the gradients live in its flat buffer (being all-reduced
             # in place right now); finish_gradients() binds param.grad to those views.  Handing them
             # to autograd would make AccumulateGrad clone ~200 tensors out of a buffer in flight.
             return (None,) * (5 + len(ctx.names))
-        return (None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
+        return (None, None, None, None, None) + tuple(grads[n] if (live or not n.startswith("projector.")) else None
+                                                      for n in ctx.names)
 
 
 class SalsaNextProto(nn.Module):
@@ -178,6 +185,7 @@ class SalsaNextProto(nn.Module):
         self._grad_ready = None       # data parallel: called when all gradients are written
         self._block_done = None       # data parallel: called per block in backward order
         self._flat_grads = None
+        self._grads_live = True       # False after a backward pass without the embedding branch: projector.* have no gradient
         self._bind_grads = False      # TrainStep: write the gradients into one persistent buffer and bind param.grad
         self._static_bank = False     # TrainStep(graph=True): update the prototype bank in place instead of re-binding it
         self._labelled_hint = None    # TrainStep: (idx, count) of the labelled pixels for THIS forward (consumed by it)
@@ -249,6 +257,7 @@ class SalsaNextProto(nn.Module):
     _SKIP = ("prototypes", "feat_norm.weight", "feat_norm.bias", "mask_norm.weight", "mask_norm.bias")
     # class-level defaults (subclasses with their own __init__ inherit them)
     _bind_grads = False
+    _grads_live = True
     _static_bank = False
     _labelled_hint = None
     _own_flat = None

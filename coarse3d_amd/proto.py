@@ -126,7 +126,10 @@ def prototype_step(feat_nhwc, P, label, proto_loss, noise=None, momentum=0.999, 
             rp[:cap] = rows
             rows = rp
         sim = ops.gemm_rows(rows, ops.pack_weights(w_oihw, 0), m * c)
-        cmap = torch.empty(n + 1, device=idx.device, dtype=torch.int32)           # slot n swallows the padding entries
+        # pixel -> compact row; slot n swallows the padding entries.  Zero-filled: a labelled pixel BEYOND the capacity
+        # (the caller's overflow check raises for it, a step or two later in a captured run) reads row 0 -- wrong
+        # numbers for a step that is about to be refused, never an out-of-range row
+        cmap = torch.zeros(n + 1, device=idx.device, dtype=torch.int32)
         cmap.scatter_(0, torch.where(ok, idx, torch.full_like(idx, n)), ar.to(torch.int32))
     else:
         rows, sim = similarity(feat_nhwc, bank_l2, P["feat_norm.weight"], P["feat_norm.bias"])

@@ -202,7 +202,8 @@ class RangeNetBackbone(Backbone):
             if self.on_block_done is not None:
                 with self._fork():
                     self.on_block_done(tag)
-        if d_feat is not None and self.return_feat:
+        self.embed_ran = d_feat is not None and self.return_feat
+        if self.embed_ran:
             feat_a, z0, emb, embn, norm = self.tape["embed"]
             d_embn = torch.empty_like(embn)
             d_feat = d_feat.contiguous()

@@ -172,7 +172,8 @@ class SqueezeSegBackbone(RangeNetBackbone):
             if self.on_block_done is not None:
                 with self._fork():
                     self.on_block_done(tag)
-        if d_feat is not None and self.return_feat:
+        self.embed_ran = d_feat is not None and self.return_feat
+        if self.embed_ran:
             feat_a, z0, emb, embn, norm, live, live_off = self.tape["embed"]
             d_embn = torch.empty_like(embn)
             d_feat = d_feat.contiguous()

@@ -37,7 +37,7 @@ class TrainStep:
         # write the gradients into one persistent buffer and bind param.grad itself (models that know the switch;
         # under a wrapper -- DistributedDataParallel hooks, coarse3d_amd.dist.DataParallel -- gradients keep going
         # through autograd / the wrapper's flat buffer).
-        if self.net is model and hasattr(model, "_bind_grads") and os.environ.get("C3D_BIND_GRADS", "1") != "0":
+        if self.net is model and hasattr(model, "_bind_grads"):
             model._bind_grads = True
         self.n_classes = n_classes
         self.n_epochs = n_epochs
@@ -60,25 +60,31 @@ class TrainStep:
         self.std = torch.as_tensor(feature_std, dtype=torch.float32, device=dev) if feature_std is not None else None
         # trainer.py:146-151: AdamW(params, lr) -- cfg.weight_decay is NOT passed (default 0.01).  On the device the
         # same optimiser runs in its fused form (one multi-tensor launch per ~30 tensors instead of ~20 elementwise
-        # passes over the 192 parameter tensors: 0.38 -> 0.1 ms per step); C3D_FUSED_ADAMW=0 keeps the default form.
+        # passes over the 192 parameter tensors: 0.38 -> 0.1 ms per step).
         if optimizer is None:
-            fused = dev.type == "cuda" and os.environ.get("C3D_FUSED_ADAMW", "1") != "0"
-            # (not with a contrast warm-up: parameters without a gradient must be skipped, see coarse3d_amd/optim.py)
-            flat = (fused and getattr(model, "_bind_grads", False) and contrast_warmup == 0
-                    and os.environ.get("C3D_FLAT_ADAMW", "1") != "0")
-            views = None
-            if flat:
-                named, names, _ = model._cached()
-                views = model._bound_grad_views(names)    # None while some param.grad is pending (e.g. a second TrainStep)
+            fused = dev.type == "cuda"
+            named = views = flat_buf = None
+            if fused:
+                if self.net is model and getattr(model, "_bind_grads", False):
+                    named, names, _ = model._cached()
+                    views = model._bound_grad_views(names)    # None while some param.grad is pending (e.g. a second TrainStep)
+                    flat_buf = model._own_flat[1] if views is not None else None
+                elif hasattr(model, "flat") and getattr(self.net, "_flat_grads", None) is not None:
+                    # coarse3d_amd.dist.DataParallel: the gradients already live in ONE flat buffer (laid out in backward
+                    # completion order, all-reduced in place); the parameters and moments take the same layout
+                    P = dict(self.net._trainable())
+                    named = [(n, P[n]) for n in model.flat.names]
+                    views, flat_buf = model.flat.views, model.flat.flat
             if views is not None:
-                # one parameter group, one formula: step all tensors as ONE flat buffer (coarse3d_amd/optim.py)
+                # one parameter group, one formula: step all tensors as ONE flat buffer (coarse3d_amd/optim.py); parameters
+                # without a gradient (the projector during a contrast warm-up) are skipped as torch's AdamW skips them
                 from .optim import FlatAdamW
-                optimizer = FlatAdamW(named, views, model._own_flat[1], lr=lr)
-                own = model._own_flat
-                model.invalidate_caches()             # parameter storage moved into the flat buffer
-                model._own_flat = own
-                if hasattr(model, "_packs"):
-                    model._packs = ops.PackCache()
+                optimizer = FlatAdamW(named, views, flat_buf, lr=lr, all_params=list(self.net.parameters()))
+                own = self.net._own_flat
+                self.net.invalidate_caches()             # parameter storage moved into the flat buffer
+                self.net._own_flat = own
+                if hasattr(self.net, "_packs"):
+                    self.net._packs = ops.PackCache()
             else:
                 optimizer = torch.optim.AdamW(self.net.parameters(), lr=lr, **({"fused": True} if fused else {}))
         self.optimizer = optimizer
@@ -92,30 +98,40 @@ class TrainStep:
         # (weak labels: always); otherwise the sync-free PyTorch-op restatements
         self.fused_loss_head = True
         self.pl_noise = None     # test hook: Exp(1) noise [B, C, HW] for the pseudo-label selection
-        # prototype similarity at the labelled pixels only (C3D_SPARSE_PROTO=0: the full [N, C*M] map every step)
-        self.sparse_proto = os.environ.get("C3D_SPARSE_PROTO", "1") != "0"
+        # prototype similarity at the labelled pixels only (False: the full [N, C*M] map every step)
+        self.sparse_proto = True
         # captured step (hipGraph): opt-in, C3D_GRAPH=1 makes it the default of this process
         self.graph = (os.environ.get("C3D_GRAPH", "0") == "1") if graph is None else bool(graph)
         if graph_warmup < 2:
             raise ValueError("graph_warmup >= 2: the first eager step records the weight repacks the plan needs, the "
                              "second builds the batched-repack table; neither may happen inside a capture")
         self.graph_warmup = graph_warmup
-        self.capacity_check_every = 64
         if self.graph and hasattr(self.optimizer, "tensor_lr"):
             self.optimizer.tensor_lr = True          # a captured update must not bake a Python float in
-        self._graphs = {}
-        self._eager_steps = 0
+        # One graph per (input shape, dtype, embedding branch on / off) -- NOT per epoch: the one epoch-dependent number
+        # of the step, the pseudo-label ratio (trainer.py:655-661), travels as a device scalar like the learning rate.
+        # All captures share one memory pool (only one step's tensors are live at a time) and at most ``max_graphs``
+        # are kept (least recently used goes first), so a 100-epoch run holds one step's activations, not one per epoch.
+        self._graphs = {}                # key -> dict(graph, static inputs, results, eager steps seen, ...)
+        self.max_graphs = 4
+        self._pool = None
+        self._ratio_t = torch.zeros(1, device=dev, dtype=torch.float32) if dev.type == "cuda" else None
+        self._ratio_seen = None
         self._replays = 0
+        self._captures = 0
+        # labelled-pixel count of every replay, copied to pinned host memory without a synchronisation and checked
+        # when it has arrived (a step or two later): more labelled pixels than the shape-static list holds raises
+        self._cnt_ring = []
 
     def step(self, x, train_label, eval_label, epoch=0):
         """x [B,5,H,W] fp32, labels [B,H,W] int64 (0 = ignore).  Returns dict of 0-dim loss tensors
         (still on the device: nothing here synchronises with the host except Lovasz' nonzero).
 
         ``graph=True``: after ``graph_warmup`` eager steps the whole step -- input normalisation, forward,
-        prototype update, losses, pseudo-label selection, backward, AdamW: ~700 kernel launches -- is captured in
-        ONE hipGraph per (input shape, epoch) and replayed with a single launch (the host needs ~24 ms to enqueue
-        the launches of a step one by one; a 32x1024 step takes the GPU less than that).  The returned tensors
-        are then the graph's static outputs: they are overwritten by the next step."""
+        prototype update, losses, pseudo-label selection, backward, the data-parallel exchanges, AdamW: ~700 kernel
+        launches -- is captured in ONE hipGraph per (input shape, embedding branch on / off) and replayed with a single
+        launch (the host needs ~20 ms to enqueue the launches of a step one by one; a 32x1024 step takes the GPU less
+        than that).  The returned tensors are then the graph's static outputs: they are overwritten by the next step."""
         if self.graph:
             return self._graph_step(x, train_label, eval_label, epoch)
         lov_valid = None
@@ -136,7 +152,7 @@ class TrainStep:
             self.scheduler.step()
         return res
 
-    def _body(self, x, train_label, eval_label, epoch, lov_valid, lov_count):
+    def _body(self, x, train_label, eval_label, epoch, lov_valid, lov_count, ratio=None):
         """Everything of the step that runs on the device.  ``lov_count`` (device int32 [1]): ``lov_valid`` is the
         fixed-capacity list of ``loss_head.valid_indices_static`` (the shape-static, capturable form)."""
         net = self.net
@@ -181,7 +197,8 @@ class TrainStep:
         if self.w_con > 0 and return_feat:
             if self.entropy_selection:
                 with torch.no_grad():
-                    ratio = select_ratio_for(epoch, self.n_epochs)
+                    if ratio is None:       # (captured / shape-static step: the device scalar TrainStep._sync_ratio keeps)
+                        ratio = select_ratio_for(epoch, self.n_epochs)
                     lab_c, mask_c = contrast.entropy_selection(
                         pred.detach().permute(0, 2, 3, 1).contiguous(), train_label, eval_label, ratio,
                         noise=self.pl_noise, ignore_cls=self.ignore_cls)
@@ -206,10 +223,16 @@ class TrainStep:
 
     # ------------------------------------------------------------------ captured step
     def _graph_supported(self):
-        """The captured step covers the single-process configuration the bench and the reference's one-GPU runs use;
-        anything it cannot express raises here instead of replaying something else."""
+        """The captured step covers a plain model and ``coarse3d_amd.dist.DataParallel`` (the exchanges are then part
+        of the graph: RCCL collectives are capturable); anything it cannot express raises here instead of replaying
+        something else."""
+        if self.net is not self.model and not hasattr(self.model, "flat"):
+            return ("the model is wrapped by something other than coarse3d_amd.dist.DataParallel (stock "
+                    "DistributedDataParallel reduces through autograd hooks on the host)")
         if self.net is not self.model:
-            return "the model is wrapped (data parallel: the exchanges stay eager)"
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl":
+                return f"the process group's backend is {dist.get_backend()!r}: only RCCL collectives can be captured"
         if not (self.fused_loss_head and self.ignore_cls == 0 and self.w_lov > 0):
             return "the captured step needs the fused loss head (ignore_cls == 0, Lovasz on)"
         if self.pl_noise is not None or self.contrast.uniforms is not None or self.contrast.perms is not None:
@@ -218,58 +241,114 @@ class TrainStep:
             return "injected randomness (test hooks) lives on the host"
         if not hasattr(self.net, "_static_bank"):
             return "the model does not know the in-place bank update"
-        if os.environ.get("C3D_WGRAD_STREAM", "0") == "1":
-            return "the weight-gradient side stream is not part of the captured step"
+        if type(self.optimizer).__name__ != "FlatAdamW":
+            return ("the captured step needs the flat optimiser (coarse3d_amd.optim.FlatAdamW: learning rate as a device "
+                    "scalar, gradient-less parameters skipped); a user-supplied optimiser runs with graph=False")
         return None
+
+    def _sync_ratio(self, epoch):
+        r = float(np.float32(select_ratio_for(epoch, self.n_epochs)))
+        if r != self._ratio_seen:
+            self._ratio_t.fill_(r)
+            self._ratio_seen = r
 
     def _graph_step(self, x, train_label, eval_label, epoch):
         why = self._graph_supported()
         if why is not None:
             raise RuntimeError(f"TrainStep(graph=True): {why}")
-        key = (tuple(x.shape), str(x.dtype), int(epoch))
+        return_feat = epoch >= self.contrast_warmup
+        key = (tuple(x.shape), str(x.dtype), bool(return_feat))
         ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._graphs[key] = {"graph": None, "eager": 0, "used": 0}
+        ent["used"] = self._replays + self._captures + sum(e["eager"] for e in self._graphs.values())
         opt = self.optimizer
-        if hasattr(opt, "sync_lr"):
-            opt.sync_lr()                                # schedulers write param_groups["lr"]; the graph reads a device scalar
-        if ent is None and self._eager_steps < self.graph_warmup:
-            # lazy initialisation (weight-pack table, kernel attributes, cuRAND-free philox state, the flat optimiser
-            # buffers) must happen outside a capture: the first steps run eagerly -- on the same shape-static loss
-            # head the graph uses, so that eager and captured steps are the same arithmetic
-            self._eager_steps += 1
-            self.net._static_bank = True
+        opt.sync_lr()                                    # schedulers write param_groups["lr"]; the graph reads a device scalar
+        self._sync_ratio(epoch)
+        self._poll_capacity()
+        packs = getattr(self.net, "_packs", None)
+        if ent["graph"] is not None and packs is not None and ent["packs_generation"] != packs.generation:
+            ent["graph"] = None                          # the weight-repack table moved: its address is baked into the graph
+            ent["eager"] = min(ent["eager"], self.graph_warmup - 1)
+        self.net._static_bank = True
+        if ent["graph"] is None and ent["eager"] < self.graph_warmup:
+            # lazy initialisation (weight-pack table, kernel attributes, philox state, the optimiser's segments) must
+            # happen outside a capture: the first steps of every configuration run eagerly -- on the same shape-static
+            # loss head and device scalars the graph uses, so that eager and captured steps are the same arithmetic
+            ent["eager"] += 1
             idx, cnt = loss_head.valid_indices_static(train_label, self.ignore_cls)
-            res = self._body(x, train_label, eval_label, epoch, idx, cnt)
-            self._check_capacity(cnt)
+            res = self._body(x, train_label, eval_label, epoch, idx, cnt, ratio=self._ratio_t)
+            self._check_capacity(int(cnt))
             if self.scheduler is not None:
                 self.scheduler.step()
             return res
-        if ent is None:
-            self.net._static_bank = True
+        if ent["graph"] is None:
+            self._evict(keep=key)
             sx, st, se = x.clone(), train_label.clone(), eval_label.clone()
-            self._check_capacity(loss_head.valid_indices_static(st, self.ignore_cls)[1])
+            self._check_capacity(int(loss_head.valid_indices_static(st, self.ignore_cls)[1]))
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                idx, cnt = loss_head.valid_indices_static(st, self.ignore_cls)
-                res = self._body(sx, st, se, epoch, idx, cnt)
+            from . import dist as c3d_dist
+            counts0 = dict(c3d_dist.COUNTS)
+            exposed, c3d_dist.EXPOSED = c3d_dist.EXPOSED, None      # HIP events cannot time launches inside a capture
+            try:
+                # thread_local: torch.distributed's watchdog thread may query events while this thread captures
+                with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
+                    idx, cnt = loss_head.valid_indices_static(st, self.ignore_cls)
+                    res = self._body(sx, st, se, epoch, idx, cnt, ratio=self._ratio_t)
+            finally:
+                c3d_dist.EXPOSED = exposed
             res["lov_count"] = cnt
-            ent = self._graphs[key] = (g, sx, st, se, res)
-        g, sx, st, se, res = ent
-        sx.copy_(x)
-        st.copy_(train_label)
-        se.copy_(eval_label)
-        g.replay()
+            ent.update(graph=g, sx=sx, st=st, se=se, res=res,
+                       packs_generation=packs.generation if packs is not None else 0,
+                       collectives={k: c3d_dist.COUNTS[k] - counts0[k] for k in counts0})
+            for k in counts0:                            # the capture itself executed nothing
+                c3d_dist.COUNTS[k] = counts0[k]
+            self._captures += 1
+        ent["sx"].copy_(x)
+        ent["st"].copy_(train_label)
+        ent["se"].copy_(eval_label)
+        ent["graph"].replay()
         self._replays += 1
-        if self._replays % self.capacity_check_every == 1:
-            self._check_capacity(res["lov_count"])
+        if ent["collectives"]:
+            from . import dist as c3d_dist
+            for k, v in ent["collectives"].items():
+                c3d_dist.COUNTS[k] += v
+        self._watch_capacity(ent["res"]["lov_count"])
         if self.scheduler is not None:
             self.scheduler.step()
-        return res
+        return ent["res"]
 
-    def _check_capacity(self, count):
+    def _evict(self, keep):
+        """Drop least-recently-used captured graphs beyond ``max_graphs`` (their tensors live in the shared pool, which
+        later captures reuse)."""
+        live = [k for k, e in self._graphs.items() if e["graph"] is not None and k != keep]
+        live.sort(key=lambda k: self._graphs[k]["used"])
+        while len(live) + 1 > self.max_graphs:
+            k = live.pop(0)
+            del self._graphs[k]
+
+    def _check_capacity(self, n):
         """More labelled pixels than the fused loss head sorts in LDS cannot go through the shape-static step (its
-        list would be truncated): checked on the first steps and then every ``capacity_check_every`` replays (one
-        4-byte read-back; with weak labels the count is ~1e3 of 8192)."""
-        n = int(count)
+        list would be truncated)."""
         if n > ops.lovasz_max_pixels():
             raise RuntimeError(f"TrainStep(graph=True): {n} labelled pixels exceed the fused loss head's capacity "
                                f"({ops.lovasz_max_pixels()}); train fully supervised batches with graph=False")
+
+    def _watch_capacity(self, count):
+        """Queue an asynchronous read-back of this replay's labelled-pixel count (4 bytes into pinned memory)."""
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(count, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._cnt_ring.append((ev, host))
+        if len(self._cnt_ring) > 8:                      # never more than a few steps behind
+            ev0, h0 = self._cnt_ring.pop(0)
+            ev0.synchronize()
+            self._check_capacity(int(h0))
+
+    def _poll_capacity(self):
+        while self._cnt_ring and self._cnt_ring[0][0].query():
+            _, h = self._cnt_ring.pop(0)
+            self._check_capacity(int(h))

@@ -107,7 +107,11 @@ typedef struct {
                                v is the final value) takes them in its epilogue and spares c3d_bn_bwd_reduce's two
                                tensor reads                                                                        */
   int32_t stat_mul_cstride;
-  int32_t reserved2;
+  int32_t variant;          /* 0 = the library picks the kernel schedule.  Test / A-B selector of kernels that compute
+                               the same bits with another schedule (tests/test_gpu_conv.py compares them):
+                               bits 0-1, 1x1 convs with Cout > 64 on the bf16x3 engine (conv_pw3.hip): 1 = fused kernel
+                               with eight waves, 2 = with four waves, 3 = round 2's phased kernel;
+                               bit 2, nine-tap convs on the bf16x3 engine (conv_x3.hip): round 2's phased kernel   */
   const float* acc_scale_dev; /* EXPERIMENT (mfma_bf16 == 4): NULL, or a device scalar the accumulators are multiplied
                                with before bias / activation -- the inverse of a per-tensor gradient exponent
                                (c3d_grad_exponent)                                                            */
@@ -385,6 +389,12 @@ int c3d_pl_select(const float* w_pl, const int32_t* amax, const int64_t* eval_la
                   const int64_t* train_label, const float* noise, const int32_t* tl_counts,
                   int B, int n, int C, int ignore_label, float ratio, int32_t* scratch,
                   uint8_t* chosen, int64_t* labels_out, uint8_t* mask_out, c3d_stream stream);
+/* the same with select_ratio (trainer.py:655-661, a function of the epoch) read from a device scalar: a captured
+ * training step (hipGraph) is then valid for every epoch                                                */
+int c3d_pl_select_dev(const float* w_pl, const int32_t* amax, const int64_t* eval_label,
+                      const int64_t* train_label, const float* noise, const int32_t* tl_counts,
+                      int B, int n, int C, int ignore_label, const float* ratio_dev, int32_t* scratch,
+                      uint8_t* chosen, int64_t* labels_out, uint8_t* mask_out, c3d_stream stream);
 /* anchor_sampling: bit-exact torch.multinomial(replacement=True) per present (b,c) pair;
  * the t-th present pair consumes uniforms[t][0..A).  counts/idx from c3d_group_compact.
  * slot [B*C], cum [B][C][n] are scratch.  Outputs anchor_idx [B*C][A] (pixel in image),

@@ -221,15 +221,127 @@ def test_flat_adamw_checkpoints_are_torch_adamw_checkpoints():
     opt2.load_state_dict({"flat": True, "step": opt.step_t, "exp_avg": opt.exp_avg, "exp_avg_sq": opt.exp_avg_sq,
                           "param_groups": [{"lr": 5e-3}]})
     assert opt2.param_groups[0]["lr"] == 5e-3 and float(opt2.step_t) == 3
-    # per-parameter step counts that differ cannot be expressed by one flat update
-    bad = ref.state_dict()
-    bad["state"][1]["step"] = bad["state"][1]["step"] + 1
-    with pytest.raises(ValueError):
-        opt2.load_state_dict(bad)
+    # per-parameter step counts that differ (parameters that were not always trained together: the projector during the
+    # reference's contrast warm-up) become separate segments of the flat update -- and keep matching torch
+    odd = ref.state_dict()
+    odd["state"][1]["step"] = odd["state"][1]["step"] + 1
+    opt2.load_state_dict(odd)
+    assert len(opt2._segments) == 3 and [float(s[2]) for s in opt2._segments] == [4.0, 5.0, 4.0]
+    odd_params = [torch.nn.Parameter(p.detach().clone()) for _, p in named2]
+    odd_ref = torch.optim.AdamW(odd_params, lr=opt2.param_groups[0]["lr"])
+    odd_ref.load_state_dict(odd)
+    for (n, p), op, gr in zip(named2, odd_params, grads(9, shapes)):
+        views2[n].copy_(gr)
+        p.grad = views2[n]
+        op.grad = gr.clone()
+    opt2.step()
+    odd_ref.step()
+    for (_, p), op in zip(named2, odd_params):
+        assert torch.allclose(p, op, rtol=1e-6, atol=1e-7)
+    back = opt2.state_dict()["state"]
+    assert float(back[1]["step"]) == 6.0 and float(back[0]["step"]) == 5.0
+    # a parameter WITHOUT a gradient is skipped like torch skips it: no decay, no step, no state movement
+    before = named2[1][1].detach().clone()
+    named2[1][1].grad = None
+    opt2.step()
+    assert torch.equal(named2[1][1].detach(), before) and float(opt2.state_dict()["state"][1]["step"]) == 6.0
+    assert float(opt2.state_dict()["state"][0]["step"]) == 6.0
     # a parameter that left the flat buffer
     named2[0][1].data = named2[0][1].data.clone()
     with pytest.raises(RuntimeError):
         opt2.step()
+
+
+def test_flat_adamw_round_trips_with_torch_adamw_on_the_real_module():
+    """the reference builds ``AdamW(model.parameters())`` -- 197 parameters for SalsaNextProto, of which the
+    frozen ``prototypes`` (index 0) and the ``feat_norm`` / ``mask_norm`` LayerNorms (193-196) never get state -- and
+    checkpoints that layout (trainer.py:129,146-151).  FlatAdamW steps the 192 trained tensors as one buffer but must
+    write and read the 197-entry layout: torch -> FlatAdamW -> torch on the real module, with identical continued
+    updates; during a contrast warm-up (no gradient for the projector, config_semantic_kitti.yaml:20) the projector's
+    parameters are skipped and come back without state, as torch leaves them."""
+    import torch
+    from coarse3d_amd.optim import FlatAdamW
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+
+    def model(seed):
+        torch.manual_seed(seed)
+        return SalsaNextProto(5, 20, 20, 0, use_prototype=True)
+
+    def fake_grads(m, step, skip_projector):
+        g = torch.Generator().manual_seed(500 + step)
+        out = {}
+        for n, p in m.named_parameters():
+            if n in m._SKIP or (skip_projector and n.startswith("projector.")):
+                continue
+            out[n] = torch.randn(p.shape, generator=g) * 0.01
+        return out
+
+    # torch's optimiser on the reference's terms: two warm-up steps without projector gradients, one full step
+    m_t = model(3)
+    names_all = [n for n, _ in m_t.named_parameters()]
+    assert len(names_all) == 197 and names_all[0] == "prototypes" and names_all[193].startswith("feat_norm")
+    opt_t = torch.optim.AdamW(m_t.parameters(), lr=1e-3)
+    m_f = model(3)
+    m_f._bind_grads = True
+    named, names, _ = m_f._cached()
+    views = m_f._bound_grad_views(names)
+    opt_f = FlatAdamW(named, views, m_f._own_flat[1], lr=1e-3, all_params=list(m_f.parameters()))
+    assert len(opt_f.param_groups[0]["params"]) == 197
+    for step, warm in enumerate((True, True, False)):
+        gr = fake_grads(m_t, step, warm)
+        P_t, P_f = dict(m_t.named_parameters()), dict(m_f.named_parameters())
+        for n in names:
+            P_t[n].grad = gr[n].clone() if n in gr else None
+            if n in gr:
+                views[n].copy_(gr[n])
+                P_f[n].grad = views[n]
+            else:
+                P_f[n].grad = None
+        opt_t.step()
+        opt_f.step()
+    for (n, a), (_, b) in zip(m_t.named_parameters(), m_f.named_parameters()):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-8), n
+    sd_t, sd_f = opt_t.state_dict(), opt_f.state_dict()
+    assert sd_f["param_groups"][0]["params"] == list(range(197)) == sd_t["param_groups"][0]["params"]
+    assert set(sd_f["state"]) == set(sd_t["state"]) and 0 not in sd_f["state"] and 193 not in sd_f["state"]
+    proj = [i for i, n in enumerate(names_all) if n.startswith("projector.")]
+    assert all(float(sd_f["state"][i]["step"]) == 1.0 for i in proj) and float(sd_f["state"][1]["step"]) == 3.0
+    for i in sd_t["state"]:
+        assert float(sd_t["state"][i]["step"]) == float(sd_f["state"][i]["step"])
+        assert torch.allclose(sd_t["state"][i]["exp_avg_sq"], sd_f["state"][i]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    # FlatAdamW checkpoint -> torch.optim.AdamW(net.parameters()); torch checkpoint -> a fresh FlatAdamW; one more step each
+    m_t2 = model(3)
+    m_t2.load_state_dict(m_f.state_dict())
+    opt_t2 = torch.optim.AdamW(m_t2.parameters(), lr=1e-3)
+    import copy
+    opt_t2.load_state_dict(copy.deepcopy(sd_f))           # (torch aliases the step tensors of the dict it loads)
+    m_f2 = model(3)
+    m_f2.load_state_dict(m_t.state_dict())
+    m_f2._bind_grads = True
+    named2, names2, _ = m_f2._cached()
+    views2 = m_f2._bound_grad_views(names2)
+    opt_f2 = FlatAdamW(named2, views2, m_f2._own_flat[1], lr=1e-3, all_params=list(m_f2.parameters()))
+    opt_f2.load_state_dict(copy.deepcopy(sd_t))
+    assert len(opt_f2._segments) == 2                      # [backbone + head | projector]
+    gr = fake_grads(m_t, 9, False)
+    for mm, vv in ((m_t, None), (m_t2, None), (m_f2, views2)):
+        for n, p in mm.named_parameters():
+            if n in gr:
+                if vv is None:
+                    p.grad = gr[n].clone()
+                else:
+                    vv[n].copy_(gr[n])
+                    p.grad = vv[n]
+    opt_t.step()
+    opt_t2.step()
+    opt_f2.step()
+    for (n, a), (_, b), (_, c) in zip(m_t.named_parameters(), m_t2.named_parameters(), m_f2.named_parameters()):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-8) and torch.allclose(a, c, rtol=1e-6, atol=1e-8), n
+    # round 3's checkpoints (the 192 trained parameters only) still load
+    old = {"state": {j: sd_f["state"][i] for j, i in enumerate(opt_f._index) if i in sd_f["state"]},
+           "param_groups": [dict(sd_f["param_groups"][0], params=list(range(192)))]}
+    opt_f2.load_state_dict(old)
+    assert float(opt_f2.state_dict()["state"][1]["step"]) == 3.0
 
 
 def test_tile_row_rule_of_the_host_mirror_matches_the_library():

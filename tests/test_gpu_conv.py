@@ -320,7 +320,7 @@ def test_fused_pointwise_kernel_is_bit_identical_to_the_phased_one(B, H, W, srcC
         wp = ops.pack_weights(w, mode=0)
         outs = {}
         for fused in ("2", "1", "0"):       # four waves x 128 couts (default) / eight waves x 256 couts / round 2's phased kernel
-            monkeypatch.setenv("C3D_PW3_FUSED", fused)
+            monkeypatch.setattr(ops, "CONV_VARIANT", {"2": 2, "1": 1, "0": 3}[fused])      # c3d_conv_desc.variant
             y, part = ops.conv_forward(srcs, wp, bias, Cout, [(0, 0)], lrelu=True, stats=True)
             torch.cuda.synchronize()
             outs[fused] = (y.clone(), part.clone())
@@ -337,14 +337,13 @@ def test_fused_pointwise_kernel_random_configurations():
     configurations: 1-3 sources at channel offsets inside wider tensors, each with or without BatchNorm affine /
     LeakyReLU, ragged W, couts that leave ragged tiles, output at a channel offset of a wider tensor, accumulate
     mode, with and without bias / statistics, forward packs and input-gradient (transposed, sliced) packs."""
-    import os
     import random
     from coarse3d_amd import ops
     rnd = random.Random(77)
     dev = "cuda"
     prev = ops.matrix_precision_state()
     ops.set_matrix_precision("bf16x3")
-    saved = os.environ.get("C3D_PW3_FUSED")
+    saved = ops.CONV_VARIANT
     try:
         for case in range(24):
             g = torch.Generator().manual_seed(1000 + case)
@@ -375,7 +374,7 @@ def test_fused_pointwise_kernel_random_configurations():
             acc, stats, lrelu = rnd.random() < 0.4, rnd.random() < 0.5, rnd.random() < 0.5
             outs = {}
             for fused in ("0", "1", "2"):
-                os.environ["C3D_PW3_FUSED"] = fused
+                ops.CONV_VARIANT = {"0": 3, "1": 1, "2": 2}[fused]           # c3d_conv_desc.variant
                 out = base.clone()
                 _, part = ops.conv_forward(srcs, wp, bias, Cout, [(0, 0)], lrelu=lrelu, stats=stats, out=out, out_coff=ocoff,
                                            accumulate=acc)
@@ -387,10 +386,7 @@ def test_fused_pointwise_kernel_random_configurations():
                 if stats:
                     assert torch.equal(outs[fused][1], outs["0"][1]), (tag, fused)
     finally:
-        if saved is None:
-            os.environ.pop("C3D_PW3_FUSED", None)
-        else:
-            os.environ["C3D_PW3_FUSED"] = saved
+        ops.CONV_VARIANT = saved
         ops.set_matrix_precision(*prev)
 
 
@@ -400,14 +396,13 @@ def test_fused_multitap_kernel_is_bit_identical_to_the_phased_one():
     three tap patterns, 1-3 sources at channel offsets with or without BatchNorm affine / LeakyReLU, ragged H / W
     (zero padding after the transform at every border), 32- and 64-wide cout tiles with ragged couts, output at a
     channel offset, accumulate mode, eight and six plane products (forward / input-gradient launches)."""
-    import os
     import random
     from coarse3d_amd import ops
     rnd = random.Random(99)
     dev = "cuda"
     prev = ops.matrix_precision_state()
     ops.set_matrix_precision("bf16x3")
-    saved = os.environ.get("C3D_X3_FUSED")
+    saved = ops.CONV_VARIANT
     try:
         for case in range(28):
             g = torch.Generator().manual_seed(2000 + case)
@@ -435,7 +430,7 @@ def test_fused_multitap_kernel_is_bit_identical_to_the_phased_one():
             taps = ops.conv_taps(k, k, dil, pad)
             outs = {}
             for fused in ("0", "1"):
-                os.environ["C3D_X3_FUSED"] = fused
+                ops.CONV_VARIANT = 0 if fused == "1" else 4               # c3d_conv_desc.variant bit 2: the phased kernel
                 out = base.clone()
                 _, part = ops.conv_forward(srcs, wp, bias, Cout, taps, lrelu=lrelu, stats=stats, out=out, out_coff=ocoff,
                                            accumulate=acc, grad=six)
@@ -446,10 +441,7 @@ def test_fused_multitap_kernel_is_bit_identical_to_the_phased_one():
             if stats:
                 assert torch.equal(outs["1"][1], outs["0"][1]), tag
     finally:
-        if saved is None:
-            os.environ.pop("C3D_X3_FUSED", None)
-        else:
-            os.environ["C3D_X3_FUSED"] = saved
+        ops.CONV_VARIANT = saved
         ops.set_matrix_precision(*prev)
 
 

@@ -204,6 +204,35 @@ def test_rccl_exchange_points_in_a_single_rank_group():
     assert b["n_gpus"] == 1 and b["value"] > 0
 
 
+def test_captured_data_parallel_step_is_bit_identical_to_the_eager_one():
+    """the data-parallel step as ONE hipGraph.  Under coarse3d_amd.dist.DataParallel in a 1-rank
+    RCCL group every exchange point issues its real collective (84 SyncBatchNorm all-reduces, the gradient buckets from
+    the weight-gradient stream, the bank mean); TrainStep(graph=True) captures them with the ~700 kernels of the step
+    (torch.distributed's RCCL calls are capturable; the side stream forks from and joins the capturing stream).  Six
+    steps with the epoch -- hence the pseudo-label ratio -- changing every step: ONE graph, four replays, and every loss,
+    parameter, BatchNorm statistic, the bank and the AdamW state equal the eager data-parallel run bit for bit.  The
+    exchanges are counted per replay as they are per eager step, and a replayed step costs the host < 5 ms (eager:
+    ~20 ms of launches)."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29763")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(here, "_dp_graph_worker.py")], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["diff"] == [], out["diff"][:10]
+    assert out["graphs"] == [0, 1] and out["replays"] == [0, 4] and out["trained"]
+    assert out["counts"][0] == out["counts"][1] and out["counts"][1]["syncbn"] >= 6 * 80, out["counts"]
+    assert out["counts"][1]["gradient_buckets"] >= 6 and out["counts"][1]["prototype_bank"] == 6
+    assert out["host_ms_last_step"][1] < 5.0, out["host_ms_last_step"]
+    from _measure import record
+    record("dp_graph/host_ms_per_replayed_step", out["host_ms_last_step"][1])
+    record("dp_graph/host_ms_per_eager_step", out["host_ms_last_step"][0])
+
+
 @pytest.mark.parametrize("net", ["salsanext", "rangenet21", "squeezeseg21"])
 def test_every_backbone_reports_all_gradient_blocks_under_a_process_group(net):
     """The bucketed gradient all-reduce sends a finished PREFIX of the flat gradient buffer, which is only right if

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the wide pointwise kernel (csrc/conv_pw3.hip) at the step's shapes, fused vs phased
-(C3D_PW3_FUSED), bf16x3 engine.  Run on the GPU box: python tools/bench_pw3.py"""
+(ops.CONV_VARIANT = c3d_conv_desc.variant), bf16x3 engine.  Run on the GPU box: python tools/bench_pw3.py"""
 import json
 import os
 import sys
@@ -45,7 +45,7 @@ def main():
         flops = 2.0 * B * H * W * Ci * Co
         r = dict(shape=[B, H, W, Ci, Co], affine=aff)
         for fused in ("0", "1", "2", "0", "1", "2"):
-            os.environ["C3D_PW3_FUSED"] = fused
+            ops.CONV_VARIANT = {"0": 3, "1": 1, "2": 2}.get(str(fused), 0)
             ms = timeit(lambda: ops.conv_forward([src], wp, bias, Co, [(0, 0)], lrelu=True, out=out, stat_partial=part))
             key = {"0": "phased", "1": "fused8", "2": "fused4"}[fused]
             r.setdefault(key + "_ms", []).append(round(ms, 4))

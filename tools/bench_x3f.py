@@ -43,7 +43,7 @@ for (B, H, W, Ci, Co, k, dil, pad) in shapes:
     r = dict(shape=[B, H, W, Ci, Co, k, dil])
     for grad in (False, True):
         for fused in ("0", "1", "0", "1"):
-            os.environ["C3D_X3_FUSED"] = fused
+            ops.CONV_VARIANT = 4 if str(fused) == "0" else 0
             ms = timeit(lambda: ops.conv_forward([src], wp, None, Co, taps, lrelu=True, out=out, stat_partial=part, grad=grad))
             key = ("six_" if grad else "fwd_") + ("fused" if fused == "1" else "phased")
             r.setdefault(key + "_ms", []).append(round(ms, 4))

@@ -25,7 +25,7 @@ o32, st32, g32 = run_oracle(st, x, masks, dataset, d_prob, d_feat, torch.float32
 o64, _, g64 = run_oracle(st, x, masks, dataset, d_prob, d_feat, torch.float64)
 print("oracles %.0f s" % (time.time() - t0), flush=True)
 for six in (("0", "1") if ENGINE == "bf16x3" else ("0",)):
-    os.environ["C3D_SIX_FWD_TAPS"] = six
+    ops.SIX_FWD_MIN_PIXELS = 0 if six == "1" else 1 << 60      # six plane products in every forward multi-tap conv / eight
     P = {k: v.to(dev).clone() for k, v in st.items()}
     bb = Backbone(P, ncls, dataset)
     out = bb.forward(x.to(dev), True, {k: v.to(dev) for k, v in masks.items()}, True)

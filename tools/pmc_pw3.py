@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The 704 -> 704 projector GEMM on the three pointwise kernels (for a rocprofv3 --pmc run, see tools/pmc_summary.py):
-C3D_PW3_FUSED = 0 (round 2's phased kernel), 1 (fused, eight waves), 2 (fused, four waves x two workgroups per CU)."""
+ops.CONV_VARIANT (c3d_conv_desc.variant): 3 (round 2's phased kernel), 1 (fused, eight waves), 2 (fused, four waves x two workgroups per CU)."""
 import os
 import sys
 
@@ -17,7 +17,7 @@ for (B, H, W, Ci, Co) in [(8, 32, 1024, 704, 704), (8, 64, 2048, 256, 400), (8, 
     src = ops.Source(x)
     out = torch.empty(B, H, W, Co, device=dev)
     for fused in ("0", "1", "2"):
-        os.environ["C3D_PW3_FUSED"] = fused
+        ops.CONV_VARIANT = {"0": 3, "1": 1, "2": 2}.get(str(fused), 0)
         for _ in range(3):
             ops.conv_forward([src], wp, None, Co, [(0, 0)], lrelu=True, out=out, stats=True)
 torch.cuda.synchronize()
