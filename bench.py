@@ -37,6 +37,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import coarse3d_amd  # noqa: E402,F401  (process-wide runtime defaults are set at import, before the first GPU call)
 
 FEATURE_MEAN = [12.12, 10.88, 0.23, -1.04, 0.21]     # config_semantic_kitti.yaml sensor.img_means
 FEATURE_STD = [12.32, 11.47, 6.91, 0.86, 0.16]       # config_semantic_kitti.yaml:148-153

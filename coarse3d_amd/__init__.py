@@ -6,3 +6,15 @@ SalsaNext forward/backward plan, ``pc_processor`` the mirror of the reference mo
 ``trainer`` the step orchestration, ``dist`` the data-parallel exchange points.
 """
 __version__ = "0.1.0"
+
+import os as _os
+
+# hipGraph replays on this ROCm (torch 2.10 bundles HIP 7.0.2): with the runtime's "graph packet capture" (AQL packets of
+# a graph built once and re-submitted) a captured graph faults -- "Memory access fault by GPU" -- the first time it is
+# replayed after ~2 000 unrelated launches on the device, e.g. a validation pass between two training epochs
+# (tools/graph_staleness_probe.py; 600-1 500 intervening launches are fine, 2 000 fault, every time).  Building the
+# packets at each launch instead costs ~6 ms of host time per replayed training step and NOTHING in wall time (33.2 vs 33.2 ms
+# at 8x64x2048, 19.5 vs 19.5 ms at 16x32x1024: the GPU is the bound either way), so that is the default here.  The
+# runtime reads the variable when it initialises: it takes effect if this package is imported before the first GPU call of the
+# process; ``DEBUG_CLR_GRAPH_PACKET_CAPTURE=1`` in the environment keeps the runtime's default.
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")

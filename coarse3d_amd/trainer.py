@@ -122,6 +122,8 @@ class TrainStep:
         # labelled-pixel count of every replay, copied to pinned host memory without a synchronisation and checked
         # when it has arrived (a step or two later): more labelled pixels than the shape-static list holds raises
         self._cnt_ring = []
+        self._cnt_host = None
+        self._cnt_free = None
 
     def step(self, x, train_label, eval_label, epoch=0):
         """x [B,5,H,W] fp32, labels [B,H,W] int64 (0 = ignore).  Returns dict of 0-dim loss tensors
@@ -288,6 +290,7 @@ class TrainStep:
             self._check_capacity(int(loss_head.valid_indices_static(st, self.ignore_cls)[1]))
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()
+            self._drain_process_group()
             g = torch.cuda.CUDAGraph()
             from . import dist as c3d_dist
             counts0 = dict(c3d_dist.COUNTS)
@@ -320,6 +323,25 @@ class TrainStep:
             self.scheduler.step()
         return ent["res"]
 
+    @staticmethod
+    def _drain_process_group():
+        """Before a capture that contains collectives: torch.distributed's watchdog thread polls the completion events of
+        the collectives issued so far, and HIP refuses an event query once the event's stream (the process group's
+        communication stream) has joined a capture -- which it does with the first captured collective.  Let everything
+        issued so far finish and the watchdog retire it; collectives issued DURING a capture are not handed to the
+        watchdog."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        torch.cuda.synchronize()
+        pg = dist.distributed_c10d._get_default_group()
+        wait = getattr(pg, "_wait_for_pending_works", None)
+        if wait is not None:
+            wait()
+        else:                                            # older torch: the watchdog sweeps every 100 ms
+            import time
+            time.sleep(0.5)
+
     def _evict(self, keep):
         """Drop least-recently-used captured graphs beyond ``max_graphs`` (their tensors live in the shared pool, which
         later captures reuse)."""
@@ -337,18 +359,24 @@ class TrainStep:
                                f"({ops.lovasz_max_pixels()}); train fully supervised batches with graph=False")
 
     def _watch_capacity(self, count):
-        """Queue an asynchronous read-back of this replay's labelled-pixel count (4 bytes into pinned memory)."""
-        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-        host.copy_(count, non_blocking=True)
+        """Queue an asynchronous read-back of this replay's labelled-pixel count: 4 bytes into one of eight slots of a
+        pinned buffer allocated once (a fresh pinned allocation per step costs ~10 ms of host time while the GPU is busy)."""
+        if self._cnt_host is None:
+            self._cnt_host = torch.zeros(8, dtype=torch.int32).pin_memory()
+            self._cnt_free = list(range(8))
+        if not self._cnt_free:                           # never more than eight steps behind
+            ev0, slot0 = self._cnt_ring.pop(0)
+            ev0.synchronize()
+            self._cnt_free.append(slot0)
+            self._check_capacity(int(self._cnt_host[slot0]))
+        slot = self._cnt_free.pop(0)
+        self._cnt_host[slot:slot + 1].copy_(count, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._cnt_ring.append((ev, host))
-        if len(self._cnt_ring) > 8:                      # never more than a few steps behind
-            ev0, h0 = self._cnt_ring.pop(0)
-            ev0.synchronize()
-            self._check_capacity(int(h0))
+        self._cnt_ring.append((ev, slot))
 
     def _poll_capacity(self):
         while self._cnt_ring and self._cnt_ring[0][0].query():
-            _, h = self._cnt_ring.pop(0)
-            self._check_capacity(int(h))
+            _, slot = self._cnt_ring.pop(0)
+            self._cnt_free.append(slot)
+            self._check_capacity(int(self._cnt_host[slot]))

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
+import coarse3d_amd  # noqa: E402,F401  (runtime defaults before the first GPU call)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))          # tests/_measure.py
+import coarse3d_amd  # noqa: E402,F401  (process-wide runtime defaults are set at import, before the first GPU call)
 
 
 def pytest_configure(config):
