@@ -38,7 +38,9 @@ class WgradDesc(C.Structure):
                 ("dw", C.c_void_p), ("accumulate", C.c_int32), ("partial", C.c_void_p), ("mfma_bf16", C.c_int32),
                 ("lrelu_slope", C.c_float), ("dz_bf16", C.c_int32), ("reserved", C.c_int32),
                 ("bias_partial", C.c_void_p), ("dbias", C.c_void_p), ("bias_n", C.c_int32), ("reserved2", C.c_int32),
-                ("dz_scale", C.c_void_p), ("out_scale_dev", C.c_void_p)]
+                ("dz_scale", C.c_void_p), ("out_scale_dev", C.c_void_p),
+                ("fuse_dy", C.c_void_p), ("fuse_act", C.c_void_p), ("fuse_k1", C.c_void_p), ("fuse_k2", C.c_void_p),
+                ("fuse_k3", C.c_void_p), ("fuse_sum", C.c_void_p)]
 
 
 class PackEntry(C.Structure):

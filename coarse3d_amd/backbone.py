@@ -29,6 +29,10 @@ BN_MOMENTUM = 0.1
 # BatchNorm-backward sums in the epilogue of the last input-gradient conv (see _conv_backward); False: always the
 # separate reduce pass (module flag for tests / A-B runs)
 FUSE_BN_REDUCE = True
+# BatchNorm / LeakyReLU backward applied ON LOAD by the layer's first weight-gradient launch (round 4; ops.conv_wgrad(fuse=...)):
+# the apply pass (dy, a -> dz: three tensor passes at HBM speed, 53 launches and the largest kernel of the round-3 step)
+# disappears; dz is bit-identical.  False: the separate c3d_bn_bwd_apply pass (module flag for tests / A-B runs)
+FUSE_BN_APPLY = True
 
 
 class Act:
@@ -437,7 +441,7 @@ class Backbone:
         else:
             ops.axpy(g, act.grad)
 
-    def _bn_backward(self, bn, dy, a, c, mode, slope=0.0, k=None, part=None, gmax=None):
+    def _bn_backward(self, bn, dy, a, c, mode, slope=0.0, k=None, part=None, gmax=None, coeffs_only=False):
         """dy: gradient w.r.t. BN(a) [mode 0] or LeakyReLU(BN(a)) [mode 1] -> (dz = d/da, partial with
         sum(dz)); writes the BatchNorm parameter gradients.  SyncBN: the fp64 sums are all-reduced
         (``k``: coefficients already computed by ``_bn_backward_group``)."""
@@ -455,6 +459,8 @@ class Backbone:
                 self.reduce_fn(sums)
                 k = ops.bn_bwd_coeffs(sums, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
                                       G[f"{bn.name}.weight"], G[f"{bn.name}.bias"], local)
+        if coeffs_only:
+            return k
         return ops.bn_bwd_apply(dy, a, c, mode, k, pre_s, pre_h, slope=slope, gmax=gmax)
 
     def _bn_backward_group(self, items):
@@ -535,14 +541,27 @@ class Backbone:
                 self._gmax_next = 0
             gmax = pool[self._gmax_next:self._gmax_next + 1]
             self._gmax_next += 1
-        if rec.mode == 0 or rec.mode == 1:
+        # conv -> LeakyReLU [-> BatchNorm] layers on one stream: the first weight-gradient launch applies the BatchNorm /
+        # LeakyReLU backward while it stages dy and writes dz for the input-gradient convs below (no apply pass).  With a
+        # side stream (data parallel) the weight gradients must not sit on the critical path: separate pass as before.
+        fuse = (FUSE_BN_APPLY and rec.mode in (0, 2) and self.side is None and gmax is None and dy.dtype == torch.float32
+                and tuple(dy.shape) == tuple(a.shape) and dy.is_contiguous() and ops.wgrad_fusable(rec.srcs[0], a, c))
+        fuse_args = None
+        if fuse:
+            kk = None
+            if rec.mode == 0:
+                kk = self._bn_backward(rec.bn, dy, a, c, 0, rec.slope, k, rec.out.bwd_partial, coeffs_only=True)
+                rec.out.bwd_partial = None
+            dz, pz = torch.empty_like(a), None
+            fuse_args = (dy, a, kk)
+        elif rec.mode == 0 or rec.mode == 1:
             dz, pz = self._bn_backward(rec.bn, dy, a, c, rec.mode, rec.slope, k, rec.out.bwd_partial, gmax=gmax)
             rec.out.bwd_partial = None
         elif rec.mode == 2:
             dz, pz = ops.bn_bwd_apply(dy, a, c, 2, slope=rec.slope, gmax=gmax)
         else:
             dz, pz = ops.bn_bwd_apply(dy, dy, cpad, 3, dz=dy)
-        if self.capture is not None:
+        if self.capture is not None and not fuse:
             self.capture[name] = (rec, None if dy is dz else dy.clone(), dz.clone())
         w = self.P[f"{name}.weight"] if rec.weight is None else rec.weight
         dw = G[f"{name}.weight"] if rec.dweight is None else rec.dweight
@@ -555,9 +574,13 @@ class Backbone:
             off = 0
             for s in rec.srcs:
                 ops.conv_wgrad(s.src(rec.src_lrelu), dz, dw, rec.taps, cin_off=off, slope=rec.slope,
-                               bias_partial=pz if db is not None else None, dbias=db, f16x2=wg16)
+                               bias_partial=pz if (db is not None and fuse_args is None) else None, dbias=db, f16x2=wg16,
+                               fuse=fuse_args)
                 db = None
+                fuse_args = None          # the first launch wrote dz: the other sources of a concatenated input read it
                 off += s.t.shape[3]
+        if self.capture is not None and fuse:
+            self.capture[name] = (rec, dy.clone(), dz.clone())
         ntaps = ops.negate_taps(rec.taps)
         off = 0
         gsrc = ops.Source(dz)

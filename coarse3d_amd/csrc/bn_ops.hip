@@ -207,7 +207,9 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
         c3d_vec<V> dz;
 #pragma unroll
         for (int q = 0; q < V; ++q) {
-          float da = k1.v[q] * dy.v[q] + k2.v[q] * a.v[q] + k3.v[q];
+          // (explicit operation order: the weight-gradient kernel that applies this on load, wgrad_tr.hip, produces
+          //  the same bits)
+          float da = fmaf(k2.v[q], a.v[q], fmaf(k1.v[q], dy.v[q], k3.v[q]));
           if (p.mode == 0 || p.mode == 2) da *= (a.v[q] > 0.f) ? 1.f : p.slope;
           dz.v[q] = da;
         }

@@ -17,6 +17,14 @@ struct WgradArgs {
   float* partial;
   int tiles_x, tiles_y, ntiles, strips, tiles_per_strip;
   const float* dz_scale = nullptr;   // f16x2 experiment: per-cout scale of dz on load
+  // BatchNorm / LeakyReLU backward on load (c3d_wgrad_desc.fuse_*): dz is then written, not read
+  const float* f_dy = nullptr;
+  const float* f_act = nullptr;
+  const float* f_k1 = nullptr;
+  const float* f_k2 = nullptr;
+  const float* f_k3 = nullptr;
+  float* f_sum = nullptr;
+  int f_sum_n = 0;
   int ci_slices, co_slices;
   float slope;
 };

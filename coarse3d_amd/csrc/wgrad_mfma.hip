@@ -403,6 +403,19 @@ int launch_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// c3d_wgrad_desc.fuse_*: the shapes / engines that have the fused form (wgrad_tr.hip, three planes, fp32 tensors)
+static bool fuse_supported(const c3d_wgrad_desc* d) {
+  return planes_for(d) == 3 && !d->dz_bf16 && !d->x.bf16 && d->Cout % 4 == 0 && d->dz_cstride % 4 == 0;
+}
+
+extern "C" int c3d_wgrad_fused_sum_n(const c3d_wgrad_desc* d) {
+  if (!d || !fuse_supported(d)) return 0;
+  WgradArgs a;
+  WgCfg c;
+  plan(d, a, c);
+  return a.strips * (256 / (c.CO / 4));
+}
+
 extern "C" int64_t c3d_wgrad_partial_floats(const c3d_wgrad_desc* d) {
   WgradArgs a;
   WgCfg c;
@@ -436,6 +449,15 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   C3D_REQUIRE(a.slope <= 1.f, "wgrad: LeakyReLU slopes above 1 are not supported (the kernels evaluate max(v, slope * v))");
   WgCfg c;
   plan(d, a, c);
+  if (d->fuse_dy) {
+    C3D_REQUIRE(fuse_supported(d), "wgrad: fuse_dy needs the bf16x3 engine (mfma_bf16 == 2), fp32 tensors and Cout % 4 == 0");
+    C3D_REQUIRE(d->fuse_act && d->fuse_sum && d->dz != d->fuse_dy, "wgrad: fuse_dy needs fuse_act, fuse_sum and a dz buffer of its own");
+    C3D_REQUIRE((d->fuse_k1 == nullptr) == (d->fuse_k2 == nullptr) && (d->fuse_k1 == nullptr) == (d->fuse_k3 == nullptr),
+                "wgrad: fuse_k1 / k2 / k3 come together");
+    a.f_dy = d->fuse_dy; a.f_act = d->fuse_act; a.f_k1 = d->fuse_k1; a.f_k2 = d->fuse_k2; a.f_k3 = d->fuse_k3;
+    a.f_sum = d->fuse_sum;
+    a.f_sum_n = a.strips * (256 / (c.CO / 4));
+  }
   hipStream_t st = (hipStream_t)stream;
   const int planes = planes_for(d);
   const int rc = planes ? c3d_wgrad_launch_tr(planes, c.id, halo, a, st)

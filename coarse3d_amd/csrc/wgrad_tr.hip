@@ -143,7 +143,12 @@ __device__ __forceinline__ void c3d_wg_static_for(F&& f) {
   }
 }
 
-template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO>
+// FA ("fused apply", round 4): the BatchNorm / LeakyReLU backward of the layer runs while dz is staged -- the producer
+// waves read dy and the layer's stored output instead of dz, form dz = LeakyReLU'(act) * (k1 * dy + k2 * act + k3), write
+// it out for the input-gradient convolution that follows (workgroups of cin slice 0 only) and keep its per-channel sums
+// (the bias gradient).  The separate c3d_bn_bwd_apply pass (three tensor passes at HBM speed, the largest kernel of the
+// round-3 step) disappears; the arithmetic is the same fmaf chain, dz is bit-identical.
+template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool FA = false>
 __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   constexpr int WK = 4 / (WCI * WCO);
   constexpr int CI = 32 * CI_T * WCI;  // cin slice of the workgroup
@@ -190,8 +195,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   // tile per CU in flight left the kernel bound by memory latency)
   struct Stage {
     f32x4 px[X_PT], pd[D_PT];
+    f32x4 pa[FA ? D_PT : 1];   // FA: the layer's stored output at the dz units (pd then holds dy)
     unsigned inb;   // units of px that came from inside the image (the others are zero padding)
     unsigned dmask; // same for pd
+    int dt;         // FA: element offset of the tile's first pixel in its image (uniform), for the dz store
+    size_t dimg;    // FA: element offset of the image (uniform)
   };
   const int xc4 = tid % (CI / 4);          // 256 % (CI/4) == 0: fixed channel quad per thread
   const int xc = ci0 + xc4 * 4;
@@ -224,6 +232,20 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   const bool dc_ok = dc + 3 < a.dz_cstride;
   if constexpr (NP == 2) {
     if (a.dz_scale && dc + 3 < a.Cout) dsc = *reinterpret_cast<const f32x4*>(a.dz_scale + dc);
+  }
+  // FA: BatchNorm-backward coefficients of this thread's four channels (channels beyond Cout give dz = 0), running sums of dz
+  f32x4 fk1 = {0.f, 0.f, 0.f, 0.f}, fk2 = fk1, fk3 = fk1, fsum = fk1;
+  const bool fwrite = FA && ci0 == 0;                 // one cin slice per cout slice writes dz and the sums (uniform)
+  if constexpr (FA) {
+    if (dc + 3 < a.Cout) {
+      if (a.f_k1) {
+        fk1 = *reinterpret_cast<const f32x4*>(a.f_k1 + dc);
+        fk2 = *reinterpret_cast<const f32x4*>(a.f_k2 + dc);
+        fk3 = *reinterpret_cast<const f32x4*>(a.f_k3 + dc);
+      } else {
+        fk1 = f32x4{1.f, 1.f, 1.f, 1.f};
+      }
+    }
   }
   unsigned xoff[HALO > 0 ? X_PT : 1];
   if constexpr (HALO > 0) {
@@ -313,10 +335,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     };
     auto load_dz = [&](auto bf_tag) {
       constexpr bool DBF = decltype(bf_tag)::value;
+      if constexpr (FA) {
+        sg.dt = dt;
+        sg.dimg = dimg;
+      }
 #pragma unroll
       for (int i = 0; i < D_PT; ++i) {
         const int off = dt + (((i * DSTEP) / 32) * a.W + (i * DSTEP) % 32) * a.dz_cstride + (int)doff0;
-        if constexpr (DBF) {
+        if constexpr (FA) {
+          const unsigned o2 = ((dmask >> i) & 1u) ? (unsigned)off : 0u;
+          sg.pd[i] = c3d_ld4u<false>(a.f_dy, dimg, o2);
+          sg.pa[i] = c3d_ld4u<false>(a.f_act, dimg, o2);
+        } else if constexpr (DBF) {
           // bf16 gradient, one plane: the four values go to LDS as they are -- the raw 8 bytes travel in the first two
           // lanes of the register set (no widening here, no rounding back in store_tile: 8 of the ~10 VALU instructions
           // a dz unit cost the producer waves, which bound this mode)
@@ -360,7 +390,24 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
       const int u = tid + i * 256;
       if (u < D_UNITS) {
         u32x2 pl[NP];
-        if (NP == 1 && a.dz_bf16) {       // raw bf16 (load_dz)
+        if constexpr (FA) {
+          const bool in = (sg.dmask >> i) & 1u;
+          f32x4 t;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            // the arithmetic of bn_bwd_kernel<true> (bn_ops.hip), same operation order: bit-identical dz
+            float da = fmaf(fk2[q], sg.pa[i][q], fmaf(fk1[q], sg.pd[i][q], fk3[q]));
+            da *= (sg.pa[i][q] > 0.f) ? 1.f : a.slope;
+            t[q] = in ? da : 0.f;
+          }
+          fsum += t;
+          if (fwrite && in) {
+            const unsigned off = (unsigned)(sg.dt + (((i * DSTEP) / 32) * a.W + (i * DSTEP) % 32) * a.dz_cstride + (int)doff0);
+            float* ob = const_cast<float*>(a.dz) + sg.dimg;
+            *reinterpret_cast<f32x4*>(ob + off) = t;
+          }
+          split_planes<NP>(t, pl);
+        } else if (NP == 1 && a.dz_bf16) {       // raw bf16 (load_dz)
           const bool in = (sg.dmask >> i) & 1u;
           pl[0] = u32x2{in ? __float_as_uint(sg.pd[i][0]) : 0u, in ? __float_as_uint(sg.pd[i][1]) : 0u};
         } else {
@@ -426,6 +473,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
       }
       __syncthreads();
       ++mt;
+    }
+    if constexpr (FA) {
+      // per-thread sums of dz over the strip: [Cout][2][strips * DSTEP], row 0 (the launch's fold adds them in fp64)
+      if (fwrite) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (dc + q < a.Cout) a.f_sum[((size_t)(dc + q) * 2) * a.f_sum_n + strip * DSTEP + dp0] = fsum[q];
+      }
     }
     if (WK > 1) {
       for (int t = 0; t < a.T; ++t) {
@@ -597,8 +652,20 @@ int launch_tr(const WgradArgs& a, hipStream_t st) {
   size_t lds = 2 * (size_t)NP * ((size_t)(TRW + 2 * HALO) * (32 + 2 * HALO) * CI + (size_t)TRW * 32 * CO) * 2;   // two tile buffers
   const size_t red = (size_t)(WK - 1) * WCI * WCO * CI_T * CO_T * 1024 * sizeof(float);
   if (red > lds) lds = red;
-  c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO>>();
   dim3 grid(a.strips * a.ci_slices * a.co_slices);
+  if constexpr (NP == 3) {
+    if (a.f_dy) {       // BatchNorm / LeakyReLU backward on load
+      if (a.f_sum_n != a.strips * (256 / (CO / 4))) {
+        c3d_set_error("wgrad: fuse_sum was not sized with c3d_wgrad_fused_sum_n()");
+        return 1;
+      }
+      c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true>>();
+      hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true>), grid, dim3(512), lds, st, a);
+      C3D_CHECK_LAUNCH();
+      return 0;
+    }
+  }
+  c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO>>();
   hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO>), grid, dim3(512), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;

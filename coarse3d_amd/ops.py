@@ -379,10 +379,14 @@ def _wgrad_kernel_name(ci, co, nt, halo):
     return f"wgrad_mfma_kernel<{cfg}, {'true' if MFMA_MODE == 1 else 'false'}>"
 
 
-def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_partial=None, dbias=None, f16x2=None):
+def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_partial=None, dbias=None, f16x2=None, fuse=None):
     """dw[:, cin_off:cin_off+src.C] (+)= sum_p dz[p] (x) transformed src[p + tap].
     bias_partial [>=Cout, 2, n] + dbias [Cout]: the launch that folds the weight-gradient strips folds the layer's
-    bias-gradient partials too (instead of a separate bias_from_partials launch)."""
+    bias-gradient partials too (instead of a separate bias_from_partials launch).
+    fuse = (dy, act, k): BatchNorm / LeakyReLU backward on load (c3d_wgrad_desc.fuse_*) -- ``dz`` is then an OUTPUT:
+    the launch forms dz = LeakyReLU'(act) * (k[0] * dy + k[1] * act + k[2]) (k None: LeakyReLU'(act) * dy) while it
+    stages its tiles, writes it to ``dz`` and folds sum(dz) into ``dbias`` (if given).  bf16x3 engine, fp32 tensors of
+    one shape; ``wgrad_fusable`` says whether a layer qualifies."""
     d = L.WgradDesc()
     src.fill(d.x)
     b, h, w = src.t.shape[:3]
@@ -402,6 +406,23 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_p
     n = L.lib().c3d_wgrad_partial_floats(C.byref(d))
     part = torch.empty(n, device=dz.device, dtype=torch.float32)
     d.partial = part.data_ptr()
+    if fuse is not None:
+        dy, act, k = fuse
+        if not (dy.shape == act.shape == dz.shape and dy.dtype == act.dtype == dz.dtype == torch.float32
+                and dy.is_contiguous() and act.is_contiguous() and dz.data_ptr() != dy.data_ptr()):
+            raise ValueError("conv_wgrad(fuse=...): dy, act and dz must be distinct contiguous fp32 tensors of one shape")
+        d.fuse_dy, d.fuse_act = dy.data_ptr(), act.data_ptr()
+        if k is not None:
+            d.fuse_k1, d.fuse_k2, d.fuse_k3 = k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr()
+        nsum = L.lib().c3d_wgrad_fused_sum_n(C.byref(d))
+        if nsum <= 0:
+            raise RuntimeError("conv_wgrad(fuse=...): this layer shape / engine has no fused form (ops.wgrad_fusable)")
+        zsum = torch.empty(dw.shape[0], 2, nsum, device=dz.device, dtype=torch.float32)
+        d.fuse_sum = zsum.data_ptr()
+        if bias_partial is not None:
+            raise ValueError("conv_wgrad(fuse=...): the bias partials are the launch's own sums of dz")
+        if dbias is not None:
+            bias_partial = zsum
     if bias_partial is not None:
         if dbias is None or dbias.shape[0] != dw.shape[0] or bias_partial.shape[0] < dw.shape[0]:
             raise ValueError("conv_wgrad: bias_partial needs a dbias of Cout entries")
@@ -415,6 +436,12 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_p
     with _Timed(name, 2.0 * b * h * w * dw.shape[0] * len(taps) * src.C, (h, w, ci, co, nt, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
     return dw
+
+
+def wgrad_fusable(src, act, cout):
+    """Whether conv_wgrad(fuse=...) exists for a layer: exact-split engine, fp32 tensors, unpadded channel count."""
+    return (MFMA_MODE == 2 and src.t.dtype == torch.float32 and act.dtype == torch.float32 and act.shape[3] == cout
+            and cout % 4 == 0 and tuple(src.t.shape[:3]) == tuple(act.shape[:3]))
 
 
 # ---------------------------------------------------------------------------- BatchNorm

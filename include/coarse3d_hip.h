@@ -178,8 +178,25 @@ typedef struct {
    * c3d_grad_exponent_max) while it is staged, x with 2^6; the fold multiplies 2^-6 * *out_scale_dev (2^-s) back */
   const float* dz_scale;
   const float* out_scale_dev;
+  /* BatchNorm / LeakyReLU backward ON LOAD (round 4; mfma_bf16 == 2, fp32 tensors).  fuse_dy != NULL: `dz` is an OUTPUT.
+   * The launch reads the gradient at the layer's consumer-visible output (fuse_dy) and the layer's stored output
+   * (fuse_act = LeakyReLU(conv + bias), pre-BatchNorm), forms
+   *     dz = LeakyReLU'(act) * (k1[c] * dy + k2[c] * act + k3[c])        (k1 == NULL: dz = LeakyReLU'(act) * dy)
+   * while it stages its pixel tiles -- what c3d_bn_bwd_apply computes in a pass of its own (modes 0 and 2) -- uses it as
+   * the weight gradient's operand, WRITES it to `dz` (the input-gradient convolution that follows reads it) and leaves the
+   * per-channel sums of dz in fuse_sum [Cout][2][c3d_wgrad_fused_sum_n()] (row 0; the bias gradient: pass it as
+   * bias_partial with bias_n = that n).  All three tensors share dz_cstride; `dz` must not alias fuse_dy.
+   * Reference: autograd of BatchNorm2d + LeakyReLU in salsanext_proto.py:56-62,117-140,185-205.                        */
+  const float* fuse_dy;
+  const float* fuse_act;
+  const float* fuse_k1;
+  const float* fuse_k2;
+  const float* fuse_k3;
+  float* fuse_sum;
 } c3d_wgrad_desc;
 int64_t c3d_wgrad_partial_floats(const c3d_wgrad_desc* d);
+/* entries per channel of fuse_sum for this descriptor (0: this shape / engine has no fused form -- run c3d_bn_bwd_apply) */
+int c3d_wgrad_fused_sum_n(const c3d_wgrad_desc* d);
 int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream);
 
 /* ------------------------------------------------------------------ BatchNorm2d (train mode)

@@ -332,6 +332,53 @@ def test_fused_pointwise_kernel_is_bit_identical_to_the_phased_one(B, H, W, srcC
         ops.set_matrix_precision(*prev)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,dil,pad,bn", [
+    (2, 32, 256, 32, 32, 3, 1, 1, True), (2, 32, 256, 32, 32, 3, 2, 2, True), (2, 32, 256, 64, 64, 3, 2, 2, True),
+    (2, 32, 256, 64, 64, 2, 2, 1, True), (2, 32, 200, 32, 64, 2, 2, 1, True), (2, 16, 512, 128, 128, 3, 1, 1, True),
+    (2, 32, 256, 96, 32, 1, 1, 0, True), (4, 16, 256, 256, 256, 1, 1, 0, True), (2, 16, 256, 256, 128, 1, 1, 0, True),
+    (2, 32, 256, 32, 64, 1, 1, 0, False), (1, 40, 232, 64, 64, 3, 1, 1, False), (3, 8, 97, 32, 32, 3, 1, 1, True),
+])
+def test_batchnorm_backward_applied_on_load_by_the_weight_gradient(B, H, W, Cin, Cout, k, dil, pad, bn):
+    """Round 4: ops.conv_wgrad(fuse=(dy, act, k)) -- the layer's first weight-gradient launch
+    forms dz = LeakyReLU'(act) * (k1 dy + k2 act + k3) while it stages its tiles (wgrad_tr.hip, FA), writes dz for the
+    input-gradient conv and folds sum(dz) into the bias gradient; c3d_bn_bwd_apply's pass disappears.  Against the
+    two-launch path on every weight-gradient tiling (3x3 with both halos, 2x2, 1x1 with one and several cin slices,
+    ragged W / H, with BatchNorm coefficients and LeakyReLU-only): dz and dw bit-identical, bias gradient to fp32
+    summation order."""
+    from coarse3d_amd import ops
+    dev = "cuda"
+    g = torch.Generator().manual_seed(31 * Cin + Cout + k + dil)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    act = torch.nn.functional.leaky_relu(torch.randn(B, H, W, Cout, generator=g), 0.01).to(dev)
+    dy = torch.randn(B, H, W, Cout, generator=g).to(dev)
+    kk = (torch.randn(3, Cout, generator=g) * torch.tensor([[1.0], [0.1], [0.01]])).to(dev) if bn else None
+    sc, sh = (torch.rand(Cin, generator=g) + 0.5).to(dev), (torch.randn(Cin, generator=g) * 0.3).to(dev)
+    taps = ops.conv_taps(k, k, dil, pad)
+    _PREV.append(ops.matrix_precision_state())
+    ops.set_matrix_precision("bf16x3")
+    try:
+        src = ops.Source(x, sc, sh, lrelu=True)
+        assert ops.wgrad_fusable(src, act, Cout)
+        # two launches: apply pass, then the weight gradient reading dz
+        dz_ref, pz = ops.bn_bwd_apply(dy, act, Cout, 0 if bn else 2, kk)
+        dw_ref = torch.zeros(Cout, Cin, k, k, device=dev)
+        db_ref = torch.zeros(Cout, device=dev)
+        ops.conv_wgrad(src, dz_ref, dw_ref, taps, bias_partial=pz, dbias=db_ref)
+        # one launch
+        dz = torch.full_like(act, float("nan"))
+        dw = torch.zeros_like(dw_ref)
+        db = torch.zeros_like(db_ref)
+        ops.conv_wgrad(src, dz, dw, taps, dbias=db, fuse=(dy, act, kk))
+        torch.cuda.synchronize()
+        assert torch.equal(dz, dz_ref)
+        assert torch.equal(dw, dw_ref)
+        assert float((db - db_ref).abs().max()) <= 2e-6 * float(dz_ref.abs().sum(dim=(0, 1, 2)).max())
+        ref64 = dz_ref.double().sum(dim=(0, 1, 2))
+        assert float((db.double() - ref64).abs().max()) <= 1e-6 * float(dz_ref.double().abs().sum(dim=(0, 1, 2)).max())
+    finally:
+        ops.set_matrix_precision(*_PREV.pop())
+
+
 def test_fused_pointwise_kernel_random_configurations():
     """Both geometries of the fused kernel against the phased one, bit for bit, over 24 seeded random launch
     configurations: 1-3 sources at channel offsets inside wider tensors, each with or without BatchNorm affine /

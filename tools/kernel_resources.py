@@ -4,7 +4,7 @@ usage: kernel_resources.py coarse3d_amd/csrc/conv_mfma.hip"""
 import re, subprocess, sys
 src = sys.argv[1]
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
-       "-fno-fast-math", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+       "-fno-fast-math", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 name, rec = None, {}
 for line in out.splitlines():
