@@ -40,7 +40,16 @@ class WgradDesc(C.Structure):
                 ("bias_partial", C.c_void_p), ("dbias", C.c_void_p), ("bias_n", C.c_int32), ("reserved2", C.c_int32),
                 ("dz_scale", C.c_void_p), ("out_scale_dev", C.c_void_p),
                 ("fuse_dy", C.c_void_p), ("fuse_act", C.c_void_p), ("fuse_k1", C.c_void_p), ("fuse_k2", C.c_void_p),
-                ("fuse_k3", C.c_void_p), ("fuse_sum", C.c_void_p)]
+                ("fuse_k3", C.c_void_p), ("fuse_sum", C.c_void_p), ("fold_out", C.c_void_p)]
+
+
+class WgradFold(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("dw", C.c_void_p),
+                ("strips", C.c_int32), ("T", C.c_int32), ("CI", C.c_int32), ("CO", C.c_int32), ("ci_slices", C.c_int32),
+                ("co_slices", C.c_int32), ("Cin_src", C.c_int32), ("Cout", C.c_int32), ("Cin_total", C.c_int32),
+                ("cin_off", C.c_int32), ("accumulate", C.c_int32), ("main_blocks", C.c_int32), ("nblocks", C.c_int32),
+                ("block0", C.c_int32), ("bias_partial", C.c_void_p), ("dbias", C.c_void_p), ("bias_n", C.c_int32),
+                ("out_scale", C.c_float), ("out_scale_dev", C.c_void_p)]
 
 
 class PackEntry(C.Structure):

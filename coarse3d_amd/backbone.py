@@ -33,6 +33,9 @@ FUSE_BN_REDUCE = True
 # the apply pass (dy, a -> dz: three tensor passes at HBM speed, 53 launches and the largest kernel of the round-3 step)
 # disappears; dz is bit-identical.  False: the separate c3d_bn_bwd_apply pass (module flag for tests / A-B runs)
 FUSE_BN_APPLY = True
+# strips -> dw folds of the weight gradients queued and run in batches of 32 per launch (ops.WgradFolds); False: one fold
+# launch behind every weight-gradient launch
+DEFER_WGRAD_FOLDS = True
 
 
 class Act:
@@ -677,6 +680,15 @@ class Backbone:
     def backward(self, d_prob=None, d_feat=None, grads=None):
         """d_prob [B,Ho,Wo,C], d_feat [B,Ho,Wo,256] (NHWC, either may be None).  ``grads``: optional
         dict name -> preallocated gradient tensor (reference layout); returned filled."""
+        # the strips -> dw folds of the weight gradients are queued and run in batches (ops.WgradFolds): at the end of the
+        # pass, or -- data parallel -- whenever a block's gradients are about to be sent
+        prev, ops.WGRAD_FOLDS = ops.WGRAD_FOLDS, (ops.WgradFolds() if DEFER_WGRAD_FOLDS else None)
+        try:
+            return self._backward(d_prob, d_feat, grads)
+        finally:
+            ops.WGRAD_FOLDS = prev
+
+    def _backward(self, d_prob, d_feat, grads):
         P = self.P
         if grads is None:
             grads = {k: torch.empty_like(v) for k, v in P.items()
@@ -692,6 +704,8 @@ class Backbone:
             # bucket all-reduce is issued from the side stream so the main stream never waits
             if self.on_block_done is not None:
                 with self._fork():
+                    if ops.WGRAD_FOLDS is not None:
+                        ops.WGRAD_FOLDS.flush()
                     self.on_block_done(tag)
 
         if d_prob is None:
@@ -749,6 +763,9 @@ class Backbone:
         done("downCntx2")
         self._ctx_backward("downCntx", first=True)
         done("downCntx")
+        if ops.WGRAD_FOLDS is not None:
+            with self._fork():
+                ops.WGRAD_FOLDS.flush()
         self._join()
         self.tape = None
         return grads

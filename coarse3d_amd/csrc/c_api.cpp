@@ -11,10 +11,11 @@ extern "C" void c3d_set_error(const char* msg) {
 extern "C" const char* c3d_last_error(void) { return g_err; }
 extern "C" int c3d_version(void) { return 101; }
 // sizeof of the descriptor structs, so that a binding can verify its mirror of the layouts
-extern "C" int c3d_abi_sizes(int32_t* out4) {
-  out4[0] = (int32_t)sizeof(c3d_src);
-  out4[1] = (int32_t)sizeof(c3d_conv_desc);
-  out4[2] = (int32_t)sizeof(c3d_wgrad_desc);
-  out4[3] = (int32_t)sizeof(c3d_pack_entry);
+extern "C" int c3d_abi_sizes(int32_t* out5) {
+  out5[0] = (int32_t)sizeof(c3d_src);
+  out5[1] = (int32_t)sizeof(c3d_conv_desc);
+  out5[2] = (int32_t)sizeof(c3d_wgrad_desc);
+  out5[3] = (int32_t)sizeof(c3d_pack_entry);
+  out5[4] = (int32_t)sizeof(c3d_wgrad_fold);
   return 0;
 }

@@ -280,31 +280,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
 
 // dw[cout][cin_off + cin][t] (+)= sum_strips partial.  Block = 32 outputs x 8 strip lanes.
 // Blocks beyond `main_blocks` fold the layer's bias-gradient partials (one channel each; c3d_wgrad_desc.bias_partial).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                           int strips, int T, int CI, int CO, int ci_slices,
-                                                           int co_slices, int Cin_src, int Cout, int Cin_total,
-                                                           int cin_off, int accumulate, int main_blocks,
-                                                           const float* __restrict__ bias_partial, int bias_n,
-                                                           float* __restrict__ dbias, float out_scale,
-                                                           const float* __restrict__ out_scale_dev) {
-  __shared__ double red[8][32];
-  const double osc = out_scale_dev ? (double)out_scale * (double)*out_scale_dev : (double)out_scale;   // powers of two: exact
-  if ((int)blockIdx.x >= main_blocks) {
-    const int c = blockIdx.x - main_blocks;
-    const float* p = bias_partial + (size_t)c * 2 * bias_n;
+// One fold = one c3d_wgrad_fold record; `blk` is the block's index within the fold.
+__device__ __forceinline__ void wgrad_fold_body(const c3d_wgrad_fold& f, int blk, double (*red)[32]) {
+  const double osc = f.out_scale_dev ? (double)f.out_scale * (double)*f.out_scale_dev : (double)f.out_scale;   // powers of two: exact
+  const int main_blocks = f.main_blocks;
+  if (blk >= main_blocks) {
+    const int c = blk - main_blocks;
+    const float* p = f.bias_partial + (size_t)c * 2 * f.bias_n;
     double s = 0.0;
-    for (int t = threadIdx.x; t < bias_n; t += 256) s += (double)p[t];
+    for (int t = threadIdx.x; t < f.bias_n; t += 256) s += (double)p[t];
     s = c3d_wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) dbias[c] = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    if (threadIdx.x == 0) f.dbias[c] = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
     return;
   }
+  const int T = f.T, CI = f.CI, CO = f.CO, ci_slices = f.ci_slices, strips = f.strips;
   const size_t slice_floats = (size_t)T * CI * CO;
-  const int nsl = ci_slices * co_slices;
+  const int nsl = ci_slices * f.co_slices;
   const size_t total = slice_floats * nsl;
   const int o = threadIdx.x & 31, lanek = threadIdx.x >> 5;
-  for (size_t base = (size_t)blockIdx.x * 32; base < total; base += (size_t)main_blocks * 32) {
+  for (size_t base = (size_t)blk * 32; base < total; base += (size_t)main_blocks * 32) {
     const size_t e = base + o;
     double s = 0.0;
     int t = 0, ci = 0, co = 0;
@@ -317,9 +313,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       t = r / ((size_t)CO * CI);
       ci += (sl % ci_slices) * CI;
       co += (sl / ci_slices) * CO;
-      valid = ci < Cin_src && co < Cout;
+      valid = ci < f.Cin_src && co < f.Cout;
       if (valid) {
-        const float* p = partial + (size_t)sl * strips * slice_floats + r;
+        const float* p = f.partial + (size_t)sl * strips * slice_floats + r;
         int k = lanek;
         for (; k + 24 < strips; k += 32) {     // 4 independent loads in flight
           const float v0 = p[(size_t)k * slice_floats], v1 = p[(size_t)(k + 8) * slice_floats];
@@ -336,11 +332,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
       for (int k = 0; k < 8; ++k) v += red[k][o];
       v *= osc;
-      float* d = dw + ((size_t)co * Cin_total + cin_off + ci) * T + t;
-      *d = accumulate ? (*d + (float)v) : (float)v;
+      float* d = f.dw + ((size_t)co * f.Cin_total + f.cin_off + ci) * T + t;
+      *d = f.accumulate ? (*d + (float)v) : (float)v;
     }
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(c3d_wgrad_fold f) {
+  __shared__ double red[8][32];
+  wgrad_fold_body(f, blockIdx.x, red);
+}
+
+// Up to FOLD_BATCH folds in ONE launch (the records travel as kernel arguments: no table in device memory, nothing to
+// upload, capturable as it is).  Round 3 ran 74 fold launches of ~9 us per training step, one behind each weight-gradient
+// launch; nothing reads a weight gradient before the optimiser does, so the backward pass now queues them and folds
+// them all at its end (coarse3d_amd.ops.WgradFolds).
+constexpr int FOLD_BATCH = 32;
+struct FoldBatch {
+  c3d_wgrad_fold f[FOLD_BATCH];
+  int n;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(FoldBatch b) {
+  __shared__ double red[8][32];
+  int e = 0;
+  const int blk = blockIdx.x;
+  while (e + 1 < b.n && blk >= b.f[e + 1].block0) ++e;       // block -> fold (b.n <= 32: a short scalar walk)
+  wgrad_fold_body(b.f[e], blk - b.f[e].block0, red);
 }
 
 // bf16 planes of the operands (wgrad_tr.hip) or 0 = the fp32-MFMA kernel of this file.
@@ -468,10 +486,37 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   if (blocks > 8192) blocks = 8192;
   const bool bias = d->bias_partial != nullptr;
   C3D_REQUIRE(!bias || (d->dbias != nullptr && d->bias_n > 0), "wgrad: bias_partial needs dbias and bias_n");
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks + (bias ? d->Cout : 0)), dim3(256), 0, st, a.partial, d->dw, a.strips,
-                     d->ntaps, c.CI, c.CO, a.ci_slices, a.co_slices, d->x.C, d->Cout, d->Cin_total, d->cin_off, d->accumulate,
-                     blocks, d->bias_partial, d->bias_n, d->dbias, d->mfma_bf16 == 4 ? 1.f / 64.f : 1.f,
-                     d->mfma_bf16 == 4 ? d->out_scale_dev : nullptr);
+  c3d_wgrad_fold f;
+  f.partial = a.partial; f.dw = d->dw;
+  f.strips = a.strips; f.T = d->ntaps; f.CI = c.CI; f.CO = c.CO; f.ci_slices = a.ci_slices; f.co_slices = a.co_slices;
+  f.Cin_src = d->x.C; f.Cout = d->Cout; f.Cin_total = d->Cin_total; f.cin_off = d->cin_off; f.accumulate = d->accumulate;
+  f.main_blocks = blocks; f.nblocks = blocks + (bias ? d->Cout : 0); f.block0 = 0;
+  f.bias_partial = d->bias_partial; f.dbias = d->dbias; f.bias_n = d->bias_n;
+  f.out_scale = d->mfma_bf16 == 4 ? 1.f / 64.f : 1.f;
+  f.out_scale_dev = d->mfma_bf16 == 4 ? d->out_scale_dev : nullptr;
+  if (d->fold_out) {          // deferred: the caller folds a batch of them with c3d_wgrad_fold_batch
+    *d->fold_out = f;
+    return 0;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(f.nblocks), dim3(256), 0, st, f);
   C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_wgrad_fold_batch(const c3d_wgrad_fold* folds, int n, c3d_stream stream) {
+  C3D_REQUIRE(folds != nullptr && n >= 0, "wgrad_fold_batch: null table");
+  for (int i0 = 0; i0 < n; i0 += FOLD_BATCH) {
+    FoldBatch b;
+    b.n = n - i0 < FOLD_BATCH ? n - i0 : FOLD_BATCH;
+    int blocks = 0;
+    for (int i = 0; i < b.n; ++i) {
+      b.f[i] = folds[i0 + i];
+      C3D_REQUIRE(b.f[i].partial && b.f[i].dw && b.f[i].nblocks > 0, "wgrad_fold_batch: a record was not filled by c3d_conv_wgrad");
+      b.f[i].block0 = blocks;
+      blocks += b.f[i].nblocks;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+    C3D_CHECK_LAUNCH();
+  }
   return 0;
 }

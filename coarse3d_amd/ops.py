@@ -427,15 +427,48 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_p
         if dbias is None or dbias.shape[0] != dw.shape[0] or bias_partial.shape[0] < dw.shape[0]:
             raise ValueError("conv_wgrad: bias_partial needs a dbias of Cout entries")
         d.bias_partial, d.dbias, d.bias_n = bias_partial.data_ptr(), dbias.data_ptr(), bias_partial.shape[2]
+    folds = WGRAD_FOLDS
+    if folds is not None and not accumulate:
+        rec = L.WgradFold()
+        d.fold_out = C.addressof(rec)
     if KERNEL_EVENTS is None:        # (the kernel-name mirror only serves the per-kernel event timers)
         L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
+        if d.fold_out:
+            folds.add(rec, part, bias_partial)
         return dw
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
     co, ci, nt = dw.shape[0], src.C, len(taps)
     name = _wgrad_kernel_name(ci, co, nt, halo)
     with _Timed(name, 2.0 * b * h * w * dw.shape[0] * len(taps) * src.C, (h, w, ci, co, nt, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
+    if d.fold_out:
+        folds.add(rec, part, bias_partial)
     return dw
+
+
+class WgradFolds:
+    """Pending folds of weight-gradient partials (c3d_wgrad_desc.fold_out).  While one is installed (``ops.WGRAD_FOLDS``)
+    ``conv_wgrad`` launches its matrix kernel only and queues the strips -> dw fold here; ``flush()`` runs them all in
+    ceil(n / 32) launches (round 3: 74 launches of ~9 us per step, one behind every weight-gradient launch).  Nothing in
+    the backward pass reads a weight gradient, so the backbone flushes once at its end (data parallel: whenever a
+    gradient bucket is about to be sent).  The partial buffers are kept alive until the flush."""
+
+    def __init__(self):
+        self.records, self.keep = [], []
+
+    def add(self, rec, *tensors):
+        self.records.append(rec)
+        self.keep.append(tensors)
+
+    def flush(self):
+        n = len(self.records)
+        if n:
+            arr = (L.WgradFold * n)(*self.records)
+            L.check(L.lib().c3d_wgrad_fold_batch(arr, n, _stream()), "c3d_wgrad_fold_batch")
+        self.records, self.keep = [], []
+
+
+WGRAD_FOLDS = None       # installed by Backbone.backward for the duration of the pass
 
 
 def wgrad_fusable(src, act, cout):

@@ -27,9 +27,9 @@ typedef void* c3d_stream;
 
 const char* c3d_last_error(void);
 int c3d_version(void);
-/* out4 = sizeof(c3d_src), sizeof(c3d_conv_desc), sizeof(c3d_wgrad_desc), sizeof(c3d_pack_entry):
+/* out5 = sizeof(c3d_src), sizeof(c3d_conv_desc), sizeof(c3d_wgrad_desc), sizeof(c3d_pack_entry), sizeof(c3d_wgrad_fold):
  * lets a foreign-language binding check its mirror of the struct layouts (host call, no GPU) */
-int c3d_abi_sizes(int32_t* out4);
+int c3d_abi_sizes(int32_t* out5);
 /* number of workgroups conv kernels will use for an [B,H,W] image: size of stat partial bufs */
 int c3d_conv_num_mtiles(int B, int H, int W);
 
@@ -141,6 +141,20 @@ typedef struct {
 } c3d_pack_entry;
 int c3d_pack_weights_batch(const c3d_pack_entry* table_dev, int n, c3d_stream stream);
 
+/* One pending fold of weight-gradient partials (strips -> dw), filled by c3d_conv_wgrad when c3d_wgrad_desc.fold_out is
+ * set and executed, many per launch, by c3d_wgrad_fold_batch.  HOST memory.                                          */
+typedef struct {
+  const float* partial;
+  float* dw;
+  int32_t strips, T, CI, CO, ci_slices, co_slices, Cin_src, Cout, Cin_total, cin_off, accumulate;
+  int32_t main_blocks, nblocks, block0;
+  const float* bias_partial;
+  float* dbias;
+  int32_t bias_n;
+  float out_scale;
+  const float* out_scale_dev;
+} c3d_wgrad_fold;
+
 /* dW[cout][cin_off + cin][t] (OIHW, full Cin_total) = sum_pixels dz[p][cout] * x[p + tap t][cin]
  * x is given as ONE transformed source (call once per source of a concatenated input).
  * Replaces autograd's conv weight gradient for the layers listed above.
@@ -193,10 +207,17 @@ typedef struct {
   const float* fuse_k2;
   const float* fuse_k3;
   float* fuse_sum;
+  /* NULL: the call folds its strips into dw right away (one more tiny launch).  Else a HOST record that receives the
+   * pending fold; `partial` (and bias_partial) must then stay valid until c3d_wgrad_fold_batch has run on the stream.
+   * Two deferred folds of one batch must not accumulate into the same dw elements.                                  */
+  c3d_wgrad_fold* fold_out;
 } c3d_wgrad_desc;
 int64_t c3d_wgrad_partial_floats(const c3d_wgrad_desc* d);
 /* entries per channel of fuse_sum for this descriptor (0: this shape / engine has no fused form -- run c3d_bn_bwd_apply) */
 int c3d_wgrad_fused_sum_n(const c3d_wgrad_desc* d);
+/* folds[0 .. n) (HOST array of records filled by c3d_conv_wgrad) in ceil(n / 32) launches; nothing in the training step reads
+ * a weight gradient before the optimiser, so one call at the end of the backward pass replaces ~70 tiny launches     */
+int c3d_wgrad_fold_batch(const c3d_wgrad_fold* folds, int n, c3d_stream stream);
 int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream);
 
 /* ------------------------------------------------------------------ BatchNorm2d (train mode)

@@ -29,10 +29,10 @@ def test_ctypes_struct_mirrors_match_the_c_layouts():
     gives the descriptor structs of include/coarse3d_hip.h (a silent mismatch would shift every
     field after the first divergence)."""
     from coarse3d_amd import _lib as L
-    out = (ctypes.c_int32 * 4)()
+    out = (ctypes.c_int32 * 5)()
     assert L.lib().c3d_abi_sizes(out) == 0
     assert list(out) == [ctypes.sizeof(L.Src), ctypes.sizeof(L.ConvDesc), ctypes.sizeof(L.WgradDesc),
-                         ctypes.sizeof(L.PackEntry)]
+                         ctypes.sizeof(L.PackEntry), ctypes.sizeof(L.WgradFold)]
     # a refused call reports why, without touching the GPU
     d = L.ConvDesc()
     d.nsrc = 7
