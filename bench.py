@@ -260,18 +260,22 @@ def load_pmc(wl):
 def peak_for(kernel_name):
     """Matrix-pipe ceiling (TFLOP/s, fp32-equivalent) of one kernel instance: the dense bf16 peak divided by the plane
     products the instance runs per fp32 multiply-add; fp32 MFMA kernels against the fp32 MFMA peak."""
-    if kernel_name.startswith("conv_pw3f_kernel"):       # <NT, WN>: the fused bf16x3 kernel, six plane products
+    base = kernel_name.split("<")[0]
+    targs = [t.strip() for t in kernel_name[len(base) + 1:].rstrip(">").split(",")] if "<" in kernel_name else []
+    if base == "conv_pw3f_kernel":       # <NT, WN>: the fused bf16x3 kernel, six plane products
         return PEAK_BF16_MFMA_TFLOPS / 6.0
-    if kernel_name.startswith("conv_pw3_kernel"):        # <NT, NP>; NP = 3 runs six plane products
-        return PEAK_BF16_MFMA_TFLOPS / 6.0 if kernel_name.endswith(", 3>") else PEAK_BF16_MFMA_TFLOPS
-    if kernel_name.startswith(("conv_x3_kernel", "conv_x3f_kernel")):   # <NT, HALO, TT, SIX>
-        return PEAK_BF16_MFMA_TFLOPS / (6.0 if kernel_name.endswith("true>") else 8.0)
-    if kernel_name.startswith("conv_bfp_kernel"):
-        return PEAK_BF16_MFMA_TFLOPS / 8.0 if kernel_name.rstrip(">").endswith("3") else PEAK_BF16_MFMA_TFLOPS
-    if kernel_name.startswith("wgrad_mfma_kernel") and kernel_name.endswith("true>"):
-        return PEAK_BF16_MFMA_TFLOPS
-    if kernel_name.startswith("wgrad_tr_kernel"):
-        return PEAK_BF16_MFMA_TFLOPS / 6.0 if kernel_name.startswith("wgrad_tr_kernel<3") else PEAK_BF16_MFMA_TFLOPS
+    if base == "conv_pw3_kernel":        # <NT, NP>; NP = 3 runs six plane products
+        return PEAK_BF16_MFMA_TFLOPS / 6.0 if targs[1] == "3" else PEAK_BF16_MFMA_TFLOPS
+    if base in ("conv_x3_kernel", "conv_x3f_kernel"):   # <NT, HALO, TT, SIX[, planes]>
+        if len(targs) > 4 and targs[4] == "2":
+            return PEAK_BF16_MFMA_TFLOPS / 3.0          # (the f16x2 experiment: three products)
+        return PEAK_BF16_MFMA_TFLOPS / (6.0 if targs[3] == "true" else 8.0)
+    if base == "conv_bfp_kernel":        # <TR, NT, CK, HALO, TT, NP>; NP = 3: eight plane products
+        return PEAK_BF16_MFMA_TFLOPS / 8.0 if targs[5] == "3" else PEAK_BF16_MFMA_TFLOPS
+    if base == "wgrad_mfma_kernel":      # <..., BF>
+        return PEAK_BF16_MFMA_TFLOPS if targs[-1] == "true" else PEAK_FP32_MFMA_TFLOPS
+    if base == "wgrad_tr_kernel":        # <NP, ..., FA>: NP = 3 runs six plane products
+        return PEAK_BF16_MFMA_TFLOPS / 6.0 if targs[0] == "3" else PEAK_BF16_MFMA_TFLOPS
     return PEAK_FP32_MFMA_TFLOPS
 
 

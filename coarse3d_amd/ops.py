@@ -319,8 +319,9 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
             # nine taps: the fused kernel (round 3), four taps: the phased one; CONV_VARIANT & 4 forces the phased one
             fused_ = nt_ == 9 and not (CONV_VARIANT & 4)
+            # (names as rocprofv3 prints them: the fused kernel carries its plane count as a fifth template argument)
             name = (f"conv_x3{'f' if fused_ else ''}_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, {nt_}, "
-                    f"{'true' if grad else 'false'}>")
+                    f"{'true' if grad else 'false'}{', 3' if fused_ else ''}>")
         elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
             name = _pw3_kernel_name(_pw3_tile(b, h, w, cout), sum(s.C for s in srcs), cout)
         elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
@@ -352,14 +353,14 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         return out, stat_partial
     name, halo = kernel_name()
     if six and not grad:
-        name = name.replace(", false>", ", true>")
+        name = name.replace(", false>", ", true>").replace(", false, 3>", ", true, 3>")
     with _Timed(name, 2.0 * b * h * w * cout * len(taps) * sum(s.C for s in srcs),
                 (h, w, sum(s.C for s in srcs), cout, nt_, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_forward(C.byref(d), _stream()), "c3d_conv_forward")
     return out, stat_partial
 
 
-def _wgrad_kernel_name(ci, co, nt, halo):
+def _wgrad_kernel_name(ci, co, nt, halo, fused=False):
     """Mirrors c3d_wgrad_cfg() (csrc/wgrad_common.h) and the launch tables of wgrad_mfma.hip / wgrad_tr.hip."""
     tr = MFMA_MODE != 0
     hl = 1 if halo <= 1 else 2
@@ -374,8 +375,8 @@ def _wgrad_kernel_name(ci, co, nt, halo):
             cfg = f"4, 1, 2, 1, 1, {2 if x3 else 4}, {hl}" if co > 32 else f"4, 1, 1, 1, 1, 4, {hl}"
     else:
         cfg = f"9, 1, 1, 1, 2, {4 if (tr and not x3) else 2}, {hl}" if co > 32 else f"9, 1, 1, 1, 1, 4, {hl}"
-    if tr:
-        return f"wgrad_tr_kernel<{3 if MFMA_MODE == 2 else 1}, {cfg}>"
+    if tr:       # (the ninth template argument: BatchNorm backward applied on load, conv_wgrad(fuse=...))
+        return f"wgrad_tr_kernel<{3 if MFMA_MODE == 2 else 1}, {cfg}, {'true' if fused else 'false'}>"
     return f"wgrad_mfma_kernel<{cfg}, {'true' if MFMA_MODE == 1 else 'false'}>"
 
 
@@ -438,7 +439,7 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_p
         return dw
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
     co, ci, nt = dw.shape[0], src.C, len(taps)
-    name = _wgrad_kernel_name(ci, co, nt, halo)
+    name = _wgrad_kernel_name(ci, co, nt, halo, fused=fuse is not None)
     with _Timed(name, 2.0 * b * h * w * dw.shape[0] * len(taps) * src.C, (h, w, ci, co, nt, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
     if d.fold_out:

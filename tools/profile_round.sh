@@ -10,7 +10,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 rm -rf /tmp/p_stats /tmp/p_fetch /tmp/p_write      # a stale CSV from an earlier call must not be picked up below
 mkdir -p $OUT /tmp/p_stats /tmp/p_fetch /tmp/p_write
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-second-engine --prewarm 0 --graph off $@"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-second-engine --no-configs --prewarm 0 --graph off $@"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o s -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -o f -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_fetch.log 2>&1
