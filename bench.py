@@ -711,12 +711,13 @@ def main():
             r = Bench(dict(wl, matrix_dtype="f32"), dev, 0, 1, False).run(False, k2, w2, 0, False)
             engines["f32_mfma"] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "steps": k2, "dtype": DTYPE_NOTE["f32"],
                                    "launch": "kernel by kernel"}
-            r = b.run(False, k2, w2, 0, False, wgrad_stream="1")
+            r = b.run(True, k2, 3, 0, False, wgrad_stream="1")
             engines["bf16x3_wgrad_on_second_stream"] = {
-                "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": k2, "launch": "kernel by kernel",
-                "note": "the headline engine with the weight-gradient chain of the backward pass on a second HIP stream (C3D_WGRAD_STREAM=1; what "
-                        "data-parallel runs use).  Off by default on one GPU because the kernels of the two streams share the CUs and every "
-                        "per-kernel duration of `roofline` would inflate"}
+                "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": k2, "launch": "one hipGraph replay per step",
+                "note": "the headline step with the weight-gradient chain of the backward pass on a second HIP stream (C3D_WGRAD_STREAM=1; what "
+                        "data-parallel runs use to hide the SyncBatchNorm exchanges).  The BatchNorm-backward apply pass is then a pass of its own "
+                        "again (on one stream the first weight-gradient launch of a layer applies it on load).  Not the default on one GPU: the "
+                        "kernels of two streams share the CUs, nothing is gained"}
             # the data-parallel step on this one GPU: a 1-rank RCCL group in which every exchange point issues its real collective
             try:
                 engines["dp_single_rank_rccl"] = dp_single_rank(wl, dev, k2, w2)
