@@ -40,7 +40,8 @@ class WgradDesc(C.Structure):
                 ("bias_partial", C.c_void_p), ("dbias", C.c_void_p), ("bias_n", C.c_int32), ("reserved2", C.c_int32),
                 ("dz_scale", C.c_void_p), ("out_scale_dev", C.c_void_p),
                 ("fuse_dy", C.c_void_p), ("fuse_act", C.c_void_p), ("fuse_k1", C.c_void_p), ("fuse_k2", C.c_void_p),
-                ("fuse_k3", C.c_void_p), ("fuse_sum", C.c_void_p), ("fold_out", C.c_void_p)]
+                ("fuse_k3", C.c_void_p), ("fuse_sum", C.c_void_p), ("fuse_pre_scale", C.c_void_p), ("fuse_pre_shift", C.c_void_p),
+                ("fold_out", C.c_void_p)]
 
 
 class WgradFold(C.Structure):

@@ -332,7 +332,19 @@ class Backbone:
         G = self.grads
         w = self.P[f"{name}.weight"]
         cout = rec.cout
-        dz, pz = self._bn_backward(rec.bn, dy, rec.out.t, cout, 1, 0.0, k)
+        # the BatchNorm (-> LeakyReLU) backward of this layer on load of its first weight-gradient launch, like the other
+        # layers (FUSE_BN_APPLY; 704 channels at half resolution: the one large apply pass that was left)
+        first = hi[0][0]
+        fuse = (FUSE_BN_APPLY and self.side is None and dy.dtype == torch.float32 and tuple(dy.shape) == tuple(rec.out.t.shape)
+                and dy.is_contiguous() and ops.wgrad_fusable(first, rec.out.t, cout))
+        if fuse:
+            kk = self._bn_backward(rec.bn, dy, rec.out.t, cout, 1, 0.0, k, coeffs_only=True)
+            dz, pz = torch.empty_like(rec.out.t), None
+            db = G.get(f"{name}.bias")
+            ops.conv_wgrad(first.src(), dz, G[f"{name}.weight"], rec.taps, cin_off=hi[0][1], dbias=db,
+                           fuse=(dy, rec.out.t, kk, (rec.bn.scale, rec.bn.shift)))
+        else:
+            dz, pz = self._bn_backward(rec.bn, dy, rec.out.t, cout, 1, 0.0, k)
         if self.capture is not None:
             # test hook: the layer as the reference sees it -- ONE 1x1 conv over the resampled, concatenated skips
             hh, wh = dz.shape[1], dz.shape[2]
@@ -346,8 +358,8 @@ class Backbone:
             dzs.append(ops.bilinear_bwd(d, dz))
         dw = G[f"{name}.weight"]
         with self._fork(dz, pz, *dzs):
-            db = G.get(f"{name}.bias")
-            for src, o, c, _ in hi:
+            db = None if fuse else G.get(f"{name}.bias")
+            for src, o, c, _ in (hi[1:] if fuse else hi):
                 ops.conv_wgrad(src.src(), dz, dw, rec.taps, cin_off=o, bias_partial=pz if db is not None else None, dbias=db)
                 db = None
             for (sk, o, c), d in zip(lo, dzs):
@@ -457,8 +469,7 @@ class Backbone:
                 k = ops.bn_bwd_coeffs_partials(part, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
                                                G[f"{bn.name}.weight"], G[f"{bn.name}.bias"])
             else:
-                sums = ops.stat_reduce(part, c)
-                local = sums.clone()      # dgamma/dbeta stay rank-local (averaged with the other grads)
+                sums, local = ops.stat_reduce(part, c, copy=True)      # dgamma/dbeta stay rank-local (averaged with the other grads)
                 self.reduce_fn(sums)
                 k = ops.bn_bwd_coeffs(sums, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
                                       G[f"{bn.name}.weight"], G[f"{bn.name}.bias"], local)

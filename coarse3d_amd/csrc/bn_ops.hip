@@ -18,7 +18,7 @@ namespace {
 
 // partial [C][2][n] fp32  ->  sums [C][2] fp64.  One block per channel, contiguous reads.
 __global__ __launch_bounds__(256) void stat_reduce_kernel(const float* __restrict__ partial, int n, int C,
-                                                         double* __restrict__ sums) {
+                                                         double* __restrict__ sums, double* __restrict__ sums_copy = nullptr) {
   __shared__ double red[2][4];
   const int c = blockIdx.x;
   const float* p = partial + (size_t)c * 2 * n;
@@ -37,6 +37,10 @@ __global__ __launch_bounds__(256) void stat_reduce_kernel(const float* __restric
   if (threadIdx.x == 0) {
     sums[c * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     sums[c * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (sums_copy) {        // the rank-local copy a data-parallel BatchNorm backward keeps next to the all-reduced sums
+      sums_copy[c * 2 + 0] = sums[c * 2 + 0];
+      sums_copy[c * 2 + 1] = sums[c * 2 + 1];
+    }
   }
 }
 
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BwdArgs p) {
     auto body = [&](c3d_vec<V> dy, const c3d_vec<V>& a, int i) {
       if (p.mode == 1) {
 #pragma unroll
-        for (int q = 0; q < V; ++q) dy.v[q] *= (a.v[q] * ps.v[q] + psh.v[q] > 0.f) ? 1.f : p.slope;
+        for (int q = 0; q < V; ++q) dy.v[q] *= (fmaf(a.v[q], ps.v[q], psh.v[q]) > 0.f) ? 1.f : p.slope;
       }
       if (!APPLY) {
 #pragma unroll
@@ -288,7 +292,13 @@ __global__ void sums_to_f32_kernel(const double* __restrict__ sums, int C, int c
 }  // namespace
 
 extern "C" int c3d_stat_reduce(const float* partial, int n, int C, double* sums, c3d_stream stream) {
-  hipLaunchKernelGGL(stat_reduce_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, n, C, sums);
+  hipLaunchKernelGGL(stat_reduce_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, n, C, sums, (double*)nullptr);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_stat_reduce2(const float* partial, int n, int C, double* sums, double* sums_copy, c3d_stream stream) {
+  hipLaunchKernelGGL(stat_reduce_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, n, C, sums, sums_copy);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -24,6 +24,8 @@ struct WgradArgs {
   const float* f_k2 = nullptr;
   const float* f_k3 = nullptr;
   float* f_sum = nullptr;
+  const float* f_ps = nullptr;       // pre-activation affine of a conv -> BatchNorm -> LeakyReLU layer (mode 1), or NULL
+  const float* f_psh = nullptr;
   int f_sum_n = 0;
   int ci_slices, co_slices;
   float slope;

@@ -474,6 +474,9 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
                 "wgrad: fuse_k1 / k2 / k3 come together");
     a.f_dy = d->fuse_dy; a.f_act = d->fuse_act; a.f_k1 = d->fuse_k1; a.f_k2 = d->fuse_k2; a.f_k3 = d->fuse_k3;
     a.f_sum = d->fuse_sum;
+    C3D_REQUIRE((d->fuse_pre_scale == nullptr) == (d->fuse_pre_shift == nullptr) && (!d->fuse_pre_scale || d->fuse_k1),
+                "wgrad: fuse_pre_scale / fuse_pre_shift come together and need the BatchNorm coefficients");
+    a.f_ps = d->fuse_pre_scale; a.f_psh = d->fuse_pre_shift;
     a.f_sum_n = a.strips * (256 / (c.CO / 4));
   }
   hipStream_t st = (hipStream_t)stream;

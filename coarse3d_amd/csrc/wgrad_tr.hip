@@ -234,7 +234,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     if (a.dz_scale && dc + 3 < a.Cout) dsc = *reinterpret_cast<const f32x4*>(a.dz_scale + dc);
   }
   // FA: BatchNorm-backward coefficients of this thread's four channels (channels beyond Cout give dz = 0), running sums of dz
-  f32x4 fk1 = {0.f, 0.f, 0.f, 0.f}, fk2 = fk1, fk3 = fk1, fsum = fk1;
+  f32x4 fk1 = {0.f, 0.f, 0.f, 0.f}, fk2 = fk1, fk3 = fk1, fsum = fk1, fps = fk1, fpsh = fk1;
+  const bool fpre = FA && a.f_ps != nullptr;          // conv -> BatchNorm -> LeakyReLU layer: activation derivative at BN(act) (uniform)
   const bool fwrite = FA && ci0 == 0;                 // one cin slice per cout slice writes dz and the sums (uniform)
   if constexpr (FA) {
     if (dc + 3 < a.Cout) {
@@ -242,6 +243,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
         fk1 = *reinterpret_cast<const f32x4*>(a.f_k1 + dc);
         fk2 = *reinterpret_cast<const f32x4*>(a.f_k2 + dc);
         fk3 = *reinterpret_cast<const f32x4*>(a.f_k3 + dc);
+        if (fpre) {
+          fps = *reinterpret_cast<const f32x4*>(a.f_ps + dc);
+          fpsh = *reinterpret_cast<const f32x4*>(a.f_psh + dc);
+        }
       } else {
         fk1 = f32x4{1.f, 1.f, 1.f, 1.f};
       }
@@ -396,8 +401,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             // the arithmetic of bn_bwd_kernel<true> (bn_ops.hip), same operation order: bit-identical dz
-            float da = fmaf(fk2[q], sg.pa[i][q], fmaf(fk1[q], sg.pd[i][q], fk3[q]));
-            da *= (sg.pa[i][q] > 0.f) ? 1.f : a.slope;
+            float dyq = sg.pd[i][q];
+            if (fpre) dyq *= (fmaf(sg.pa[i][q], fps[q], fpsh[q]) > 0.f) ? 1.f : a.slope;
+            float da = fmaf(fk2[q], sg.pa[i][q], fmaf(fk1[q], dyq, fk3[q]));
+            if (!fpre) da *= (sg.pa[i][q] > 0.f) ? 1.f : a.slope;
             t[q] = in ? da : 0.f;
           }
           fsum += t;

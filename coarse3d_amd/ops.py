@@ -384,7 +384,7 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_p
     """dw[:, cin_off:cin_off+src.C] (+)= sum_p dz[p] (x) transformed src[p + tap].
     bias_partial [>=Cout, 2, n] + dbias [Cout]: the launch that folds the weight-gradient strips folds the layer's
     bias-gradient partials too (instead of a separate bias_from_partials launch).
-    fuse = (dy, act, k): BatchNorm / LeakyReLU backward on load (c3d_wgrad_desc.fuse_*) -- ``dz`` is then an OUTPUT:
+    fuse = (dy, act, k[, (pre_scale, pre_shift)]): BatchNorm / LeakyReLU backward on load (c3d_wgrad_desc.fuse_*) -- ``dz`` is then an OUTPUT:
     the launch forms dz = LeakyReLU'(act) * (k[0] * dy + k[1] * act + k[2]) (k None: LeakyReLU'(act) * dy) while it
     stages its tiles, writes it to ``dz`` and folds sum(dz) into ``dbias`` (if given).  bf16x3 engine, fp32 tensors of
     one shape; ``wgrad_fusable`` says whether a layer qualifies."""
@@ -408,13 +408,16 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_p
     part = torch.empty(n, device=dz.device, dtype=torch.float32)
     d.partial = part.data_ptr()
     if fuse is not None:
-        dy, act, k = fuse
+        dy, act, k = fuse[:3]
+        pre = fuse[3] if len(fuse) > 3 else None          # (pre_scale, pre_shift): conv -> BatchNorm -> LeakyReLU layer
         if not (dy.shape == act.shape == dz.shape and dy.dtype == act.dtype == dz.dtype == torch.float32
                 and dy.is_contiguous() and act.is_contiguous() and dz.data_ptr() != dy.data_ptr()):
             raise ValueError("conv_wgrad(fuse=...): dy, act and dz must be distinct contiguous fp32 tensors of one shape")
         d.fuse_dy, d.fuse_act = dy.data_ptr(), act.data_ptr()
         if k is not None:
             d.fuse_k1, d.fuse_k2, d.fuse_k3 = k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr()
+        if pre is not None:
+            d.fuse_pre_scale, d.fuse_pre_shift = pre[0].data_ptr(), pre[1].data_ptr()
         nsum = L.lib().c3d_wgrad_fused_sum_n(C.byref(d))
         if nsum <= 0:
             raise RuntimeError("conv_wgrad(fuse=...): this layer shape / engine has no fused form (ops.wgrad_fusable)")
@@ -487,10 +490,14 @@ def _dp(t):
     return t.data_ptr() if t is not None else None
 
 
-def stat_reduce(partial, c, sums=None):
-    """partial [C,2,n] fp32 -> sums [C,2] fp64."""
+def stat_reduce(partial, c, sums=None, copy=False):
+    """partial [C,2,n] fp32 -> sums [C,2] fp64 (copy=True: returns (sums, a second copy written by the same launch))."""
     if sums is None:
         sums = torch.empty(c, 2, device=partial.device, dtype=torch.float64)
+    if copy:
+        other = torch.empty_like(sums)
+        _call("c3d_stat_reduce2", _dp(partial), partial.shape[2], c, _dp(sums), _dp(other), _stream())
+        return sums, other
     _call("c3d_stat_reduce", _dp(partial), partial.shape[2], c, _dp(sums), _stream())
     return sums
 

@@ -196,7 +196,10 @@ typedef struct {
    * The launch reads the gradient at the layer's consumer-visible output (fuse_dy) and the layer's stored output
    * (fuse_act = LeakyReLU(conv + bias), pre-BatchNorm), forms
    *     dz = LeakyReLU'(act) * (k1[c] * dy + k2[c] * act + k3[c])        (k1 == NULL: dz = LeakyReLU'(act) * dy)
-   * while it stages its pixel tiles -- what c3d_bn_bwd_apply computes in a pass of its own (modes 0 and 2) -- uses it as
+   * or, with fuse_pre_scale / fuse_pre_shift (a conv -> BatchNorm -> LeakyReLU layer: the derivative of the activation is
+   * taken at BN(act) and multiplies dy first, c3d_bn_bwd_apply's mode 1),
+   *     dz = k1[c] * (LeakyReLU'(act * pre_scale[c] + pre_shift[c]) * dy) + k2[c] * act + k3[c]
+   * while it stages its pixel tiles -- what c3d_bn_bwd_apply computes in a pass of its own (modes 0, 1 and 2) -- uses it as
    * the weight gradient's operand, WRITES it to `dz` (the input-gradient convolution that follows reads it) and leaves the
    * per-channel sums of dz in fuse_sum [Cout][2][c3d_wgrad_fused_sum_n()] (row 0; the bias gradient: pass it as
    * bias_partial with bias_n = that n).  All three tensors share dz_cstride; `dz` must not alias fuse_dy.
@@ -207,6 +210,8 @@ typedef struct {
   const float* fuse_k2;
   const float* fuse_k3;
   float* fuse_sum;
+  const float* fuse_pre_scale;
+  const float* fuse_pre_shift;
   /* NULL: the call folds its strips into dw right away (one more tiny launch).  Else a HOST record that receives the
    * pending fold; `partial` (and bias_partial) must then stay valid until c3d_wgrad_fold_batch has run on the stream.
    * Two deferred folds of one batch must not accumulate into the same dw elements.                                  */
@@ -226,6 +231,9 @@ int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream);
 
 /* partial [C][2][n] fp32 (per-tile sum, sumsq) -> sums [C][2] fp64 */
 int c3d_stat_reduce(const float* partial, int n, int C, double* sums, c3d_stream stream);
+/* the same, written twice: sums is about to be all-reduced in place, sums_copy stays rank-local (SyncBatchNorm backward:
+ * dgamma / dbeta come from the local sums, the input gradient from the global ones)                     */
+int c3d_stat_reduce2(const float* partial, int n, int C, double* sums, double* sums_copy, c3d_stream stream);
 /* sums + count -> consumer-side affine scale=gamma*invstd, shift=beta-mean*scale; saves
  * mean/invstd for backward; updates running stats (momentum, unbiased var) when non-NULL.   */
 int c3d_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,

@@ -379,6 +379,38 @@ def test_batchnorm_backward_applied_on_load_by_the_weight_gradient(B, H, W, Cin,
         ops.set_matrix_precision(*_PREV.pop())
 
 
+def test_batchnorm_then_leakyrelu_backward_applied_on_load():
+    """The conv -> BatchNorm -> LeakyReLU form (c3d_bn_bwd_apply mode 1: the activation's derivative is taken at BN(act) and
+    multiplies dy first) of the fused apply -- projector.proj.0, 704 output channels, the one large apply pass round 4's
+    first version left: dz, dw bit-identical to the two-launch path, bias gradient to summation order."""
+    from coarse3d_amd import ops
+    dev = "cuda"
+    g = torch.Generator().manual_seed(77)
+    B, H, W, Cin, Cout = 2, 16, 256, 64, 704
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    act = torch.randn(B, H, W, Cout, generator=g).to(dev)
+    dy = torch.randn(B, H, W, Cout, generator=g).to(dev)
+    kk = (torch.randn(3, Cout, generator=g) * torch.tensor([[1.0], [0.1], [0.01]])).to(dev)
+    ps, psh = (torch.rand(Cout, generator=g) + 0.5).to(dev), (torch.randn(Cout, generator=g) * 0.5).to(dev)
+    _PREV.append(ops.matrix_precision_state())
+    ops.set_matrix_precision("bf16x3")
+    try:
+        src = ops.Source(x)
+        dz_ref, pz = ops.bn_bwd_apply(dy, act, Cout, 1, kk, ps, psh)
+        dw_ref = torch.zeros(Cout, Cin + 128, 1, 1, device=dev)
+        db_ref = torch.zeros(Cout, device=dev)
+        ops.conv_wgrad(src, dz_ref, dw_ref, [(0, 0)], cin_off=0, bias_partial=pz, dbias=db_ref)
+        dz = torch.full_like(act, float("nan"))
+        dw, db = torch.zeros_like(dw_ref), torch.zeros_like(db_ref)
+        ops.conv_wgrad(src, dz, dw, [(0, 0)], cin_off=0, dbias=db, fuse=(dy, act, kk, (ps, psh)))
+        torch.cuda.synchronize()
+        assert torch.equal(dz, dz_ref) and torch.equal(dw, dw_ref)
+        assert float((db.double() - dz_ref.double().sum(dim=(0, 1, 2))).abs().max()) <= 1e-6 * float(dz_ref.double().abs().sum(dim=(0, 1, 2)).max())
+        assert float(dz.abs().max()) > 0 and not torch.equal(dz, ops.bn_bwd_apply(dy, act, Cout, 0, kk)[0])
+    finally:
+        ops.set_matrix_precision(*_PREV.pop())
+
+
 def test_fused_pointwise_kernel_random_configurations():
     """Both geometries of the fused kernel against the phased one, bit for bit, over 24 seeded random launch
     configurations: 1-3 sources at channel offsets inside wider tensors, each with or without BatchNorm affine /
