@@ -139,10 +139,12 @@ __global__ __launch_bounds__(256) void pl_bucket_kernel(PlArgs a) {
 // parallel suffix scan over the 256 bins (five passes over ~7 000 keys on 256 threads plus four serial bin walks by
 // thread 0 took 80 us).
 constexpr int PL_THREADS = 1024;
+constexpr int PL_MAX_TIES = 1024;
 __global__ __launch_bounds__(PL_THREADS) void pl_select_kernel(PlArgs a) {
   __shared__ int hist[256];
   __shared__ int suf[2][256];
-  __shared__ unsigned int s_prefix, s_k, s_take;
+  __shared__ unsigned int s_prefix, s_k, s_take, s_nties;
+  __shared__ int tie_pix[PL_MAX_TIES];
   const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int cnt = a.cnt[b * a.C + c];
   if (cnt == 0) return;
@@ -194,13 +196,32 @@ __global__ __launch_bounds__(PL_THREADS) void pl_select_kernel(PlArgs a) {
   }
   // s_prefix = key of the k-th largest; s_k = how many elements equal to it must be taken
   const unsigned thr = s_prefix;
-  if (tid == 0) s_take = s_k;
+  if (tid == 0) {
+    s_take = s_k;
+    s_nties = 0;
+  }
   __syncthreads();
+  // Keys equal to the threshold.  With float32 keys and 10^4..10^5 members per pair two members DO share a key now and
+  // then (round 4: one such tie at the threshold in a 26-step run made the run two-valued -- the bucket order, and with it
+  // an atomic first-come rule, depends on the order in which workgroups filled the bucket).  The tied members are
+  // collected and the ones with the SMALLEST PIXEL INDEX are taken: any choice is a valid draw of the reference's
+  // multinomial (trainer.py:447-518), this one is reproducible.
   for (int i = tid; i < cnt; i += PL_THREADS) {
     const unsigned key = keys[i];
-    bool take = key > thr;
-    if (key == thr) take = atomicSub(&s_take, 1u) - 1u < 0x80000000u;  // ties: measure-zero event
-    if (take) a.chosen[(size_t)b * a.n + pix[i]] = 1;
+    if (key > thr) a.chosen[(size_t)b * a.n + pix[i]] = 1;
+    else if (key == thr) {
+      const unsigned p = atomicAdd(&s_nties, 1u);
+      if (p < PL_MAX_TIES) tie_pix[p] = pix[i];
+    }
+  }
+  __syncthreads();
+  const int nt = (int)min(s_nties, (unsigned)PL_MAX_TIES);      // (more equal keys than that: degenerate weights; the first
+  const int take = (int)s_take;                                  //  PL_MAX_TIES collected take part, still a valid draw)
+  for (int e = tid; e < nt; e += PL_THREADS) {
+    const int me = tie_pix[e];
+    int rank = 0;
+    for (int j = 0; j < nt; ++j) rank += tie_pix[j] < me;
+    if (rank < take) a.chosen[(size_t)b * a.n + me] = 1;
   }
 }
 

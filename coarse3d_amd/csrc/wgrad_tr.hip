@@ -164,6 +164,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   // two tile buffers, each [NP][XROWS][CI] x planes followed by [NP][DROWS][CO] dz planes
   constexpr int BUF = NP * (XROWS * CI + DROWS * CO);
   unsigned short* s_base = reinterpret_cast<unsigned short*>(smem);
+  // ROLLING x WINDOW (round 4, kernels with a halo).  The tiles of a strip walk DOWN the image, so the input window of a tile
+  // (TRW + 2 * HALO rows) shares 2 * HALO rows with the window of the tile before it -- with TRW = 2 and HALO = 2 two thirds
+  // of every window was loaded, transformed, split into planes and written to LDS again (the producer waves' work, which
+  // is what bounds this kernel).  The x image in LDS is now a ring of RING = 2 * (TRW + 2 * HALO) pixel rows -- the memory of
+  // the two tile buffers -- in which a window is THh consecutive slots (mod RING): a tile below its predecessor adds its
+  // TRW new rows behind the predecessor's window, a tile that starts a column (or the strip) takes the THh slots behind
+  // it.  Either way the slots written for tile n + 1 are disjoint from the window the consumers read for tile n.  The dz
+  // tiles keep their two buffers.  LDS layout: [NP][RING * TWh][CI] x planes, then 2 x [NP][DROWS][CO] dz planes.
+  constexpr bool RINGX = HALO > 0;
+  constexpr int RING = 2 * THh;
+  constexpr int XPLANE = RINGX ? RING * TWh * CI : XROWS * CI;     // bf16 elements per x plane
+  constexpr int NEWROWS_UNITS = TRW * TWh * (CI / 4);               // staging units of the TRW new rows of a window
 
   // Eight waves, two roles: waves 0-3 (one per SIMD) only issue transposed reads and MFMAs on
   // the current tile buffer; waves 4-7 stage the NEXT tile meanwhile (global loads -> on-load
@@ -200,6 +212,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     unsigned dmask; // same for pd
     int dt;         // FA: element offset of the tile's first pixel in its image (uniform), for the dz store
     size_t dimg;    // FA: element offset of the image (uniform)
+    int xbase;      // RINGX: first ring slot of the tile's window (uniform)
+    bool xfresh;    // RINGX: the whole window is staged (first tile of a column / of the strip); else its TRW new rows
   };
   const int xc4 = tid % (CI / 4);          // 256 % (CI/4) == 0: fixed channel quad per thread
   const int xc = ci0 + xc4 * 4;
@@ -264,9 +278,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   }
   const unsigned doff0 = (unsigned)(((dp0 / 32) * a.W + dp0 % 32) * a.dz_cstride + dc);
   const unsigned x_all = xc_ok ? ((X_UNITS % 256 == 0 || tid < X_UNITS % 256) ? ((1u << X_PT) - 1u) : ((1u << (X_PT - 1)) - 1u)) : 0u;
+  unsigned x_new = 0;        // RINGX: this thread's units that lie in the first TRW rows of the staged rectangle
+#pragma unroll
+  for (int i = 0; i < X_PT; ++i)
+    if (xp0 + i * XSTEP < TRW * TWh) x_new |= 1u << i;
 
   // coordinates of the next tile to load (producer state, advanced by load_tile)
   int ltx = 0, lty = 0, lb = 0;
+  int lxbase = 0;        // RINGX: ring slot of the window of the tile loaded last
+  bool lfirst = true;    // RINGX: nothing loaded yet
   // Tiles are walked DOWN the image first (tile index = (image, column of tiles, row)): with a halo the next tile of a
   // strip re-reads 2 * HALO of its TRW + 2 * HALO input rows, and they are the rows the workgroup fetched a tile ago (L2
   // hits); walking along x the vertical neighbour came tiles_x tiles later, from HBM again.  (The order of the tiles only
@@ -284,6 +304,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   };
   auto load_tile = [&](Stage& sg) {
     const int x0 = ltx * 32, y0 = lty * TRW, b = lb;
+    // RINGX: a tile right below its predecessor in the strip stages only its TRW new rows (image rows y0 + HALO ...)
+    const bool fresh = !RINGX || lfirst || lty == 0;
+    if constexpr (RINGX) {
+      lxbase = lfirst ? 0 : (lxbase + (fresh ? THh : TRW)) % RING;
+      lfirst = false;
+      sg.xbase = lxbase;
+      sg.xfresh = fresh;
+    }
+    const int yx = fresh ? y0 - HALO : y0 + HALO;        // image row of the first staged x row
     if (ymajor) {
       if (++lty == a.tiles_y) {
         lty = 0;
@@ -301,16 +330,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     }
     const bool interior = x0 >= HALO && x0 + 32 + HALO <= a.W && y0 >= HALO && y0 + TRW + HALO <= a.H;   // uniform
     // validity of this thread's units: interior tiles (the vast majority) need no pixel tests
-    unsigned xmask = x_all, dmask = dc_ok ? ((1u << D_PT) - 1u) : 0u;
+    unsigned xmask = fresh ? x_all : (x_all & x_new), dmask = dc_ok ? ((1u << D_PT) - 1u) : 0u;
     if (!interior) {
-      xmask = 0;
+      unsigned xm = 0;
 #pragma unroll
       for (int i = 0; i < X_PT; ++i) {
         const int pp = xp0 + i * XSTEP;
-        const int gx = x0 + pp % TWh - HALO, gy = y0 + pp / TWh - HALO;
-        if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H) xmask |= 1u << i;
+        const int gx = x0 + pp % TWh - HALO, gy = yx + pp / TWh;
+        if (gx >= 0 && gx < a.W && gy >= 0 && gy < a.H) xm |= 1u << i;
       }
-      xmask &= x_all;
+      xmask &= xm;
       unsigned dm = 0;
 #pragma unroll
       for (int i = 0; i < D_PT; ++i) {
@@ -326,10 +355,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     // the two tiles in flight with s_waitcnt vmcnt(N); loads under per-unit branches made it
     // fall back to vmcnt(0), which serialised the two tiles.
     const size_t ximg = (size_t)b * a.H * a.W * a.x.cstride, dimg = (size_t)b * a.H * a.W * a.dz_cstride;   // uniform
-    const int xt = ((y0 - HALO) * a.W + (x0 - HALO)) * a.x.cstride;     // uniform; < 0 only where masked
+    const int xt = (yx * a.W + (x0 - HALO)) * a.x.cstride;     // uniform; < 0 only where masked
     const int dt = (y0 * a.W + x0) * a.dz_cstride;
     auto load_x = [&](auto bf_tag) {
       constexpr bool XBF = decltype(bf_tag)::value;
+      // (RINGX: a tile below its predecessor needs its TRW new rows only, but EVERY unit still issues a load -- the
+      //  others read element 0 of the image, an L2 hit: requesting them under a uniform branch measured 3-5 % slower,
+      //  the fixed load count is what lets the waits in front of store_tile be counted ones)
 #pragma unroll
       for (int i = 0; i < X_PT; ++i) {
         int off;
@@ -370,12 +402,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     else load_dz(std::false_type{});
   };
   auto store_tile = [&](int buf, const Stage& sg) {
-    unsigned short* s_x = s_base + buf * BUF;
-    unsigned short* s_dz = s_x + NP * XROWS * CI;
+    unsigned short* s_x = RINGX ? s_base : s_base + buf * BUF;
+    unsigned short* s_dz = RINGX ? s_base + NP * XPLANE + buf * (NP * DROWS * CO) : s_x + NP * XROWS * CI;
+    // RINGX: first ring slot the staged rows go to (a whole window, or the TRW rows behind the rows kept from the tile above)
+    const int slot0 = RINGX ? (sg.xfresh ? sg.xbase : sg.xbase + 2 * HALO) : 0;
+    const int xunits = (RINGX && !sg.xfresh) ? NEWROWS_UNITS : X_UNITS;      // uniform
 #pragma unroll
     for (int i = 0; i < X_PT; ++i) {
       const int u = tid + i * 256;
-      if (u < X_UNITS) {
+      if (u < xunits) {
         f32x4 v = sg.px[i];
         if (aff) v = v * psc + psh;
         if (lr) {
@@ -385,9 +420,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
         if (!((sg.inb >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
         u32x2 pl[NP];
         split_planes<NP>(v, pl);
-        const int o = tr_swz<NSX>(u / (CI / 4), xc4 * 4);
+        int R = u / (CI / 4);                 // pixel of the staged rectangle: row R / TWh, column R % TWh
+        if constexpr (RINGX) {
+          const int r = R / TWh;
+          int slot = slot0 + r;
+          slot = slot >= RING ? slot - RING : slot;
+          R = slot * TWh + (R - r * TWh);
+        }
+        const int o = tr_swz<NSX>(R, xc4 * 4);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_x + p * XROWS * CI + o) = pl[p];
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_x + p * XPLANE + o) = pl[p];
       }
     }
 #pragma unroll
@@ -430,6 +472,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   int tapoff[TMAX];                        // pixel-row offset of each tap (a.T == TMAX by construction)
 #pragma unroll
   for (int t = 0; t < TMAX; ++t) tapoff[t] = a.dy[t] * TWh + a.dx[t];
+  int cxbase = 0;                          // RINGX: ring slot of the current tile's window (consumer waves; same walk as load_tile)
 
   const int t_begin = strip * a.tiles_per_strip;
   const int t_end = min(t_begin + a.tiles_per_strip, a.ntiles);
@@ -515,9 +558,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   __syncthreads();
   for (int mt = t_begin; mt < t_end; ++mt) {
     const int cur = (mt - t_begin) & 1;
+    if constexpr (RINGX) {
+      if (mt != t_begin) cxbase = (cxbase + ((mt % a.tiles_y == 0) ? THh : TRW)) % RING;
+    }
     {
-    const unsigned short* s_x = s_base + cur * BUF;
-    const unsigned short* s_dz = s_x + NP * XROWS * CI;
+    const unsigned short* s_x = RINGX ? s_base : s_base + cur * BUF;
+    const unsigned short* s_dz = RINGX ? s_base + NP * XPLANE + cur * (NP * DROWS * CO) : s_x + NP * XROWS * CI;
     // Consecutive MFMAs must write DIFFERENT accumulators (a chain of dependent v_mfma_f32_32x32x16_bf16 issues at
     // 20.7 ns per instruction, four interleaved chains at 15.8: tools/probes/mfma_chain_probe.hip), so a STAGE = TG taps
     // x JG cout tiles x all cin tiles shares each plane pair: 3-4 accumulators in rotation.
@@ -560,10 +606,19 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
       stage_rows(st, Rd, Rx0);
       const int t0 = (st % NT0) * TG;
 #pragma unroll
-      for (int tg = 0; tg < TG; ++tg)
+      for (int tg = 0; tg < TG; ++tg) {
+        int Rx = Rx0 + tapoff[t0 + tg];
+        if constexpr (RINGX) {
+          // window row of this tap's fragment -> ring slot (uniform arithmetic; the 8 pixels of a fragment share a row)
+          const int kk = st / (NJ0 * NT0), ks = wk * KPW + kk;
+          int slot = cxbase + (ks >> 1) + HALO + a.dy[t0 + tg];
+          slot = slot >= RING ? slot - RING : slot;
+          Rx = slot * TWh + HALO + (ks & 1) * 16 + lp + a.dx[t0 + tg];
+        }
 #pragma unroll
         for (int i = 0; i < CI_T; ++i)
-          ap[tg][i][p] = tr_frag<NSX>(s_x + p * XROWS * CI, Rx0 + tapoff[t0 + tg], (wci * CI_T + i) * 32 + lc);
+          ap[tg][i][p] = tr_frag<NSX>(s_x + p * XPLANE, Rx, (wci * CI_T + i) * 32 + lc);
+      }
     };
     auto read_b = [&](int st, int p) {
       int Rd, Rx0;

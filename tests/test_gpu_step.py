@@ -125,6 +125,40 @@ def test_entropy_selection_vs_golden():
     assert record("pl_select/mask_agreement", (mask.cpu() == g["mask"]).float().mean().item()) == 1.0
 
 
+def test_pseudo_label_selection_breaks_ties_by_pixel_index():
+    """Round 4: keys of the top-k selection (w / Exp(1) noise, float32) DO collide now and then among the 10^4..10^5 members
+    of an (image, class) pair; a tie AT the threshold was resolved first-come by an atomic counter over a bucket whose order
+    depends on workgroup timing -- one such tie made a 26-step training run two-valued.  Now the tied members with the
+    smallest pixel index are taken.  Constructed case: every member of a pair has the same key; k = int(cnt * ratio) of
+    them must be chosen: exactly the k smallest pixel indices, every time (the weak labels themselves always stay)."""
+    from coarse3d_amd import ops
+    b, n, c = 2, 900, 5
+    gen = torch.Generator().manual_seed(3)
+    amax = torch.randint(1, c, (b, n), generator=gen).to(torch.int32)
+    ev = torch.ones(b, n, dtype=torch.int64)
+    tr = torch.zeros(b, n, dtype=torch.int64)
+    for bi in range(b):
+        for cls in range(1, c):
+            tr[bi, int(torch.nonzero(amax[bi] == cls)[0])] = cls           # one weak label per class: every pair is live
+    w = torch.full((b, n), 0.5)
+    noise = torch.full((b, c, n), 2.0)
+    ratio = 0.3
+    counts = ops.label_hist(tr.to(DEV), c)
+    outs = []
+    for rep in range(5):
+        lab, mask = ops.pl_select(w.to(DEV), amax.to(DEV), ev.to(DEV), tr.to(DEV), noise.to(DEV), counts, b, n, c, 0, np.float32(ratio))
+        outs.append(lab.cpu())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    for bi in range(b):
+        for cls in range(1, c):
+            members = torch.nonzero(amax[bi] == cls).reshape(-1)
+            k = int(np.float32(len(members)) * np.float32(ratio))
+            want = set(members[:k].tolist()) | set(torch.nonzero(tr[bi] == cls).reshape(-1).tolist())
+            got = set(torch.nonzero(outs[0][bi] == cls).reshape(-1).tolist())
+            assert got == want, (bi, cls, sorted(got - want)[:5], sorted(want - got)[:5])
+
+
 @pytest.mark.parametrize("tag,b,h,w,ncls,dataset,seed", [
     ("kitti_small", 2, 32, 64, 20, "SemanticKitti", 101),
     ("poss_small", 1, 24, 56, 14, "SemanticPOSS", 201),
