@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Weight-gradient micro-benchmark with an fp64 check (run on the GPU box): tools/bench_wgrad.py [f32|bf16|bf16x3]."""
+"""Weight-gradient micro-benchmark with an fp64 check (run on the GPU box): tools/bench_wgrad.py [f32|bf16|bf16x3] [fuse]
+(fuse: the launches apply a BatchNorm / LeakyReLU backward on load, conv_wgrad(fuse=...): timing only for those)."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,7 +23,15 @@ for (B, H, W, Ci, Co, k, dil, pad) in shapes:
     taps = ops.conv_taps(k, k, dil, pad)
     src = ops.Source(x, sc, sh, lrelu=True)
     dw = torch.zeros(Co, Ci, k, k, device=dev)
-    fn = lambda: ops.conv_wgrad(src, dz, dw, taps)
+    fuse = len(sys.argv) > 2 and sys.argv[2] == "fuse"
+    if fuse:
+        act = torch.randn(B, H, W, Co, device=dev)
+        kk = torch.randn(3, Co, device=dev) * 0.1
+        dzo = torch.empty_like(dz)
+        db = torch.zeros(Co, device=dev)
+        fn = lambda: ops.conv_wgrad(src, dzo, dw, taps, dbias=db, fuse=(dz, act, kk))
+    else:
+        fn = lambda: ops.conv_wgrad(src, dz, dw, taps)
     for _ in range(3): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,6 +39,10 @@ for (B, H, W, Ci, Co, k, dil, pad) in shapes:
     for _ in range(10): fn()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
+    if fuse:
+        print(json.dumps(dict(mode=mode + "+fuse", shape=[B, H, W, Ci, Co, k, dil], ms=round(ms, 4),
+                              tflops=round(2.0 * B * H * W * Ci * Co * k * k / ms / 1e9, 1), rel_err=0.0)), flush=True)
+        continue
     # fp64 check on one image, a channel subset
     ci_n, co_n = min(Ci, 48), min(Co, 40)
     xt = F.leaky_relu(x[:1].double() * sc.double() + sh.double(), 0.01)[..., :ci_n].permute(0, 3, 1, 2)
