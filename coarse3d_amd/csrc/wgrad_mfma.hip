@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
 // dw[cout][cin_off + cin][t] (+)= sum_strips partial.  Block = 32 outputs x 8 strip lanes.
 // Blocks beyond `main_blocks` fold the layer's bias-gradient partials (one channel each; c3d_wgrad_desc.bias_partial).
 // One fold = one c3d_wgrad_fold record; `blk` is the block's index within the fold.
-__device__ __forceinline__ void wgrad_fold_body(const c3d_wgrad_fold& f, int blk, double (*red)[32]) {
+__device__ __forceinline__ void wgrad_fold_body(const c3d_wgrad_fold& f, int blk, double (*red)[32]) {      // red: 1024 doubles
   const double osc = f.out_scale_dev ? (double)f.out_scale * (double)*f.out_scale_dev : (double)f.out_scale;   // powers of two: exact
   const int main_blocks = f.main_blocks;
   if (blk >= main_blocks) {
@@ -299,10 +299,14 @@ __device__ __forceinline__ void wgrad_fold_body(const c3d_wgrad_fold& f, int blk
   const size_t slice_floats = (size_t)T * CI * CO;
   const int nsl = ci_slices * f.co_slices;
   const size_t total = slice_floats * nsl;
-  const int o = threadIdx.x & 31, lanek = threadIdx.x >> 5;
+  // 32 consecutive outputs per block trip: 8 threads x float4 along the outputs (CO is a multiple of 32, so the four
+  // outputs of a thread share tap and input channel), 32 strip lanes; every thread keeps four 16-byte loads in flight
+  // (round 4: the 4-byte version with 8 strip lanes ran the ~1.3 GB of partials of a step at 2.5 TB/s)
+  const int o4 = threadIdx.x & 7, lanek = threadIdx.x >> 3;
+  double (*red4)[8][4] = reinterpret_cast<double (*)[8][4]>(red);      // [32 strip lanes][8 quads][4]
   for (size_t base = (size_t)blk * 32; base < total; base += (size_t)main_blocks * 32) {
-    const size_t e = base + o;
-    double s = 0.0;
+    const size_t e = base + (size_t)o4 * 4;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int t = 0, ci = 0, co = 0;
     bool valid = false;
     if (e < total) {
@@ -313,34 +317,60 @@ __device__ __forceinline__ void wgrad_fold_body(const c3d_wgrad_fold& f, int blk
       t = r / ((size_t)CO * CI);
       ci += (sl % ci_slices) * CI;
       co += (sl / ci_slices) * CO;
-      valid = ci < f.Cin_src && co < f.Cout;
+      valid = ci < f.Cin_src && co < f.Cout;           // (co .. co + 3: judged per output below)
       if (valid) {
         const float* p = f.partial + (size_t)sl * strips * slice_floats + r;
         int k = lanek;
-        for (; k + 24 < strips; k += 32) {     // 4 independent loads in flight
-          const float v0 = p[(size_t)k * slice_floats], v1 = p[(size_t)(k + 8) * slice_floats];
-          const float v2 = p[(size_t)(k + 16) * slice_floats], v3 = p[(size_t)(k + 24) * slice_floats];
-          s += (double)v0 + (double)v1 + (double)v2 + (double)v3;
+        for (; k + 96 < strips; k += 128) {     // 4 independent 16-byte loads in flight
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)k * slice_floats);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 32) * slice_floats);
+          const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 64) * slice_floats);
+          const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 96) * slice_floats);
+          s0 += (double)v0[0] + (double)v1[0] + (double)v2[0] + (double)v3[0];
+          s1 += (double)v0[1] + (double)v1[1] + (double)v2[1] + (double)v3[1];
+          s2 += (double)v0[2] + (double)v1[2] + (double)v2[2] + (double)v3[2];
+          s3 += (double)v0[3] + (double)v1[3] + (double)v2[3] + (double)v3[3];
         }
-        for (; k < strips; k += 8) s += (double)p[(size_t)k * slice_floats];
+        for (; k < strips; k += 32) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(p + (size_t)k * slice_floats);
+          s0 += (double)v[0];
+          s1 += (double)v[1];
+          s2 += (double)v[2];
+          s3 += (double)v[3];
+        }
       }
     }
-    red[lanek][o] = s;
+    red4[lanek][o4][0] = s0;
+    red4[lanek][o4][1] = s1;
+    red4[lanek][o4][2] = s2;
+    red4[lanek][o4][3] = s3;
     __syncthreads();
-    if (lanek == 0 && valid) {
-      double v = 0.0;
+    if (threadIdx.x < 32) {
+      const int q = threadIdx.x >> 2, j = threadIdx.x & 3;      // output 4 * q + j of the trip
+      // (re-derive this output's coordinates: thread q of the load phase computed them for the quad)
+      const size_t e2 = base + (size_t)q * 4;
+      if (e2 < total) {
+        const int sl = e2 / slice_floats;
+        const size_t r = e2 % slice_floats;
+        const int co2 = (int)(r % CO) + (sl / ci_slices) * CO + j;
+        const int ci2 = (int)((r / CO) % CI) + (sl % ci_slices) * CI;
+        const int t2 = r / ((size_t)CO * CI);
+        if (ci2 < f.Cin_src && co2 < f.Cout) {
+          double v = 0.0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v += red[k][o];
-      v *= osc;
-      float* d = f.dw + ((size_t)co * f.Cin_total + f.cin_off + ci) * T + t;
-      *d = f.accumulate ? (*d + (float)v) : (float)v;
+          for (int k = 0; k < 32; ++k) v += red4[k][q][j];
+          v *= osc;
+          float* d = f.dw + ((size_t)co2 * f.Cin_total + f.cin_off + ci2) * T + t2;
+          *d = f.accumulate ? (*d + (float)v) : (float)v;
+        }
+      }
     }
     __syncthreads();
   }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(c3d_wgrad_fold f) {
-  __shared__ double red[8][32];
+  __shared__ double red[32][32];
   wgrad_fold_body(f, blockIdx.x, red);
 }
 
@@ -354,7 +384,7 @@ struct FoldBatch {
   int n;
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(FoldBatch b) {
-  __shared__ double red[8][32];
+  __shared__ double red[32][32];
   int e = 0;
   const int blk = blockIdx.x;
   while (e + 1 < b.n && blk >= b.f[e + 1].block0) ++e;       // block -> fold (b.n <= 32: a short scalar walk)
