@@ -768,6 +768,11 @@ def short_config(c, dev, steps, events):
     eager = b.run(False, steps, 2, 1, events)
     cap = b.run(True, steps, 3, 0, False)
     roof = b.roofline(eager) if events else None
+    if roof is not None:             # (the per-kernel table and the long notes are in the headline's roofline object)
+        (roof.get("hbm_kernels") or {}).pop("kernels", None)
+        for k in ("peak_note", "dominant_kernel_is", "traffic_source", "dominant_kernel_measured_in"):
+            roof.pop(k, None)
+        roof["all_mfma_kernels"] = {k: v for k, v in roof["all_mfma_kernels"].items() if not k.endswith("note")}
     torch.cuda.empty_cache()
     hbm_frac = None
     if roof is not None and roof.get("step_hbm_traffic_GB"):
