@@ -26,7 +26,7 @@ for mode in (sys.argv[1:] or ["f32", "bf16"]):
     ops.set_matrix_precision(mode)
     torch.manual_seed(0)
     m = SalsaNextProto(5, C, 20, 0, use_prototype=True).to(dev).train()
-    ts = TrainStep(m, C, proto_loss=True, lr=2e-3, n_epochs=100, num_anchor=128)
+    ts = TrainStep(m, C, proto_loss=True, lr=2e-3, n_epochs=100, num_anchor=128)      # C3D_GRAPH=1: the captured step
     log = []
     for s in range(150):
         x, tr, ev = batch(s)
