@@ -231,7 +231,8 @@ def test_captured_data_parallel_step_is_bit_identical_to_the_eager_one():
     assert out["graphs"] == [0, 1] and out["replays"] == [0, 4] and out["trained"]
     assert out["counts"][0] == out["counts"][1] and out["counts"][1]["syncbn"] >= 6 * 80, out["counts"]
     assert out["counts"][1]["gradient_buckets"] >= 6 and out["counts"][1]["prototype_bank"] == 6
-    assert out["host_ms_last_step"][1] < 5.0, out["host_ms_last_step"]
+    # (2.8 ms against 14.1 ms launch by launch on the box this was written on; hosts of this pool differ by 2x)
+    assert out["host_ms_last_step"][1] < max(5.0, 0.5 * out["host_ms_last_step"][0]), out["host_ms_last_step"]
     from _measure import record
     record("dp_graph/host_ms_per_replayed_step", out["host_ms_last_step"][1])
     record("dp_graph/host_ms_per_eager_step", out["host_ms_last_step"][0])
