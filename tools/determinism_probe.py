@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Run-to-run determinism of the captured training step: 20 steps at the headline shape, per-step loss and per-parameter
+checksums written to a JSON file; run it a few times and compare the files (round 4: a key tie at the threshold of the
+pseudo-label selection made such runs two-valued).  usage: python tools/determinism_probe.py out.json"""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import coarse3d_amd, torch, bench
