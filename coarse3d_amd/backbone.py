@@ -40,7 +40,7 @@ DEFER_WGRAD_FOLDS = True
 
 class Act:
     """An activation tensor as consumers see it: raw NHWC tensor + optional affine of its BN."""
-    __slots__ = ("t", "scale", "shift", "grad", "mask", "no_grad", "producer", "first_consumer", "bwd_partial")
+    __slots__ = ("t", "scale", "shift", "grad", "mask", "no_grad", "producer", "first_consumer", "bwd_partial", "bn_alias")
 
     def __init__(self, t, scale=None, shift=None, mask=None):
         self.t, self.scale, self.shift = t, scale, shift
@@ -50,6 +50,7 @@ class Act:
         self.producer = None        # the conv record whose output this is
         self.first_consumer = None  # name of the first conv (forward order) that reads it = the LAST one to add to its gradient
         self.bwd_partial = None     # (sum dy, sum dy*a) partials taken in the epilogue of that last input-gradient launch
+        self.bn_alias = None        # a residual sum x + BN(a): the Act of a -- its gradient IS the gradient at that BatchNorm's output
 
     def src(self, lrelu=False):
         return ops.Source(self.t, self.scale, self.shift, lrelu=lrelu)
@@ -212,6 +213,7 @@ class Backbone:
         a1 = self._conv(f"{name}.conv2", [s], 3, 1, 1, bn=f"{name}.bn1")
         a2 = self._conv(f"{name}.conv3", [a1], 3, 2, 2, bn=f"{name}.bn2")
         out = Act(ops.affine_add(s.t, a2.t, a2.scale, a2.shift))
+        out.bn_alias = a2           # d(out) is d(BN(a2)): the last input-gradient launch into out can take bn2's backward sums
         self.tape[f"{name}.out"] = (s, a2, out)
         return out
 
@@ -616,13 +618,16 @@ class Backbone:
                 # that BatchNorm's backward sums (sum dy, sum dy * a) there and spare its c3d_bn_bwd_reduce pass (two
                 # tensor reads per layer; 31 of the 43 BatchNorm layers end this way).  bf16x3 engine, fp32 tensors.
                 part = None
-                p_ = s.producer
+                # (a residual sum x + BN(a) passes its gradient on unchanged: the same sums, multiplied with a, for that layer)
+                tgt = s if s.bn_alias is None else s.bn_alias
+                p_ = tgt.producer
                 if (FUSE_BN_REDUCE and ops.MFMA_MODE == 2 and self.train and p_ is not None and p_.mode == 0 and p_.bn is not None
-                        and s.first_consumer == name and s.t.dtype == torch.float32 and s.t.shape[3] == cs):
+                        and s.first_consumer == name and tgt.t.dtype == torch.float32 and tgt.t.shape[3] == cs
+                        and tuple(tgt.t.shape) == tuple(s.t.shape)):
                     part = torch.empty(cs, 2, ops.num_mtiles(*s.t.shape[:3]), device=s.t.device, dtype=torch.float32)
                 ops.conv_forward([gsrc], wd, None, cs, ntaps, out=s.grad, accumulate=acc, grad=True,
-                                 stat_partial=part, stat_mul=s.t if part is not None else None, f16x2_inv=ginv)
-                s.bwd_partial = part
+                                 stat_partial=part, stat_mul=tgt.t if part is not None else None, f16x2_inv=ginv)
+                tgt.bwd_partial = part
             off += cs
         rec.out.grad = None
 
