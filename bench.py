@@ -615,6 +615,12 @@ def main():
         # launch_ranks() touches the GPU (no torch.cuda call), so starting children is safe.
         raise SystemExit(launch_ranks(args.gpus))
 
+    # this process's stdout carries ONE line.  Whatever a library writes to file descriptor 1 meanwhile (RCCL prints a version
+    # banner at its first collective) goes to stderr; the JSON line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -756,7 +762,8 @@ def main():
     if rank == 0:
         import ctypes
         ctypes.CDLL(None).fflush(None)
-        print(line, flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (line + "\n").encode())
 
 
 def short_config(c, dev, steps, events):

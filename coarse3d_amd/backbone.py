@@ -225,6 +225,9 @@ class Backbone:
             pend = self._bn_group_begin(grp)
             short = self._conv(f"{name}.conv1", [xin], 1, 1, 0, lrelu=True)
             self._bn_group_end(pend)
+            # backward runs conv2 before conv1 whatever the forward order: conv1's input gradient is the last one into xin
+            if xin.first_consumer == f"{name}.conv2":
+                xin.first_consumer = f"{name}.conv1"
         else:
             short = self._conv(f"{name}.conv1", [xin], 1, 1, 0, lrelu=True)
             r1 = self._conv(f"{name}.conv2", [xin], 3, 1, 1, bn=f"{name}.bn1")
