@@ -269,6 +269,8 @@ def peak_for(kernel_name):
     if base in ("conv_x3_kernel", "conv_x3f_kernel"):   # <NT, HALO, TT, SIX[, planes]>
         if len(targs) > 4 and targs[4] == "2":
             return PEAK_BF16_MFMA_TFLOPS / 3.0          # (the f16x2 experiment: three products)
+        if len(targs) > 4 and targs[4] == "1":
+            return PEAK_BF16_MFMA_TFLOPS                # the bf16 engine: one plane, one product
         return PEAK_BF16_MFMA_TFLOPS / (6.0 if targs[3] == "true" else 8.0)
     if base == "conv_bfp_kernel":        # <TR, NT, CK, HALO, TT, NP>; NP = 3: eight plane products
         return PEAK_BF16_MFMA_TFLOPS / 8.0 if targs[5] == "3" else PEAK_BF16_MFMA_TFLOPS

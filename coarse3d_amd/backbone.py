@@ -277,10 +277,10 @@ class Backbone:
         slice of the weight at their own resolution -- 60 % fewer MFMAs in forward, input gradient and weight gradient
         of the step's largest layer -- an identity-resampled skip is read in place, and the 704-channel concatenation
         never exists.  The arithmetic is reassociated (sum over channels before instead of after the interpolation:
-        rounding-level differences, inside every golden's 1e-4).  fp32 tensors only (the bf16-storage mode keeps the
-        concatenation)."""
+        rounding-level differences, inside every golden's 1e-4).  bf16 activation storage: the low-resolution shares stay
+        fp32 until their interpolated sum is stored."""
         return (len(self.skips) == 4
-                and all(s.t.dtype == torch.float32 and s.scale is None for s in self.skips))
+                and all(s.t.dtype == self.skips[0].t.dtype and s.scale is None for s in self.skips))
 
     def _proj0_forward(self, hh, wh, defer_bn):
         name, bn = "projector.proj.0", "projector.proj.1"
@@ -303,13 +303,15 @@ class Backbone:
         taps = [(0, 0)]
         # low-resolution shares, then their interpolated sum as the initial value of z
         ts = []
+        store = self.skips[0].t.dtype
         for sk, o, c in lo:
-            t, _ = ops.conv_forward([sk.src()], self.packs.get(w, 0, c_off=o, c_cnt=c), None, cout, taps)
+            t = torch.empty(b, sk.t.shape[1], sk.t.shape[2], cout, device=sk.t.device, dtype=torch.float32)
+            ops.conv_forward([sk.src()], self.packs.get(w, 0, c_off=o, c_cnt=c), None, cout, taps, out=t)
             ts.append(t)
         if len(ts) == 2:
-            z = ops.bilinear_sum2(ts[0], ts[1], hh, wh)
+            z = ops.bilinear_sum2(ts[0], ts[1], hh, wh, out_dtype=store)
         else:
-            z = ops.bilinear(ts[0], hh, wh)
+            z = ops.bilinear(ts[0], hh, wh, out_dtype=store)
         # the high-resolution sources are contiguous in the weight's input channels: ONE multi-source launch, which
         # accumulates into z and takes the BatchNorm statistics of the final values in its epilogue
         h_off, h_cnt = hi[0][1], sum(h[2] for h in hi)
@@ -359,7 +361,7 @@ class Backbone:
             self.capture[name] = (rec, dy.clone(), dz.clone())
         dzs = []
         for sk, o, c in lo:
-            d = torch.empty(sk.t.shape[0], sk.t.shape[1], sk.t.shape[2], cout, device=dz.device, dtype=torch.float32)
+            d = torch.empty(sk.t.shape[0], sk.t.shape[1], sk.t.shape[2], cout, device=dz.device, dtype=dz.dtype)
             dzs.append(ops.bilinear_bwd(d, dz))
         dw = G[f"{name}.weight"]
         with self._fork(dz, pz, *dzs):

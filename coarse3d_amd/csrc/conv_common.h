@@ -26,6 +26,7 @@ struct ConvArgs {
   const float* stat_mul;     // NULL, or the tensor whose product with the stored values replaces v*v in stat_partial
   int stat_mul_cs;
   int variant = 0;         // c3d_conv_desc.variant (schedule selector of the bit-identity tests)
+  bool one_plane = false;  // conv_x3.hip: the bf16 engine's fused nine-tap kernel (one plane, bf16 tensors)
   bool f16x2 = false;      // EXPERIMENT (mfma_bf16 == 4): two fp16 planes / three products where a kernel has the variant
   const float* acc_scale_dev = nullptr;   // times this device scalar, if any (per-tensor gradient exponent)
   float acc_scale = 1.f;   // the accumulators are multiplied by this before bias / activation (1: fma(acc, 1, bias) == acc + bias);

@@ -319,6 +319,16 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
     for (int s = 0; s < d->nsrc; ++s) k32 = k32 && (d->src[s].C % 32 == 0);
     const bool x3 = d->mfma_bf16 >= 2;      // 3 = the exact-split engine with six plane products (input gradients)
     a.six = d->mfma_bf16 == 3;
+    if (!x3 && tr == 8 && d->ntaps == 9 && d->wpack_planes && !(d->variant & 4)) {
+      // bf16 engine, nine taps, every source a bf16 tensor: the fused kernel with one plane (conv_x3.hip); variant & 4 keeps
+      // the phased conv_bfp kernel (bit-identity test)
+      bool all_bf = true;
+      for (int s = 0; s < d->nsrc; ++s) all_bf = all_bf && d->src[s].bf16 != 0;
+      if (all_bf) {
+        a.one_plane = true;
+        return c3d_conv_forward_x3(a, halo, st);
+      }
+    }
     if (x3 && tr == 8 && d->ntaps > 1) {
       C3D_REQUIRE(d->wpack_planes, "conv: multi-tap bf16x3 convs need a c3d_pack_weights(mode | 2) pack (wpack_planes = 1)");
       return c3d_conv_forward_x3(a, halo, st);

@@ -306,9 +306,24 @@ struct c3d_x3_products_f16 {
   static constexpr int last_b(int p) { int l = -1; for (int q = 0; q < N; ++q) if (pb(q) == p) l = q; return l; }
 };
 
-template <int NT, int HALO, int TT, bool SIX, int NPL = 3>
+// NPL = 1 (round 4, the `bf16` mixed-precision engine, BASELINE configs[2]): one bf16 plane per operand -- the activations are
+// rounded once while they are staged (BFS: read from bf16 tensors, 8 bytes per unit), the weights are plane 0 of the pack --
+// and ONE product per tap; the fragments of the next tap are then read into a second register set while the current tap is
+// multiplied.  Same tile, LDS image and accumulation order as conv_bfp_kernel<8, NT, 16, HALO, 9, 1>: bit-identical outputs
+// (tests/test_gpu_bf16_storage.py).
+struct c3d_x3_products_one {
+  static constexpr int N = 1;
+  static constexpr int pa(int) { return 0; }
+  static constexpr int pb(int) { return 0; }
+  static constexpr int last_a(int) { return 0; }
+  static constexpr int last_b(int) { return 0; }
+};
+
+template <int NT, int HALO, int TT, bool SIX, int NPL = 3, bool BFS = false>
 __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
+  static_assert(!BFS || NPL == 1, "bf16 sources belong to the one-plane engine");
   constexpr bool F16 = NPL == 2;
+  constexpr unsigned EB = BFS ? 2u : 4u;           // bytes per stored activation element
   typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
   constexpr int TR = 8, CQ = 4;                    // 16 channels per K chunk
   constexpr int TWh = 32 + 2 * HALO, THh = TR + 2 * HALO;
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   constexpr int WG_ROWS = G * TN;
   constexpr int W_UNITS = WG_ROWS * CQ;
   constexpr int W_PT = (W_UNITS + 255) / 256;
-  using PR = std::conditional_t<F16, c3d_x3_products_f16, c3d_x3_products<SIX>>;
+  using PR = std::conditional_t<F16, c3d_x3_products_f16, std::conditional_t<NPL == 1, c3d_x3_products_one, c3d_x3_products<SIX>>>;
   constexpr int NQ = PR::N;
 
   // LDS rows are padded to whole staging units (64 rows per unit index): unit i of a thread is row tid/4 + 64 i,
@@ -396,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   int lstep = 0;
   float lslope = 1.f;
   int ls = 0, lc0 = 0, lC = 0, lk = 0;     // input cursor: source, channel inside it, its width, chunk index
-  const unsigned img_bytes_per_c = (unsigned)a.B * a.H * a.W * 4;
+  const unsigned img_bytes_per_c = (unsigned)a.B * a.H * a.W * EB;
   auto open_src = [&](int s) {
     const c3d_src& sr = a.src[s];
     rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sr.ptr), 0, img_bytes_per_c * sr.cstride, 0x00020000);
@@ -404,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
     for (int i = 0; i < IN_PT; ++i) {
       const int p = r0 + 64 * i;
       const int prel = (p / TWh - HALO) * a.W + (p % TWh - HALO);
-      vin[i] = ((inb >> i) & 1u) ? (unsigned)(((tile_pix + prel) * sr.cstride + sr.coff + c4 * 4) * 4) : OOB;
+      vin[i] = ((inb >> i) & 1u) ? (unsigned)(((tile_pix + prel) * sr.cstride + sr.coff + c4 * 4) * EB) : OOB;
     }
     if (sr.scale) {
       rs_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sr.scale), 0, 0x7fffffff, 0x00020000);
@@ -432,13 +447,17 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   const int nwq = nchunks * NG;
 
   // ---- registers in flight
-  f32x4 pin[IN_PT];                        // raw input of the chunk after next (after its atoms ran: of the one after)
+  f32x4 pin[BFS ? 1 : IN_PT];              // raw input of the chunk after next (after its atoms ran: of the one after)
+  u32x2 pinb[BFS ? IN_PT : 1];             // BFS: the same, four bf16 per unit
   u32x2 npl[IN_PT][NPL];                   // the next chunk's planes, waiting for the store phase
   u32x2 pw[W_PT][NPL];
   f32x4 pwf[F16 ? W_PT : 1];               // F16: the raw fp32 weight units in flight
   f32x4 psc, psh;
   float pslope;
-  auto load_in = [&](int i) { pin[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vin[i], lc0 * 4, 0)); };
+  auto load_in = [&](int i) {
+    if constexpr (BFS) pinb[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_in, vin[i], lc0 * 2, 0);
+    else pin[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vin[i], lc0 * 4, 0));
+  };
   auto load_aff = [&]() {
     const int so = (lstep >> 6) * lc0 * 4;
     psc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_sc, vaff, so, 0));
@@ -499,7 +518,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
       const unsigned keep = 0u - ((inb >> i) & 1u);
 #pragma unroll
       for (int q = 2 * r; q < 2 * r + 2; ++q) {
-        const float v = __builtin_fmaf(pin[i][q], psc[q], psh[q]);
+        float x;
+        if constexpr (BFS) x = __uint_as_float((q & 1) ? (pinb[i][q >> 1] & 0xffff0000u) : (pinb[i][q >> 1] << 16));
+        else x = pin[i][q];
+        const float v = __builtin_fmaf(x, psc[q], psh[q]);
         sv[q] = __uint_as_float(__float_as_uint(__builtin_fmaxf(v, v * pslope)) & keep);
       }
     } else {
@@ -519,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
       h[1] = (__bf16)sv[2 * e + 1];
       const unsigned pk = __builtin_bit_cast(unsigned, h);
       npl[i][p][e] = pk;
-      if constexpr (p < 2) {
+      if constexpr (p + 1 < NPL) {
         sv[2 * e] -= __uint_as_float(pk << 16);
         sv[2 * e + 1] -= __uint_as_float(pk & 0xffff0000u);
       }
@@ -567,29 +589,34 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
     constexpr int NS = G * NQ;                        // slots = products
     const unsigned short* s_w = s_w0 + wb * WBUF;
     unsigned short* d_w = s_w0 + (wb ^ 1) * WBUF;
-    bf16x8 ap[NPL][RPW];
-    bf16x8 bq[NPL][NJ];
+    constexpr int NFB = NQ == 1 ? 2 : NPL;            // fragment register sets: one per plane; one plane: two, by tap parity
+    bf16x8 ap[NFB][RPW];
+    bf16x8 bq[NFB][NJ];
     // (no plane both closes a tap and opens the next one -- static_assert below -- so one register set per plane)
-    static_assert(PR::last_a(PR::pa(0)) != NQ - 1 && PR::last_b(PR::pb(0)) != NQ - 1, "a tap must not open with the plane it closed with");
+    static_assert(NQ == 1 || (PR::last_a(PR::pa(0)) != NQ - 1 && PR::last_b(PR::pb(0)) != NQ - 1),
+                  "a tap must not open with the plane it closed with");
     // (`fresh` is zero, but opaque to the compiler and redefined per tap row: the 2 x 9 fragment row addresses are then
     //  recomputed next to their reads -- a few VALU in the MFMA shadow -- instead of being hoisted out of the chunk loop
     //  into 18 registers, which pushed the 64-cout dilation-2 kernel into scratch; a kernel with scratch gets ONE
     //  workgroup per CU on this GPU whatever its LDS and register budget says: matrix pipe busy 0.36 instead of 0.71)
     int fresh = 0;
     asm volatile("" : "+v"(fresh));
+    // plane p of tap tg into register set p (one plane: set tg & 1)
     auto read_a = [&](int tg, int p) {
       const int t = g * G + tg;
+      const int rs = NQ == 1 ? (tg & 1) : p;
 #pragma unroll
       for (int i = 0; i < RPW; ++i) {
         const int R = (wm + i * WM + HALO + a.dy[t]) * TWh + HALO + a.dx[t] + l31 + fresh;
-        ap[p][i] = *reinterpret_cast<const bf16x8*>(s_in + p * IN_ROWS_P * 16 + R * 16 + swz_half(R, half));
+        ap[rs][i] = *reinterpret_cast<const bf16x8*>(s_in + p * IN_ROWS_P * 16 + R * 16 + swz_half(R, half));
       }
     };
     auto read_b = [&](int tg, int p) {
+      const int rs = NQ == 1 ? (tg & 1) : p;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int R = tg * TN + j * 32 + l31;
-        bq[p][j] = *reinterpret_cast<const bf16x8*>(s_w + p * WG_ROWS_P * 16 + R * 16 + swz_half(R, half));
+        bq[rs][j] = *reinterpret_cast<const bf16x8*>(s_w + p * WG_ROWS_P * 16 + R * 16 + swz_half(R, half));
       }
     };
     // first tap: all six fragments, in the order the products need them
@@ -606,7 +633,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     c3d_x3_static_for<0, NS>([&](auto s_tag) {
       constexpr int s = decltype(s_tag)::value, tg = s / NQ, q = s % NQ;
-      constexpr int PA = PR::pa(q), PB = PR::pb(q);
+      constexpr int PA = NQ == 1 ? (tg & 1) : PR::pa(q), PB = NQ == 1 ? (tg & 1) : PR::pb(q);      // register sets
+      // one plane: the next tap's fragments are requested BEFORE this tap's products (they land in the other register set)
+      if constexpr (NQ == 1 && tg + 1 < G) {
+        read_a(tg + 1, 0);
+        read_b(tg + 1, 0);
+      }
 #pragma unroll
       for (int i = 0; i < RPW; ++i)
 #pragma unroll
@@ -618,7 +650,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA][i], bq[PB][j], acc[i][j], 0, 0, 0);
         }
       // fragments of the next tap: each plane right after its last product of this tap
-      if constexpr (tg + 1 < G) {
+      if constexpr (NQ > 1 && tg + 1 < G) {
         if constexpr (PR::last_a(PA) == q) read_a(tg + 1, PA);
         if constexpr (PR::last_b(PB) == q) read_b(tg + 1, PB);
       }
@@ -668,21 +700,22 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   };
   if (NPW == 1 || nj >= NPW) k_loop(std::integral_constant<int, NPW>{});
   else k_loop(std::integral_constant<int, 1>{});
-  conv_epilogue<TR, NT, WM, WN, false, false, 256, false, true>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
+  conv_epilogue<TR, NT, WM, WN, NPL == 1, false, 256, false, NPL >= 2>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
+                                                                       tile_pix);
 }
 
-template <int NT, int HALO, int TT, bool SIX, int NPL = 3>
+template <int NT, int HALO, int TT, bool SIX, int NPL = 3, bool BFS = false>
 int launch_x3f_s(ConvArgs& a, hipStream_t st) {
   constexpr int G = (TT == 9) ? 3 : TT;
   constexpr int IN_PT = ((8 + 2 * HALO) * (32 + 2 * HALO) * 4 + 255) / 256, W_PT = (G * 32 * NT * 4 + 255) / 256;
   size_t lds = (size_t)NPL * (IN_PT * 64 + 2 * W_PT * 64) * 16 * 2;      // rows padded to whole staging units
   const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
   if (lds < red) lds = red;
-  c3d_opt_in_lds<&conv_x3f_kernel<NT, HALO, TT, SIX, NPL>>();
+  c3d_opt_in_lds<&conv_x3f_kernel<NT, HALO, TT, SIX, NPL, BFS>>();
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
   if (NPL == 2) a.acc_scale = 1.f / 65536.f;           // operands staged times 2^6 and 2^10
-  hipLaunchKernelGGL((conv_x3f_kernel<NT, HALO, TT, SIX, NPL>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_x3f_kernel<NT, HALO, TT, SIX, NPL, BFS>), grid, dim3(256), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -722,5 +755,9 @@ int launch_x3_taps(ConvArgs& a, int halo, hipStream_t st) {
 // called by c3d_conv_forward for mfma_bf16 == 2, 8-row tiles, 4 or 9 taps; a.wpack must be a
 // c3d_pack_weights(mode | 2) pack (fp32 image followed by the three bf16 planes)
 int c3d_conv_forward_x3(ConvArgs& a, int halo, hipStream_t st) {
+  if (a.one_plane) {      // the bf16 engine's nine-tap convs over bf16 tensors (c3d_conv_forward checked both)
+    if (c3d_wide_cout_tiles(a)) return halo <= 1 ? launch_x3f_s<2, 1, 9, true, 1, true>(a, st) : launch_x3f_s<2, 2, 9, true, 1, true>(a, st);
+    return halo <= 1 ? launch_x3f_s<1, 1, 9, true, 1, true>(a, st) : launch_x3f_s<1, 2, 9, true, 1, true>(a, st);
+  }
   return c3d_wide_cout_tiles(a) ? launch_x3_taps<2>(a, halo, st) : launch_x3_taps<1>(a, halo, st);
 }

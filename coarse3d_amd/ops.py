@@ -171,7 +171,7 @@ def pack_weights(w, mode=0, c_off=0, c_cnt=None, kpad=None):
     # bf16-pipe engines: the pre-split bf16 planes follow the fp32 image for the kernels that read them
     # (bf16x3 multi-tap convs: csrc/conv_x3.hip; 1x1 convs with more than 64 outputs in both bf16 modes:
     # csrc/conv_pw3.hip -- the "bf16" mode reads the first plane only, which is the RNE-rounded weight)
-    planes = (MFMA_MODE == 2 and t > 1) or (MFMA_MODE != 0 and t == 1 and n > 64)
+    planes = (MFMA_MODE == 2 and t > 1) or (MFMA_MODE == 1 and t == 9) or (MFMA_MODE != 0 and t == 1 and n > 64)
     dst = torch.empty(numel * 5 // 2 if planes else numel, device=w.device, dtype=torch.float32)
     L.check(L.lib().c3d_pack_weights(_p(w), _p(dst), cout, cin, t, mode | (2 if planes else 0), c_off, c_cnt, kpad,
                                      _stream()), "c3d_pack_weights")
@@ -322,6 +322,9 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
             # (names as rocprofv3 prints them: the fused kernel carries its plane count as a fifth template argument)
             name = (f"conv_x3{'f' if fused_ else ''}_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, {nt_}, "
                     f"{'true' if grad else 'false'}{', 3' if fused_ else ''}>")
+        elif (MFMA_MODE == 1 and tr == 8 and nt_ == 9 and d.wpack_planes and not (CONV_VARIANT & 4)
+              and all(s.t.dtype == torch.bfloat16 for s in srcs)):      # the fused nine-tap kernel with one plane (csrc/conv_x3.hip)
+            name = f"conv_x3f_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, 9, true, 1, true>"
         elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
             name = _pw3_kernel_name(_pw3_tile(b, h, w, cout), sum(s.C for s in srcs), cout)
         elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
@@ -727,13 +730,16 @@ def bilinear(src, hd, wd, dst=None, dcoff=0, c=None, scoff=0, out_dtype=None):
     return dst
 
 
-def bilinear_sum2(src1, src2, hd, wd):
-    """bilinear(src1 -> hd x wd) + bilinear(src2 -> hd x wd), NHWC fp32 tensors with the same channel count."""
+def bilinear_sum2(src1, src2, hd, wd, out_dtype=torch.float32):
+    """bilinear(src1 -> hd x wd) + bilinear(src2 -> hd x wd), NHWC fp32 tensors with the same channel count (the result may be a
+    bf16 activation tensor)."""
     b, h1, w1, c = src1.shape
     _, h2, w2, c2 = src2.shape
     assert c == c2 and src1.dtype == src2.dtype == torch.float32 and src1.is_contiguous() and src2.is_contiguous()
-    dst = torch.empty(b, hd, wd, c, device=src1.device, dtype=torch.float32)
-    _call("c3d_bilinear_sum2", _dp(src1), h1, w1, _dp(src2), h2, w2, _dp(dst), hd, wd, b, c, _stream())
+    assert out_dtype in (torch.float32, torch.bfloat16)
+    dst = torch.empty(b, hd, wd, c, device=src1.device, dtype=out_dtype)
+    _call("c3d_bilinear_sum2", _dp(src1), h1, w1, _dp(src2), h2, w2, _dp(dst), hd, wd, b, c, int(out_dtype == torch.bfloat16),
+          _stream())
     return dst
 
 

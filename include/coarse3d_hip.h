@@ -111,7 +111,9 @@ typedef struct {
                                the same bits with another schedule (tests/test_gpu_conv.py compares them):
                                bits 0-1, 1x1 convs with Cout > 64 on the bf16x3 engine (conv_pw3.hip): 1 = fused kernel
                                with eight waves, 2 = with four waves, 3 = round 2's phased kernel;
-                               bit 2, nine-tap convs on the bf16x3 engine (conv_x3.hip): round 2's phased kernel   */
+                               bit 2, nine-tap convs on the bf16x3 engine (conv_x3.hip) and -- over bf16 tensors -- on the
+                               bf16 engine: the phased kernel (round 2's conv_x3_kernel / conv_bfp_kernel) instead of the
+                               fused one                                                                             */
   const float* acc_scale_dev; /* EXPERIMENT (mfma_bf16 == 4): NULL, or a device scalar the accumulators are multiplied
                                with before bias / activation -- the inverse of a per-tensor gradient exponent
                                (c3d_grad_exponent)                                                            */
@@ -329,12 +331,12 @@ int c3d_softmax_bwd(const float* prob, const float* dprob, int B, int H, int W, 
 /* F.interpolate(bilinear, align_corners=True) between channel slices of NHWC tensors (:470-490) */
 int c3d_bilinear(const float* src, int Hs, int Ws, int scs, int scoff, float* dst, int Hd,
                  int Wd, int dcs, int dcoff, int B, int C, int bf16_mask, c3d_stream stream);
-/* dst[B,Hd,Wd,C] = bilinear(src1[B,Hs1,Ws1,C]) + bilinear(src2[B,Hs2,Ws2,C]) (align_corners=True, fp32, dense
- * channels).  A 1x1 convolution commutes with the resampling of its input: ProjectionV1's first conv over the
+/* dst[B,Hd,Wd,C] = bilinear(src1[B,Hs1,Ws1,C]) + bilinear(src2[B,Hs2,Ws2,C]) (align_corners=True, fp32 sources, dense
+ * channels; dst_bf16 != 0: dst is a bf16 activation tensor).  A 1x1 convolution commutes with the resampling of its input: ProjectionV1's first conv over the
  * concatenation of four resampled skips (salsanext_proto.py:466-483, projector.py:18) is evaluated per skip at the
  * skip's own resolution where that has fewer pixels, and the low-resolution results meet here.            */
 int c3d_bilinear_sum2(const float* src1, int Hs1, int Ws1, const float* src2, int Hs2, int Ws2,
-                      float* dst, int Hd, int Wd, int B, int C, c3d_stream stream);
+                      float* dst, int Hd, int Wd, int B, int C, int dst_bf16, c3d_stream stream);
 /* dsrc (+)= bilinear^T(ddst): deterministic gather over the destination pixels that read each
  * source pixel (no atomics); accumulate != 0 adds to the existing dsrc.  ddst_rowmask (may be NULL): one bit per
  * destination pixel (bit p & 31 of word p >> 5, p = (b*Hd + y)*Wd + x); pixels whose bit is clear are known to hold

@@ -160,3 +160,41 @@ def test_conv_engine_bf16_vs_fp32_storage(k, dil, pad, cin, cout):
     ops.conv_wgrad(ops.Source(x, sc, sh), dz, dw32, taps)
     ops.conv_wgrad(ops.Source(x.bfloat16(), sc, sh), dz.bfloat16(), dw16, taps)
     close32(dw16, dw32, "wgrad", 1e-5)
+
+
+@pytest.mark.parametrize("b,h,w,srcs,cout,dil,acc", [
+    (2, 16, 95, (32,), 64, 1, False),       # ragged last pixel tile
+    (2, 16, 64, (32,), 32, 2, False),       # 32-cout tiles, dilation 2
+    (1, 8, 160, (64, 32), 64, 2, False),    # two sources (the UpBlock skip read in place)
+    (2, 24, 64, (48,), 80, 1, False),       # ragged last cout tile, three chunks
+    (4, 64, 256, (32,), 64, 1, True),       # >= 192 workgroups: 64-cout tiles; accumulating launch
+    (1, 16, 128, (160,), 64, 1, False),     # ten chunks
+])
+def test_fused_nine_tap_kernel_with_one_plane_is_bit_identical(b, h, w, srcs, cout, dil, acc):
+    """The bf16 engine's nine-tap convs over bf16 tensors run conv_x3f_kernel<..., 1, true> (round 4: staging dealt into the MFMA
+    stream, one plane); c3d_conv_desc.variant & 4 keeps the phased conv_bfp kernel.  Same rounding points, same accumulation
+    order: outputs and statistics partials must be the same bits."""
+    from coarse3d_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(11)
+    xs = [torch.randn(b, h, w, c, device=DEV, generator=g).bfloat16() for c in srcs]
+    aff = [(torch.rand(c, device=DEV, generator=g) + 0.5, torch.randn(c, device=DEV, generator=g) * 0.2) for c in srcs]
+    cin = sum(srcs)
+    wt = torch.randn(cout, cin, 3, 3, device=DEV, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, device=DEV, generator=g) * 0.1
+    taps = ops.conv_taps(3, 3, dil, dil)
+    wp = ops.pack_weights(wt, 0)
+    assert wp.c3d_planes
+    sources = [ops.Source(x, sc, sh, lrelu=(i == 0)) for i, (x, (sc, sh)) in enumerate(zip(xs, aff))]
+    out0 = torch.randn(b, h, w, cout, device=DEV, generator=g).bfloat16()
+    res = {}
+    for variant in (0, 4):
+        ops.CONV_VARIANT = variant
+        try:
+            out = out0.clone()
+            y, p = ops.conv_forward(sources, wp, bias, cout, taps, lrelu=True, stats=True, out=out, accumulate=acc)
+        finally:
+            ops.CONV_VARIANT = 0
+        res[variant] = (y.clone(), p.clone())
+    assert torch.equal(res[0][0], res[4][0]), float((res[0][0].float() - res[4][0].float()).abs().max())
+    assert torch.equal(res[0][1], res[4][1])
+    assert bool(torch.isfinite(res[0][0].float()).all())
