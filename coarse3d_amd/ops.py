@@ -319,9 +319,10 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
             # nine taps: the fused kernel (round 3), four taps: the phased one; CONV_VARIANT & 4 forces the phased one
             fused_ = nt_ == 9 and not (CONV_VARIANT & 4)
-            # (names as rocprofv3 prints them: the fused kernel carries its plane count as a fifth template argument)
+            # (names as rocprofv3 prints them: the fused kernel carries its plane count and its bf16-source flag as fifth and
+            #  sixth template arguments)
             name = (f"conv_x3{'f' if fused_ else ''}_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, {nt_}, "
-                    f"{'true' if grad else 'false'}{', 3' if fused_ else ''}>")
+                    f"{'true' if grad else 'false'}{', 3, false' if fused_ else ''}>")
         elif (MFMA_MODE == 1 and tr == 8 and nt_ == 9 and d.wpack_planes and not (CONV_VARIANT & 4)
               and all(s.t.dtype == torch.bfloat16 for s in srcs)):      # the fused nine-tap kernel with one plane (csrc/conv_x3.hip)
             name = f"conv_x3f_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, 9, true, 1, true>"

@@ -288,3 +288,30 @@ def test_bench_line_carries_the_contract_fields_and_both_launch_modes():
     line_off = json.loads(off.stdout.strip().splitlines()[-1])
     assert "launch_by_launch" not in line_off and "launch" not in line_off["config"] and line_off["value"] > 0
     assert line_off["config"]["final_loss"] == line["config"]["final_loss"]       # the same first pass
+
+
+def test_bench_stdout_is_one_json_line_and_a_stalled_captured_pass_leaves_the_eager_line():
+    """bench.py in a 1-rank RCCL group (RCCL prints a version banner to stdout at its first collective: the process's
+    stdout must still be the ONE JSON line), and the guard of the captured data-parallel pass: with C3D_CAPTURE_TIMEOUT
+    shorter than a capture the run ends with exit code 0 and the line of the launch-by-launch pass it had measured."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--height", "32",
+           "--width", "256", "--no-cpu-baseline", "--no-kernel-events", "--no-second-engine", "--no-configs"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", HSA_ENABLE_IPC_MODE_LEGACY="0", C3D_SINGLE_RANK_COLLECTIVES="1")
+    ok = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    lines = [ln for ln in ok.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:-1]
+    full = json.loads(lines[0])
+    assert "hipGraph" in full["config"]["launch"] and full["config"]["collectives_per_step"]["in_captured_step"] > 0
+    stalled = subprocess.run(cmd, env=dict(env, C3D_CAPTURE_TIMEOUT="0.05", MASTER_PORT="29742"), capture_output=True, text=True, timeout=600)
+    assert stalled.returncode == 0, stalled.stderr[-2000:]
+    lines = [ln for ln in stalled.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    short = json.loads(lines[0])
+    assert "abandoned" in short["config"]["launch"] and "launch_by_launch" not in short
+    assert short["value"] == full["launch_by_launch"]["value"] or short["value"] > 0
+    assert short["config"]["final_loss"] == full["config"]["final_loss"]
