@@ -148,8 +148,15 @@ __device__ __forceinline__ void c3d_wg_static_for(F&& f) {
 // it out for the input-gradient convolution that follows (workgroups of cin slice 0 only) and keep its per-channel sums
 // (the bias gradient).  The separate c3d_bn_bwd_apply pass (three tensor passes at HBM speed, the largest kernel of the
 // round-3 step) disappears; the arithmetic is the same fmaf chain, dz is bit-identical.
-template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool FA = false>
+// RAW (round 4, the bf16 engine over bf16 tensors): the tiles in flight travel as the 8 bytes per unit they are loaded as -- half
+// the registers of the widened values -- and FOUR tiles are kept in flight instead of two.  A tile of this mode is 8-16 KB of
+// loads; with two in flight per workgroup the weight gradients of this engine took exactly as long as on fp32 tensors (122 us
+// for the 64 -> 64 1x1 layer at 8 x 64 x 2048 either way: 2.2 vs 4.4 TB/s), bound by requests in flight, not by bytes.
+template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool FA = false, bool RAW = false>
 __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
+  static_assert(!RAW || (NP == 1 && !FA), "raw bf16 stages belong to the one-plane engine without the fused apply");
+  constexpr int DEPTH = RAW ? 4 : 2;   // tiles the producer waves keep in flight (register sets)
+  using SU = std::conditional_t<RAW, u32x2, f32x4>;   // a staged unit in flight: four bf16 as loaded, or four floats
   constexpr int WK = 4 / (WCI * WCO);
   constexpr int CI = 32 * CI_T * WCI;  // cin slice of the workgroup
   constexpr int CO = 32 * CO_T * WCO;  // cout slice of the workgroup
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   // one register set per tile in flight; the producers keep TWO tiles of loads outstanding (one
   // tile per CU in flight left the kernel bound by memory latency)
   struct Stage {
-    f32x4 px[X_PT], pd[D_PT];
+    SU px[X_PT], pd[D_PT];
     f32x4 pa[FA ? D_PT : 1];   // FA: the layer's stored output at the dz units (pd then holds dy)
     unsigned inb;   // units of px that came from inside the image (the others are zero padding)
     unsigned dmask; // same for pd
@@ -302,7 +309,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     }
     lb = mt / (a.tiles_x * a.tiles_y);
   };
-  auto load_tile = [&](Stage& sg) {
+  // (always_inline: with four register sets there are ~18 call sites, and a call that is not inlined puts the sets in scratch)
+  auto load_tile = [&](Stage& sg) __attribute__((always_inline)) {
     const int x0 = ltx * 32, y0 = lty * TRW, b = lb;
     // RINGX: a tile right below its predecessor in the strip stages only its TRW new rows (image rows y0 + HALO ...)
     const bool fresh = !RINGX || lfirst || lty == 0;
@@ -367,7 +375,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
         int off;
         if constexpr (HALO > 0) off = xt + (int)xoff[i];
         else off = xt + (((i * XSTEP) / 32) * a.W + (i * XSTEP) % 32) * a.x.cstride + (int)xoff[0];
-        sg.px[i] = c3d_ld4u<XBF>(a.x.ptr, ximg, ((xmask >> i) & 1u) ? (unsigned)off : 0u);
+        const unsigned o2 = ((xmask >> i) & 1u) ? (unsigned)off : 0u;
+        if constexpr (RAW) {
+          const char* bp = c3d_uniform_ptr(reinterpret_cast<const unsigned short*>(a.x.ptr) + ximg);
+          sg.px[i] = __builtin_bit_cast(u32x2, *(const __attribute__((address_space(1))) c3d_u32x2*)(bp + (size_t)(o2 * 2u)));
+        } else {
+          sg.px[i] = c3d_ld4u<XBF>(a.x.ptr, ximg, o2);
+        }
       }
     };
     auto load_dz = [&](auto bf_tag) {
@@ -379,7 +393,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
 #pragma unroll
       for (int i = 0; i < D_PT; ++i) {
         const int off = dt + (((i * DSTEP) / 32) * a.W + (i * DSTEP) % 32) * a.dz_cstride + (int)doff0;
-        if constexpr (FA) {
+        if constexpr (RAW) {
+          const char* bp = c3d_uniform_ptr(reinterpret_cast<const unsigned short*>(a.dz) + dimg);
+          const unsigned o2 = ((dmask >> i) & 1u) ? (unsigned)off : 0u;
+          sg.pd[i] = __builtin_bit_cast(u32x2, *(const __attribute__((address_space(1))) c3d_u32x2*)(bp + (size_t)(o2 * 2u)));
+        } else if constexpr (FA) {
           const unsigned o2 = ((dmask >> i) & 1u) ? (unsigned)off : 0u;
           sg.pd[i] = c3d_ld4u<false>(a.f_dy, dimg, o2);
           sg.pa[i] = c3d_ld4u<false>(a.f_act, dimg, o2);
@@ -396,12 +414,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
         }
       }
     };
-    if (NP == 1 && a.x.bf16) load_x(std::true_type{});
-    else load_x(std::false_type{});
-    if (NP == 1 && a.dz_bf16) load_dz(std::true_type{});
-    else load_dz(std::false_type{});
+    if constexpr (RAW) {
+      load_x(std::true_type{});
+      load_dz(std::true_type{});
+    } else {
+      if (NP == 1 && a.x.bf16) load_x(std::true_type{});
+      else load_x(std::false_type{});
+      if (NP == 1 && a.dz_bf16) load_dz(std::true_type{});
+      else load_dz(std::false_type{});
+    }
   };
-  auto store_tile = [&](int buf, const Stage& sg) {
+  auto store_tile = [&](int buf, const Stage& sg) __attribute__((always_inline)) {
     unsigned short* s_x = RINGX ? s_base : s_base + buf * BUF;
     unsigned short* s_dz = RINGX ? s_base + NP * XPLANE + buf * (NP * DROWS * CO) : s_x + NP * XROWS * CI;
     // RINGX: first ring slot the staged rows go to (a whole window, or the TRW rows behind the rows kept from the tile above)
@@ -411,7 +434,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     for (int i = 0; i < X_PT; ++i) {
       const int u = tid + i * 256;
       if (u < xunits) {
-        f32x4 v = sg.px[i];
+        f32x4 v;
+        if constexpr (RAW) {
+          v = f32x4{__uint_as_float(sg.px[i][0] << 16), __uint_as_float(sg.px[i][0] & 0xffff0000u), __uint_as_float(sg.px[i][1] << 16),
+                    __uint_as_float(sg.px[i][1] & 0xffff0000u)};
+        } else {
+          v = sg.px[i];
+        }
         if (aff) v = v * psc + psh;
         if (lr) {
 #pragma unroll
@@ -437,7 +466,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
       const int u = tid + i * 256;
       if (u < D_UNITS) {
         u32x2 pl[NP];
-        if constexpr (FA) {
+        if constexpr (RAW) {
+          const bool in = (sg.dmask >> i) & 1u;
+          pl[0] = u32x2{in ? sg.pd[i][0] : 0u, in ? sg.pd[i][1] : 0u};
+        } else if constexpr (FA) {
           const bool in = (sg.dmask >> i) & 1u;
           f32x4 t;
 #pragma unroll
@@ -456,11 +488,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
             *reinterpret_cast<f32x4*>(ob + off) = t;
           }
           split_planes<NP>(t, pl);
-        } else if (NP == 1 && a.dz_bf16) {       // raw bf16 (load_dz)
-          const bool in = (sg.dmask >> i) & 1u;
-          pl[0] = u32x2{in ? __float_as_uint(sg.pd[i][0]) : 0u, in ? __float_as_uint(sg.pd[i][1]) : 0u};
         } else {
-          split_planes<NP>(((sg.dmask >> i) & 1u) ? (NP == 2 ? sg.pd[i] * dsc : sg.pd[i]) : f32x4{0.f, 0.f, 0.f, 0.f}, pl);
+          if (NP == 1 && a.dz_bf16) {       // raw bf16 in the first two lanes (load_dz)
+            const bool in = (sg.dmask >> i) & 1u;
+            pl[0] = u32x2{in ? __float_as_uint(sg.pd[i][0]) : 0u, in ? __float_as_uint(sg.pd[i][1]) : 0u};
+          } else {
+            split_planes<NP>(((sg.dmask >> i) & 1u) ? (NP == 2 ? sg.pd[i] * dsc : sg.pd[i]) : f32x4{0.f, 0.f, 0.f, 0.f}, pl);
+          }
         }
         const int o = tr_swz<NSD>(u / (CO / 4), (u % (CO / 4)) * 4);
 #pragma unroll
@@ -479,6 +513,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   // ---- producer waves: stage tile mt+1 while the consumers work on tile mt; they take part in
   //      every barrier of the consumer path below (tile loop + K-split fold) and nothing else
   if (producer) {
+   if constexpr (DEPTH == 2) {
     Stage sa, sb;      // tile n of the strip travels through set / LDS buffer (n - t_begin) & 1
     int mt = t_begin;
     if (t_end - t_begin >= 5) {
@@ -524,6 +559,57 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
       __syncthreads();
       ++mt;
     }
+   } else {
+    // DEPTH register sets: tile n of the strip (relative index) travels through set n % DEPTH and LDS buffer n & 1; while the
+    // consumers work on tile r, tiles r + 1 ... r + DEPTH are loaded or in flight.  Same barrier count as above: one in front
+    // of the tile loop, one per tile.
+    static_assert(DEPTH % 2 == 0, "the LDS buffer of a tile is its index's parity");
+    Stage st[DEPTH];
+    int mt = t_begin;
+    if (t_end - t_begin > 2 * DEPTH) {
+      // long strips: no condition around a load (counted waits, see above)
+      seek_tile(t_begin);
+      c3d_wg_static_for<0, DEPTH>([&](auto k_tag) { load_tile(st[decltype(k_tag)::value]); });
+      store_tile(0, st[0]);
+      load_tile(st[0]);
+      __syncthreads();
+      while (mt + 2 * DEPTH < t_end) {      // DEPTH tiles per trip; the last load of a trip is tile mt + 2 * DEPTH
+        c3d_wg_static_for<1, DEPTH + 1>([&](auto j_tag) {
+          constexpr int J = decltype(j_tag)::value;
+          store_tile(J & 1, st[J % DEPTH]);
+          load_tile(st[J % DEPTH]);
+          __syncthreads();
+        });
+        mt += DEPTH;
+      }
+    } else {
+      if (t_begin < t_end) {
+        seek_tile(t_begin);
+        load_tile(st[0]);
+        c3d_wg_static_for<1, DEPTH>([&](auto k_tag) {
+          constexpr int K = decltype(k_tag)::value;
+          if (t_begin + K < t_end) load_tile(st[K]);
+        });
+        store_tile(0, st[0]);
+        if (t_begin + DEPTH < t_end) load_tile(st[0]);
+      }
+      __syncthreads();
+    }
+    // tail (mt - t_begin is a multiple of DEPTH here): the same steps with every store / load under its test
+    while (mt < t_end) {
+      c3d_wg_static_for<1, DEPTH + 1>([&](auto j_tag) {
+        constexpr int J = decltype(j_tag)::value;
+        if (mt < t_end) {
+          if (mt + 1 < t_end) {
+            store_tile(J & 1, st[J % DEPTH]);
+            if (mt + 1 + DEPTH < t_end) load_tile(st[J % DEPTH]);
+          }
+          __syncthreads();
+          ++mt;
+        }
+      });
+    }
+   }
     if constexpr (FA) {
       // per-thread sums of dz over the strip: [Cout][2][strips * DSTEP], row 0 (the launch's fold adds them in fp64)
       if (fwrite) {
@@ -723,6 +809,14 @@ int launch_tr(const WgradArgs& a, hipStream_t st) {
       }
       c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true>>();
       hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true>), grid, dim3(512), lds, st, a);
+      C3D_CHECK_LAUNCH();
+      return 0;
+    }
+  }
+  if constexpr (NP == 1) {
+    if (a.x.bf16 && a.dz_bf16 && !a.f_dy) {       // bf16 tensors on both sides: raw stages, four tiles in flight
+      c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, true>>();
+      hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, true>), grid, dim3(512), lds, st, a);
       C3D_CHECK_LAUNCH();
       return 0;
     }

@@ -364,7 +364,7 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     return out, stat_partial
 
 
-def _wgrad_kernel_name(ci, co, nt, halo, fused=False):
+def _wgrad_kernel_name(ci, co, nt, halo, fused=False, raw=False):
     """Mirrors c3d_wgrad_cfg() (csrc/wgrad_common.h) and the launch tables of wgrad_mfma.hip / wgrad_tr.hip."""
     tr = MFMA_MODE != 0
     hl = 1 if halo <= 1 else 2
@@ -379,8 +379,10 @@ def _wgrad_kernel_name(ci, co, nt, halo, fused=False):
             cfg = f"4, 1, 2, 1, 1, {2 if x3 else 4}, {hl}" if co > 32 else f"4, 1, 1, 1, 1, 4, {hl}"
     else:
         cfg = f"9, 1, 1, 1, 2, {4 if (tr and not x3) else 2}, {hl}" if co > 32 else f"9, 1, 1, 1, 1, 4, {hl}"
-    if tr:       # (the ninth template argument: BatchNorm backward applied on load, conv_wgrad(fuse=...))
-        return f"wgrad_tr_kernel<{3 if MFMA_MODE == 2 else 1}, {cfg}, {'true' if fused else 'false'}>"
+    if tr:       # (ninth template argument: BatchNorm backward applied on load, conv_wgrad(fuse=...); tenth: raw bf16 stages, four
+        # tiles in flight -- the bf16 engine with bf16 tensors on both sides)
+        return (f"wgrad_tr_kernel<{3 if MFMA_MODE == 2 else 1}, {cfg}, {'true' if fused else 'false'}, "
+                f"{'true' if (raw and MFMA_MODE == 1 and not fused) else 'false'}>")
     return f"wgrad_mfma_kernel<{cfg}, {'true' if MFMA_MODE == 1 else 'false'}>"
 
 
@@ -446,7 +448,8 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_p
         return dw
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
     co, ci, nt = dw.shape[0], src.C, len(taps)
-    name = _wgrad_kernel_name(ci, co, nt, halo, fused=fuse is not None)
+    name = _wgrad_kernel_name(ci, co, nt, halo, fused=fuse is not None,
+                              raw=src.t.dtype == torch.bfloat16 and dz.dtype == torch.bfloat16)
     with _Timed(name, 2.0 * b * h * w * dw.shape[0] * len(taps) * src.C, (h, w, ci, co, nt, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
     if d.fold_out:
