@@ -264,6 +264,8 @@ def peak_for(kernel_name):
     targs = [t.strip() for t in kernel_name[len(base) + 1:].rstrip(">").split(",")] if "<" in kernel_name else []
     if base == "conv_pw3f_kernel":       # <NT, WN>: the fused bf16x3 kernel, six plane products
         return PEAK_BF16_MFMA_TFLOPS / 6.0
+    if base == "conv_pw1_kernel":        # <NT>: the bf16 engine's wide 1x1 kernel, one product
+        return PEAK_BF16_MFMA_TFLOPS
     if base == "conv_pw3_kernel":        # <NT, NP>; NP = 3 runs six plane products
         return PEAK_BF16_MFMA_TFLOPS / 6.0 if targs[1] == "3" else PEAK_BF16_MFMA_TFLOPS
     if base in ("conv_x3_kernel", "conv_x3f_kernel"):   # <NT, HALO, TT, SIX[, planes]>

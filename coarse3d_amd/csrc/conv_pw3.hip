@@ -32,6 +32,15 @@
 
 namespace {
 
+template <int I, int N, class F>
+__device__ __forceinline__ void c3d_pw_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    c3d_pw_static_for<I + 1, N>(f);
+  }
+}
+
+
 // NP = 3: bf16x3 (exact split, eight plane products).  NP = 1: "bf16" mode -- operands rounded to
 // bf16 (the h plane of the pack IS the RNE-rounded weight), one product, fp32 or bf16 tensors.
 template <int NT, int NP>
@@ -242,6 +251,205 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
   }
   conv_epilogue<TR, NT, WM, WN, NP == 1, true, 512, true, NP == 3>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
                                                   tile_pix);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Round 4, the `bf16` engine over bf16 tensors (BASELINE configs[2]): conv_pw3_kernel<NT, 1>'s tile, LDS image, rounding
+// points and accumulation order (outputs bit-identical, tests/test_gpu_bf16_storage.py) with FOUR K chunks in flight.
+// One plane makes a chunk 8 MFMAs per wave (0.1 us) against 8 KB of input and 8 KB of weights per workgroup, and there is
+// one workgroup per CU: with one chunk in flight every chunk cost a memory latency (192 -> 704 at 8 x 32 x 1024: 12 chunks and
+// 26 us per workgroup, 320 us for 470 MB).  The raw units are cheap to keep (8 bytes: two registers), so chunks c + 1 ...
+// c + 4 are in flight while chunk c is multiplied: a ring of four register sets by chunk index, every load a buffer load
+// whose offset goes out of range past the last chunk (no traffic, no condition around a load: the waits stay counted), the
+// trip count rounded up to a multiple of four (a chunk of zeros adds nothing).  The on-load transform reads scale / shift /
+// LeakyReLU slope of its four channels from a table in LDS (one formula for every source: fma(x, scale, shift), then
+// max(v, v * slope) with slope 1 where there is no activation -- the values the phased kernel computes).
+template <int NT>
+__global__ __launch_bounds__(512, 1) void conv_pw1_kernel(ConvArgs a) {
+  constexpr int TR = 8, CQ = 4;                    // 16 channels per K chunk
+  constexpr int TN = 32 * NT;
+  constexpr int WM = 4, WN = 2, RPW = 2, NPW = NT / WN;
+  constexpr int IN_ROWS = TR * 32;
+  constexpr int IN_PT = IN_ROWS * CQ / 512;        // 2
+  constexpr int W_PT = TN * CQ / 512;              // 2 (NT = 8) or 1 (NT = 4)
+  constexpr int BUF = (IN_ROWS + TN) * 16;         // bf16 elements per LDS buffer
+  constexpr int DEPTH = 4;                         // chunks in flight (register sets)
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short* s_base = reinterpret_cast<unsigned short*>(smem);   // 2 x { [IN_ROWS][16], [TN][16] }, then the affine table
+  const int K = a.Kq * 4;
+  float* s_aff = reinterpret_cast<float*>(s_base + 2 * BUF);          // [3][K]: scale, shift, slope per input channel
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave % WM, wn = wave / WM;
+
+  const int ntile = a.B * a.tiles_y * a.tiles_x;
+  const int logical = c3d_xcd_remap(blockIdx.x, ntile * a.ntn);
+  const int mt = logical / a.ntn;
+  const int n0 = (logical % a.ntn) * TN;
+  const int tx = mt % a.tiles_x;
+  const int ty = (mt / a.tiles_x) % a.tiles_y;
+  const int b = mt / (a.tiles_x * a.tiles_y);
+  const int x0 = tx * 32, y0 = ty * TR;
+
+  f32x16 acc[RPW][NPW];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i)
+#pragma unroll
+    for (int j = 0; j < NPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- the affine table
+  {
+    int k0 = 0;
+    for (int s = 0; s < a.nsrc; ++s) {
+      const c3d_src& sr = a.src[s];
+      for (int k = tid; k < sr.C; k += 512) {
+        s_aff[k0 + k] = sr.scale ? sr.scale[k] : 1.f;
+        s_aff[K + k0 + k] = sr.scale ? sr.shift[k] : 0.f;
+        s_aff[2 * K + k0 + k] = sr.lrelu ? a.slope : 1.f;
+      }
+      k0 += sr.C;
+    }
+  }
+
+  // ---- load cursor: buffer loads, one 32-bit offset per unit (pixels beyond the image and couts beyond Cout are CLAMPED
+  //      to valid ones as in the phased kernel: their products only reach outputs the epilogue masks)
+  const int c4 = tid % CQ;
+  const size_t tile_pix = (size_t)(b * a.H + y0) * a.W + x0;
+  int pixrel[IN_PT];
+#pragma unroll
+  for (int i = 0; i < IN_PT; ++i) {
+    const int p = tid / CQ + i * (512 / CQ);
+    const int gx = min(x0 + (p & 31), a.W - 1), gy = min(y0 + (p >> 5), a.H - 1);
+    pixrel[i] = (gy - y0) * a.W + (gx - x0);
+  }
+  const unsigned wplane_b = (unsigned)a.Kq * a.Cout * 8;                        // bytes of a bf16 weight plane (T = 1)
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.wpack) + (size_t)a.Kq * a.Cout * 4, 0, wplane_b, 0x00020000);     // plane 0, behind the fp32 image
+  unsigned vw[W_PT];
+#pragma unroll
+  for (int i = 0; i < W_PT; ++i) {
+    const int u = tid + i * 512;
+    const int n = min(n0 + u % TN, a.Cout - 1), kq = u / TN;
+    vw[i] = (unsigned)((kq * a.Cout + n) * 8);
+  }
+  __amdgpu_buffer_rsrc_t rs_in;
+  unsigned vin[IN_PT];
+  int ls = 0, lc0 = 0, lC = 0, lk = 0;
+  unsigned lpast = 0;                      // all ones once the cursor is past the last chunk: loads then read nothing
+  const unsigned img_bytes_per_c = (unsigned)a.B * a.H * a.W * 2;
+  auto open_src = [&](int s) {
+    const c3d_src& sr = a.src[s];
+    rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sr.ptr), 0, img_bytes_per_c * sr.cstride, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < IN_PT; ++i) vin[i] = (unsigned)(((tile_pix + pixrel[i]) * sr.cstride + sr.coff + c4 * 4) * 2);
+    lC = sr.C;
+    lc0 = 0;
+  };
+  open_src(0);
+  const int nchunks = a.Kq / 4;            // K / 16
+  u32x2 pin[DEPTH][IN_PT], pw[DEPTH][W_PT];
+  auto load_chunk = [&](auto slot_tag) __attribute__((always_inline)) {      // the cursor's chunk into set `slot`, then the cursor moves on
+    constexpr int S = decltype(slot_tag)::value;
+#pragma unroll
+    for (int i = 0; i < IN_PT; ++i) pin[S][i] = __builtin_amdgcn_raw_buffer_load_b64(rs_in, vin[i] | lpast, lc0 * 2, 0);
+#pragma unroll
+    for (int i = 0; i < W_PT; ++i) pw[S][i] = __builtin_amdgcn_raw_buffer_load_b64(rs_w, vw[i] | lpast, lk * a.Cout * 32, 0);
+    if (lk + 1 < nchunks) {
+      ++lk;
+      lc0 += 16;
+      if (lc0 >= lC) open_src(++ls);
+    } else {
+      lpast = 0xffffffffu;
+    }
+  };
+  int sk = 0;                              // first channel of the chunk the next store_chunk writes
+  auto store_chunk = [&](int buf, auto slot_tag) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_tag)::value;
+    unsigned short* s_in = s_base + buf * BUF;
+    unsigned short* s_w = s_in + IN_ROWS * 16;
+    const int ka = min(sk, K - 16) + c4 * 4;                 // (chunks of the rounded-up trip count: any valid row of the table)
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(s_aff + ka);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(s_aff + K + ka);
+    const f32x4 sl = *reinterpret_cast<const f32x4*>(s_aff + 2 * K + ka);
+    sk += 16;
+#pragma unroll
+    for (int i = 0; i < IN_PT; ++i) {
+      const u32x2 r = pin[S][i];
+      f32x4 v = f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+                      __uint_as_float(r[1] & 0xffff0000u)};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float t = __builtin_fmaf(v[q], sc[q], sh[q]);
+        v[q] = __builtin_fmaxf(t, t * sl[q]);
+      }
+      u32x2 pl[1];
+      split4_planes<1>(v, pl);
+      const int R = tid / CQ + i * (512 / CQ);
+      *reinterpret_cast<u32x2*>(s_in + R * 16 + swz_quad(R, c4)) = pl[0];
+    }
+#pragma unroll
+    for (int i = 0; i < W_PT; ++i) {
+      const int u = tid + i * 512;
+      const int R = u % TN, kq = u / TN;
+      *reinterpret_cast<u32x2*>(s_w + R * 16 + swz_quad(R, kq)) = pw[S][i];
+    }
+  };
+
+  // live 32-wide cout sub-tiles of this tile, dealt alternately to the two cout wave groups
+  const int live = min(NT, (a.Cout - n0 + 31) / 32);
+  const int nj = (live - wn + WN - 1) / WN;
+  auto mfma_chunk = [&](int buf, auto nj_tag) {
+    constexpr int NJ = decltype(nj_tag)::value;
+    const unsigned short* s_in = s_base + buf * BUF;
+    const unsigned short* s_w = s_in + IN_ROWS * 16;
+    bf16x8 ap[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int R = (wm + i * WM) * 32 + l31;
+      ap[i] = *reinterpret_cast<const bf16x8*>(s_in + R * 16 + swz_half(R, half));
+    }
+    bf16x8 bp[2];
+    auto load_b = [&](int j) {
+      const int R = (j * WN + wn) * 32 + l31;
+      bp[j & 1] = *reinterpret_cast<const bf16x8*>(s_w + R * 16 + swz_half(R, half));
+    };
+    if (NJ > 0) load_b(0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (j + 1 < NJ) load_b(j + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i], bp[j & 1], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- prologue: chunks 0 .. DEPTH - 1 requested, chunk 0 staged, chunk DEPTH requested into its set
+  c3d_pw_static_for<0, DEPTH>([&](auto d_tag) { load_chunk(d_tag); });
+  __syncthreads();                         // the affine table is complete
+  store_chunk(0, std::integral_constant<int, 0>{});
+  load_chunk(std::integral_constant<int, 0>{});
+  __syncthreads();
+  for (int c0 = 0; c0 < nchunks; c0 += DEPTH) {
+    c3d_pw_static_for<0, DEPTH>([&](auto j_tag) {
+      constexpr int J = decltype(j_tag)::value;           // chunk c0 + J: LDS buffer J & 1 (DEPTH is even), register set J
+      constexpr int cur = J & 1;
+      using next_set = std::integral_constant<int, (J + 1) % DEPTH>;
+      store_chunk(cur ^ 1, next_set{});    // chunk c0 + J + 1 (zeros past the end), requested DEPTH chunks ago
+      load_chunk(next_set{});              // chunk c0 + J + 1 + DEPTH
+      if (nj >= NPW) mfma_chunk(cur, std::integral_constant<int, NPW>{});
+      else if (NPW > 3 && nj == 3) mfma_chunk(cur, std::integral_constant<int, (NPW > 3 ? 3 : 1)>{});
+      else if (NPW > 2 && nj == 2) mfma_chunk(cur, std::integral_constant<int, (NPW > 2 ? 2 : 1)>{});
+      else if (nj == 1) mfma_chunk(cur, std::integral_constant<int, 1>{});
+      __syncthreads();                     // the other buffer is complete, this one is free again
+    });
+  }
+  conv_epilogue<TR, NT, WM, WN, true, true, 512, true, false>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -568,6 +776,19 @@ int launch_pw3f(ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
+template <int NT>
+int launch_pw1(ConvArgs& a, hipStream_t st) {
+  size_t lds = (size_t)2 * (8 * 32 + 32 * NT) * 16 * 2 + (size_t)3 * a.Kq * 4 * sizeof(float);    // two buffers + the affine table
+  const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
+  if (lds < red) lds = red;
+  c3d_opt_in_lds<&conv_pw1_kernel<NT>>();
+  a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
+  dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
+  hipLaunchKernelGGL((conv_pw1_kernel<NT>), grid, dim3(512), lds, st, a);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int NT, int NP>
 int launch_pw3(ConvArgs& a, hipStream_t st) {
   size_t lds = (size_t)2 * NP * (8 * 32 + 32 * NT) * 16 * 2;
@@ -601,5 +822,9 @@ int c3d_conv_forward_pw3(ConvArgs& a, int planes, bool wide, hipStream_t st) {
     }
     return wide ? launch_pw3<8, 3>(a, st) : launch_pw3<4, 3>(a, st);
   }
+  // one plane: over bf16 tensors the kernel with four chunks in flight (c3d_conv_desc.variant & 3 == 3: the phased one)
+  bool all_bf = (a.variant & 3) != 3;
+  for (int s = 0; s < a.nsrc; ++s) all_bf = all_bf && a.src[s].bf16 != 0;
+  if (all_bf) return wide ? launch_pw1<8>(a, st) : launch_pw1<4>(a, st);
   return wide ? launch_pw3<8, 1>(a, st) : launch_pw3<4, 1>(a, st);
 }

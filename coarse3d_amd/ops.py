@@ -261,12 +261,13 @@ def _pw3_tile(b, h, w, cout):
     return 0
 
 
-def _pw3_kernel_name(nt, k, cout):
+def _pw3_kernel_name(nt, k, cout, bf16_srcs=False):
     """Kernel instance c3d_conv_forward_pw3() launches (csrc/conv_pw3.hip): bf16x3 runs the fused kernel
     conv_pw3f_kernel<NT, WN> -- WN = 2: eight waves, WN = 1: four waves x 128 couts, two workgroups per CU
-    (short K, couts a multiple of 128) -- the "bf16" mode round 2's conv_pw3_kernel<NT, 1>."""
+    (short K, couts a multiple of 128) -- the "bf16" mode conv_pw1_kernel<NT> over bf16 tensors (four chunks in flight),
+    else round 2's conv_pw3_kernel<NT, 1>."""
     if MFMA_MODE != 2:
-        return f"conv_pw3_kernel<{nt}, 1>"
+        return f"conv_pw1_kernel<{nt}>" if (bf16_srcs and (CONV_VARIANT & 3) != 3) else f"conv_pw3_kernel<{nt}, 1>"
     mode = CONV_VARIANT & 3
     if mode == 3:
         return f"conv_pw3_kernel<{nt}, 3>"
@@ -327,7 +328,8 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
               and all(s.t.dtype == torch.bfloat16 for s in srcs)):      # the fused nine-tap kernel with one plane (csrc/conv_x3.hip)
             name = f"conv_x3f_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, 9, true, 1, true>"
         elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
-            name = _pw3_kernel_name(_pw3_tile(b, h, w, cout), sum(s.C for s in srcs), cout)
+            name = _pw3_kernel_name(_pw3_tile(b, h, w, cout), sum(s.C for s in srcs), cout,
+                                    bf16_srcs=all(s.t.dtype == torch.bfloat16 for s in srcs))
         elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
             np_ = 3 if MFMA_MODE == 2 else 1
             wide_ = _wide_cout_tiles(b, h, w, cout, tr)

@@ -198,3 +198,45 @@ def test_fused_nine_tap_kernel_with_one_plane_is_bit_identical(b, h, w, srcs, co
     assert torch.equal(res[0][0], res[4][0]), float((res[0][0].float() - res[4][0].float()).abs().max())
     assert torch.equal(res[0][1], res[4][1])
     assert bool(torch.isfinite(res[0][0].float()).all())
+
+
+@pytest.mark.parametrize("b,h,w,srcs,cout,acc", [
+    (2, 16, 95, (64,), 96, False),          # ragged pixel tile, 128-cout tiles with a ragged last sub-tile
+    (1, 8, 160, (64, 128), 704, False),     # two sources, 256-cout tiles (256 + 256 + 192), twelve chunks
+    (2, 8, 64, (48,), 160, False),          # three chunks: the trip count is rounded up to four (a chunk of zeros)
+    (1, 16, 128, (704,), 256, True),        # 44 chunks, accumulating launch (an input gradient into an existing one)
+    (4, 32, 128, (16,), 272, False),        # one chunk
+])
+def test_wide_pointwise_kernel_with_four_chunks_in_flight_is_bit_identical(b, h, w, srcs, cout, acc):
+    """The bf16 engine's 1x1 convs with more than 64 outputs over bf16 tensors run conv_pw1_kernel (round 4: four K chunks in
+    flight in raw registers, buffer loads, affine table in LDS); c3d_conv_desc.variant & 3 == 3 keeps round 2's phased
+    conv_pw3_kernel<NT, 1>.  Same rounding points and accumulation order: the same bits."""
+    from coarse3d_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(17)
+    xs = [torch.randn(b, h, w, c, device=DEV, generator=g).bfloat16() for c in srcs]
+    cin = sum(srcs)
+    wt = torch.randn(cout, cin, 1, 1, device=DEV, generator=g) / cin ** 0.5
+    bias = torch.randn(cout, device=DEV, generator=g) * 0.1
+    taps = [(0, 0)]
+    wp = ops.pack_weights(wt, 0)
+    assert wp.c3d_planes
+    sources = []
+    for i, x in enumerate(xs):
+        if i == 0:       # BatchNorm affine + LeakyReLU on load
+            sources.append(ops.Source(x, torch.rand(x.shape[3], device=DEV, generator=g) + 0.5,
+                                      torch.randn(x.shape[3], device=DEV, generator=g) * 0.2, lrelu=True))
+        else:            # a plain tensor
+            sources.append(ops.Source(x))
+    out0 = torch.randn(b, h, w, cout, device=DEV, generator=g).bfloat16()
+    res = {}
+    for variant in (0, 3):
+        ops.CONV_VARIANT = variant
+        try:
+            out = out0.clone()
+            y, p = ops.conv_forward(sources, wp, bias, cout, taps, lrelu=True, stats=True, out=out, accumulate=acc)
+        finally:
+            ops.CONV_VARIANT = 0
+        res[variant] = (y.clone(), p.clone())
+    assert torch.equal(res[0][0], res[3][0]), float((res[0][0].float() - res[3][0].float()).abs().max())
+    assert torch.equal(res[0][1], res[3][1])
+    assert bool(torch.isfinite(res[0][0].float()).all())
