@@ -240,3 +240,28 @@ def test_wide_pointwise_kernel_with_four_chunks_in_flight_is_bit_identical(b, h,
     assert torch.equal(res[0][0], res[3][0]), float((res[0][0].float() - res[3][0].float()).abs().max())
     assert torch.equal(res[0][1], res[3][1])
     assert bool(torch.isfinite(res[0][0].float()).all())
+
+
+@pytest.mark.parametrize("k,dil,srcs,cout", [(1, 1, (64, 128), 704), (1, 1, (32,), 48), (3, 2, (32,), 64), (3, 1, (48,), 80), (2, 2, (64,), 64)])
+def test_bf16_output_stores_match_the_fp32_output_of_the_same_kernel(k, dil, srcs, cout):
+    """bf16 outputs leave the conv epilogue as 4-byte stores (the lanes of a cout pair swap one value per register pair); the
+    same launch with an fp32 output tensor takes the plain stores.  Equal up to the final rounding, every element in place --
+    fresh and accumulating launches, ragged pixel and cout tiles."""
+    from coarse3d_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(23)
+    b, h, w = 2, 16, 95
+    xs = [torch.randn(b, h, w, c, device=DEV, generator=g).bfloat16() for c in srcs]
+    cin = sum(srcs)
+    wt = torch.randn(cout, cin, k, k, device=DEV, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, device=DEV, generator=g) * 0.1
+    taps = ops.conv_taps(k, k, dil, dil if k == 3 else (1 if k == 2 else 0))
+    wp = ops.pack_weights(wt, 0)
+    sources = [ops.Source(x, torch.rand(x.shape[3], device=DEV, generator=g) + 0.5, torch.randn(x.shape[3], device=DEV, generator=g) * 0.2)
+               for x in xs]
+    for acc in (False, True):
+        o0 = r16(torch.randn(b, h, w, cout + 16, device=DEV, generator=g))        # a wider tensor: channel offset 16
+        o32, o16 = o0.clone(), o0.bfloat16()
+        ops.conv_forward(sources, wp, bias, cout, taps, lrelu=True, out=o32, out_coff=16, accumulate=acc)
+        ops.conv_forward(sources, wp, bias, cout, taps, lrelu=True, out=o16, out_coff=16, accumulate=acc)
+        close16(o16[..., 16:], o32[..., 16:], f"bf16 stores, accumulate={acc}")
+        assert torch.equal(o16[..., :16].float(), o0[..., :16])                     # nothing written beside the slice
