@@ -322,8 +322,9 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
             fused_ = nt_ == 9 and not (CONV_VARIANT & 4)
             # (names as rocprofv3 prints them: the fused kernel carries its plane count and its bf16-source flag as fifth and
             #  sixth template arguments)
+            six_ = grad or b * h * w >= SIX_FWD_MIN_PIXELS          # (the fourth template argument: six plane products)
             name = (f"conv_x3{'f' if fused_ else ''}_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, {nt_}, "
-                    f"{'true' if grad else 'false'}{', 3, false' if fused_ else ''}>")
+                    f"{'true' if six_ else 'false'}{', 3, false' if fused_ else ''}>")
         elif (MFMA_MODE == 1 and tr == 8 and nt_ == 9 and d.wpack_planes and not (CONV_VARIANT & 4)
               and all(s.t.dtype == torch.bfloat16 for s in srcs)):      # the fused nine-tap kernel with one plane (csrc/conv_x3.hip)
             name = f"conv_x3f_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, 9, true, 1, true>"
@@ -358,8 +359,6 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         L.check(L.lib().c3d_conv_forward(C.byref(d), _stream()), "c3d_conv_forward")
         return out, stat_partial
     name, halo = kernel_name()
-    if six and not grad:
-        name = name.replace(", false>", ", true>").replace(", false, 3>", ", true, 3>")
     with _Timed(name, 2.0 * b * h * w * cout * len(taps) * sum(s.C for s in srcs),
                 (h, w, sum(s.C for s in srcs), cout, nt_, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_forward(C.byref(d), _stream()), "c3d_conv_forward")
