@@ -646,13 +646,19 @@ struct Bl2Args {
   const float* src2; int Hs2, Ws2, scs2;
   float ry2, rx2;
 };
-__global__ __launch_bounds__(256) void bilinear_sum2_kernel(Bl2Args q, int chunks_per_row, int q_shift) {
+// Work order (round 4): channel blocks of qb quads OUTERMOST -- item = (channel block, destination row, chunk of the row's
+// pixels).  Row-major over all 704 channels a destination row needs 2.9 + 1.4 MB of source rows, more than an XCD's 4 MB of
+// L2 together with the 2.9 MB it writes: the sources (230 MB) came from HBM five times (1.9 GB per launch for 0.97 GB of
+// tensors).  With 64-channel blocks the rows two consecutive items share are 0.4 MB.
+__global__ __launch_bounds__(256) void bilinear_sum2_kernel(Bl2Args q, int chunks_per_row, int qb, int qb_shift) {
   constexpr int V = 4;
   const BlArgs& p = q.a;
-  const int Q = p.C / V;
-  const int row_elems = p.Wd * Q;
+  const int row_elems = p.Wd * qb;                 // elements (channel quads) of one destination row inside a channel block
   const int item = c3d_xcd_remap(blockIdx.x, gridDim.x);
-  const int row = item / chunks_per_row, chunk = item - row * chunks_per_row;
+  const int nrows = p.B * p.Hd;
+  const int cb = item / (nrows * chunks_per_row);
+  const int rem = item - cb * (nrows * chunks_per_row);
+  const int row = rem / chunks_per_row, chunk = rem - row * chunks_per_row;
   const int b = row / p.Hd, yd = row - b * p.Hd;
   int y0, y1, u0, u1;
   float ly, lu;
@@ -665,8 +671,8 @@ __global__ __launch_bounds__(256) void bilinear_sum2_kernel(Bl2Args q, int chunk
   for (int k = 0; k < BL_IT; ++k) {
     const int e = (chunk * BL_IT + k) * 256 + threadIdx.x;
     if (e < row_elems) {
-      const int xd = q_shift >= 0 ? e >> q_shift : e / Q;
-      const int c = (e - xd * Q) * V;
+      const int xd = qb_shift >= 0 ? e >> qb_shift : e / qb;
+      const int c = (cb * qb + (e - xd * qb)) * V;
       int x0, x1, w0, w1;
       float lx, lw;
       bl_coords(xd, p.rx, p.Ws, x0, x1, lx);
@@ -726,7 +732,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(BlArgs p, int accumul
   float* dsrc = const_cast<float*>(p.src);
   {
     // (items ordered in column bands so that the destination rows two source rows share stay L2-resident: measured
-    //  neutral, 394 -> 383 us on the 1 GB embedding gradient; loads batched ahead of the adds: slower, 471 us)
+    //  neutral, 394 -> 383 us on the 1 GB embedding gradient; loads batched ahead of the adds: slower, 471 us; round 4:
+    //  64-channel blocks outermost, which is worth 15 % in bilinear_sum2_kernel: neutral to worse here, 263 -> 283 us)
     const int item = c3d_xcd_remap(blockIdx.x, gridDim.x);
     const int row = item / chunks_per_row, chunk = item - row * chunks_per_row;
     const int b = row / p.Hs, ys = row - b * p.Hs;
@@ -1103,9 +1110,11 @@ extern "C" int c3d_bilinear_sum2(const float* src1, int Hs1, int Ws1, const floa
   q.rx2 = Wd > 1 ? (float)(Ws2 - 1) / (float)(Wd - 1) : 0.f;
   C3D_REQUIRE((int64_t)Wd * C < (1ll << 31), "bilinear_sum2: a row exceeds 2^31 elements");
   // (eight channels per thread for a bf16 result -- 16-byte stores -- measured slower: 399 vs 333 us at 8 x 32 x 1024 x 704)
-  const int chunks = bl_chunks(Wd * (C / 4), BL_IT);
-  C3D_REQUIRE((int64_t)B * Hd * chunks < (1ll << 31), "bilinear_sum2: grid too large");
-  hipLaunchKernelGGL(bilinear_sum2_kernel, dim3(B * Hd * chunks), dim3(256), 0, ST, q, chunks, bl_shift(C / 4));
+  const int Q = C / 4;
+  const int qb = (Q > 16 && Q % 16 == 0) ? 16 : Q;            // quads per channel block (64 channels), or no blocking
+  const int chunks = bl_chunks(Wd * qb, BL_IT);
+  C3D_REQUIRE((int64_t)(Q / qb) * B * Hd * chunks < (1ll << 31), "bilinear_sum2: grid too large");
+  hipLaunchKernelGGL(bilinear_sum2_kernel, dim3((Q / qb) * B * Hd * chunks), dim3(256), 0, ST, q, chunks, qb, bl_shift(qb));
   C3D_CHECK_LAUNCH();
   return 0;
 }
