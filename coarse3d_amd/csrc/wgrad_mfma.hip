@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   }
 }
 
-// dw[cout][cin_off + cin][t] (+)= sum_strips partial.  Block = 32 outputs x 8 strip lanes.
+// dw[cout][cin_off + cin][t] (+)= sum_strips partial.  Block = 256 outputs x 4 strip lanes.
 // Blocks beyond `main_blocks` fold the layer's bias-gradient partials (one channel each; c3d_wgrad_desc.bias_partial).
 // One fold = one c3d_wgrad_fold record; `blk` is the block's index within the fold.
 __device__ __forceinline__ void wgrad_fold_body(const c3d_wgrad_fold& f, int blk, double (*red)[32]) {      // red: 1024 doubles
@@ -299,39 +299,34 @@ __device__ __forceinline__ void wgrad_fold_body(const c3d_wgrad_fold& f, int blk
   const size_t slice_floats = (size_t)T * CI * CO;
   const int nsl = ci_slices * f.co_slices;
   const size_t total = slice_floats * nsl;
-  // 32 consecutive outputs per block trip: 8 threads x float4 along the outputs (CO is a multiple of 32, so the four
-  // outputs of a thread share tap and input channel), 32 strip lanes; every thread keeps four 16-byte loads in flight
-  // (round 4: the 4-byte version with 8 strip lanes ran the ~1.3 GB of partials of a step at 2.5 TB/s)
-  const int o4 = threadIdx.x & 7, lanek = threadIdx.x >> 3;
-  double (*red4)[8][4] = reinterpret_cast<double (*)[8][4]>(red);      // [32 strip lanes][8 quads][4]
-  for (size_t base = (size_t)blk * 32; base < total; base += (size_t)main_blocks * 32) {
+  // 256 consecutive outputs per block trip: 64 threads x float4 along the outputs (CO is a multiple of 32, so the four
+  // outputs of a thread share tap and input channel), one strip lane per wave; every thread keeps four 16-byte loads in
+  // flight.  (Round 4, first form: 32 outputs x 32 strip lanes -- every strip contributed 128 contiguous bytes to a block,
+  // strips are 10^5 bytes apart: ~1.3 GB of partials per step at 2.4 TB/s.  A wave now reads 1 KB contiguous per strip.)
+  const int o4 = threadIdx.x & 63, lanek = threadIdx.x >> 6;
+  double (*red4)[64][4] = reinterpret_cast<double (*)[64][4]>(red);      // [4 strip lanes][64 quads][4]
+  for (size_t base = (size_t)blk * 256; base < total; base += (size_t)main_blocks * 256) {
     const size_t e = base + (size_t)o4 * 4;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int t = 0, ci = 0, co = 0;
-    bool valid = false;
     if (e < total) {
       const int sl = e / slice_floats;
       const size_t r = e % slice_floats;
-      co = r % CO;
-      ci = (r / CO) % CI;
-      t = r / ((size_t)CO * CI);
-      ci += (sl % ci_slices) * CI;
-      co += (sl / ci_slices) * CO;
-      valid = ci < f.Cin_src && co < f.Cout;           // (co .. co + 3: judged per output below)
-      if (valid) {
+      const int co = (int)(r % CO) + (sl / ci_slices) * CO;
+      const int ci = (int)((r / CO) % CI) + (sl % ci_slices) * CI;
+      if (ci < f.Cin_src && co < f.Cout) {                 // (co .. co + 3: judged per output below)
         const float* p = f.partial + (size_t)sl * strips * slice_floats + r;
         int k = lanek;
-        for (; k + 96 < strips; k += 128) {     // 4 independent 16-byte loads in flight
+        for (; k + 12 < strips; k += 16) {     // 4 independent 16-byte loads in flight
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)k * slice_floats);
-          const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 32) * slice_floats);
-          const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 64) * slice_floats);
-          const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 96) * slice_floats);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 4) * slice_floats);
+          const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 8) * slice_floats);
+          const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 12) * slice_floats);
           s0 += (double)v0[0] + (double)v1[0] + (double)v2[0] + (double)v3[0];
           s1 += (double)v0[1] + (double)v1[1] + (double)v2[1] + (double)v3[1];
           s2 += (double)v0[2] + (double)v1[2] + (double)v2[2] + (double)v3[2];
           s3 += (double)v0[3] + (double)v1[3] + (double)v2[3] + (double)v3[3];
         }
-        for (; k < strips; k += 32) {
+        for (; k < strips; k += 4) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(p + (size_t)k * slice_floats);
           s0 += (double)v[0];
           s1 += (double)v[1];
@@ -345,9 +340,8 @@ __device__ __forceinline__ void wgrad_fold_body(const c3d_wgrad_fold& f, int blk
     red4[lanek][o4][2] = s2;
     red4[lanek][o4][3] = s3;
     __syncthreads();
-    if (threadIdx.x < 32) {
-      const int q = threadIdx.x >> 2, j = threadIdx.x & 3;      // output 4 * q + j of the trip
-      // (re-derive this output's coordinates: thread q of the load phase computed them for the quad)
+    {
+      const int q = threadIdx.x >> 2, j = threadIdx.x & 3;      // output 4 * q + j of the trip: every thread finishes one
       const size_t e2 = base + (size_t)q * 4;
       if (e2 < total) {
         const int sl = e2 / slice_floats;
@@ -356,9 +350,7 @@ __device__ __forceinline__ void wgrad_fold_body(const c3d_wgrad_fold& f, int blk
         const int ci2 = (int)((r / CO) % CI) + (sl % ci_slices) * CI;
         const int t2 = r / ((size_t)CO * CI);
         if (ci2 < f.Cin_src && co2 < f.Cout) {
-          double v = 0.0;
-#pragma unroll
-          for (int k = 0; k < 32; ++k) v += red4[k][q][j];
+          double v = (red4[0][q][j] + red4[1][q][j]) + (red4[2][q][j] + red4[3][q][j]);
           v *= osc;
           float* d = f.dw + ((size_t)co2 * f.Cin_total + f.cin_off + ci2) * T + t2;
           *d = f.accumulate ? (*d + (float)v) : (float)v;
@@ -515,7 +507,7 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
                         : (d->mfma_bf16 == 1 ? launch_id<true>(c.id, halo, a, st) : launch_id<false>(c.id, halo, a, st));
   if (rc) return rc;
   const size_t total = (size_t)d->ntaps * c.CI * c.CO * a.ci_slices * a.co_slices;
-  int blocks = (int)((total + 31) / 32);
+  int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   const bool bias = d->bias_partial != nullptr;
   C3D_REQUIRE(!bias || (d->dbias != nullptr && d->bias_n > 0), "wgrad: bias_partial needs dbias and bias_n");
