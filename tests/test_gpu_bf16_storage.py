@@ -265,3 +265,25 @@ def test_bf16_output_stores_match_the_fp32_output_of_the_same_kernel(k, dil, src
         ops.conv_forward(sources, wp, bias, cout, taps, lrelu=True, out=o16, out_coff=16, accumulate=acc)
         close16(o16[..., 16:], o32[..., 16:], f"bf16 stores, accumulate={acc}")
         assert torch.equal(o16[..., :16].float(), o0[..., :16])                     # nothing written beside the slice
+
+
+@pytest.mark.parametrize("k,dil,pad,cin,cout", [(1, 1, 0, 64, 64), (3, 2, 2, 32, 64), (2, 2, 1, 64, 64), (1, 1, 0, 192, 256)])
+def test_weight_gradient_with_four_raw_tiles_in_flight_equals_the_two_deep_kernel(k, dil, pad, cin, cout):
+    """bf16 tensors on both sides: wgrad_tr_kernel<1, ..., RAW = true> (round 4: the staged units stay the 8 bytes they are loaded
+    as, four tiles in flight).  fp32 tensors holding the same bf16 values take the two-deep kernel, which rounds them to the same
+    bf16 operands.  Same tiles in the same order: the same bits -- at a size whose strips are long enough for the steady-state
+    loop of the producers (16 tiles per strip) as well as at a small one (prologue / tail only)."""
+    from coarse3d_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(29)
+    for (b, h, w) in ((8, 64, 1024), (2, 16, 95)):
+        x = r16(torch.randn(b, h, w, cin, device=DEV, generator=g))
+        cp = (cout + 15) // 16 * 16
+        dz = r16(torch.randn(b, h, w, cp, device=DEV, generator=g))
+        sc, sh = torch.rand(cin, device=DEV, generator=g) + 0.5, torch.randn(cin, device=DEV, generator=g) * 0.2
+        taps = ops.conv_taps(k, k, dil, pad)
+        dw32 = torch.zeros(cout, cin, k, k, device=DEV)
+        dw16 = torch.zeros_like(dw32)
+        ops.conv_wgrad(ops.Source(x, sc, sh, lrelu=True), dz, dw32, taps)
+        ops.conv_wgrad(ops.Source(x.bfloat16(), sc, sh, lrelu=True), dz.bfloat16(), dw16, taps)
+        assert torch.equal(dw16, dw32), ((b, h, w), float((dw16 - dw32).abs().max() / dw32.abs().max()))
+        assert float(dw32.abs().max()) > 0
