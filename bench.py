@@ -274,7 +274,7 @@ def peak_for(kernel_name):
         if len(targs) > 4 and targs[4] == "1":
             return PEAK_BF16_MFMA_TFLOPS                # the bf16 engine: one plane, one product
         return PEAK_BF16_MFMA_TFLOPS / (6.0 if targs[3] == "true" else 8.0)
-    if base == "conv_bfp_kernel":        # <TR, NT, CK, HALO, TT, NP>; NP = 3: eight plane products
+    if base == "conv_bfp_kernel":        # <TR, NT, CK, HALO, TT, NP, BFS>; NP = 3: eight plane products
         return PEAK_BF16_MFMA_TFLOPS / 8.0 if targs[5] == "3" else PEAK_BF16_MFMA_TFLOPS
     if base == "wgrad_mfma_kernel":      # <..., BF>
         return PEAK_BF16_MFMA_TFLOPS if targs[-1] == "true" else PEAK_FP32_MFMA_TFLOPS

@@ -60,8 +60,15 @@ __device__ __forceinline__ void split4(f32x4 v, u32x2 (&out)[NP]) {
   }
 }
 
-template <int TR, int NT, int CK, int HALO, int TT, int NP>
-__global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) ? 3 : 2) void conv_bfp_kernel(ConvArgs a) {
+// BFS (round 4, NP = 1 with every source a bf16 tensor): the chunk in flight stays the 8 bytes per unit it is loaded as (widened
+// when it is stored to LDS), which makes room for DEEPER K chunks -- 64 channels for 1x1 convs, 32 for the four-tap ones:
+// with 16 / 32-channel chunks a pixel contributes 32 / 64 bytes to a load instruction and this kernel took as long over bf16
+// tensors as over fp32 ones (requests, not bytes: 704 -> 64 at 8 x 32 x 1024 even 248 vs 166 us).
+template <int TR, int NT, int CK, int HALO, int TT, int NP, bool BFS = false>
+__global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8) && !(BFS && NT == 2 && (CK == 64 || (TT == 4 && CK == 32)))) ? 3 : 2)
+    void conv_bfp_kernel(ConvArgs a) {
+  static_assert(!BFS || NP == 1, "raw bf16 staging belongs to the one-plane engine");
+  using PinT = std::conditional_t<BFS, u32x2, f32x4>;
   constexpr int CSB = CK + 8;            // bf16 elements per LDS row
   constexpr int TWh = 32 + 2 * HALO;
   constexpr int THh = TR + 2 * HALO;
@@ -108,7 +115,8 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // ---- register staging (prefetch) state, as in conv_mfma.hip
-  f32x4 pin[IN_PT], pw[W_PT];
+  PinT pin[IN_PT];
+  f32x4 pw[W_PT];
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   const int c4 = tid % CQ;
   unsigned inb = 0;
@@ -141,23 +149,34 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
 
   auto load_chunk = [&](int s, int c0, int kbase) {
     const c3d_src& sr = a.src[s];
-    if (NP == 1 && sr.bf16) {        // bf16 activation storage: 8-byte loads, widened in registers
+    if constexpr (BFS) {             // every source is bf16: the 8 bytes stay as they are until store_chunk
       const unsigned short* base = reinterpret_cast<const unsigned short*>(sr.ptr) + tile_pix * sr.cstride + sr.coff + c0 + c4 * 4;
 #pragma unroll
       for (int i = 0; i < IN_PT; ++i) {
-        pin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if ((inb >> i) & 1u) {
-          const c3d_u32x2 r = *reinterpret_cast<const c3d_u32x2*>(base + (ptrdiff_t)pixrel[i] * sr.cstride);
-          pin[i] = f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
-                         __uint_as_float(r[1] & 0xffff0000u)};
+        pin[i] = u32x2{0u, 0u};
+        if ((inb >> i) & 1u) pin[i] = __builtin_bit_cast(u32x2, *reinterpret_cast<const c3d_u32x2*>(base + (ptrdiff_t)pixrel[i] * sr.cstride));
+      }
+    } else if (NP == 1 && sr.bf16) {        // bf16 activation storage: 8-byte loads, widened in registers
+      if constexpr (!BFS) {
+        const unsigned short* base = reinterpret_cast<const unsigned short*>(sr.ptr) + tile_pix * sr.cstride + sr.coff + c0 + c4 * 4;
+#pragma unroll
+        for (int i = 0; i < IN_PT; ++i) {
+          pin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if ((inb >> i) & 1u) {
+            const c3d_u32x2 r = *reinterpret_cast<const c3d_u32x2*>(base + (ptrdiff_t)pixrel[i] * sr.cstride);
+            pin[i] = f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+                           __uint_as_float(r[1] & 0xffff0000u)};
+          }
         }
       }
     } else {
-      const float* base = sr.ptr + tile_pix * sr.cstride + sr.coff + c0 + c4 * 4;
+      if constexpr (!BFS) {
+        const float* base = sr.ptr + tile_pix * sr.cstride + sr.coff + c0 + c4 * 4;
 #pragma unroll
-      for (int i = 0; i < IN_PT; ++i) {
-        pin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if ((inb >> i) & 1u) pin[i] = *reinterpret_cast<const f32x4*>(base + (ptrdiff_t)pixrel[i] * sr.cstride);
+        for (int i = 0; i < IN_PT; ++i) {
+          pin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if ((inb >> i) & 1u) pin[i] = *reinterpret_cast<const f32x4*>(base + (ptrdiff_t)pixrel[i] * sr.cstride);
+        }
       }
     }
     if (sr.scale) {
@@ -180,7 +199,13 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
     for (int i = 0; i < IN_PT; ++i) {
       const int u = tid + i * 256;
       if (u < IN_UNITS) {
-        f32x4 v = pin[i];
+        f32x4 v;
+        if constexpr (BFS) {
+          v = f32x4{__uint_as_float(pin[i][0] << 16), __uint_as_float(pin[i][0] & 0xffff0000u), __uint_as_float(pin[i][1] << 16),
+                    __uint_as_float(pin[i][1] & 0xffff0000u)};
+        } else {
+          v = pin[i];
+        }
         if ((inb >> i) & 1u) {
           if (aff) v = v * psc + psh;
           if (lr) {
@@ -284,16 +309,16 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8)) 
                                                                      tile_pix);
 }
 
-template <int TR, int NT, int CK, int HALO, int TT, int NP>
+template <int TR, int NT, int CK, int HALO, int TT, int NP, bool BFS = false>
 int launch_bfp(ConvArgs& a, hipStream_t st) {
   constexpr int CSB = CK + 8;
   size_t lds = (size_t)NP * ((size_t)(TR + 2 * HALO) * (32 + 2 * HALO) + (size_t)TT * 32 * NT) * CSB * 2;
   const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
   if (lds < red) lds = red;
-  c3d_opt_in_lds<&conv_bfp_kernel<TR, NT, CK, HALO, TT, NP>>();
+  c3d_opt_in_lds<&conv_bfp_kernel<TR, NT, CK, HALO, TT, NP, BFS>>();
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
-  hipLaunchKernelGGL((conv_bfp_kernel<TR, NT, CK, HALO, TT, NP>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_bfp_kernel<TR, NT, CK, HALO, TT, NP, BFS>), grid, dim3(256), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -306,9 +331,39 @@ int launch_bfp_taps(ConvArgs& a, int halo, hipStream_t st) {
   return launch_bfp<TR, NT, 16, 2, 9, NP>(a, st);
 }
 
+// one plane, 8-row tiles, every source a bf16 tensor (see BFS at the kernel): 1x1 convs in chunks of 64 channels (32 where a
+// source's width is not a multiple of 64), four-tap convs in chunks of 32 (16 likewise).  c3d_conv_desc.variant & 8: the
+// plain instantiations (tests).  Returns -1 when the launch has no such form.
+template <int NT>
+int launch_bfp_bf16_sources(ConvArgs& a, int halo, hipStream_t st) {
+  bool all_bf = !(a.variant & 8), c32 = true, c64 = true;
+  for (int s = 0; s < a.nsrc; ++s) {
+    all_bf = all_bf && a.src[s].bf16 != 0;
+    c32 = c32 && a.src[s].C % 32 == 0;
+    c64 = c64 && a.src[s].C % 64 == 0;
+  }
+  if (!all_bf) return -1;
+  if (a.T == 1) {
+    if (c64) return launch_bfp<8, NT, 64, 0, 1, 1, true>(a, st);
+    if (c32) return launch_bfp<8, NT, 32, 0, 1, 1, true>(a, st);
+    return launch_bfp<8, NT, 16, 0, 1, 1, true>(a, st);
+  }
+  if (a.T == 4) {
+    if (c32) return halo <= 1 ? launch_bfp<8, NT, 32, 1, 4, 1, true>(a, st) : launch_bfp<8, NT, 32, 2, 4, 1, true>(a, st);
+    return halo <= 1 ? launch_bfp<8, NT, 16, 1, 4, 1, true>(a, st) : launch_bfp<8, NT, 16, 2, 4, 1, true>(a, st);
+  }
+  return -1;
+}
+
 template <int NP>
 int dispatch_bfp(ConvArgs& a, int tr, int halo, bool k32, hipStream_t st) {
   const bool wide = c3d_wide_cout_tiles(a);
+  if constexpr (NP == 1) {
+    if (tr == 8) {
+      const int rc = wide ? launch_bfp_bf16_sources<2>(a, halo, st) : launch_bfp_bf16_sources<1>(a, halo, st);
+      if (rc >= 0) return rc;
+    }
+  }
   if (tr == 8 && a.T == 1 && k32) return wide ? launch_bfp<8, 2, 32, 0, 1, NP>(a, st) : launch_bfp<8, 1, 32, 0, 1, NP>(a, st);
   if (tr == 8) return wide ? launch_bfp_taps<8, 2, NP>(a, halo, st) : launch_bfp_taps<8, 1, NP>(a, halo, st);
   if (tr == 4) return wide ? launch_bfp_taps<4, 2, NP>(a, halo, st) : launch_bfp_taps<4, 1, NP>(a, halo, st);

@@ -331,11 +331,17 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
             name = _pw3_kernel_name(_pw3_tile(b, h, w, cout), sum(s.C for s in srcs), cout,
                                     bf16_srcs=all(s.t.dtype == torch.bfloat16 for s in srcs))
-        elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip
+        elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip (the trailing template argument: raw bf16 staging)
             np_ = 3 if MFMA_MODE == 2 else 1
             wide_ = _wide_cout_tiles(b, h, w, cout, tr)
-            name = (f"conv_bfp_kernel<8, {2 if wide_ else 1}, 32, 0, 1, {np_}>" if k32 else
-                    f"conv_bfp_kernel<{tr}, {2 if (wide_ or tr == 2) else 1}, 16, {hh}, {nt_}, {np_}>")
+            bfs_ = (np_ == 1 and tr == 8 and nt_ in (1, 4) and not (CONV_VARIANT & 8) and all(s.t.dtype == torch.bfloat16 for s in srcs))
+            if bfs_:        # launch_bfp_bf16_sources(): deeper K chunks where every source's width allows
+                c32_, c64_ = all(s.C % 32 == 0 for s in srcs), all(s.C % 64 == 0 for s in srcs)
+                ck_ = (64 if c64_ else 32 if c32_ else 16) if nt_ == 1 else (32 if c32_ else 16)
+                name = f"conv_bfp_kernel<8, {2 if wide_ else 1}, {ck_}, {hh}, {nt_}, 1, true>"
+            else:
+                name = (f"conv_bfp_kernel<8, {2 if wide_ else 1}, 32, 0, 1, {np_}, false>" if k32 else
+                        f"conv_bfp_kernel<{tr}, {2 if (wide_ or tr == 2) else 1}, 16, {hh}, {nt_}, {np_}, false>")
         elif k32:         # mirrors c3d_conv_forward / launch_taps() in csrc/conv_mfma.hip
             wide = cout > 64 and (cout + 127) // 128 * 128 <= (cout + 63) // 64 * 64
             name = f"conv_mfma_kernel<8, {4 if wide else (2 if cout > 32 else 1)}, 32, 0, 1>"

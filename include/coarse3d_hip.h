@@ -113,7 +113,10 @@ typedef struct {
                                with eight waves, 2 = with four waves, 3 = round 2's phased kernel;
                                bit 2, nine-tap convs on the bf16x3 engine (conv_x3.hip) and -- over bf16 tensors -- on the
                                bf16 engine: the phased kernel (round 2's conv_x3_kernel / conv_bfp_kernel) instead of the
-                               fused one                                                                             */
+                               fused one;
+                               bit 3, the bf16 engine's 1x1 / four-tap convs with <= 64 outputs over bf16 tensors
+                               (conv_bfp.hip): 16 / 32-channel K chunks widened at load instead of the deeper chunks of
+                               raw bf16                                                                              */
   const float* acc_scale_dev; /* EXPERIMENT (mfma_bf16 == 4): NULL, or a device scalar the accumulators are multiplied
                                with before bias / activation -- the inverse of a per-tensor gradient exponent
                                (c3d_grad_exponent)                                                            */

@@ -287,3 +287,43 @@ def test_weight_gradient_with_four_raw_tiles_in_flight_equals_the_two_deep_kerne
         ops.conv_wgrad(ops.Source(x.bfloat16(), sc, sh, lrelu=True), dz.bfloat16(), dw16, taps)
         assert torch.equal(dw16, dw32), ((b, h, w), float((dw16 - dw32).abs().max() / dw32.abs().max()))
         assert float(dw32.abs().max()) > 0
+
+
+@pytest.mark.parametrize("k,dil,pad,srcs,cout,acc", [
+    (1, 1, 0, (64,), 64, False), (1, 1, 0, (192,), 64, False), (1, 1, 0, (64, 128), 48, False), (1, 1, 0, (96,), 32, False),
+    (1, 1, 0, (48,), 32, False), (1, 1, 0, (704,), 64, True), (2, 2, 1, (64,), 64, False), (2, 2, 1, (128,), 48, True), (2, 2, 1, (48,), 32, False),
+])
+def test_deeper_chunks_of_raw_bf16_match_the_plain_kernel(k, dil, pad, srcs, cout, acc):
+    """The bf16 engine's 1x1 / four-tap convs with <= 64 outputs over bf16 tensors stage their input as raw bf16 in K chunks of
+    64 / 32 channels (conv_bfp_kernel<..., BFS = true>; c3d_conv_desc.variant & 8: the 32 / 16-channel chunks widened at load).
+    1x1: the same k order, the same bits.  Four taps: the k steps of a chunk run tap by tap, so the fp32 accumulation order
+    differs -- equal to fp32 rounding, far inside the bf16 rounding of the stored result."""
+    from coarse3d_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(53)
+    b, h, w = 2, 16, 95
+    xs = [torch.randn(b, h, w, c, device=DEV, generator=g).bfloat16() for c in srcs]
+    cin = sum(srcs)
+    wt = torch.randn(cout, cin, k, k, device=DEV, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, device=DEV, generator=g) * 0.1
+    taps = ops.conv_taps(k, k, dil, pad)
+    wp = ops.pack_weights(wt, 0)
+    sources = [ops.Source(x, torch.rand(x.shape[3], device=DEV, generator=g) + 0.5, torch.randn(x.shape[3], device=DEV, generator=g) * 0.2,
+                          lrelu=(i == 0)) for i, x in enumerate(xs)]
+    out0 = r16(torch.randn(b, h, w, cout, device=DEV, generator=g))        # (accumulating launches: the same old values in both layouts)
+    res = {}
+    for variant in (0, 8):
+        ops.CONV_VARIANT = variant
+        try:
+            o32, o16 = out0.clone(), out0.bfloat16()
+            _, p32 = ops.conv_forward(sources, wp, bias, cout, taps, lrelu=True, stats=True, out=o32, accumulate=acc)
+            ops.conv_forward(sources, wp, bias, cout, taps, lrelu=True, out=o16, accumulate=acc)
+        finally:
+            ops.CONV_VARIANT = 0
+        res[variant] = (o32.clone(), o16.clone(), p32.clone())
+    if k == 1:
+        for a_, b_ in zip(res[0], res[8]):
+            assert torch.equal(a_, b_)
+    else:
+        close32(res[0][0], res[8][0], "four taps, fp32 output", 2e-6)
+        close32(res[0][2], res[8][2], "four taps, statistics", 2e-6)
+        close16(res[0][1], res[8][0], "four taps, bf16 output")
