@@ -114,6 +114,40 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     constexpr bool ACC = decltype(accumulate_tag)::value;
     using OT = typename decltype(type_tag)::type;
     OT* obase = reinterpret_cast<OT*>(a.out) + obase_i;
+    if constexpr (std::is_same_v<OT, __bf16> && !ACC && !STATMUL && !ILV && (NT / WN) > 1) {
+      // bf16 output, several ADJACENT cout sub-tiles per wave: a sub-tile is 64 bytes of a pixel, half a cache line, and a
+      // launch that mostly writes (192 -> 704) took as long as over fp32 tensors.  With the sub-tiles innermost the wave's
+      // consecutive stores cover NPW x 64 contiguous bytes of the same pixel.
+      bool allfull = true;
+#pragma unroll
+      for (int j = 0; j < NPW; ++j)
+        if (a.Cout - n0 - (wn * NPW + j) * 32 < 32) allfull = false;
+      if (allfull) {
+        float bj[NPW];
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+          bj[j] = a.bias ? a.bias[n0 + (wn * NPW + j) * 32 + l31] : 0.f;
+          s1[j] = 0.f;
+          s2v[j] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+          OT* orow = obase + (ptrdiff_t)((wm + i * WM) * a.W + 4 * half) * ocs + wn * NPW * 32;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) {
+              float v = __builtin_fmaf(acc[i][j][r], asc, bj[j]);
+              if (a.epi_lrelu) v = c3d_lrelu(v, a.slope);
+              __builtin_nontemporal_store((OT)v, &orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs + j * 32]);
+              s1[j] += v;
+              s2v[j] += v * v;
+            }
+          }
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
       const int cl = (ILV ? j * WN + wn : wn * NPW + j) * 32;

@@ -400,9 +400,10 @@ __global__ __launch_bounds__(512, 1) void conv_pw1_kernel(ConvArgs a) {
     }
   };
 
-  // live 32-wide cout sub-tiles of this tile, dealt alternately to the two cout wave groups
+  // live 32-wide cout sub-tiles of this tile: wave group wn owns sub-tiles wn * NPW ... (adjacent in memory: the epilogue's
+  // consecutive stores then cover NPW x 64 contiguous bytes of a pixel; the phased kernel deals them alternately)
   const int live = min(NT, (a.Cout - n0 + 31) / 32);
-  const int nj = (live - wn + WN - 1) / WN;
+  const int nj = max(0, min(NPW, live - wn * NPW));
   auto mfma_chunk = [&](int buf, auto nj_tag) {
     constexpr int NJ = decltype(nj_tag)::value;
     const unsigned short* s_in = s_base + buf * BUF;
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw1_kernel(ConvArgs a) {
     }
     bf16x8 bp[2];
     auto load_b = [&](int j) {
-      const int R = (j * WN + wn) * 32 + l31;
+      const int R = (wn * NPW + j) * 32 + l31;
       bp[j & 1] = *reinterpret_cast<const bf16x8*>(s_w + R * 16 + swz_half(R, half));
     };
     if (NJ > 0) load_b(0);
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw1_kernel(ConvArgs a) {
       __syncthreads();                     // the other buffer is complete, this one is free again
     });
   }
-  conv_epilogue<TR, NT, WM, WN, true, true, 512, true, false>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
+  conv_epilogue<TR, NT, WM, WN, true, false, 512, true, false>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
 }
 
 // ---------------------------------------------------------------------------------------------------
