@@ -17,4 +17,12 @@ import os as _os
 # at 8x64x2048, 19.5 vs 19.5 ms at 16x32x1024: the GPU is the bound either way), so that is the default here.  The
 # runtime reads the variable when it initialises: it takes effect if this package is imported before the first GPU call of the
 # process; ``DEBUG_CLR_GRAPH_PACKET_CAPTURE=1`` in the environment keeps the runtime's default.
+import sys as _sys
+
+_t = _sys.modules.get("torch")
+_hip_up = bool(_t is not None and hasattr(_t, "cuda") and _t.cuda.is_initialized())
+# False: the HIP runtime was already initialised when this package was imported and the variable was not "0" then -- the
+# runtime keeps its faulting default for this process.  TrainStep(graph=True) refuses to capture in that case.
+GRAPH_REPLAY_SAFE = not (_hip_up and _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0")
 _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+del _t, _hip_up

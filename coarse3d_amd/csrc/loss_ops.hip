@@ -215,8 +215,31 @@ __global__ __launch_bounds__(PL_THREADS) void pl_select_kernel(PlArgs a) {
     }
   }
   __syncthreads();
-  const int nt = (int)min(s_nties, (unsigned)PL_MAX_TIES);      // (more equal keys than that: degenerate weights; the first
-  const int take = (int)s_take;                                  //  PL_MAX_TIES collected take part, still a valid draw)
+  const int take = (int)s_take;
+  if (s_nties > (unsigned)PL_MAX_TIES) {
+    // More equal keys than the list holds (degenerate weights: saturated-entropy or zero-weight pixels with k reaching into
+    // them).  Same rule, without the list: bisection on the pixel index for the smallest P with `take` tied members at
+    // pixel <= P (pixel indices are distinct, so exactly `take` members qualify) -- ~log2(n) passes over the bucket, only
+    // ever in this case.  (Round 4 took the first PL_MAX_TIES collected: arrival order of an atomic, and fewer than k
+    // pixels when take > PL_MAX_TIES -- ADVICE round 4.)
+    int lo = 0, hi = a.n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      __syncthreads();
+      if (tid == 0) s_nties = 0;
+      __syncthreads();
+      unsigned local = 0;
+      for (int i = tid; i < cnt; i += PL_THREADS) local += (keys[i] == thr && pix[i] <= mid) ? 1u : 0u;
+      if (local) atomicAdd(&s_nties, local);
+      __syncthreads();
+      if ((int)s_nties >= take) hi = mid;
+      else lo = mid + 1;
+    }
+    for (int i = tid; i < cnt; i += PL_THREADS)
+      if (keys[i] == thr && pix[i] <= lo) a.chosen[(size_t)b * a.n + pix[i]] = 1;
+    return;
+  }
+  const int nt = (int)s_nties;
   for (int e = tid; e < nt; e += PL_THREADS) {
     const int me = tie_pix[e];
     int rank = 0;

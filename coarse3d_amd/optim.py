@@ -68,6 +68,9 @@ class FlatAdamW(torch.optim.Optimizer):
         self.tensor_lr = False
         self._params = params
         self._index = [pos[id(p)] for p in params]       # flat parameter -> index in model.parameters()
+        # bumped whenever the segment list (boundaries or step-counter tensors) is replaced: a captured step has the
+        # old slices and counters baked in and must be dropped (TrainStep._graph_step compares it, like packs.generation)
+        self.generation = 0
 
     @property
     def step_t(self):
@@ -97,6 +100,7 @@ class FlatAdamW(torch.optim.Optimizer):
                 raise RuntimeError("FlatAdamW: the set of parameters with a gradient changed inside a graph capture; run "
                                    "an eager step in this configuration first")
             self._segments = out
+            self.generation += 1
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -173,6 +177,9 @@ class FlatAdamW(torch.optim.Optimizer):
         (``{"flat": True, step, exp_avg, exp_avg_sq}``).  Parameters without an entry start from zero moments and step
         0; runs of parameters with equal step counts become the segments of the flat update."""
         dev = self.flat_param.device
+        if self.flat_param.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("FlatAdamW.load_state_dict inside a graph capture")
+        self.generation += 1                 # new step-counter tensors / segment boundaries: captured steps are stale
         if sd.get("flat"):
             self._segments = [[0, len(self._params), torch.zeros((), device=dev, dtype=torch.float32)]]
             self.step_t.copy_(sd["step"])

@@ -243,6 +243,11 @@ class TrainStep:
             return "injected randomness (test hooks) lives on the host"
         if not hasattr(self.net, "_static_bank"):
             return "the model does not know the in-place bank update"
+        import coarse3d_amd
+        if not coarse3d_amd.GRAPH_REPLAY_SAFE and os.environ.get("C3D_GRAPH_UNSAFE") != "1":
+            return ("the HIP runtime was initialised before `import coarse3d_amd` without DEBUG_CLR_GRAPH_PACKET_CAPTURE=0: a "
+                    "captured step would fault when replayed after ~2 000 unrelated launches (coarse3d_amd/__init__.py).  Import "
+                    "coarse3d_amd before the first torch.cuda call, export the variable, or set C3D_GRAPH_UNSAFE=1 to capture anyway")
         if type(self.optimizer).__name__ != "FlatAdamW":
             return ("the captured step needs the flat optimiser (coarse3d_amd.optim.FlatAdamW: learning rate as a device "
                     "scalar, gradient-less parameters skipped); a user-supplied optimiser runs with graph=False")
@@ -271,6 +276,11 @@ class TrainStep:
         packs = getattr(self.net, "_packs", None)
         if ent["graph"] is not None and packs is not None and ent["packs_generation"] != packs.generation:
             ent["graph"] = None                          # the weight-repack table moved: its address is baked into the graph
+            ent["eager"] = min(ent["eager"], self.graph_warmup - 1)
+        if ent["graph"] is not None and ent.get("opt_generation") != getattr(opt, "generation", None):
+            # the optimiser's segments were re-cut (another configuration's eager step) or replaced (load_state_dict):
+            # the graph increments step counters and updates slices that are no longer the optimiser's
+            ent["graph"] = None
             ent["eager"] = min(ent["eager"], self.graph_warmup - 1)
         self.net._static_bank = True
         if ent["graph"] is None and ent["eager"] < self.graph_warmup:
@@ -305,6 +315,7 @@ class TrainStep:
             res["lov_count"] = cnt
             ent.update(graph=g, sx=sx, st=st, se=se, res=res,
                        packs_generation=packs.generation if packs is not None else 0,
+                       opt_generation=getattr(opt, "generation", None),
                        collectives={k: c3d_dist.COUNTS[k] - counts0[k] for k in counts0})
             for k in counts0:                            # the capture itself executed nothing
                 c3d_dist.COUNTS[k] = counts0[k]
@@ -374,6 +385,18 @@ class TrainStep:
         ev = torch.cuda.Event()
         ev.record()
         self._cnt_ring.append((ev, slot))
+
+    def flush(self):
+        """Wait for every queued labelled-pixel count and check it.  The capacity check of a captured step is asynchronous:
+        an overflow raises one to eight steps late, AFTER the offending replay's optimizer update (made with a truncated
+        Lovasz / prototype list) has been applied -- the weights, moments and bank are contaminated from that step on, so
+        treat the error as fatal for the run (resume from the last checkpoint with graph=False).  Call this before writing
+        a checkpoint and at the end of an epoch so that an overflow in the last steps cannot go unnoticed."""
+        while self._cnt_ring:
+            ev, slot = self._cnt_ring.pop(0)
+            ev.synchronize()
+            self._cnt_free.append(slot)
+            self._check_capacity(int(self._cnt_host[slot]))
 
     def _poll_capacity(self):
         while self._cnt_ring and self._cnt_ring[0][0].query():

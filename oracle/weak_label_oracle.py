@@ -7,12 +7,20 @@ only by tests/; never by the product package.
 Parity status: PINNED for everything the reference script computes in NumPy -- tests/golden/
 make_golden_weak_label.py runs the reference's own ``__getitem__`` on scan files and stores its
 outputs in tests/golden/weak_label.npz, which tests/test_oracle_golden.py replays here.  The
-voxel grid itself comes from open3d (``open3d==0.15.2``, requirements.txt:1), which is absent
-from this image and not vendored by the reference: ``voxel_coords`` restates its published rule
-(VoxelGrid::CreateFromPointCloud: origin = min_bound - voxel_size/2; voxel index =
-floor((point - origin) / voxel_size), double arithmetic on the float32 points) and the golden
-generator feeds the SAME rule to the reference script through a stand-in ``open3d`` module --
-that one step is restated, not pinned.
+voxel grid itself comes from open3d (``open3d==0.15.2``, requirements.txt:1), a third-party
+dependency that is absent from this image and not vendored by the reference: **parity UNPINNED
+against open3d binaries**.  ``voxel_coords`` restates open3d's published algorithm --
+``VoxelGrid::CreateFromPointCloud`` / ``CreateFromPointCloudWithinBounds``
+(cpp/open3d/geometry/VoxelGridFactory.cpp at tag v0.15.2: min_bound = GetMinBound() -
+voxel_size * 0.5, origin_ = min_bound, index = int(floor((point - min_bound) / voxel_size)))
+and ``VoxelGrid::GetVoxel`` (cpp/open3d/geometry/VoxelGrid.cpp: floor((point - origin_) /
+voxel_size_).cast<int>()), double arithmetic on the float32 points (``Vector3dVector``), a TRUE
+division per component (Eigen >= 3.3) -- and is checked against a second, scalar-by-scalar C
+restatement of the same published functions (oracle/open3d_voxel_rule.c) and against
+hand-derived expectations on edge-case vectors (tests/golden/weak_label_edges.npz: points
+on voxel faces, negative coordinates, a one-point cloud, float32 points a few ulps from a face
+where a reciprocal-multiply implementation lands in the neighbouring voxel).  The golden
+generator feeds the SAME rule to the reference script through a stand-in ``open3d`` module.
 """
 import numpy as np
 

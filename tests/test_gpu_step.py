@@ -125,14 +125,17 @@ def test_entropy_selection_vs_golden():
     assert record("pl_select/mask_agreement", (mask.cpu() == g["mask"]).float().mean().item()) == 1.0
 
 
-def test_pseudo_label_selection_breaks_ties_by_pixel_index():
+@pytest.mark.parametrize("n", [900, 9000])
+def test_pseudo_label_selection_breaks_ties_by_pixel_index(n):
     """Round 4: keys of the top-k selection (w / Exp(1) noise, float32) DO collide now and then among the 10^4..10^5 members
     of an (image, class) pair; a tie AT the threshold was resolved first-come by an atomic counter over a bucket whose order
     depends on workgroup timing -- one such tie made a 26-step training run two-valued.  Now the tied members with the
     smallest pixel index are taken.  Constructed case: every member of a pair has the same key; k = int(cnt * ratio) of
-    them must be chosen: exactly the k smallest pixel indices, every time (the weak labels themselves always stay)."""
+    them must be chosen: exactly the k smallest pixel indices, every time (the weak labels themselves always stay).
+    n = 9000 (round 5, ADVICE): ~2 250 tied members per pair, more than the kernel's LDS list of 1 024 holds, and k = 675
+    of them to take -- the rule is the same (bisection on the pixel index over the whole bucket)."""
     from coarse3d_amd import ops
-    b, n, c = 2, 900, 5
+    b, c = 2, 5
     gen = torch.Generator().manual_seed(3)
     amax = torch.randint(1, c, (b, n), generator=gen).to(torch.int32)
     ev = torch.ones(b, n, dtype=torch.int64)
@@ -408,19 +411,24 @@ def test_second_golden_step_anchor_and_sinkhorn_rates_at_the_real_anchor_count()
                         "position_ref": pos_ref, "u": u, "bin_edge": edge,
                         "distance_in_fp32_ulps_of_the_edge": abs(u - edge) / (edge * 2.0 ** -23)})
     record("step2/anchor_moved_detail", details)
+    # Bounds at 2x the measured values, per engine (round 5; round 4 held 40 draws / 168 ulps for
+    # both): exact-split engine 8 moved draws, farthest 62.6 fp32 ulps from its bin edge; strict fp32-MFMA engine 14 / 125.8
+    # (profiles/round4_parity_measured*.json).
+    moved_bound, ulp_bound = {"bf16x3": (16, 126.0), "f32": (28, 252.0)}[engine]
     for d_ in details:
         # Every moved draw sits on the NEIGHBOURING candidate with u next to the bin edge between the two.  How near: the
         # edge is a normalised running sum of the class's candidate weights exp(-H^2) (hundreds of candidates here, 20-50 in
         # the first golden step), and the HIP forward's probabilities agree with the reference's to ~1e-5 relative, not
         # bit for bit -- an edge moves by up to that much.  Measured on MI355X: 4 ... 126 fp32 ulps (profiles/
-        # round4_parity_measured*.json); bound 2e-5 relative (168 ulps), a fifth of the north star's 1e-4.
+        # round4_parity_measured*.json); bound: 2x the engine's measured maximum (1.5e-5 / 3e-5 relative, against the north
+        # star's 1e-4 for the values the edge is computed from).
         assert abs(d_["position_got"] - d_["position_ref"]) == 1, d_
-        assert d_["distance_in_fp32_ulps_of_the_edge"] * 2.0 ** -23 <= 2e-5, d_
+        assert d_["distance_in_fp32_ulps_of_the_edge"] <= ulp_bound, d_
     record("step2/anchor_moved_max_distance_ulps", max([d_["distance_in_fp32_ulps_of_the_edge"] for d_ in details] or [0.0]))
     # Expected count: a draw moves when u falls between the two engines' versions of an edge; with ~3e-6 relative edge
     # noise and ~500 candidates per pair that is ~7e-4 per draw, ~14 of 19 456 -- on ANY fp32 engine (measured: 8 on the
     # exact-split engine, 14 on the strict fp32-MFMA engine, whose 2304 of 2304 on the first golden step was luck)
-    assert n_moved <= 40, n_moved
+    assert n_moved <= moved_bound, (engine, n_moved)
     assert rel(res["contrast"], g["contrast"]) < (1e-5 if n_moved == 0 else 1e-4)
     assert rel(res["loss"], g["loss"]) < 2e-5
     record("step2/contrast_rel_err", rel(res["contrast"], g["contrast"]))
@@ -739,6 +747,46 @@ def test_one_captured_graph_per_shape_across_epochs_and_the_contrast_warmup():
     n7 = int(ts.step(x, tr, ev, epoch=7)["mask_contra"].sum())
     n5 = int(ts.step(x, tr, ev, epoch=5)["mask_contra"].sum())
     assert n7 > n5 > 0 and len([e for e in ts._graphs.values() if e["graph"] is not None]) == 2
+
+
+def test_captured_step_is_dropped_when_the_optimiser_state_is_replaced():
+    """``FlatAdamW.load_state_dict`` (a resume) replaces the step-counter tensors and possibly the
+    segment boundaries a captured step has baked in.  ``FlatAdamW.generation`` is bumped and ``TrainStep`` drops the graph,
+    runs one eager step and captures again: losses, parameters and AdamW state equal the never-captured run bit for bit,
+    and the checkpointed step counters keep counting."""
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    from coarse3d_amd.trainer import TrainStep
+    b, h, w, ncls = 2, 32, 128, 20
+    batches = [W.synthetic_batch(b, h, w, ncls, 900 + i, 0.02, gh=8, gw=16) for i in range(8)]
+    runs = []
+    for warm in (1000, 2):
+        torch.manual_seed(41)
+        m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True).to(DEV).train()
+        ts = TrainStep(m, ncls, proto_loss=True, lr=2e-3, num_anchor=32, graph=True, graph_warmup=warm)
+        torch.manual_seed(42)
+        losses = []
+        for i, (x, tr, ev) in enumerate(batches):
+            if i == 4:       # checkpoint round trip in the middle of training (trainer.py:129, main.py:141,154)
+                gen = ts.optimizer.generation
+                ts.flush()
+                ts.optimizer.load_state_dict(ts.optimizer.state_dict())
+                assert ts.optimizer.generation == gen + 1
+            res = ts.step(x.to(DEV), tr.to(DEV), ev.to(DEV), epoch=10)
+            losses.append({k: res[k].clone() for k in ("loss", "ce", "lov", "contrast")})
+        ts.flush()
+        runs.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}, ts.optimizer.state_dict(), ts))
+    assert runs[0][3]._captures == 0 and runs[1][3]._captures == 2
+    for i, (la, lb) in enumerate(zip(runs[0][0], runs[1][0])):
+        for k in la:
+            assert torch.equal(la[k], lb[k]), (i, k)
+    for k, v in runs[0][1].items():
+        assert torch.equal(v, runs[1][1][k]), k
+    sa, sb = runs[0][2]["state"], runs[1][2]["state"]
+    assert sa.keys() == sb.keys()
+    for i in sa:
+        for k in ("step", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(sa[i][k], sb[i][k]), (i, k)
+    assert all(float(st["step"]) == float(len(batches)) for st in sb.values())
 
 
 def test_captured_step_survives_thousands_of_unrelated_launches_between_replays():

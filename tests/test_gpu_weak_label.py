@@ -35,6 +35,21 @@ def test_matches_reference_script_outputs():
         assert (info["point2voxel"].cpu().numpy() == info_o["point2voxel"]).all()
 
 
+def test_voxel_rule_edge_cases():
+    """The device's voxel indices on the edge-case vectors of the published open3d rule (tests/golden/
+    make_golden_weak_label_edges.py; tests/test_oracle_golden.py pins both CPU restatements to the same file): points on
+    voxel faces, negative coordinates, a one-point cloud, float32 points a few ulps from a face of the 0.06 m grid."""
+    g = np.load(os.path.join(GOLD, "weak_label_edges.npz"))
+    for tag in ("exact.a", "exact.b", "exact.c", "exact.d", "near.a"):
+        xyz, want, vs = g[f"{tag}.xyz"], g[f"{tag}.want"], float(g[f"{tag}.voxel_size"])
+        scan = np.concatenate([xyz, np.zeros((len(xyz), 1), np.float32)], 1)
+        lab = np.ones(len(xyz), dtype=np.int32)
+        _, info = PD.voxel_weak_labels(torch.from_numpy(scan).cuda(), torch.from_numpy(lab).cuda(), vs, 0.001, True,
+                                       generator=torch.Generator(device="cuda").manual_seed(1), return_info=True)
+        assert (info["point2voxel"].cpu().numpy() == want).all(), tag
+        assert info["num_voxel"] == len(np.unique(want, axis=0))
+
+
 def test_full_size_scan_vs_oracle_and_properties():
     """120k points, 0.06 m voxels, 0.1 % (the SemanticKITTI setting of the reference, :321-335)."""
     rs = np.random.RandomState(3)
