@@ -296,6 +296,10 @@ class TrainStep:
             return res
         if ent["graph"] is None:
             self._evict(keep=key)
+            if not any(e["graph"] is not None for e in self._graphs.values()):
+                # the last graph that used the shared pool is gone (dropped above, or evicted): the allocator has released
+                # the pool and refuses its handle ("use_count > 0" assert in capture_begin) -- start a new one
+                self._pool = None
             sx, st, se = x.clone(), train_label.clone(), eval_label.clone()
             self._check_capacity(int(loss_head.valid_indices_static(st, self.ignore_cls)[1]))
             if self._pool is None:
