@@ -36,7 +36,7 @@ class WgradDesc(C.Structure):
                 ("ntaps", C.c_int32), ("tap_dy", C.c_int32 * 9), ("tap_dx", C.c_int32 * 9),
                 ("Cin_total", C.c_int32), ("cin_off", C.c_int32),
                 ("dw", C.c_void_p), ("accumulate", C.c_int32), ("partial", C.c_void_p), ("mfma_bf16", C.c_int32),
-                ("lrelu_slope", C.c_float), ("dz_bf16", C.c_int32), ("reserved", C.c_int32),
+                ("lrelu_slope", C.c_float), ("dz_bf16", C.c_int32), ("variant", C.c_int32),
                 ("bias_partial", C.c_void_p), ("dbias", C.c_void_p), ("bias_n", C.c_int32), ("reserved2", C.c_int32),
                 ("dz_scale", C.c_void_p), ("out_scale_dev", C.c_void_p),
                 ("fuse_dy", C.c_void_p), ("fuse_act", C.c_void_p), ("fuse_k1", C.c_void_p), ("fuse_k2", C.c_void_p),
@@ -72,7 +72,12 @@ def lib():
                 "`make -C coarse3d_amd/csrc`). There is no CPU fallback.")
         _lib = C.CDLL(LIB_PATH)
         for name, (res, args) in prototypes().items():
-            fn = getattr(_lib, name)          # AttributeError = header/library mismatch
+            try:
+                fn = getattr(_lib, name)          # AttributeError = header/library mismatch
+            except AttributeError:
+                if os.environ.get("C3D_LIB"):     # an OLDER build loaded for a same-box A/B (tools/ab_lib.sh): newer entry points are absent
+                    continue
+                raise
             fn.restype, fn.argtypes = res, args
     return _lib
 

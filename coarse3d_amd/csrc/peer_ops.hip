@@ -1,0 +1,192 @@
+// SyncBatchNorm statistics exchange between the ranks of ONE node through IPC-mapped peer memory.
+//
+// Replaces the dist.all_reduce of torch.nn.SyncBatchNorm's forward / backward (the reference wraps its model with
+// torch.nn.SyncBatchNorm.convert_sync_batchnorm, tasks/weak_segmentation/trainer.py:54) for the 43 + 43 tiny fp64 vectors
+// of a training step (<= 704 x 2 doubles each).  Through torch.distributed every one of them is a RCCL launch of its own
+// (~17 us of launch cost in a 1-rank group before any xGMI latency; 84 blocking exchanges per step).  Here one small
+// kernel per exchange: every rank WRITES its vector into its slot of every peer's mailbox (device memory of the peer,
+// mapped here with hipIpcOpenMemHandle -- xGMI stores), publishes a sequence number behind it, waits for the sequence
+// numbers of all peers in its own mailbox and sums the slots in rank order -- the same order on every rank, so the result
+// is bit-identical everywhere and run to run.  One process per GPU; gradients and the prototype bank stay on RCCL.
+//
+// Protocol (per rank: mailbox = header | flags[2][W] | slots[2][W][CAP] doubles; W = C3D_PEER_MAX_RANKS):
+//   seq = ++calls (a counter in the rank's OWN mailbox header: device memory, so a captured hipGraph keeps counting; every
+//   rank makes the same sequence of calls, as with any collective); parity = seq & 1.
+//   1. for every rank p (itself included): peer[p].slots[parity][me][0 .. n) = buf           (system-scope stores)
+//   2. system-scope release fence, then peer[p].flags[parity][me] = seq                       (one lane per peer)
+//   3. wait until own.flags[parity][q] == seq for every rank q (relaxed system-scope polls with s_sleep, BOUNDED: after
+//      ~C3D_PEER_TIMEOUT_S seconds the status word is set and the kernel gives up -- a missing peer must not hang the GPU)
+//   4. system-scope acquire fence, buf[i] = sum_q own.slots[parity][q][i] in rank order
+// Two parities suffice: a rank can only reach call seq + 2 after it has seen every peer's seq + 1, which the peer
+// publishes from a kernel that runs after its call-seq kernel has finished reading (stream order).
+// The mailbox is fine-grained device memory (hipDeviceMallocFinegrained: what RCCL itself uses for its flags), zeroed once.
+#include <string.h>
+#include "common.h"
+#include "../../include/coarse3d_hip.h"
+
+namespace {
+
+constexpr int PEER_HEADER_BYTES = 256;
+constexpr int PEER_W = C3D_PEER_MAX_RANKS;
+
+struct PeerArgs {
+  unsigned char* box[PEER_W];     // mailbox of rank p as mapped in this process (box[rank] = own)
+  int rank, world, cap;
+  double* buf;
+  int n;
+  unsigned long long timeout_ticks;     // of the 100 MHz wall clock
+};
+
+__device__ __forceinline__ unsigned long long* peer_flags(unsigned char* box, int parity, int r) {
+  return reinterpret_cast<unsigned long long*>(box + PEER_HEADER_BYTES) + parity * PEER_W + r;
+}
+__device__ __forceinline__ double* peer_slot(unsigned char* box, int cap, int parity, int r) {
+  return reinterpret_cast<double*>(box + PEER_HEADER_BYTES + 2 * PEER_W * sizeof(unsigned long long)) + ((size_t)parity * PEER_W + r) * cap;
+}
+
+__global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs a) {
+  __shared__ unsigned long long s_seq;
+  __shared__ int s_fail;
+  const int tid = threadIdx.x;
+  unsigned char* own = a.box[a.rank];
+  unsigned long long* calls = reinterpret_cast<unsigned long long*>(own);
+  unsigned int* status = reinterpret_cast<unsigned int*>(own + 8);
+  if (tid == 0) {
+    s_seq = *calls + 1ull;
+    s_fail = 0;
+  }
+  __syncthreads();
+  const unsigned long long seq = s_seq;
+  const int parity = (int)(seq & 1ull);
+  // 1. my vector into my slot of every mailbox
+  for (int p = 0; p < a.world; ++p) {
+    double* dst = peer_slot(a.box[p], a.cap, parity, a.rank);
+    for (int i = tid; i < a.n; i += 256) __hip_atomic_store(dst + i, a.buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // 2. publish: the stores above must be visible system-wide before the sequence number is
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid < a.world) __hip_atomic_store(peer_flags(a.box[tid], parity, a.rank), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // 3. wait for everybody's vector (bounded)
+  if (tid < a.world) {
+    const unsigned long long* f = peer_flags(own, parity, tid);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > a.timeout_ticks) {
+        s_fail = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if (s_fail) {          // a peer never arrived: say so (the host raises at its next check) and leave buf as it is
+    if (tid == 0) {
+      *status = 1u;
+      *calls = seq;
+    }
+    return;
+  }
+  // 4. the sum, in rank order
+  for (int i = tid; i < a.n; i += 256) {
+    double s = 0.0;
+    for (int q = 0; q < a.world; ++q) s += __hip_atomic_load(peer_slot(own, a.cap, parity, q) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    a.buf[i] = s;
+  }
+  if (tid == 0) *calls = seq;
+}
+
+}  // namespace
+
+extern "C" int c3d_peer_desc_bytes(void) { return (int)sizeof(c3d_peer_desc); }
+
+extern "C" int64_t c3d_peer_mailbox_bytes(int cap_doubles) {
+  if (cap_doubles <= 0) return 0;
+  return (int64_t)PEER_HEADER_BYTES + 2 * PEER_W * (int64_t)sizeof(unsigned long long) + 2ll * PEER_W * cap_doubles * (int64_t)sizeof(double);
+}
+
+extern "C" int c3d_peer_alloc(int64_t bytes, void** ptr, void* handle64) {
+  C3D_REQUIRE(ptr && handle64 && bytes > 0, "peer_alloc: null pointer or empty mailbox");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI carries IPC handles as 64 bytes");
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) {
+    c3d_set_error(hipGetErrorString(e));
+    return 1;
+  }
+  e = hipMemset(p, 0, (size_t)bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  hipIpcMemHandle_t h;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess) {
+    c3d_set_error(hipGetErrorString(e));
+    (void)hipFree(p);
+    return 1;
+  }
+  memcpy(handle64, &h, 64);
+  *ptr = p;
+  return 0;
+}
+
+extern "C" int c3d_peer_open(const void* handle64, void** ptr) {
+  C3D_REQUIRE(ptr && handle64, "peer_open: null pointer");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, 64);
+  void* p = nullptr;
+  const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) {
+    c3d_set_error(hipGetErrorString(e));
+    return 1;
+  }
+  *ptr = p;
+  return 0;
+}
+
+extern "C" int c3d_peer_close(void* ptr) {
+  if (ptr && hipIpcCloseMemHandle(ptr) != hipSuccess) {
+    c3d_set_error("peer_close: hipIpcCloseMemHandle failed");
+    return 1;
+  }
+  return 0;
+}
+
+extern "C" int c3d_peer_free(void* ptr) {
+  if (ptr && hipFree(ptr) != hipSuccess) {
+    c3d_set_error("peer_free: hipFree failed");
+    return 1;
+  }
+  return 0;
+}
+
+extern "C" int c3d_peer_allreduce_f64(const c3d_peer_desc* d, double* buf, int n, c3d_stream stream) {
+  C3D_REQUIRE(d != nullptr && buf != nullptr, "peer_allreduce: null pointer");
+  C3D_REQUIRE(d->world >= 1 && d->world <= PEER_W && d->rank >= 0 && d->rank < d->world, "peer_allreduce: bad rank / world");
+  C3D_REQUIRE(n >= 0 && n <= d->cap_doubles, "peer_allreduce: the vector does not fit the mailbox slot");
+  if (n == 0) return 0;
+  PeerArgs a;
+  for (int p = 0; p < PEER_W; ++p) a.box[p] = p < d->world ? static_cast<unsigned char*>(d->mailbox[p]) : nullptr;
+  for (int p = 0; p < d->world; ++p) C3D_REQUIRE(a.box[p] != nullptr, "peer_allreduce: a peer mailbox is not mapped");
+  a.rank = d->rank; a.world = d->world; a.cap = d->cap_doubles; a.buf = buf; a.n = n;
+  const double secs = d->timeout_s > 0.f ? d->timeout_s : 20.f;
+  a.timeout_ticks = (unsigned long long)(secs * 100e6);
+  hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+// status word of the rank's own mailbox (host read: synchronises the calling thread with the device).  0 = fine;
+// 1 = an exchange gave up waiting for a peer (its result was NOT a sum)
+extern "C" int c3d_peer_status(const c3d_peer_desc* d, int32_t* status_out, int64_t* calls_out) {
+  C3D_REQUIRE(d != nullptr && status_out != nullptr, "peer_status: null pointer");
+  unsigned long long hdr[2] = {0, 0};
+  const hipError_t e = hipMemcpy(hdr, d->mailbox[d->rank], sizeof(hdr), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) {
+    c3d_set_error(hipGetErrorString(e));
+    return 1;
+  }
+  *status_out = (int32_t)(hdr[1] & 0xffffffffull);
+  if (calls_out) *calls_out = (int64_t)hdr[0];
+  return 0;
+}

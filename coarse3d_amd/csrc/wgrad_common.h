@@ -29,6 +29,7 @@ struct WgradArgs {
   int f_sum_n = 0;
   int ci_slices, co_slices;
   float slope;
+  int variant = 0;                   // c3d_wgrad_desc.variant
 };
 
 // A workgroup owns a (CI cin, CO cout) slice and TRW x 32 pixel tiles.

@@ -397,6 +397,11 @@ void plan(const c3d_wgrad_desc* d, WgradArgs& a, WgCfg& c) {
     if (m > halo) halo = m;
   }
   c = c3d_wgrad_cfg(d->ntaps, d->x.C, d->Cout, planes_for(d) == 2 ? 3 : planes_for(d), halo);     // (two fp16 planes: the tiles of three)
+  // BatchNorm backward on load over 256-cout slices keeps dy AND the stored output of 8 units per thread in flight, twice:
+  // wgrad_tr_kernel<3, 1, 2, 4, 2, 2, 1, 0, true> spilled 50 registers (184 scratch instructions, 108 full drains of the loads
+  // in flight; 51-76 TF where the unfused instance makes 149-176).  The fused launch takes the 128 x 128 slice instead
+  // (x is staged twice, it is the narrow side; no spill).  Round 5.
+  if (d->fuse_dy && planes_for(d) == 3 && c.id == 0 && !(d->variant & 4)) c = WgCfg{1, 128, 128, 1};
   a.tiles_x = (d->W + 31) / 32;
   a.tiles_y = (d->H + c.TRW - 1) / c.TRW;
   a.ntiles = d->B * a.tiles_x * a.tiles_y;
@@ -486,6 +491,7 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
               "wgrad: mfma_bf16 == 4 (f16x2 experiment) needs dz_scale, out_scale_dev, fp32 tensors and more than one tap");
   a.partial = d->partial;
   a.slope = c3d_slope_or_default(d->lrelu_slope);
+  a.variant = d->variant;
   C3D_REQUIRE(a.slope <= 1.f, "wgrad: LeakyReLU slopes above 1 are not supported (the kernels evaluate max(v, slope * v))");
   WgCfg c;
   plan(d, a, c);

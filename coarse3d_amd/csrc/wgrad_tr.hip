@@ -47,6 +47,9 @@
 
 namespace {
 
+// lean register sets from this many tiles per column on (launch_tr)
+constexpr int C3D_WGRAD_LEAN_MIN_TILES_Y = 8;
+
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -152,7 +155,16 @@ __device__ __forceinline__ void c3d_wg_static_for(F&& f) {
 // the registers of the widened values -- and FOUR tiles are kept in flight instead of two.  A tile of this mode is 8-16 KB of
 // loads; with two in flight per workgroup the weight gradients of this engine took exactly as long as on fp32 tensors (122 us
 // for the 64 -> 64 1x1 layer at 8 x 64 x 2048 either way: 2.2 vs 4.4 TB/s), bound by requests in flight, not by bytes.
-template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool FA = false, bool RAW = false>
+// LEAN (round 5, kernels with a halo): the register sets in flight carry only the TRW NEW rows of a window.  Round 4's sets were
+// sized for a whole window (TRW + 2 * HALO rows) although only the first tile of a column needs one -- every other tile issued
+// the surplus loads as dummies ("every unit issues its load").  With the BatchNorm backward on load (FA: dy AND the stored
+// output in flight) that put the producer waves past the 256 registers a 512-thread workgroup has: the fused instances
+// spilled (up to 553 scratch instructions), and a scratch reload is the YOUNGEST memory operation when its value is needed,
+// so every one of them was an s_waitcnt vmcnt(0) that drained both tiles in flight (80-356 such waits per instance against 3
+// in the unfused ones; the fused 32 -> 32 3x3 weight gradient ran at 110 TF against 197 unfused).  The 2 * HALO rows that
+// only a column's first tile needs are now loaded inside store_tile of that tile, into the registers its x units have just
+// left, and converted after the dz units (whose conversion hides most of their latency).
+template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool FA = false, bool RAW = false, bool LEAN = false>
 __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   static_assert(!RAW || (NP == 1 && !FA), "raw bf16 stages belong to the one-plane engine without the fused apply");
   constexpr int DEPTH = RAW ? 4 : 2;   // tiles the producer waves keep in flight (register sets)
@@ -183,6 +195,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   constexpr int RING = 2 * THh;
   constexpr int XPLANE = RINGX ? RING * TWh * CI : XROWS * CI;     // bf16 elements per x plane
   constexpr int NEWROWS_UNITS = TRW * TWh * (CI / 4);               // staging units of the TRW new rows of a window
+  constexpr bool LEANX = LEAN && RINGX;
+  static_assert(!LEAN || (HALO > 0 && NP == 3 && !RAW), "the lean register sets belong to the three-plane kernels with a rolling window");
+  constexpr int EXTRA_UNITS = 2 * HALO * TWh * (CI / 4);            // LEANX: the rows only a column's first tile stages
 
   // Eight waves, two roles: waves 0-3 (one per SIMD) only issue transposed reads and MFMAs on
   // the current tile buffer; waves 4-7 stage the NEXT tile meanwhile (global loads -> on-load
@@ -206,8 +221,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   const int co0 = (sl / a.ci_slices) * CO;
 
   // ---- register staging (prefetch) of the next pixel tile while the current one is consumed
-  constexpr int X_UNITS = XROWS * (CI / 4);
+  constexpr int X_UNITS = LEANX ? NEWROWS_UNITS : XROWS * (CI / 4);      // x units of a register set in flight
   constexpr int X_PT = (X_UNITS + 255) / 256;
+  constexpr int E_PT = LEANX ? (EXTRA_UNITS + 255) / 256 : 0;
   constexpr int D_UNITS = DROWS * (CO / 4);
   constexpr int D_PT = (D_UNITS + 255) / 256;
   // one register set per tile in flight; the producers keep TWO tiles of loads outstanding (one
@@ -221,6 +237,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     size_t dimg;    // FA: element offset of the image (uniform)
     int xbase;      // RINGX: first ring slot of the tile's window (uniform)
     bool xfresh;    // RINGX: the whole window is staged (first tile of a column / of the strip); else its TRW new rows
+    int ex0, ey0;   // LEANX: image column / row of the window's first pixel (uniform; may be negative)
+    size_t ximg;    // LEANX: element offset of the image in x (uniform)
   };
   const int xc4 = tid % (CI / 4);          // 256 % (CI/4) == 0: fixed channel quad per thread
   const int xc = ci0 + xc4 * 4;
@@ -320,7 +338,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
       sg.xbase = lxbase;
       sg.xfresh = fresh;
     }
-    const int yx = fresh ? y0 - HALO : y0 + HALO;        // image row of the first staged x row
+    const int yx = (fresh && !LEANX) ? y0 - HALO : y0 + HALO;        // image row of the first x row of the register set
+    if constexpr (LEANX) {
+      sg.ex0 = x0 - HALO;
+      sg.ey0 = y0 - HALO;
+    }
     if (ymajor) {
       if (++lty == a.tiles_y) {
         lty = 0;
@@ -338,7 +360,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     }
     const bool interior = x0 >= HALO && x0 + 32 + HALO <= a.W && y0 >= HALO && y0 + TRW + HALO <= a.H;   // uniform
     // validity of this thread's units: interior tiles (the vast majority) need no pixel tests
-    unsigned xmask = fresh ? x_all : (x_all & x_new), dmask = dc_ok ? ((1u << D_PT) - 1u) : 0u;
+    unsigned xmask = (fresh || LEANX) ? x_all : (x_all & x_new), dmask = dc_ok ? ((1u << D_PT) - 1u) : 0u;
     if (!interior) {
       unsigned xm = 0;
 #pragma unroll
@@ -363,6 +385,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     // the two tiles in flight with s_waitcnt vmcnt(N); loads under per-unit branches made it
     // fall back to vmcnt(0), which serialised the two tiles.
     const size_t ximg = (size_t)b * a.H * a.W * a.x.cstride, dimg = (size_t)b * a.H * a.W * a.dz_cstride;   // uniform
+    if constexpr (LEANX) sg.ximg = ximg;
     const int xt = (yx * a.W + (x0 - HALO)) * a.x.cstride;     // uniform; < 0 only where masked
     const int dt = (y0 * a.W + x0) * a.dz_cstride;
     auto load_x = [&](auto bf_tag) {
@@ -428,8 +451,52 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     unsigned short* s_x = RINGX ? s_base : s_base + buf * BUF;
     unsigned short* s_dz = RINGX ? s_base + NP * XPLANE + buf * (NP * DROWS * CO) : s_x + NP * XROWS * CI;
     // RINGX: first ring slot the staged rows go to (a whole window, or the TRW rows behind the rows kept from the tile above)
-    const int slot0 = RINGX ? (sg.xfresh ? sg.xbase : sg.xbase + 2 * HALO) : 0;
+    const int slot0 = RINGX ? ((sg.xfresh && !LEANX) ? sg.xbase : sg.xbase + 2 * HALO) : 0;
     const int xunits = (RINGX && !sg.xfresh) ? NEWROWS_UNITS : X_UNITS;      // uniform
+    // LEANX: the 2 * HALO rows above the new ones (a column's first tile only), in rounds of X_PT units per thread
+    f32x4 pe[LEANX ? X_PT : 1];
+    unsigned emask = 0;
+    auto extra_load = [&](int j0) __attribute__((always_inline)) {
+      if constexpr (LEANX) {
+        emask = 0;
+#pragma unroll
+        for (int j = 0; j < X_PT; ++j) {
+          const int u = tid + (j0 + j) * 256;
+          const int pp = u / (CI / 4);
+          const int r = pp / TWh, col = pp - r * TWh;
+          const int gx = sg.ex0 + col, gy = sg.ey0 + r;
+          const bool in = (j0 + j) < E_PT && u < EXTRA_UNITS && xc_ok && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;
+          if (in) emask |= 1u << j;
+          pe[j] = c3d_ld4u<false>(a.x.ptr, sg.ximg, in ? (unsigned)((gy * a.W + gx) * a.x.cstride + a.x.coff + xc) : 0u);
+        }
+      }
+    };
+    auto extra_store = [&](int j0) __attribute__((always_inline)) {
+      if constexpr (LEANX) {
+#pragma unroll
+        for (int j = 0; j < X_PT; ++j) {
+          const int u = tid + (j0 + j) * 256;
+          if ((j0 + j) < E_PT && u < EXTRA_UNITS) {
+            f32x4 v = pe[j];
+            if (aff) v = v * psc + psh;
+            if (lr) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q], a.slope);
+            }
+            if (!((emask >> j) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            u32x2 pl[NP];
+            split_planes<NP>(v, pl);
+            const int pp = u / (CI / 4);
+            const int r = pp / TWh;
+            int slot = sg.xbase + r;
+            slot = slot >= RING ? slot - RING : slot;
+            const int o = tr_swz<NSX>(slot * TWh + (pp - r * TWh), xc4 * 4);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_x + p * XPLANE + o) = pl[p];
+          }
+        }
+      }
+    };
 #pragma unroll
     for (int i = 0; i < X_PT; ++i) {
       const int u = tid + i * 256;
@@ -460,6 +527,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_x + p * XPLANE + o) = pl[p];
       }
+    }
+    if constexpr (LEANX) {
+      if (sg.xfresh) extra_load(0);          // into the registers the x units above have left; converted behind the dz units
     }
 #pragma unroll
     for (int i = 0; i < D_PT; ++i) {
@@ -499,6 +569,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
         const int o = tr_swz<NSD>(u / (CO / 4), (u % (CO / 4)) * 4);
 #pragma unroll
         for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_dz + p * DROWS * CO + o) = pl[p];
+      }
+    }
+    if constexpr (LEANX) {
+      if (sg.xfresh) {
+        extra_store(0);
+#pragma unroll
+        for (int j0 = X_PT; j0 < E_PT; j0 += X_PT) {     // (TRW < 2 * HALO: further rounds, load and convert back to back)
+          extra_load(j0);
+          extra_store(j0);
+        }
       }
     }
   };
@@ -628,6 +708,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   }
 
   // ---- consumer waves
+  // (round 5: s_setprio 1 / 3 for these waves measured nothing on fifteen layer shapes, fused and plain -- the consumers do not
+  //  lose issue slots to the producer waves; what they wait for is the producers' tile)
   // (tried: 32-wide channel tiles dealt to the waves interleaved, dead tiles of a ragged last slice skipped under
   //  wave-uniform tests -- 704 = 5.5 x 128 = 2.75 x 256 leaves 16 % dead MFMAs.  The scalar branches around the
   //  MFMAs cost every instance more than the dead work: 704x704 layer 1.97 -> 2.11 ms, the step 197 -> 191 img/s.)
@@ -793,7 +875,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   }
 }
 
-template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO>
+template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool LEAN_FA = false>
 int launch_tr(const WgradArgs& a, hipStream_t st) {
   constexpr int WK = 4 / (WCI * WCO);
   constexpr int CI = 32 * CI_T * WCI, CO = 32 * CO_T * WCO;
@@ -806,6 +888,21 @@ int launch_tr(const WgradArgs& a, hipStream_t st) {
       if (a.f_sum_n != a.strips * (256 / (CO / 4))) {
         c3d_set_error("wgrad: fuse_sum was not sized with c3d_wgrad_fused_sum_n()");
         return 1;
+      }
+      if constexpr (LEAN_FA && HALO > 0) {
+        // Lean register sets for the fused instances that spilled with whole-window sets (tools/obj_resources.py: 50-553 scratch
+        // instructions, 45-356 full drains): a column's first tile loads its upper rows inside its own staging step, which
+        // exposes part of a memory latency once per column -- taken where a column has several tiles.  Measured (round 5,
+        // 8 x 64 x 2048, fused): 32 -> 32 3x3 d2 0.179 -> 0.158 ms, 64 -> 64 2x2 0.312 -> 0.287, 128 -> 128 2x2 at half
+        // resolution 0.263 -> 0.244; the instances that did not spill lose 3-7 % in this form and keep the old one.
+        // (c3d_wgrad_desc.variant & 3: 1 / 2 force one form -- tests/test_gpu_conv.py holds the two to the same bits.)
+        const int force = a.variant & 3;
+        if (force ? force == 2 : a.tiles_y >= C3D_WGRAD_LEAN_MIN_TILES_Y) {
+          c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true, false, true>>();
+          hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true, false, true>), grid, dim3(512), lds, st, a);
+          C3D_CHECK_LAUNCH();
+          return 0;
+        }
       }
       c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true>>();
       hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true>), grid, dim3(512), lds, st, a);
@@ -837,12 +934,12 @@ int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
     case 2: return launch_tr<NP, 1, 2, 2, 1, 1, 2, 0>(a, st);
     case 3: return launch_tr<NP, 1, 1, 1, 1, 1, 4, 0>(a, st);
     case 4: return halo <= 1 ? launch_tr<NP, 4, 1, 2, 1, 1, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 4, 1, 2, 1, 1, (NP == 1 ? 4 : 2), 2>(a, st);
-    case 5: return halo <= 1 ? launch_tr<NP, 4, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 4, 1, 1, 1, 1, 4, 2>(a, st);
+    case 5: return halo <= 1 ? launch_tr<NP, 4, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 4, 1, 1, 1, 1, 4, 2, NP == 3>(a, st);
     case 8:
-      if constexpr (NP >= 2) return halo <= 1 ? launch_tr<NP, 4, 1, 2, 2, 1, 2, 1>(a, st) : launch_tr<NP, 4, 1, 2, 2, 1, 2, 2>(a, st);
+      if constexpr (NP >= 2) return halo <= 1 ? launch_tr<NP, 4, 1, 2, 2, 1, 2, 1, NP == 3>(a, st) : launch_tr<NP, 4, 1, 2, 2, 1, 2, 2, NP == 3>(a, st);
       else return -1;
     case 6: return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 2>(a, st);
-    default: return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, 4, 2>(a, st);
+    default: return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, 4, 2, NP == 3>(a, st);
   }
 }
 

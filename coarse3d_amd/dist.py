@@ -94,6 +94,36 @@ allreduce_sum_.begin = _allreduce_sum_begin
 allreduce_sum_.end = _allreduce_sum_end
 
 
+def peer_syncbn_reduce(px):
+    """The SyncBatchNorm exchange hook over a ``coarse3d_amd.peer.PeerExchange`` (IPC-mapped mailboxes, one small kernel
+    per exchange, csrc/peer_ops.hip) instead of one RCCL launch per vector.  Same interface as ``allreduce_sum_``
+    (call = blocking on the current stream; ``begin`` / ``end`` = on a side stream, under independent kernels)."""
+    def fits(t):          # (the same answer on every rank: the vectors have the same length everywhere)
+        return t.numel() <= px.desc.cap_doubles and t.dtype == torch.float64 and t.is_contiguous()
+
+    def reduce_(t):
+        if not fits(t):
+            return allreduce_sum_(t)
+        with _exposed("syncbn"):
+            px.allreduce_(t)
+        COUNTS["syncbn"] += 1
+        return t
+
+    def begin(t):
+        if not fits(t):
+            allreduce_sum_(t)
+            return None
+        COUNTS["syncbn"] += 1
+        return px.begin(t)
+
+    def end(work):
+        if work is not None:
+            with _exposed("syncbn"):
+                px.end(work)
+    reduce_.begin, reduce_.end, reduce_.peer = begin, end, px
+    return reduce_
+
+
 def allreduce_proto_sums_(t):
     """In-place sum over ranks of the per-class prototype feature sums + counts."""
     if is_dist():
@@ -222,18 +252,35 @@ class DataParallel(torch.nn.Module):
     backward); ``finish_gradients()`` waits for them and re-binds ``param.grad`` to the
     reduced flat views."""
 
-    def __init__(self, module, sync_bn=True, proto_sync="bank_mean"):
+    def __init__(self, module, sync_bn=True, proto_sync="bank_mean", syncbn_exchange="auto"):
         """proto_sync: "bank_mean" = reference semantics (mean over ranks of each rank's updated,
         l2-normalised bank, salsanext_proto.py:397-400); "sums" = all-reduce the per-class masked
         feature sums and counts and apply ONE momentum update with the global statistics (what a
-        single process on the global batch would compute, up to the per-rank Sinkhorn)."""
+        single process on the global batch would compute, up to the per-rank Sinkhorn).
+        syncbn_exchange: how the 43 + 43 fp64 statistics vectors of a step travel.  "peer" = IPC-mapped mailboxes, one
+        small kernel per exchange (coarse3d_amd/peer.py; one node, <= 8 ranks); "collective" = one torch.distributed
+        all-reduce each (RCCL / gloo); "auto" (default; C3D_SYNCBN_EXCHANGE overrides) = "peer" when the model lives on
+        a GPU and every rank could set its mailboxes up, else "collective" -- decided together, the ranks never split."""
         super().__init__()
         if proto_sync not in ("bank_mean", "sums"):
             raise ValueError(f"proto_sync must be 'bank_mean' or 'sums', got {proto_sync!r}")
+        syncbn_exchange = os.environ.get("C3D_SYNCBN_EXCHANGE", syncbn_exchange)
+        if syncbn_exchange not in ("auto", "peer", "collective"):
+            raise ValueError(f"syncbn_exchange must be 'auto', 'peer' or 'collective', got {syncbn_exchange!r}")
         self.module = module
         world = dist.get_world_size() if is_dist() else 1
         module._world = world if sync_bn else 1
         module._bn_reduce = allreduce_sum_ if (sync_bn and is_dist()) else None
+        self.peer = None
+        on_gpu = next(module.parameters()).is_cuda
+        if module._bn_reduce is not None and syncbn_exchange != "collective" and (on_gpu or syncbn_exchange == "peer"):
+            from .peer import PeerExchange
+            try:
+                self.peer = PeerExchange()          # collective: raises on every rank or on none
+                module._bn_reduce = peer_syncbn_reduce(self.peer)
+            except RuntimeError:
+                if syncbn_exchange == "peer":
+                    raise
         module._proto_mean = world_mean if (is_dist() and proto_sync == "bank_mean") else None
         module._proto_sums_reduce = allreduce_proto_sums_ if (is_dist() and proto_sync == "sums") else None
         self.flat = FlatGradients(module._trainable())

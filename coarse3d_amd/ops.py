@@ -83,6 +83,9 @@ def _bf(*tensors):
 # with Cout > 64 on the bf16x3 engine (1 = fused kernel with eight waves, 2 = with four, 3 = round 2's phased kernel);
 # bit 2 = round 2's phased kernel for nine-tap convs.  Same bits out of every variant (tests/test_gpu_conv.py).
 CONV_VARIANT = 0
+# c3d_wgrad_desc.variant (fused weight-gradient launches): 0 = the library's choice, 1 = whole-window register sets, 2 = lean
+# ones (same bits), +4 = a fused 1x1 launch keeps the unfused tile configuration
+WGRAD_VARIANT = 0
 F16X2_FWD = os.environ.get("C3D_F16X2_FWD", "0") == "1"
 F16X2_BWD = os.environ.get("C3D_F16X2_BWD", "0") == "1"     # EXPERIMENT: multi-tap input gradients too (per-tensor exponent)
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -371,25 +374,35 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     return out, stat_partial
 
 
-def _wgrad_kernel_name(ci, co, nt, halo, fused=False, raw=False):
-    """Mirrors c3d_wgrad_cfg() (csrc/wgrad_common.h) and the launch tables of wgrad_mfma.hip / wgrad_tr.hip."""
+def _wgrad_kernel_name(ci, co, nt, halo, fused=False, raw=False, h=0):
+    """Mirrors c3d_wgrad_cfg() (csrc/wgrad_common.h), plan() (wgrad_mfma.hip) and the launch tables of wgrad_mfma.hip /
+    wgrad_tr.hip (names as rocprofv3 prints them; the eleventh template argument: lean register sets, round 5)."""
     tr = MFMA_MODE != 0
     hl = 1 if halo <= 1 else 2
     x3 = tr and MFMA_MODE == 2          # three planes: the smaller pixel tiles of c3d_wgrad_cfg
+    lean_ok = False
     if nt == 1:
-        cfg = ("1, 2, 4, 2, 2, 1, 0" if (ci >= 96 and co >= 192) else "1, 2, 2, 2, 2, 1, 0" if (ci >= 96 and co >= 96)
+        wide = ci >= 96 and co >= 192 and not (fused and x3)      # (a fused launch takes the 128 x 128 slice)
+        cfg = ("1, 2, 4, 2, 2, 1, 0" if wide else "1, 2, 2, 2, 2, 1, 0" if (ci >= 96 and co >= 96)
                else f"1, 2, 2, 1, 1, {2 if tr else 4}, 0" if co > 32 else "1, 1, 1, 1, 1, 4, 0")
+        trw = 1
     elif nt == 4:
         if x3 and co > 32 and ci % 64 == 0 and halo <= 1:
-            cfg = f"4, 1, 2, 2, 1, 2, {hl}"
+            cfg, trw, lean_ok = f"4, 1, 2, 2, 1, 2, {hl}", 2, True
+        elif co > 32:
+            cfg, trw = f"4, 1, 2, 1, 1, {2 if x3 else 4}, {hl}", (2 if x3 else 4)
         else:
-            cfg = f"4, 1, 2, 1, 1, {2 if x3 else 4}, {hl}" if co > 32 else f"4, 1, 1, 1, 1, 4, {hl}"
+            cfg, trw, lean_ok = f"4, 1, 1, 1, 1, 4, {hl}", 4, hl == 2
+    elif co > 32:
+        trw = 4 if (tr and not x3) else 2
+        cfg = f"9, 1, 1, 1, 2, {trw}, {hl}"
     else:
-        cfg = f"9, 1, 1, 1, 2, {4 if (tr and not x3) else 2}, {hl}" if co > 32 else f"9, 1, 1, 1, 1, 4, {hl}"
+        cfg, trw, lean_ok = f"9, 1, 1, 1, 1, 4, {hl}", 4, hl == 2
     if tr:       # (ninth template argument: BatchNorm backward applied on load, conv_wgrad(fuse=...); tenth: raw bf16 stages, four
-        # tiles in flight -- the bf16 engine with bf16 tensors on both sides)
+        # tiles in flight -- the bf16 engine with bf16 tensors on both sides; eleventh: lean register sets)
+        lean = bool(fused and x3 and lean_ok and (h + trw - 1) // trw >= 8)
         return (f"wgrad_tr_kernel<{3 if MFMA_MODE == 2 else 1}, {cfg}, {'true' if fused else 'false'}, "
-                f"{'true' if (raw and MFMA_MODE == 1 and not fused) else 'false'}>")
+                f"{'true' if (raw and MFMA_MODE == 1 and not fused) else 'false'}, {'true' if lean else 'false'}>")
     return f"wgrad_mfma_kernel<{cfg}, {'true' if MFMA_MODE == 1 else 'false'}>"
 
 
@@ -414,12 +427,10 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_p
     d.dw, d.accumulate = dw.data_ptr(), int(accumulate)
     d.lrelu_slope = slope
     d.mfma_bf16 = MFMA_MODE           # the tiling (and with it the partial-sum size) depends on the engine
+    d.variant = WGRAD_VARIANT
     if f16x2 is not None:      # EXPERIMENT (C3D_F16X2_BWD=1): (scale [Cout] = 2^s, inv [1] = 2^-s) of grad_exponent_max
         d.mfma_bf16 = 4
         d.dz_scale, d.out_scale_dev = f16x2[0].data_ptr(), f16x2[1].data_ptr()
-    n = L.lib().c3d_wgrad_partial_floats(C.byref(d))
-    part = torch.empty(n, device=dz.device, dtype=torch.float32)
-    d.partial = part.data_ptr()
     if fuse is not None:
         dy, act, k = fuse[:3]
         pre = fuse[3] if len(fuse) > 3 else None          # (pre_scale, pre_shift): conv -> BatchNorm -> LeakyReLU layer
@@ -440,6 +451,10 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_p
             raise ValueError("conv_wgrad(fuse=...): the bias partials are the launch's own sums of dz")
         if dbias is not None:
             bias_partial = zsum
+    # (after the fuse_* fields: a fused launch may take another tile configuration, and with it another partial size)
+    n = L.lib().c3d_wgrad_partial_floats(C.byref(d))
+    part = torch.empty(n, device=dz.device, dtype=torch.float32)
+    d.partial = part.data_ptr()
     if bias_partial is not None:
         if dbias is None or dbias.shape[0] != dw.shape[0] or bias_partial.shape[0] < dw.shape[0]:
             raise ValueError("conv_wgrad: bias_partial needs a dbias of Cout entries")
@@ -456,7 +471,7 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_p
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
     co, ci, nt = dw.shape[0], src.C, len(taps)
     name = _wgrad_kernel_name(ci, co, nt, halo, fused=fuse is not None,
-                              raw=src.t.dtype == torch.bfloat16 and dz.dtype == torch.bfloat16)
+                              raw=src.t.dtype == torch.bfloat16 and dz.dtype == torch.bfloat16, h=h)
     with _Timed(name, 2.0 * b * h * w * dw.shape[0] * len(taps) * src.C, (h, w, ci, co, nt, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
     if d.fold_out:

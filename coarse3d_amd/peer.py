@@ -1,0 +1,134 @@
+"""SyncBatchNorm statistics exchange through IPC-mapped peer memory (csrc/peer_ops.hip).
+
+The reference wraps its model with ``torch.nn.SyncBatchNorm.convert_sync_batchnorm`` (tasks/weak_segmentation/trainer.py:54):
+every BatchNorm layer all-reduces its per-channel sums in forward and backward -- 43 + 43 vectors of at most 704 x 2 fp64
+per training step, each a RCCL launch of its own through ``torch.distributed`` (17 us of launch cost in a 1-rank group before
+any xGMI latency, and they block the main stream).  ``PeerExchange`` sets up, ONCE, one mailbox per rank in device memory,
+mapped into every other rank of the node (hipIpc handles travel over the existing process group); an exchange is then one
+small kernel that writes the rank's vector into every peer's mailbox, publishes a sequence number, waits (bounded) for the
+peers' and sums the slots in rank order -- the same bits on every rank.  The kernel is capturable (its sequence counter
+lives in device memory), so a captured data-parallel step keeps only the gradient buckets and the bank on RCCL.
+
+One process per GPU, all ranks on one node (IPC), at most ``C3D_PEER_MAX_RANKS`` = 8 of them.  Any transport works for the
+control plane (nccl, gloo); two ranks may share one device (tests/test_gpu_dp.py runs exactly that on the one-GPU box)."""
+import ctypes as C
+import socket
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+CAP_DOUBLES = 8192          # slot capacity: SalsaNext's largest grouped exchange is 2 x (704 + 128) doubles, SqueezeSegV3's 2 x 2304
+
+
+class PeerDesc(C.Structure):
+    _fields_ = [("mailbox", C.c_void_p * 8), ("rank", C.c_int32), ("world", C.c_int32), ("cap_doubles", C.c_int32),
+                ("timeout_s", C.c_float)]
+
+
+class PeerExchange:
+    def __init__(self, group=None, timeout_s=20.0, cap_doubles=CAP_DOUBLES):
+        """Collective: every rank of ``group`` (default: the world) must construct it at the same point.  Raises
+        RuntimeError -- on EVERY rank -- if any rank could not allocate, share or map a mailbox, or if the ranks are not
+        on one host."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("PeerExchange needs a GPU")
+        self.group = group
+        have_group = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if have_group else 0
+        self.world = dist.get_world_size(group) if have_group else 1
+        if self.world > 8:
+            raise RuntimeError(f"PeerExchange handles at most 8 ranks (one node), got {self.world}")
+        lib = L.lib()
+        self._own = None
+        self._mapped = []
+        self.desc = PeerDesc()
+        self.desc.rank, self.desc.world, self.desc.cap_doubles, self.desc.timeout_s = self.rank, self.world, cap_doubles, timeout_s
+        self.stream = torch.cuda.Stream()       # for the asynchronous form (begin / end)
+        err = None
+        handle = (C.c_ubyte * 64)()
+        try:
+            nbytes = lib.c3d_peer_mailbox_bytes(cap_doubles)
+            ptr = C.c_void_p()
+            L.check(lib.c3d_peer_alloc(nbytes, C.byref(ptr), handle), "c3d_peer_alloc")
+            self._own = ptr.value
+        except Exception as e:      # noqa: BLE001 -- the other ranks must learn about it below
+            err = f"rank {self.rank}: {e}"
+        infos = self._gather((socket.gethostname(), bytes(handle), err))
+        errs = [i[2] for i in infos if i[2]]
+        if not errs and len({i[0] for i in infos}) != 1:
+            errs = [f"the ranks run on different hosts ({sorted({i[0] for i in infos})}): IPC needs one node"]
+        if not errs:
+            try:
+                for r, (_, h, _) in enumerate(infos):
+                    if r == self.rank:
+                        self.desc.mailbox[r] = self._own
+                        continue
+                    p = C.c_void_p()
+                    L.check(lib.c3d_peer_open((C.c_ubyte * 64).from_buffer_copy(h), C.byref(p)), "c3d_peer_open")
+                    self._mapped.append(p.value)
+                    self.desc.mailbox[r] = p.value
+            except Exception as e:      # noqa: BLE001
+                err = f"rank {self.rank}: {e}"
+            errs = [e for e in self._gather(err) if e]       # (also the barrier: every mailbox is mapped before its first use)
+        if errs:
+            self.close()
+            raise RuntimeError("PeerExchange setup failed: " + "; ".join(errs))
+
+    def _gather(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def allreduce_(self, t, stream=None):
+        """In-place sum over ranks of a contiguous fp64 CUDA tensor (every rank: same call sequence, same sizes)."""
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+            raise ValueError("PeerExchange.allreduce_: contiguous fp64 CUDA tensor expected")
+        if t.numel() > self.desc.cap_doubles:
+            raise ValueError(f"PeerExchange.allreduce_: {t.numel()} values exceed the mailbox slot ({self.desc.cap_doubles})")
+        s = stream if stream is not None else torch.cuda.current_stream()
+        L.check(L.lib().c3d_peer_allreduce_f64(C.byref(self.desc), t.data_ptr(), t.numel(), C.c_void_p(s.cuda_stream)),
+                "c3d_peer_allreduce_f64")
+        return t
+
+    def begin(self, t):
+        """Asynchronous form: the exchange runs on this object's side stream, ordered after what the current stream has
+        queued; ``end`` makes the current stream wait for it.  Independent kernels queued in between run under the wait."""
+        self.stream.wait_stream(torch.cuda.current_stream())
+        t.record_stream(self.stream)
+        self.allreduce_(t, self.stream)
+        return self.stream
+
+    @staticmethod
+    def end(stream):
+        torch.cuda.current_stream().wait_stream(stream)
+
+    def check(self):
+        """Host check (synchronises): raises if an exchange gave up waiting for a peer -- its result was not a sum, and
+        everything computed from it since is wrong.  Returns the number of exchanges made."""
+        st, calls = C.c_int32(0), C.c_int64(0)
+        torch.cuda.synchronize()
+        L.check(L.lib().c3d_peer_status(C.byref(self.desc), C.byref(st), C.byref(calls)), "c3d_peer_status")
+        if st.value:
+            raise RuntimeError(f"PeerExchange: rank {self.rank} timed out waiting for a peer in one of its {calls.value} exchanges "
+                               "(a rank died, or the ranks' call sequences diverged); results since then are invalid")
+        return calls.value
+
+    def close(self):
+        lib = L.lib()
+        for p in self._mapped:
+            lib.c3d_peer_close(C.c_void_p(p))
+        self._mapped = []
+        if self._own is not None:
+            torch.cuda.synchronize()
+            lib.c3d_peer_free(C.c_void_p(self._own))
+            self._own = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 -- interpreter shutdown
+            pass

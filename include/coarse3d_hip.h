@@ -185,7 +185,10 @@ typedef struct {
   int32_t mfma_bf16;        /* as in c3d_conv_desc                                         */
   float lrelu_slope;        /* as in c3d_conv_desc                                         */
   int32_t dz_bf16;          /* 1: dz is bf16 (x.bf16 says the same for x); mfma_bf16 == 1 only */
-  int32_t reserved;
+  int32_t variant;          /* schedule selector of the bit-identity tests / A-B runs: 0 = the library's choice.  Fused launches
+                             * (fuse_dy) of the kernels with a rolling window: 1 = whole-window register sets (round 4), 2 = lean
+                             * register sets (round 5) -- the same bits either way.  Bit 2 (4): a fused 1x1 launch keeps the
+                             * 128 x 256 slice of the unfused one (another summation order)                                */
   /* optional: fold the layer's bias-gradient partials in the same launch that folds the weight-gradient strips
    * (saves one tiny launch per conv layer): dbias[c] = sum_k bias_partial[c][0][k], k < bias_n, the
    * [Cout][2][bias_n] partials c3d_bn_bwd_apply wrote (what c3d_bias_from_partials computes).  NULL = off. */
@@ -608,6 +611,33 @@ int c3d_sac_modulate_bwd(float* dm, const float* feat, const float* att, const f
                          const float* shift, int B, int H, int W, int C, float* datt, c3d_stream stream);
 int c3d_sac_fold(const float* t, int B, int H, int W, int C, int accumulate, float* dfeat,
                  c3d_stream stream);
+
+/* ------------------------------------------------------------------ SyncBatchNorm exchange through peer memory
+ * tasks/weak_segmentation/trainer.py:54 (torch.nn.SyncBatchNorm.convert_sync_batchnorm): the all-reduce of the per-channel
+ * statistics inside SyncBatchNorm's forward (sum, sum of squares) and backward (sum dy, sum dy * x_hat) -- 43 + 43 vectors of
+ * <= 704 x 2 fp64 per training step.  One process per GPU on ONE node: every rank owns a mailbox in its device memory, maps
+ * the mailboxes of its peers (hipIpc handles, passed over the existing torch.distributed group) and each exchange is one
+ * small kernel: write the vector into every peer's mailbox (xGMI stores), publish a sequence number, wait for the peers'
+ * (bounded), sum the slots in rank order -- bit-identical on every rank (csrc/peer_ops.hip).  Capturable in a hipGraph (the
+ * sequence counter lives in device memory).  Gradient buckets and the prototype bank stay on RCCL. */
+#define C3D_PEER_MAX_RANKS 8
+typedef struct {
+  void* mailbox[C3D_PEER_MAX_RANKS];   /* mailbox[r]: rank r's mailbox as mapped in THIS process (mailbox[rank] = own allocation) */
+  int32_t rank, world;
+  int32_t cap_doubles;                 /* slot capacity the mailboxes were sized for (c3d_peer_mailbox_bytes)                  */
+  float timeout_s;                     /* an exchange gives up waiting for a peer after this long (<= 0: 20 s)                */
+} c3d_peer_desc;
+int c3d_peer_desc_bytes(void);          /* sizeof(c3d_peer_desc), for a binding's layout check (host call) */
+int64_t c3d_peer_mailbox_bytes(int cap_doubles);
+/* host calls (synchronous): allocate + zero a mailbox and return its 64-byte IPC handle / map a peer's / unmap / free */
+int c3d_peer_alloc(int64_t bytes, void** ptr, void* handle64);
+int c3d_peer_open(const void* handle64, void** ptr);
+int c3d_peer_close(void* ptr);
+int c3d_peer_free(void* ptr);
+/* buf[0 .. n) (fp64, device) <- sum over ranks, in place; every rank of the group must make the same sequence of calls */
+int c3d_peer_allreduce_f64(const c3d_peer_desc* d, double* buf, int n, c3d_stream stream);
+/* host read of the rank's status word (0 = fine, 1 = an exchange timed out: its result was not a sum) and call counter */
+int c3d_peer_status(const c3d_peer_desc* d, int32_t* status_out, int64_t* calls_out);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,13 @@ def test_ctypes_struct_mirrors_match_the_c_layouts():
     assert L.lib().c3d_abi_sizes(out) == 0
     assert list(out) == [ctypes.sizeof(L.Src), ctypes.sizeof(L.ConvDesc), ctypes.sizeof(L.WgradDesc),
                          ctypes.sizeof(L.PackEntry), ctypes.sizeof(L.WgradFold)]
+    from coarse3d_amd.peer import PeerDesc
+    assert L.lib().c3d_peer_desc_bytes() == ctypes.sizeof(PeerDesc) == 80
+    assert L.lib().c3d_peer_mailbox_bytes(8192) == 256 + 2 * 8 * 8 + 2 * 8 * 8192 * 8
+    pd = PeerDesc()
+    pd.rank, pd.world, pd.cap_doubles = 3, 2, 16          # refused on the host: rank outside the group
+    assert L.lib().c3d_peer_allreduce_f64(ctypes.byref(pd), ctypes.c_void_p(8), 4, None) != 0
+    assert b"rank" in L.lib().c3d_last_error()
     # a refused call reports why, without touching the GPU
     d = L.ConvDesc()
     d.nsrc = 7

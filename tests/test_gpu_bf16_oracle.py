@@ -48,9 +48,20 @@ class bf16_engine:
         ops.set_matrix_precision(*self.prev)
 
 
-# measured on MI355X (profiles/round5_parity_measured_bf16.json) -> bound (<= 2x)
-FWD_BOUNDS = {"pred_abs_max": None, "pred_abs_mean": None, "argmax_disagree": None, "feat_cos_min": None,
-              "feat_cos_mean_gap": None, "running_stat_rel_max": None}
+# bound = <= 2x the value measured on MI355X (profiles/round5_parity_measured_bf16.json; measured value in the comment).
+# The *_over_yardstick entries are the contract in one number each: the engine's distance from the fp32 oracle divided by the
+# distance of the SAME oracle with bf16-rounded convolution operands -- measured 0.99 / 1.11 / 0.99: the HIP bf16 engine is
+# as far from the fp32 reference as the reference is from itself under bf16 operands.
+FWD_BOUNDS = {"pred_abs_max": 0.26,                    # 0.130 (yardstick 0.117)
+              "pred_abs_mean": 8.7e-3,                  # 4.34e-3 (yardstick 4.38e-3)
+              "argmax_disagree": 0.40,                  # 0.198 of the pixels of an UNTRAINED net (yardstick 0.201)
+              "argmax_disagree_margin_ge_0.05": 1.1e-2,  # 5.2e-3 where the oracle's two best classes are >= 0.05 apart
+              "feat_cos_min": 0.974,                    # 0.98685 (lower bound)
+              "feat_cos_mean_gap": 9.4e-3,              # 4.66e-3 (yardstick 4.71e-3)
+              "running_stat_rel_max": 8.5e-2,           # 4.24e-2
+              "pred_abs_mean_over_yardstick": 1.5,      # 0.993
+              "pred_abs_max_over_yardstick": 2.0,       # 1.113
+              "argmax_disagree_over_yardstick": 1.5}    # 0.987
 
 
 def test_bf16_forward_against_the_fp32_cpu_oracle():
@@ -63,6 +74,21 @@ def test_bf16_forward_against_the_fp32_cpu_oracle():
     ref_st = {k: v.clone() for k, v in st.items()}
     with torch.no_grad():
         ref = oc.backbone_forward(ref_st, x, True, masks, True, "SemanticKitti")
+        # Yardstick from the reference side: the SAME fp32 oracle with the operands of every convolution rounded to bf16
+        # (products exact, fp32 accumulation -- what bf16 MFMA operands do, and what torch.autocast(bfloat16) would do to
+        # the reference's convs).  Its distance from the fp32 oracle is the noise bf16 operands cause in THIS network on
+        # THESE weights (an untrained net amplifies rounding noise ~170x: fp32's 6e-8 arrives as 1e-5 at the output);
+        # the HIP engine must stay within a stated multiple of it.
+        orig_conv = oc._Ctx.conv
+
+        def conv_bf16(self, name, t, dilation=1, padding=0):
+            return torch.nn.functional.conv2d(t.bfloat16().float(), self.p[f"{name}.weight"].bfloat16().float(),
+                                              self.p[f"{name}.bias"], stride=1, padding=padding, dilation=dilation)
+        oc._Ctx.conv = conv_bf16
+        try:
+            yard = oc.backbone_forward({k: v.clone() for k, v in st.items()}, x, True, masks, True, "SemanticKitti")
+        finally:
+            oc._Ctx.conv = orig_conv
     with bf16_engine():
         m = SalsaNextProto(5, ncls, 20, 0, use_prototype=False)
         m.load_state_dict(st)
@@ -90,6 +116,14 @@ def test_bf16_forward_against_the_fp32_cpu_oracle():
         sel = margin >= thr
         got[f"argmax_disagree_margin_ge_{thr}"] = float(flip[sel].float().mean()) if bool(sel.any()) else 0.0
         got[f"pixels_margin_ge_{thr}"] = float(sel.float().mean())
+    dy = (yard["pred_2d"] - ref["pred_2d"]).abs()
+    got["yardstick_pred_abs_max"] = float(dy.max())
+    got["yardstick_pred_abs_mean"] = float(dy.mean())
+    got["yardstick_argmax_disagree"] = float((yard["pred_2d"].argmax(1) != ref["pred_2d"].argmax(1)).float().mean())
+    got["yardstick_feat_cos_mean_gap"] = float(1.0 - torch.nn.functional.cosine_similarity(yard["feat_2d"], ref["feat_2d"], dim=1).mean())
+    got["pred_abs_mean_over_yardstick"] = got["pred_abs_mean"] / got["yardstick_pred_abs_mean"]
+    got["pred_abs_max_over_yardstick"] = got["pred_abs_max"] / got["yardstick_pred_abs_max"]
+    got["argmax_disagree_over_yardstick"] = got["argmax_disagree"] / max(got["yardstick_argmax_disagree"], 1e-9)
     cos = torch.nn.functional.cosine_similarity(feat, ref["feat_2d"], dim=1)
     got["feat_cos_min"] = float(cos.min())
     got["feat_cos_mean_gap"] = float(1.0 - cos.mean())
@@ -111,9 +145,19 @@ def test_bf16_forward_against_the_fp32_cpu_oracle():
             assert got[k] <= bound, (k, got[k], bound)
 
 
-STEP_BOUNDS = {"ce_rel": None, "lov_rel": None, "contrast_rel": None, "loss_rel": None, "pred_abs_max": None,
-               "labels_contra_disagree": None, "prototypes_rel": None, "anchor_disagree": None, "grad_norm_rel_median": None,
-               "grad_cos_heads_min": None}
+# second reference-generated golden step (2 x 64 x 512, 512 anchors, epoch 40): bound = <= 2x measured
+STEP_BOUNDS = {"ce_rel": 7.1e-3,                        # 3.53e-3
+               "lov_rel": 9.4e-4,                       # 4.68e-4
+               "contrast_rel": 1.0e-4,                  # 4.5e-5 (a mean over 19 456 anchors: 67 % of the draws land on other
+                                                        #          pixels of their class, the loss barely moves)
+               "loss_rel": 5.0e-3,                      # 2.46e-3
+               "pred_abs_max": 0.25,                    # 0.1235 on the stored sub-grid
+               "argmax_disagree_sub": 0.27,             # 0.136 (closed-form weights: near-tied classes)
+               "labels_contra_disagree": 0.11,          # 0.0553: pseudo labels follow the argmax
+               "mask_contra_disagree": 0.10,            # 0.0493
+               "prototypes_rel": 1.7e-3,                # 8.2e-4
+               "grad_norm_rel_median": 7.3e-2,          # 3.6e-2 over the 190 parameter tensors
+               "grad_norm_rel_max": 0.96}               # 0.48 (one small tensor)
 
 
 def test_bf16_training_step_against_the_reference_generated_golden_step():

@@ -337,6 +337,9 @@ def test_fused_pointwise_kernel_is_bit_identical_to_the_phased_one(B, H, W, srcC
     (2, 32, 256, 64, 64, 2, 2, 1, True), (2, 32, 200, 32, 64, 2, 2, 1, True), (2, 16, 512, 128, 128, 3, 1, 1, True),
     (2, 32, 256, 96, 32, 1, 1, 0, True), (4, 16, 256, 256, 256, 1, 1, 0, True), (2, 16, 256, 256, 128, 1, 1, 0, True),
     (2, 32, 256, 32, 64, 1, 1, 0, False), (1, 40, 232, 64, 64, 3, 1, 1, False), (3, 8, 97, 32, 32, 3, 1, 1, True),
+    # round 5: the instances with lean register sets (columns of >= 8 tiles), ragged H / W, four taps at +-2
+    (2, 32, 256, 32, 32, 2, 4, 2, True), (1, 70, 200, 32, 32, 3, 2, 2, True), (1, 70, 200, 64, 64, 2, 2, 1, True),
+    (1, 66, 72, 128, 128, 2, 2, 1, False),
 ])
 def test_batchnorm_backward_applied_on_load_by_the_weight_gradient(B, H, W, Cin, Cout, k, dil, pad, bn):
     """Round 4: ops.conv_wgrad(fuse=(dy, act, k)) -- the layer's first weight-gradient launch
@@ -364,17 +367,29 @@ def test_batchnorm_backward_applied_on_load_by_the_weight_gradient(B, H, W, Cin,
         dw_ref = torch.zeros(Cout, Cin, k, k, device=dev)
         db_ref = torch.zeros(Cout, device=dev)
         ops.conv_wgrad(src, dz_ref, dw_ref, taps, bias_partial=pz, dbias=db_ref)
-        # one launch
-        dz = torch.full_like(act, float("nan"))
-        dw = torch.zeros_like(dw_ref)
-        db = torch.zeros_like(db_ref)
-        ops.conv_wgrad(src, dz, dw, taps, dbias=db, fuse=(dy, act, kk))
-        torch.cuda.synchronize()
-        assert torch.equal(dz, dz_ref)
-        assert torch.equal(dw, dw_ref)
-        assert float((db - db_ref).abs().max()) <= 2e-6 * float(dz_ref.abs().sum(dim=(0, 1, 2)).max())
-        ref64 = dz_ref.double().sum(dim=(0, 1, 2))
-        assert float((db.double() - ref64).abs().max()) <= 1e-6 * float(dz_ref.double().abs().sum(dim=(0, 1, 2)).max())
+        # one launch.  c3d_wgrad_desc.variant: 0 = the library's choice; 1 / 2 = whole-window / lean register sets (round 5:
+        # the fused instances that spilled carry only a window's NEW rows in flight -- the same LDS image, the same bits);
+        # +4 = a fused 1x1 launch over >= 96 x 192 channels keeps the unfused launch's 128 x 256 slice (the library's
+        # choice is the 128 x 128 one, which does not spill: another strip layout, i.e. another fp32 summation order)
+        wide = k == 1 and Cin >= 96 and Cout >= 192
+        for variant in (0, 1 | 4, 2 | 4):
+            dz = torch.full_like(act, float("nan"))
+            dw = torch.zeros_like(dw_ref)
+            db = torch.zeros_like(db_ref)
+            ops.WGRAD_VARIANT = variant
+            try:
+                ops.conv_wgrad(src, dz, dw, taps, dbias=db, fuse=(dy, act, kk))
+            finally:
+                ops.WGRAD_VARIANT = 0
+            torch.cuda.synchronize()
+            assert torch.equal(dz, dz_ref), variant
+            if variant == 0 and wide:
+                assert float((dw - dw_ref).abs().max()) <= 2e-6 * float(dw_ref.abs().max()), variant
+            else:
+                assert torch.equal(dw, dw_ref), variant
+            assert float((db - db_ref).abs().max()) <= 2e-6 * float(dz_ref.abs().sum(dim=(0, 1, 2)).max())
+            ref64 = dz_ref.double().sum(dim=(0, 1, 2))
+            assert float((db.double() - ref64).abs().max()) <= 1e-6 * float(dz_ref.double().abs().sum(dim=(0, 1, 2)).max())
     finally:
         ops.set_matrix_precision(*_PREV.pop())
 

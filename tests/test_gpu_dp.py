@@ -48,7 +48,15 @@ def _run(rank, world, port, q, b, h, w, ncls, proto_sync="bank_mean", wrap="c3d"
     if world > 1 and wrap == "c3d":
         model.finish_gradients()
     torch.cuda.synchronize()
-    res = {"grads": {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None},
+    peer_calls = -1
+    if world > 1 and wrap == "c3d":
+        # round 5: the SyncBatchNorm sums travel through IPC-mapped peer mailboxes (coarse3d_amd/peer.py), not through
+        # torch.distributed -- here between two processes that share the box's one GPU
+        assert model.peer is not None and D.COUNTS["syncbn"] > 0
+        peer_calls = model.peer.check()
+        assert peer_calls == D.COUNTS["syncbn"]
+    res = {"peer_calls": peer_calls,
+           "grads": {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None},
            "protos": m.prototypes.detach().cpu().numpy(),
            "rm": m.state_dict()["resBlock2.bn3.running_mean"].cpu().numpy(),
            "pred": out["pred_2d"].detach().cpu().numpy()}
@@ -82,6 +90,8 @@ def test_two_ranks_match_full_batch():
     # ranks agree with each other exactly on the reduced gradients
     for k in res[0]["grads"]:
         assert (res[0]["grads"][k] == res[1]["grads"][k]).all(), k
+    # every SyncBatchNorm exchange of the step went through the peer mailboxes, on both ranks alike
+    assert res[0]["peer_calls"] == res[1]["peer_calls"] >= 40
     # SyncBN: forward of each rank's image equals the full-batch forward of that image
     for r in range(2):
         assert rel(res[r]["pred"], full["pred"][r:r + 1]) < 1e-4
@@ -97,6 +107,75 @@ def test_two_ranks_match_full_batch():
     assert (res[0]["protos"] == res[1]["protos"]).all()
     n = torch.from_numpy(res[0]["protos"]).norm(dim=-1)
     assert float(n.min()) > 0.9 and float(n.max()) < 1.0 + 1e-5
+
+
+def _peer_worker(rank, world, port, q, skip_last):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coarse3d_amd.peer import PeerExchange
+    torch.cuda.set_device(0)
+    px = PeerExchange(timeout_s=2.0 if skip_last else 20.0)
+    g = torch.Generator().manual_seed(5)
+    sizes = [int(v) for v in torch.randint(1, 1665, (300,), generator=g)] + [8192, 1, 1408]
+    ok = True
+    load = torch.randn(2048, 2048, device="cuda")
+    outs = []
+    for it, n in enumerate(sizes):
+        mine = torch.arange(n, dtype=torch.float64, device="cuda") * (rank + 1) + it * 0.5 + 1.0 / (rank + 3)
+        if (it + rank) % 3 == 0:            # uneven load: one rank is late for this exchange, by a different amount each time
+            for _ in range(1 + it % 4):
+                load = torch.tanh(load @ load * 1e-3)
+        if it % 5 == 0:                     # the asynchronous form, with independent work queued under it
+            w = px.begin(mine)
+            load = load * 1.0001
+            px.end(w)
+        else:
+            px.allreduce_(mine)
+        outs.append(mine)
+    torch.cuda.synchronize()
+    for it, (n, got) in enumerate(zip(sizes, outs)):
+        want = torch.zeros(n, dtype=torch.float64)
+        for r in range(world):              # the kernel's own order: rank 0 first
+            want += torch.arange(n, dtype=torch.float64) * (r + 1) + it * 0.5 + 1.0 / (r + 3)
+        ok = ok and torch.equal(got.cpu(), want)
+    calls = px.check()
+    timed_out = False
+    dist.barrier()
+    if skip_last:
+        # a rank that never arrives must not hang the GPU: the other one gives up after timeout_s and says so
+        if rank == 0:
+            t = torch.ones(4, dtype=torch.float64, device="cuda")
+            px.allreduce_(t)
+            try:
+                px.check()
+            except RuntimeError as e:
+                timed_out = "timed out" in str(e)
+        dist.barrier()
+    q.put((rank, ok, calls, timed_out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("skip_last", [False, True])
+def test_peer_exchange_between_two_processes_on_one_device(skip_last):
+    """coarse3d_amd/peer.py + csrc/peer_ops.hip: the SyncBatchNorm sums of trainer.py:54 through
+    IPC-mapped mailboxes instead of one collective launch each.  Two PROCESSES that share this box's GPU (gloo carries the
+    64-byte IPC handles): 303 exchanges of 1 ... 8192 doubles, blocking and asynchronous, with one rank late by a varying
+    amount -- every result equals the rank-ordered fp64 sum bit for bit on both ranks.  skip_last: one rank leaves an
+    exchange out; the other's kernel gives up after its timeout instead of spinning for ever and ``check()`` raises."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + os.getpid() % 500 + (7 if skip_last else 0)
+    procs = [ctx.Process(target=_peer_worker, args=(r, 2, port, q, skip_last)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = {r: (ok, calls, to) for r, ok, calls, to in (q.get(timeout=300) for _ in range(2))}
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    assert res[0][0] and res[1][0]
+    assert res[0][1] == res[1][1] == 303
+    assert res[0][2] == bool(skip_last) and not res[1][2]
 
 
 def test_reference_wrap_syncbn_and_stock_ddp_match_full_batch():
