@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
                 ("accumulate", C.c_int32), ("stat_partial", C.c_void_p), ("lrelu_slope", C.c_float),
                 ("mfma_bf16", C.c_int32), ("out_bf16", C.c_int32), ("wpack_planes", C.c_int32),
                 ("stat_mul", C.c_void_p), ("stat_mul_cstride", C.c_int32), ("variant", C.c_int32),
-                ("acc_scale_dev", C.c_void_p)]
+                ("acc_scale_dev", C.c_void_p), ("stat_mul_bf16", C.c_int32), ("reserved", C.c_int32)]
 
 
 class WgradDesc(C.Structure):

@@ -28,7 +28,13 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 # BatchNorm-backward sums in the epilogue of the last input-gradient conv (see _conv_backward); False: always the
 # separate reduce pass (module flag for tests / A-B runs)
-FUSE_BN_REDUCE = True
+FUSE_BN_REDUCE = os.environ.get("C3D_FUSE_BN_REDUCE", "1") != "0"      # (the environment switch: same-box A/B runs)
+# The same on the bf16 engine (round 5: ConvArgs::stat_mul over bf16 tensors, tests/test_gpu_bf16_storage.py).  OFF by default:
+# measured on BASELINE configs[2] it removes 29 of the 43 reduce passes (1.13 -> 0.45 ms) but the launches that carry the
+# epilogue more than double (conv_x3f<2,2,9,..> 79 -> 180 us, conv_bfp<8,2,32,1,4,..> 56 -> 145 us: the multiplier tile is read
+# with sixteen 2-byte loads per lane and sub-tile, and these kernels are bound by requests in flight) -- 19.07 vs 17.66 ms of
+# kernels per step.  What it needs is the multiplier tile staged through LDS with 16-byte loads; until then the separate pass stays.
+FUSE_BN_REDUCE_BF16 = os.environ.get("C3D_FUSE_BN_REDUCE_BF16", "0") == "1"
 # BatchNorm / LeakyReLU backward applied ON LOAD by the layer's first weight-gradient launch (round 4; ops.conv_wgrad(fuse=...)):
 # the apply pass (dy, a -> dz: three tensor passes at HBM speed, 53 launches and the largest kernel of the round-3 step)
 # disappears; dz is bit-identical.  False: the separate c3d_bn_bwd_apply pass (module flag for tests / A-B runs)
@@ -626,12 +632,17 @@ class Backbone:
                 # (a residual sum x + BN(a) passes its gradient on unchanged: the same sums, multiplied with a, for that layer)
                 tgt = s if s.bn_alias is None else s.bn_alias
                 p_ = tgt.producer
-                if (FUSE_BN_REDUCE and ops.MFMA_MODE == 2 and self.train and p_ is not None and p_.mode == 0 and p_.bn is not None
-                        and s.first_consumer == name and tgt.t.dtype == torch.float32 and tgt.t.shape[3] == cs
+                # (round 5: the bf16 engine too, over bf16 tensors -- its BatchNorm-backward reduce pass was the second
+                #  largest kernel of BASELINE configs[2]; kernels without the epilogue answer part = None)
+                if (FUSE_BN_REDUCE and (ops.MFMA_MODE == 2 or (ops.MFMA_MODE == 1 and FUSE_BN_REDUCE_BF16)) and self.train
+                        and p_ is not None and p_.mode == 0 and p_.bn is not None
+                        and s.first_consumer == name and tgt.t.dtype == s.grad.dtype and tgt.t.shape[3] == cs
+                        and tgt.t.dtype == (torch.float32 if ops.MFMA_MODE == 2 else torch.bfloat16)
                         and tuple(tgt.t.shape) == tuple(s.t.shape)):
                     part = torch.empty(cs, 2, ops.num_mtiles(*s.t.shape[:3]), device=s.t.device, dtype=torch.float32)
-                ops.conv_forward([gsrc], wd, None, cs, ntaps, out=s.grad, accumulate=acc, grad=True,
-                                 stat_partial=part, stat_mul=tgt.t if part is not None else None, f16x2_inv=ginv)
+                _, part = ops.conv_forward([gsrc], wd, None, cs, ntaps, out=s.grad, accumulate=acc, grad=True,
+                                           stat_partial=part, stat_mul=tgt.t if part is not None else None, f16x2_inv=ginv,
+                                           stat_mul_optional=True)
                 tgt.bwd_partial = part
             off += cs
         rec.out.grad = None

@@ -64,10 +64,14 @@ __device__ __forceinline__ void split4(f32x4 v, u32x2 (&out)[NP]) {
 // when it is stored to LDS), which makes room for DEEPER K chunks -- 64 channels for 1x1 convs, 32 for the four-tap ones:
 // with 16 / 32-channel chunks a pixel contributes 32 / 64 bytes to a load instruction and this kernel took as long over bf16
 // tensors as over fp32 ones (requests, not bytes: 704 -> 64 at 8 x 32 x 1024 even 248 vs 166 us).
-template <int TR, int NT, int CK, int HALO, int TT, int NP, bool BFS = false>
-__global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8) && !(BFS && NT == 2 && (CK == 64 || (TT == 4 && CK == 32)))) ? 3 : 2)
+// SM (round 5, BFS only): the instance with the BatchNorm-backward epilogue (ConvArgs::stat_mul) -- a kernel of its own, two
+// workgroups per CU: compiled into the common instance the epilogue's multiplier tile pushed it past its register cap (303
+// spilled registers at three workgroups per CU) for EVERY launch, with or without stat_mul.
+template <int TR, int NT, int CK, int HALO, int TT, int NP, bool BFS = false, bool SM = false>
+__global__ __launch_bounds__(256, (!SM && NP == 1 && !(TT == 9 && NT == 2 && TR == 8) && !(BFS && NT == 2 && (CK == 64 || (TT == 4 && CK == 32)))) ? 3 : 2)
     void conv_bfp_kernel(ConvArgs a) {
   static_assert(!BFS || NP == 1, "raw bf16 staging belongs to the one-plane engine");
+  static_assert(!SM || BFS, "the separate stat_mul instance exists for the raw-bf16 kernels");
   using PinT = std::conditional_t<BFS, u32x2, f32x4>;
   constexpr int CSB = CK + 8;            // bf16 elements per LDS row
   constexpr int TWh = 32 + 2 * HALO;
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !(TT == 9 && NT == 2 && TR == 8) &
     c0 = c2;
     kbase = kb2;
   }
-  conv_epilogue<TR, NT, WM, WN, NP == 1, false, 256, false, NP >= 2>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
+  conv_epilogue<TR, NT, WM, WN, NP == 1, false, 256, false, (NP >= 2 || SM)>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
                                                                      tile_pix);
 }
 
@@ -315,9 +319,17 @@ int launch_bfp(ConvArgs& a, hipStream_t st) {
   size_t lds = (size_t)NP * ((size_t)(TR + 2 * HALO) * (32 + 2 * HALO) + (size_t)TT * 32 * NT) * CSB * 2;
   const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
   if (lds < red) lds = red;
-  c3d_opt_in_lds<&conv_bfp_kernel<TR, NT, CK, HALO, TT, NP, BFS>>();
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
+  if constexpr (BFS) {
+    if (a.stat_mul && a.stat_partial) {      // BatchNorm-backward sums in the epilogue: the instance that has it
+      c3d_opt_in_lds<&conv_bfp_kernel<TR, NT, CK, HALO, TT, NP, BFS, true>>();
+      hipLaunchKernelGGL((conv_bfp_kernel<TR, NT, CK, HALO, TT, NP, BFS, true>), grid, dim3(256), lds, st, a);
+      C3D_CHECK_LAUNCH();
+      return 0;
+    }
+  }
+  c3d_opt_in_lds<&conv_bfp_kernel<TR, NT, CK, HALO, TT, NP, BFS>>();
   hipLaunchKernelGGL((conv_bfp_kernel<TR, NT, CK, HALO, TT, NP, BFS>), grid, dim3(256), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;

@@ -25,6 +25,7 @@ struct ConvArgs {
   int six;                   // bf16x3: six plane products instead of eight (input-gradient convs, mfma_bf16 == 3)
   const float* stat_mul;     // NULL, or the tensor whose product with the stored values replaces v*v in stat_partial
   int stat_mul_cs;
+  int stat_mul_bf16 = 0;     // stat_mul holds bf16 (the bf16 engine): the sums then use the values as stored (rounded to bf16)
   int variant = 0;         // c3d_conv_desc.variant (schedule selector of the bit-identity tests)
   bool one_plane = false;  // conv_x3.hip: the bf16 engine's fused nine-tap kernel (one plane, bf16 tensors)
   bool f16x2 = false;      // EXPERIMENT (mfma_bf16 == 4): two fp16 planes / three products where a kernel has the variant
@@ -63,8 +64,9 @@ struct c3d_type_tag {
 // NTHR: threads of the workgroup.  SUBFAST: the straight-line path is chosen per 32-wide cout
 // sub-tile (a ragged last cout tile keeps it for its live sub-tiles); otherwise per workgroup tile
 // (fewer code paths -- the 4-wave kernels sit at their register limits).
-// STATMUL: the kernel honours ConvArgs::stat_mul (BatchNorm-backward sums in the epilogue).  Only the bf16x3 engine's
-// kernels compile it in: the 16 extra registers of the multiplier tile spill in the register-capped fp32 / bf16 kernels.
+// STATMUL: the kernel honours ConvArgs::stat_mul (BatchNorm-backward sums in the epilogue).  The bf16x3 engine's kernels
+// compile it in and, since round 5, the bf16 engine's kernels over bf16 tensors (conv_x3f one plane, conv_pw1, conv_bfp with
+// raw bf16 staging): the 16 extra registers of the multiplier tile spill in the register-capped fp32 / widening bf16 kernels.
 template <int TR, int NT, int WM, int WN, bool BF16_OUT = false, bool ILV = false, int NTHR = 256, bool SUBFAST = false,
           bool STATMUL = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TR / WM][NT / WN], float* smem, int tid,
@@ -79,6 +81,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
   const size_t obase_i = tile_pix * a.out_cstride + a.out_coff + n0 + l31;   // element index, + per-lane cout
   const bool obf = BF16_OUT && a.out_bf16 != 0;      // engines that never store bf16 compile that path out
   const float* mulp = (STATMUL && a.stat_partial) ? a.stat_mul : nullptr;
+  const bool mbf = STATMUL && BF16_OUT && a.stat_mul_bf16 != 0;      // bf16 multiplier tensor; the sums use the values as stored
   const float asc = a.acc_scale_dev ? a.acc_scale * *a.acc_scale_dev : a.acc_scale;
   // one 32-wide cout sub-tile, any position: per-element predicates
   auto slow_sub = [&](int j) {
@@ -99,8 +102,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
           const size_t o = ((size_t)(b * a.H + gy) * a.W + gx) * a.out_cstride + a.out_coff + co;
           if (a.accumulate) v += c3d_ld1(a.out, o, obf);
           c3d_st1(a.out, o, obf, v);
+          if (mulp && obf) v = (float)(__bf16)v;
           s1[j] += v;
-          s2v[j] += v * (mulp ? mulp[((size_t)(b * a.H + gy) * a.W + gx) * a.stat_mul_cs + co] : v);
+          s2v[j] += v * (mulp ? c3d_ld1(mulp, ((size_t)(b * a.H + gy) * a.W + gx) * a.stat_mul_cs + co, mbf) : v);
         }
       }
     }
@@ -114,7 +118,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     constexpr bool ACC = decltype(accumulate_tag)::value;
     using OT = typename decltype(type_tag)::type;
     OT* obase = reinterpret_cast<OT*>(a.out) + obase_i;
-    if constexpr (std::is_same_v<OT, __bf16> && !ACC && !STATMUL && !ILV && (NT / WN) > 1) {
+    if constexpr (std::is_same_v<OT, __bf16> && !ACC && !ILV && (NT / WN) > 1) if (!mulp) {
       // bf16 output, several ADJACENT cout sub-tiles per wave: a sub-tile is 64 bytes of a pixel, half a cache line, and a
       // launch that mostly writes (192 -> 704) took as long as over fp32 tensors.  With the sub-tiles innermost the wave's
       // consecutive stores cover NPW x 64 contiguous bytes of the same pixel.
@@ -174,9 +178,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         // BatchNorm-backward sums (stat_mul): the multiplier tile is requested with the old values, one round trip
         float mul[STATMUL ? 16 : 1];
         if constexpr (STATMUL) if (mulp) {
-          const float* mrow = mulp + (tile_pix + (size_t)((wm + i * WM) * a.W + 4 * half)) * a.stat_mul_cs + n0 + cl + l31;
+          const size_t mbase = (tile_pix + (size_t)((wm + i * WM) * a.W + 4 * half)) * a.stat_mul_cs + n0 + cl + l31;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) mul[r] = mrow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * a.stat_mul_cs];
+          for (int r = 0; r < 16; ++r) mul[r] = c3d_ld1(mulp, mbase + (size_t)((r & 3) + 8 * (r >> 2)) * a.stat_mul_cs, mbf);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -187,6 +191,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
           // output stream is never re-read by this kernel (same-box A/B of the step: 197.9 -> 199.2 img/s)
           if constexpr (!ACC) __builtin_nontemporal_store((OT)v, &orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs]);
           else orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs] = (OT)v;
+          if constexpr (STATMUL && std::is_same_v<OT, __bf16>) if (mulp) v = (float)(OT)v;     // the value as stored
           s1[j] += v;
           if constexpr (STATMUL) s2v[j] += v * (mulp ? mul[r] : v);
           else s2v[j] += v * v;

@@ -251,6 +251,31 @@ extern "C" int c3d_conv_num_mtiles(int B, int H, int W) {
 // smallest grid the wide pointwise kernel is launched with (see c3d_conv_forward); mirrored by ops._pw3_tile()
 static int c3d_pw3_min_workgroups() { return 128; }
 
+// Whether the kernel a descriptor selects compiles the BatchNorm-backward epilogue in (conv_common.h, STATMUL).  Mirrors the
+// dispatch of c3d_conv_forward below and of conv_bfp.hip / conv_pw3.hip for the bf16 engine.
+static bool c3d_stat_mul_kernel(const c3d_conv_desc* d) {
+  if (d->mfma_bf16 >= 2) return !d->out_bf16 && !d->stat_mul_bf16;       // every kernel of the bf16x3 engine (4: the f16x2 experiment)
+  const int tr = c3d_tile_rows(d->H);
+  if (d->mfma_bf16 != 1 || !d->out_bf16 || !d->stat_mul_bf16 || tr != 8) return false;
+  for (int s = 0; s < d->nsrc; ++s)
+    if (!d->src[s].bf16) return false;
+  if (d->ntaps == 9) return d->wpack_planes && !(d->variant & 4);                            // conv_x3f, one plane
+  if (d->ntaps == 1 && d->Cout > 64 && d->wpack_planes) {
+    const int px_tiles = d->B * ((d->W + 31) / 32) * ((d->H + tr - 1) / tr);
+    bool wide = d->Cout > 128;
+    if (wide && px_tiles * ((d->Cout + 255) / 256) < c3d_pw3_min_workgroups()) wide = false;
+    if (wide) return false;                                                                  // conv_pw1<8>: no such instance
+    if (px_tiles * ((d->Cout + 127) / 128) >= c3d_pw3_min_workgroups()) return (d->variant & 3) != 3;            // conv_pw1<4>
+  }
+  return !(d->variant & 8);                                                                  // conv_bfp, raw bf16 staging
+}
+
+extern "C" int c3d_conv_stat_mul_supported(const c3d_conv_desc* d) {
+  if (!d || !d->stat_mul || !d->stat_partial || d->nsrc < 1 || d->nsrc > C3D_MAX_SRC || d->H <= 0) return 0;
+  if (d->ntaps != 1 && d->ntaps != 4 && d->ntaps != 9) return 0;
+  return c3d_stat_mul_kernel(d) ? 1 : 0;
+}
+
 extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   C3D_REQUIRE(d != nullptr, "conv: null descriptor");
   C3D_REQUIRE(d->nsrc >= 1 && d->nsrc <= C3D_MAX_SRC, "conv: nsrc must be 1..3");
@@ -290,8 +315,10 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   a.acc_scale_dev = d->acc_scale_dev;
   a.variant = d->variant;
   C3D_REQUIRE(!d->acc_scale_dev || d->mfma_bf16 == 4, "conv: acc_scale_dev belongs to the f16x2 experiment (mfma_bf16 == 4)");
-  C3D_REQUIRE(!d->stat_mul || (d->stat_partial && !d->out_bf16 && d->stat_mul_cstride >= d->Cout && d->mfma_bf16 >= 2),
-              "conv: stat_mul needs stat_partial, fp32 output, a channel stride >= Cout and the bf16x3 engine (mfma_bf16 >= 2)");
+  a.stat_mul_bf16 = d->stat_mul_bf16;
+  C3D_REQUIRE(!d->stat_mul || (d->stat_partial && d->stat_mul_cstride >= d->Cout && c3d_stat_mul_kernel(d)),
+              "conv: stat_mul needs stat_partial, a channel stride >= Cout and a kernel with the epilogue (c3d_conv_stat_mul_supported: "
+              "the bf16x3 engine over fp32 tensors, or the bf16 engine's 8-row-tile kernels over bf16 tensors)");
   {
     bool any_bf = d->out_bf16 != 0;
     for (int s = 0; s < d->nsrc; ++s) any_bf = any_bf || d->src[s].bf16 != 0;

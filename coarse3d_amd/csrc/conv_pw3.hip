@@ -264,7 +264,8 @@ __global__ __launch_bounds__(512, 1) void conv_pw3_kernel(ConvArgs a) {
 // trip count rounded up to a multiple of four (a chunk of zeros adds nothing).  The on-load transform reads scale / shift /
 // LeakyReLU slope of its four channels from a table in LDS (one formula for every source: fma(x, scale, shift), then
 // max(v, v * slope) with slope 1 where there is no activation -- the values the phased kernel computes).
-template <int NT>
+// SM (round 5): the instance with the BatchNorm-backward epilogue (ConvArgs::stat_mul), launched when a launch asks for it
+template <int NT, bool SM = false>
 __global__ __launch_bounds__(512, 1) void conv_pw1_kernel(ConvArgs a) {
   constexpr int TR = 8, CQ = 4;                    // 16 channels per K chunk
   constexpr int TN = 32 * NT;
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw1_kernel(ConvArgs a) {
       __syncthreads();                     // the other buffer is complete, this one is free again
     });
   }
-  conv_epilogue<TR, NT, WM, WN, true, false, 512, true, false>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
+  conv_epilogue<TR, NT, WM, WN, true, false, 512, true, SM>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -782,9 +783,17 @@ int launch_pw1(ConvArgs& a, hipStream_t st) {
   size_t lds = (size_t)2 * (8 * 32 + 32 * NT) * 16 * 2 + (size_t)3 * a.Kq * 4 * sizeof(float);    // two buffers + the affine table
   const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
   if (lds < red) lds = red;
-  c3d_opt_in_lds<&conv_pw1_kernel<NT>>();
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
+  // BatchNorm-backward sums in the epilogue: the instance that has it (128-cout tiles only: with 256 the multiplier tiles of
+  // four sub-tiles per wave end up in scratch, 4 326 scratch instructions -- c3d_conv_stat_mul_supported() answers 0 there)
+  if constexpr (NT == 4) if (a.stat_mul && a.stat_partial) {
+    c3d_opt_in_lds<&conv_pw1_kernel<NT, true>>();
+    hipLaunchKernelGGL((conv_pw1_kernel<NT, true>), grid, dim3(512), lds, st, a);
+    C3D_CHECK_LAUNCH();
+    return 0;
+  }
+  c3d_opt_in_lds<&conv_pw1_kernel<NT>>();
   hipLaunchKernelGGL((conv_pw1_kernel<NT>), grid, dim3(512), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;

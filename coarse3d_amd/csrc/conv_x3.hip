@@ -319,9 +319,12 @@ struct c3d_x3_products_one {
   static constexpr int last_b(int) { return 0; }
 };
 
-template <int NT, int HALO, int TT, bool SIX, int NPL = 3, bool BFS = false>
+// SM (round 5, the one-plane kernel over bf16 tensors): the instance with the BatchNorm-backward epilogue (ConvArgs::stat_mul);
+// the common instance stays without it (34 spilled registers otherwise, for every launch)
+template <int NT, int HALO, int TT, bool SIX, int NPL = 3, bool BFS = false, bool SM = false>
 __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   static_assert(!BFS || NPL == 1, "bf16 sources belong to the one-plane engine");
+  static_assert(!SM || BFS, "the separate stat_mul instance exists for the one-plane kernel over bf16 tensors");
   constexpr bool F16 = NPL == 2;
   constexpr unsigned EB = BFS ? 2u : 4u;           // bytes per stored activation element
   typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -700,7 +703,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   };
   if (NPW == 1 || nj >= NPW) k_loop(std::integral_constant<int, NPW>{});
   else k_loop(std::integral_constant<int, 1>{});
-  conv_epilogue<TR, NT, WM, WN, NPL == 1, false, 256, false, NPL >= 2>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
+  conv_epilogue<TR, NT, WM, WN, NPL == 1, false, 256, false, (NPL >= 2 || SM)>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
                                                                        tile_pix);
 }
 
@@ -711,10 +714,18 @@ int launch_x3f_s(ConvArgs& a, hipStream_t st) {
   size_t lds = (size_t)NPL * (IN_PT * 64 + 2 * W_PT * 64) * 16 * 2;      // rows padded to whole staging units
   const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
   if (lds < red) lds = red;
-  c3d_opt_in_lds<&conv_x3f_kernel<NT, HALO, TT, SIX, NPL, BFS>>();
   a.ntn = (a.Cout + 32 * NT - 1) / (32 * NT);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * a.ntn);
   if (NPL == 2) a.acc_scale = 1.f / 65536.f;           // operands staged times 2^6 and 2^10
+  if constexpr (BFS) {
+    if (a.stat_mul && a.stat_partial) {      // BatchNorm-backward sums in the epilogue: the instance that has it
+      c3d_opt_in_lds<&conv_x3f_kernel<NT, HALO, TT, SIX, NPL, BFS, true>>();
+      hipLaunchKernelGGL((conv_x3f_kernel<NT, HALO, TT, SIX, NPL, BFS, true>), grid, dim3(256), lds, st, a);
+      C3D_CHECK_LAUNCH();
+      return 0;
+    }
+  }
+  c3d_opt_in_lds<&conv_x3f_kernel<NT, HALO, TT, SIX, NPL, BFS>>();
   hipLaunchKernelGGL((conv_x3f_kernel<NT, HALO, TT, SIX, NPL, BFS>), grid, dim3(256), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;

@@ -280,7 +280,8 @@ def _pw3_kernel_name(nt, k, cout, bf16_srcs=False):
 
 
 def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=None, out_coff=0,
-                 accumulate=False, stat_partial=None, slope=0.0, grad=False, stat_mul=None, f16x2_inv=None):
+                 accumulate=False, stat_partial=None, slope=0.0, grad=False, stat_mul=None, f16x2_inv=None,
+                 stat_mul_optional=False):
     """y = [LeakyReLU](conv(cat(transformed srcs)) + bias); optional per-tile channel stats.
     ``grad``: this launch is an input-gradient convolution (transposed weights, negated taps): the
     bf16x3 engine then accumulates six plane products instead of eight (c3d_conv_desc.mfma_bf16 = 3)."""
@@ -308,10 +309,12 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     if stats and stat_partial is None:
         stat_partial = torch.empty(cout, 2, num_mtiles(b, h, w), device=wpack.device, dtype=torch.float32)
     d.stat_partial = stat_partial.data_ptr() if stat_partial is not None else None
-    if stat_mul is not None:      # (sum v, sum v * stat_mul) instead of (sum v, sum v^2): BatchNorm-backward sums, bf16x3 engine
-        if stat_partial is None or MFMA_MODE != 2 or tuple(stat_mul.shape[:3]) != (b, h, w) or stat_mul.dtype != torch.float32:
-            raise ValueError("conv_forward: stat_mul needs statistics, the bf16x3 engine and an fp32 tensor of the output's shape")
+    use_mul = stat_mul is not None
+    if use_mul:      # (sum v, sum v * stat_mul) instead of (sum v, sum v^2): BatchNorm-backward sums in the epilogue
+        if stat_partial is None or tuple(stat_mul.shape[:3]) != (b, h, w) or stat_mul.dtype != out.dtype:
+            raise ValueError("conv_forward: stat_mul needs statistics and a tensor of the output's shape and dtype")
         d.stat_mul, d.stat_mul_cstride = stat_mul.data_ptr(), stat_mul.shape[3]
+        d.stat_mul_bf16 = int(stat_mul.dtype == torch.bfloat16)
     tr = _tile_rows(h)
     nt_ = len(taps)
     timed = KERNEL_EVENTS is not None        # the kernel-name mirror below only serves the per-kernel event timers
@@ -364,6 +367,12 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         # EXPERIMENT (C3D_F16X2_FWD=1; DESIGN.md round-4 list): forward convs over large BatchNorm populations -- where the
         # exact split already runs six products -- on two fp16 planes / three products, generic kernel
         d.mfma_bf16 = 4
+    if use_mul and not L.lib().c3d_conv_stat_mul_supported(C.byref(d)):
+        # the kernel this launch selects has no such epilogue (bf16x3 engine: fp32 tensors; bf16 engine: 8-row tiles over bf16
+        # tensors): the caller runs the separate c3d_bn_bwd_reduce pass
+        if not stat_mul_optional:
+            raise ValueError("conv_forward: this launch's kernel has no BatchNorm-backward epilogue (c3d_conv_stat_mul_supported)")
+        d.stat_mul, d.stat_mul_bf16, d.stat_partial, stat_partial = None, 0, None, None
     if not timed:
         L.check(L.lib().c3d_conv_forward(C.byref(d), _stream()), "c3d_conv_forward")
         return out, stat_partial

@@ -24,7 +24,7 @@ CAP_DOUBLES = 8192          # slot capacity: SalsaNext's largest grouped exchang
 
 class PeerDesc(C.Structure):
     _fields_ = [("mailbox", C.c_void_p * 8), ("rank", C.c_int32), ("world", C.c_int32), ("cap_doubles", C.c_int32),
-                ("timeout_s", C.c_float)]
+                ("timeout_s", C.c_float), ("one_device", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PeerExchange:
@@ -55,13 +55,17 @@ class PeerExchange:
             self._own = ptr.value
         except Exception as e:      # noqa: BLE001 -- the other ranks must learn about it below
             err = f"rank {self.rank}: {e}"
-        infos = self._gather((socket.gethostname(), bytes(handle), err))
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        dev_id = (getattr(props, "uuid", None) and str(props.uuid)) or getattr(props, "pci_bus_id", None) or torch.cuda.current_device()
+        infos = self._gather((socket.gethostname(), bytes(handle), err, str(dev_id)))
         errs = [i[2] for i in infos if i[2]]
         if not errs and len({i[0] for i in infos}) != 1:
             errs = [f"the ranks run on different hosts ({sorted({i[0] for i in infos})}): IPC needs one node"]
+        # every rank on one device (the one-GPU test box; world == 1): no system-scope fences around the write-through payload
+        self.desc.one_device = int(len({i[3] for i in infos}) == 1)
         if not errs:
             try:
-                for r, (_, h, _) in enumerate(infos):
+                for r, (_, h, _, _) in enumerate(infos):
                     if r == self.rank:
                         self.desc.mailbox[r] = self._own
                         continue

@@ -120,7 +120,15 @@ typedef struct {
   const float* acc_scale_dev; /* EXPERIMENT (mfma_bf16 == 4): NULL, or a device scalar the accumulators are multiplied
                                with before bias / activation -- the inverse of a per-tensor gradient exponent
                                (c3d_grad_exponent)                                                            */
+  int32_t stat_mul_bf16;    /* 1: stat_mul is a bf16 tensor (round 5: the bf16 engine, mfma_bf16 == 1 with out_bf16 -- the
+                               sums are then taken from the values AS STORED, i.e. rounded to bf16: what the separate
+                               c3d_bn_bwd_reduce pass would read).  c3d_conv_stat_mul_supported() says whether the kernel
+                               this descriptor selects has the epilogue                                         */
+  int32_t reserved;
 } c3d_conv_desc;
+/* 1: a launch of this descriptor (all fields filled in, stat_mul set) takes the BatchNorm-backward sums in its epilogue;
+ * 0: the selected kernel has no such epilogue (run c3d_bn_bwd_reduce); host call */
+int c3d_conv_stat_mul_supported(const c3d_conv_desc* d);
 
 /* y = epilogue(conv(transform(cat(src)))) as an implicit GEMM on fp32 MFMA.
  * Replaces nn.Conv2d (+LeakyReLU, + the batch statistics of the following BatchNorm2d) in
@@ -626,6 +634,9 @@ typedef struct {
   int32_t rank, world;
   int32_t cap_doubles;                 /* slot capacity the mailboxes were sized for (c3d_peer_mailbox_bytes)                  */
   float timeout_s;                     /* an exchange gives up waiting for a peer after this long (<= 0: 20 s)                */
+  int32_t one_device;                  /* 1: every rank of the group runs on THIS device (or world == 1): the payload's
+                                        * write-through stores + drained flag need no system-scope fences around them           */
+  int32_t reserved;
 } c3d_peer_desc;
 int c3d_peer_desc_bytes(void);          /* sizeof(c3d_peer_desc), for a binding's layout check (host call) */
 int64_t c3d_peer_mailbox_bytes(int cap_doubles);

@@ -34,7 +34,7 @@ def test_ctypes_struct_mirrors_match_the_c_layouts():
     assert list(out) == [ctypes.sizeof(L.Src), ctypes.sizeof(L.ConvDesc), ctypes.sizeof(L.WgradDesc),
                          ctypes.sizeof(L.PackEntry), ctypes.sizeof(L.WgradFold)]
     from coarse3d_amd.peer import PeerDesc
-    assert L.lib().c3d_peer_desc_bytes() == ctypes.sizeof(PeerDesc) == 80
+    assert L.lib().c3d_peer_desc_bytes() == ctypes.sizeof(PeerDesc) == 88
     assert L.lib().c3d_peer_mailbox_bytes(8192) == 256 + 2 * 8 * 8 + 2 * 8 * 8192 * 8
     pd = PeerDesc()
     pd.rank, pd.world, pd.cap_doubles = 3, 2, 16          # refused on the host: rank outside the group

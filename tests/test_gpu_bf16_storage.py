@@ -327,3 +327,63 @@ def test_deeper_chunks_of_raw_bf16_match_the_plain_kernel(k, dil, pad, srcs, cou
         close32(res[0][0], res[8][0], "four taps, fp32 output", 2e-6)
         close32(res[0][2], res[8][2], "four taps, statistics", 2e-6)
         close16(res[0][1], res[8][0], "four taps, bf16 output")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,dil,pad,acc", [
+    (2, 16, 128, 32, 32, 3, 1, 1, False), (2, 16, 128, 64, 64, 3, 2, 2, True), (2, 16, 128, 64, 64, 2, 2, 1, False),
+    (2, 16, 128, 128, 128, 2, 2, 1, True), (2, 16, 128, 32, 64, 1, 1, 0, False), (2, 16, 128, 192, 64, 1, 1, 0, True),
+    (4, 32, 512, 384, 128, 1, 1, 0, False), (2, 16, 100, 64, 32, 3, 1, 1, True), (1, 24, 72, 64, 64, 2, 2, 1, False),
+])
+def test_batchnorm_backward_sums_in_the_input_gradient_epilogue_over_bf16_tensors(B, H, W, Cin, Cout, k, dil, pad, acc):
+    """Round 5 (VERDICT round 4, next #2 ii): ConvArgs::stat_mul for the bf16 engine.  The LAST input-gradient launch into a
+    conv -> LeakyReLU -> BatchNorm layer's output leaves (sum dy, sum dy * a) per tile in its epilogue -- from the values AS
+    STORED (rounded to bf16), i.e. exactly what c3d_bn_bwd_reduce would read in a pass of its own (BASELINE configs[2]:
+    43 such passes, 1.1 ms of a 16.8 ms step).  Every kernel family of that engine over bf16 tensors (nine taps, four taps,
+    narrow and 128-wide 1x1), with and without accumulation into an existing gradient, ragged tiles: the stored gradient is
+    bit-identical to the launch without the epilogue, the folded sums agree with the separate pass to fp32 summation order."""
+    from coarse3d_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(Cin + 3 * Cout + k)
+    # an input-gradient launch: source = dz [.., Cin], output = the gradient [.., Cout] at a BatchNorm's output whose input is a
+    dz = torch.randn(B, H, W, Cin, device=DEV, generator=g).bfloat16()
+    a = torch.randn(B, H, W, Cout, device=DEV, generator=g).bfloat16()
+    w = torch.randn(Cin, Cout, k, k, device=DEV, generator=g) * 0.1          # the forward layer's weight: Cout_fwd = Cin here
+    taps = ops.negate_taps(ops.conv_taps(k, k, dil, pad))
+    kp = (Cin + 15) // 16 * 16
+    wd = ops.pack_weights(w, 1, c_off=0, c_cnt=Cout, kpad=kp)
+    old = torch.randn(B, H, W, Cout, device=DEV, generator=g).bfloat16()
+    outs = []
+    for fused in (False, True):
+        out = old.clone() if acc else torch.empty_like(old)
+        part = torch.empty(Cout, 2, ops.num_mtiles(B, H, W), device=DEV, dtype=torch.float32) if fused else None
+        _, p = ops.conv_forward([ops.Source(dz)], wd, None, Cout, taps, out=out, accumulate=acc, grad=True,
+                                stat_partial=part, stat_mul=a if fused else None, stat_mul_optional=True)
+        outs.append((out, p))
+    torch.cuda.synchronize()
+    assert outs[1][1] is not None, "this launch should have the epilogue"
+    assert torch.equal(outs[0][0], outs[1][0])
+    got = ops.stat_reduce(outs[1][1], Cout)
+    ref = ops.stat_reduce(ops.bn_bwd_reduce(outs[0][0], a, Cout, 0), Cout)
+    scale = ref.abs().max(dim=0).values.clamp_min(1e-30)
+    assert float(((got - ref).abs() / scale).max()) < 2e-6, float(((got - ref).abs() / scale).max())
+    # float64 restatement of the two sums from the stored tensors
+    dy64, a64 = outs[0][0].double(), a.double()
+    want = torch.stack([dy64.sum(dim=(0, 1, 2)), (dy64 * a64).sum(dim=(0, 1, 2))], 1)
+    assert float(((got - want).abs() / scale).max()) < 2e-5
+
+
+def test_stat_mul_is_refused_where_the_kernel_has_no_epilogue():
+    from coarse3d_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(2)
+    B, H, W, Cin, Cout = 2, 4, 64, 64, 64                     # 4-row image: 4-row tiles, the widening kernel
+    dz = torch.randn(B, H, W, Cin, device=DEV, generator=g).bfloat16()
+    a = torch.randn(B, H, W, Cout, device=DEV, generator=g).bfloat16()
+    w = torch.randn(Cin, Cout, 3, 3, device=DEV, generator=g) * 0.1
+    wd = ops.pack_weights(w, 1, c_off=0, c_cnt=Cout, kpad=64)
+    taps = ops.negate_taps(ops.conv_taps(3, 3, 1, 1))
+    part = torch.empty(Cout, 2, ops.num_mtiles(B, H, W), device=DEV)
+    out = torch.empty_like(a)
+    _, p = ops.conv_forward([ops.Source(dz)], wd, None, Cout, taps, out=out, grad=True, stat_partial=part, stat_mul=a,
+                            stat_mul_optional=True)
+    assert p is None                                          # the caller runs c3d_bn_bwd_reduce
+    with pytest.raises(ValueError):
+        ops.conv_forward([ops.Source(dz)], wd, None, Cout, taps, out=out, grad=True, stat_partial=part, stat_mul=a)
