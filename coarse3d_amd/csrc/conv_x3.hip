@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   constexpr int TWh = 32 + 2 * HALO, THh = TR + 2 * HALO;
   constexpr int TN = 32 * NT;
   constexpr int WM = 4, WN = 1, RPW = 2, NPW = NT;
-  constexpr int G = (TT == 9) ? 3 : TT;            // taps per staged weight group (tap row)
+  constexpr int G = (TT == 9) ? 3 : (TT == 4 ? 2 : TT);            // taps per staged weight group (tap row)
   constexpr int NG = TT / G;
   constexpr int IN_ROWS = THh * TWh;
   constexpr int IN_UNITS = IN_ROWS * CQ;
@@ -486,9 +486,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   // ---- atoms of the NEXT chunk's input, two lists: LOAD (the units' raw values + scale / shift, issued early in the
   //      current chunk's first tap row) and CONV (per unit: XF e0, XF e1 -- affine, LeakyReLU, zero outside the image --
   //      then two SPLIT halves per plane), which run in the later tap rows, a tap row's time after the loads: raw values
-  //      and planes never fill their registers together.  (Four taps = ONE tap row per chunk: 96 MFMAs are not enough
+  //      and planes never fill their registers together.  (Four taps as ONE tap row per chunk: 96 MFMAs are not enough
   //      lead for an HBM load -- 0.21 -> 0.26 ms on 64 -> 64 2x2 -- and reloading a unit right after its XF atoms, one
-  //      chunk earlier, spills at 64 couts per workgroup: the 2x2 convs stay on conv_x3_kernel.)
+  //      chunk earlier, spills at 64 couts per workgroup.  Round 5: four taps run as two rows of two, G = 2.)
   static_assert(NG > 1, "the fused schedule needs more than one tap row per chunk");
   f32x4 sv;
   constexpr int LOAD_ATOMS = IN_PT + 1;            // + scale / shift
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
 
 template <int NT, int HALO, int TT, bool SIX, int NPL = 3, bool BFS = false>
 int launch_x3f_s(ConvArgs& a, hipStream_t st) {
-  constexpr int G = (TT == 9) ? 3 : TT;
+  constexpr int G = (TT == 9) ? 3 : (TT == 4 ? 2 : TT);
   constexpr int IN_PT = ((8 + 2 * HALO) * (32 + 2 * HALO) * 4 + 255) / 256, W_PT = (G * 32 * NT * 4 + 255) / 256;
   size_t lds = (size_t)NPL * (IN_PT * 64 + 2 * W_PT * 64) * 16 * 2;      // rows padded to whole staging units
   const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
@@ -751,6 +751,14 @@ int launch_x3(ConvArgs& a, hipStream_t st) {
     // the fused kernel; c3d_conv_desc.variant & 4: round 2's phased kernel (the bit-identity test compares them)
     if (a.f16x2) return launch_x3f_s<NT, HALO, TT, true, 2>(a, st);           // EXPERIMENT: two fp16 planes, three products
     if (!(a.variant & 4)) return a.six ? launch_x3f_s<NT, HALO, TT, true>(a, st) : launch_x3f_s<NT, HALO, TT, false>(a, st);
+  }
+  if constexpr (TT == 4) {
+    // Round 5: the fused schedule for the four-tap convs too, as TWO tap rows of two taps per chunk (round 3 tried one row
+    // of four: no lead for the loads, 0.21 -> 0.26 ms, and left them on the phased kernel).  The next chunk's input is
+    // requested in the first row and converted in the second, 48 MFMAs later.  Measured at 8 x 64 x 2048 / 32 x 1024 /
+    // 16 x 512 / 8 x 256: 64 -> 64 0.268 -> 0.228 ms, 128 -> 128 0.194 -> 0.173, 256 -> 256 0.172 -> 0.163 and 0.069 -> 0.056,
+    // input gradients alike; bit-identical (tools/bench_x3f4.py, tests/test_gpu_conv.py).  variant & 4: the phased kernel.
+    if (!a.f16x2 && !(a.variant & 4)) return a.six ? launch_x3f_s<NT, HALO, TT, true>(a, st) : launch_x3f_s<NT, HALO, TT, false>(a, st);
   }
   return a.six ? launch_x3_s<NT, HALO, TT, true>(a, st) : launch_x3_s<NT, HALO, TT, false>(a, st);
 }

@@ -324,8 +324,8 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
         k32 = tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs)
         if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
-            # nine taps: the fused kernel (round 3), four taps: the phased one; CONV_VARIANT & 4 forces the phased one
-            fused_ = nt_ == 9 and not (CONV_VARIANT & 4)
+            # nine taps: the fused kernel (round 3); four taps: fused too since round 5; CONV_VARIANT & 4 forces the phased one
+            fused_ = nt_ in (4, 9) and not (CONV_VARIANT & 4)      # (four taps: fused since round 5)
             # (names as rocprofv3 prints them: the fused kernel carries its plane count and its bf16-source flag as fifth and
             #  sixth template arguments)
             six_ = grad or b * h * w >= SIX_FWD_MIN_PIXELS          # (the fourth template argument: six plane products)
