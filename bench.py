@@ -296,7 +296,7 @@ class Bench:
     def __init__(self, wl, dev, rank, world, dp):
         self.wl, self.dev, self.rank, self.world, self.dp = wl, dev, rank, world, dp
 
-    def build(self, graph, wgrad_stream=None):
+    def build(self, graph, wgrad_stream=None, graph_backbone=False):
         import torch
         from coarse3d_amd import dist as D
         from coarse3d_amd import ops
@@ -313,6 +313,8 @@ class Bench:
         else:
             model = SqueezeSegV3Proto(nclasses=wl["classes"], layers=int(net[-2:]), dataset=wl["dataset"], use_prototype=True)
         model = model.to(self.dev).train()
+        if graph_backbone:
+            model.graph_backbone = True        # forward / backward of the backbone as two hipGraphs behind the module API
         prev = os.environ.get("C3D_WGRAD_STREAM")
         if wgrad_stream is not None:
             os.environ["C3D_WGRAD_STREAM"] = wgrad_stream      # read whenever a backbone pass is built
@@ -360,7 +362,7 @@ class Bench:
                 d[2] += 1
         return per, table
 
-    def run(self, graph, steps, warmup, prewarm, events, wgrad_stream=None, exposed=False):
+    def run(self, graph, steps, warmup, prewarm, events, wgrad_stream=None, exposed=False, graph_backbone=False):
         """W untimed warm-up steps (after ``prewarm`` extra ones: one-time costs of a fresh box), then EXACTLY ``steps``
         timed steps between barrier + synchronize on both sides; max over ranks.  ``events``: bracket every MFMA launch of
         the last eager warm-up step with HIP events on the launch stream (survey: picks the dominant kernel instance) and,
@@ -369,7 +371,7 @@ class Bench:
         import torch.distributed as dist
         from coarse3d_amd import dist as D
         from coarse3d_amd import ops
-        model, ts = self.build(graph, wgrad_stream)
+        model, ts = self.build(graph, wgrad_stream, graph_backbone)
         try:
             if graph:
                 warmup = max(warmup, 3)            # two eager steps + the capture
@@ -759,6 +761,20 @@ def main():
                         "data-parallel runs use to hide the SyncBatchNorm exchanges).  The BatchNorm-backward apply pass is then a pass of its own "
                         "again (on one stream the first weight-gradient launch of a layer applies it on load).  Not the default on one GPU: the "
                         "kernels of two streams share the CUs, nothing is gained"}
+            # the module API as the reference's own trainer loop uses it (model(x), loss modules, loss.backward(), optimiser),
+            # with the backbone's forward / backward replayed as two hipGraphs behind it (coarse3d_amd/graphed.py)
+            try:
+                r = b.run(False, k2, 3, 0, False, graph_backbone=True)
+                engines["module_api_graphed_backbone"] = {
+                    "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": k2,
+                    "launch": "model.graph_backbone = True: the step issued call by call through the pc_processor module API -- model(x), "
+                              "the loss modules, loss.backward(), the optimiser, as tasks/weak_segmentation/trainer.py:621-704 does -- with "
+                              "the backbone's forward and backward replayed as two hipGraphs behind those calls (bit-identical to the "
+                              "launch-by-launch path: tests/test_gpu_step.py); compare with `launch_by_launch`, which is host-bound on a slow host"}
+            except Exception as e:      # noqa: BLE001
+                engines["module_api_graphed_backbone"] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
             # the data-parallel step on this one GPU: a 1-rank RCCL group in which every exchange point issues its real collective
             try:
                 engines["dp_single_rank_rccl"] = dp_single_rank(wl, dev, k2, w2)

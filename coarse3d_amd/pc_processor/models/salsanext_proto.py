@@ -19,6 +19,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from ... import contrast
+from ... import graphed as _graphed
 from ... import ops as ops_mod
 from ... import proto as proto_ops
 from ...backbone import Backbone
@@ -83,10 +84,28 @@ class _BackboneFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x, masks, return_feat, names, *tensors):
-        bb = model._make_backbone(model._tensor_dict())
-        bb.on_block_done = model._block_done
         # (training mode only: a captured eval forward -- serving.GraphedInference -- hands out the tensors of its graph)
         lazy = bool(return_feat) and model._lazy_feat()
+        ctx.graphed = None
+        if model.graph_backbone and model.training:
+            # forward / backward of the backbone as two hipGraphs behind the module API (coarse3d_amd/graphed.py)
+            gb = model._graphed_backbone()
+            keep = model._last_keep if masks is not None else None
+            injected = masks is not None and masks is model.dropout_masks
+            if gb.why_not(model, x, masks, injected) is None:
+                res = gb.forward(model, x, masks, keep, bool(return_feat), lazy, names, any(ctx.needs_input_grad))
+                if res is not None:
+                    import weakref
+                    pred, feat, ent = res
+                    ent.ctx_ref = weakref.ref(ctx)
+                    ctx.graphed = (gb, ent, lazy)
+                    ctx.names, ctx.model, ctx.return_feat, ctx.bb = names, model, return_feat, None
+                    if feat is None:
+                        feat = x.new_zeros(())
+                        ctx.mark_non_differentiable(feat)
+                    return pred, feat
+        bb = model._make_backbone(model._tensor_dict())
+        bb.on_block_done = model._block_done
         out = (bb.forward(x.detach().float(), model.training, masks, return_feat, lazy_feat=True) if lazy
                else bb.forward(x.detach().float(), model.training, masks, return_feat))
         ctx.bb, ctx.names, ctx.model = bb, names, model
@@ -100,8 +119,30 @@ class _BackboneFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_pred, d_feat):
-        bb = ctx.bb
         model = ctx.model
+        if ctx.graphed is not None:
+            gb, ent, lazy = ctx.graphed
+            d_prob = d_pred.permute(0, 2, 3, 1) if d_pred is not None else None
+            d_f = d_feat.permute(0, 2, 3, 1) if (ctx.return_feat and d_feat is not None) else None
+            grads, live = gb.backward(ent, d_prob, d_f)
+            model._grads_live = live
+            if model._bind_grads and all(p_.grad is None for _, p_ in model._cached()[0]):
+                # coarse3d_amd.trainer.TrainStep owns the optimiser loop: the persistent buffers become param.grad
+                for n, p_ in model._cached()[0]:
+                    if live or not n.startswith("projector."):
+                        p_.grad = grads[n]
+                return (None,) * (5 + len(ctx.names))
+            # handed to autograd: copies (ONE flat copy, then views), so that whatever autograd / the caller does with
+            # param.grad never aliases the buffers the next replay writes
+            flat = model._own_flat[1].clone()
+            out, off = [], 0
+            for n, p_ in model._cached()[0]:
+                k = p_.numel()
+                out.append(flat[off:off + k].view_as(p_) if (live or not n.startswith("projector.")) else None)
+                off += k
+            byname = dict(zip((n for n, _ in model._cached()[0]), out))
+            return (None, None, None, None, None) + tuple(byname[n] for n in ctx.names)
+        bb = ctx.bb
         prob = bb._prob
         d_prob = (d_pred.permute(0, 2, 3, 1).contiguous() if d_pred is not None
                   else torch.zeros_like(prob))
@@ -192,6 +233,9 @@ class SalsaNextProto(nn.Module):
         self._own_flat = None
         self._cache = None
         self._side = None             # second HIP stream (weight-gradient chain of the backward pass)
+        self.graph_backbone = _graphed.ENABLED_BY_DEFAULT   # True: forward / backward of the backbone as two hipGraphs (graphed.py)
+        self._gb = None
+        self._last_keep = None
         self._packs = ops_mod.PackCache()   # batched weight repacking (one launch per step)
 
     # ------------------------------------------------------------------ plumbing
@@ -262,6 +306,28 @@ class SalsaNextProto(nn.Module):
     _labelled_hint = None
     _own_flat = None
     _cache = None
+    graph_backbone = False
+    _gb = None
+    _last_keep = None
+
+    def _graphed_backbone(self):
+        if self._gb is None:
+            self._gb = _graphed.GraphedBackbone(self)
+        return self._gb
+
+    def _graph_grad_views(self, names):
+        """name -> view of the persistent flat gradient buffer (the one ``_bound_grad_views`` binds), unconditionally: the
+        backward GRAPH writes there on every replay."""
+        named = self._cached()[0]
+        if self._own_flat is None or self._own_flat[0] != names:
+            total = sum(p.numel() for _, p in named)
+            flat = torch.zeros(total, device=named[0][1].device, dtype=torch.float32)
+            views, off = {}, 0
+            for n, p in named:
+                views[n] = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            self._own_flat = (names, flat, views)
+        return self._own_flat[2]
 
     def _list_trainable(self):
         """(name, parameter) of everything the backward pass writes a gradient for (uncached; subclasses override)."""
@@ -326,6 +392,7 @@ class SalsaNextProto(nn.Module):
         # (thirteen slice copies per step cost ~0.6 ms of host time with the stream idle)
         total = sum(m for _, m in _DROP_SITES) * self.base_channels
         keep = (torch.rand(b * total, device=device) >= DROP_P).to(torch.float32) * (1.0 / (1.0 - DROP_P))
+        self._last_keep = keep           # (the graphed backbone copies the draw into its static buffer)
         masks, off = {}, 0
         for name, mult in _DROP_SITES:
             c = mult * self.base_channels

@@ -904,3 +904,68 @@ def test_fast_paths_of_the_training_step_change_nothing(monkeypatch):
             assert torch.equal(results[0][3][k], results[other][3][k]), (other, k)     # parameters after three updates
         assert results[0][4] == results[other][4]
         assert torch.equal(results[0][5], results[other][5])                            # the prototype bank
+
+
+def test_graphed_backbone_behind_the_module_api_is_bit_identical_to_launch_by_launch():
+    """coarse3d_amd/graphed.py (round 5): somebody who keeps the REFERENCE's trainer
+    loop -- ``out = model(x, ...)``, own loss, ``loss.backward()``, a stock ``torch.optim.AdamW``, trainer.py:621-704 --
+    issues the backbone launch by launch (~600 ctypes calls per step; on a slow host that bounds the step at a third of the
+    captured rate).  ``model.graph_backbone = True``: the backbone's forward and backward replay as two hipGraphs behind the
+    same calls.  Six steps (two eager warm-up steps, capture, replays; different batches, live dropout draws, the prototype
+    update on) against the same loop launch by launch: losses, every parameter, the bank, the BatchNorm running
+    statistics and the optimiser state agree bit for bit.  Then: a forward whose predecessor still waits for its
+    backward falls back to launch by launch (its gradients are those of the plain path), and the returned tensors are
+    the caller's to keep."""
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    b, h, w, ncls = 2, 32, 128, 20
+    batches = [W.synthetic_batch(b, h, w, ncls, 500 + i, 0.03, gh=8, gw=16) for i in range(6)]
+    gen = torch.Generator().manual_seed(9)
+    wp = [torch.randn(b, ncls, h, w, generator=gen).to(DEV) for _ in range(6)]
+    runs = []
+    for graphed in (False, True):
+        torch.manual_seed(51)
+        m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True).to(DEV).train()
+        m.graph_backbone = graphed
+        opt = torch.optim.AdamW(m.parameters(), lr=2e-3)
+        torch.manual_seed(52)
+        losses, kept = [], []
+        for i, (x, tr, ev) in enumerate(batches):
+            out = m(x.to(DEV), label=tr.to(DEV), eval_mask=(tr > 0).to(DEV), return_feat=True, proto_loss=True)
+            loss = (out["pred_2d"] * wp[i]).sum() * 1e-2 + out["feat_2d"][:, :, ::3, ::5].square().sum() * 1e-3
+            opt.zero_grad(set_to_none=(i % 2 == 0))
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+            kept.append(out["pred_2d"].detach())
+        torch.cuda.synchronize()
+        runs.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}, opt.state_dict(), m, kept))
+    gb = runs[1][3]._gb
+    assert gb is not None and gb.captures == 1 and gb.replays == 4 and gb.fallbacks == 0
+    assert runs[0][3]._gb is None
+    for i, (la, lb) in enumerate(zip(runs[0][0], runs[1][0])):
+        assert torch.equal(la, lb), i
+    for k, v in runs[0][1].items():
+        assert torch.equal(v, runs[1][1][k]), k
+    for i, st in runs[0][2]["state"].items():
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(st[k], runs[1][2]["state"][i][k]), (i, k)
+    # the outputs are the caller's: the prediction of step 2 was not overwritten by steps 3, 4, 5
+    assert torch.equal(runs[0][4][2], runs[1][4][2]) and not torch.equal(runs[1][4][2], runs[1][4][5])
+    # two forwards before a backward: the second one runs launch by launch, both backward passes are right
+    grads = []
+    for m in (runs[0][3], runs[1][3]):
+        x0, x1 = batches[0][0].to(DEV), batches[1][0].to(DEV)
+        m.dropout_masks = None
+        torch.manual_seed(77)
+        o0 = m(x0)             # (nobody reads feat_2d: the projector gets no gradient, graphed or not)
+        o1 = m(x1)
+        for p in m.parameters():
+            p.grad = None
+        ((o0["pred_2d"] * wp[0]).sum() + (o1["pred_2d"] * wp[1]).sum()).backward()
+        grads.append({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    gb = runs[1][3]._gb
+    assert gb.fallbacks >= 1, (gb.captures, gb.replays, [(k[3], k[4], k[6], e.eager, e.g_fwd is not None, e.pending) for k, e in gb.entries.items()])
+    assert grads[0].keys() == grads[1].keys()
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+
