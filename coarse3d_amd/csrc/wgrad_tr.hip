@@ -100,6 +100,19 @@ __device__ __forceinline__ s16x4 tr_read(const unsigned short* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 
+// The same from an LDS BYTE address split into a wave-uniform part (SALU arithmetic) and a per-lane constant: one v_add per
+// fragment instead of the multiply / shift / or chain of tr_swz on a per-lane row index (round 5)
+__device__ __forceinline__ s16x4 tr_read_u(unsigned byte_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)byte_addr);
+}
+template <int NS>
+__device__ __forceinline__ bf16x8 tr_frag_u(unsigned ubytes, unsigned lane_bytes) {
+  const unsigned a0 = ubytes + lane_bytes;
+  const s16x4 lo = tr_read_u(a0);
+  const s16x4 hi = tr_read_u(a0 + 4u * 32u * NS * 2u);          // four pixel rows on (same swizzle class: rows R and R + 4)
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 // one MFMA operand: channel (lane) x 8 pixels = two transposed reads 4 pixel rows apart
 template <int NS>
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned short* plane, int R, int c) {
@@ -206,7 +219,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   // phases of the two resident workgroups fell into lock-step and simply added up
   // (704x704 layer: 0.96 ms staging + 1.50 ms matrix phase -> 2.16 ms).
   const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 256;   // wave-uniform, in an SGPR
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  // (wave-uniform values pinned in SGPRs, round 5: the compiler cannot prove that threadIdx.x >> 6 or the result of an
+  //  integer division of blockIdx-derived numbers is uniform, so the consumer waves computed every fragment's ring slot --
+  //  add, compare, select, a quarter-rate v_mul_lo_u32 by the window width -- per lane: 218 VALU instructions per 108 MFMAs
+  //  of the 32 x 32 nine-tap instance, in a kernel whose MFMA and VALU streams share the SIMD's issue port -- PMC: 39 % of
+  //  the wave cycles were issue stalls.)
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & 255) >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int wci = wave % WCI, wco = (wave / WCI) % WCO, wk = wave / (WCI * WCO);
   // transposed-read source of this lane: group g = lane>>4 covers channels 16*(g&1).. of pixels 8*(g>>1)..
@@ -214,9 +232,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   const int lc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
   const int nsl = a.ci_slices * a.co_slices;
-  const int logical = c3d_xcd_remap(blockIdx.x, a.strips * nsl);
-  const int strip = logical / nsl;
-  const int sl = logical % nsl;
+  const int logical = __builtin_amdgcn_readfirstlane(c3d_xcd_remap(blockIdx.x, a.strips * nsl));
+  const int strip = __builtin_amdgcn_readfirstlane(logical / nsl);
+  const int sl = logical - strip * nsl;
   const int ci0 = (sl % a.ci_slices) * CI;
   const int co0 = (sl / a.ci_slices) * CO;
 
@@ -328,7 +346,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     lb = mt / (a.tiles_x * a.tiles_y);
   };
   // (always_inline: with four register sets there are ~18 call sites, and a call that is not inlined puts the sets in scratch)
+  const bool abl_l2 = (a.variant & 32) != 0, abl_nolds = (a.variant & 64) != 0;      // finer ablations of the producer waves
+  const bool abl_prod = (a.variant & 16) != 0;      // (variant & 16, ablation runs only: the producer waves only keep the barriers)
   auto load_tile = [&](Stage& sg) __attribute__((always_inline)) {
+    if (abl_prod) return;
     const int x0 = ltx * 32, y0 = lty * TRW, b = lb;
     // RINGX: a tile right below its predecessor in the strip stages only its TRW new rows (image rows y0 + HALO ...)
     const bool fresh = !RINGX || lfirst || lty == 0;
@@ -403,7 +424,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
           const char* bp = c3d_uniform_ptr(reinterpret_cast<const unsigned short*>(a.x.ptr) + ximg);
           sg.px[i] = __builtin_bit_cast(u32x2, *(const __attribute__((address_space(1))) c3d_u32x2*)(bp + (size_t)(o2 * 2u)));
         } else {
-          sg.px[i] = c3d_ld4u<XBF>(a.x.ptr, ximg, o2);
+          sg.px[i] = c3d_ld4u<XBF>(a.x.ptr, ximg, abl_l2 ? 0u : o2);
         }
       }
     };
@@ -433,7 +454,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
           const c3d_u32x2 r = *(const __attribute__((address_space(1))) c3d_u32x2*)(bp + (size_t)(o2 * 2u));
           sg.pd[i] = f32x4{__uint_as_float(r[0]), __uint_as_float(r[1]), 0.f, 0.f};
         } else {
-          sg.pd[i] = c3d_ld4u<DBF>(a.dz, dimg, ((dmask >> i) & 1u) ? (unsigned)off : 0u);
+          sg.pd[i] = c3d_ld4u<DBF>(a.dz, dimg, (((dmask >> i) & 1u) && !abl_l2) ? (unsigned)off : 0u);
         }
       }
     };
@@ -448,6 +469,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     }
   };
   auto store_tile = [&](int buf, const Stage& sg) __attribute__((always_inline)) {
+    if (abl_prod) return;
     unsigned short* s_x = RINGX ? s_base : s_base + buf * BUF;
     unsigned short* s_dz = RINGX ? s_base + NP * XPLANE + buf * (NP * DROWS * CO) : s_x + NP * XROWS * CI;
     // RINGX: first ring slot the staged rows go to (a whole window, or the TRW rows behind the rows kept from the tile above)
@@ -491,8 +513,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
             int slot = sg.xbase + r;
             slot = slot >= RING ? slot - RING : slot;
             const int o = tr_swz<NSX>(slot * TWh + (pp - r * TWh), xc4 * 4);
+            if (!abl_nolds) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_x + p * XPLANE + o) = pl[p];
+              for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_x + p * XPLANE + o) = pl[p];
+            }
           }
         }
       }
@@ -524,8 +548,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
           R = slot * TWh + (R - r * TWh);
         }
         const int o = tr_swz<NSX>(R, xc4 * 4);
+        if (!abl_nolds) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_x + p * XPLANE + o) = pl[p];
+          for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_x + p * XPLANE + o) = pl[p];
+        }
       }
     }
     if constexpr (LEANX) {
@@ -567,8 +593,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
           }
         }
         const int o = tr_swz<NSD>(u / (CO / 4), (u % (CO / 4)) * 4);
+        if (!abl_nolds) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_dz + p * DROWS * CO + o) = pl[p];
+          for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(s_dz + p * DROWS * CO + o) = pl[p];
+        }
       }
     }
     if constexpr (LEANX) {
@@ -588,8 +616,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   for (int t = 0; t < TMAX; ++t) tapoff[t] = a.dy[t] * TWh + a.dx[t];
   int cxbase = 0;                          // RINGX: ring slot of the current tile's window (consumer waves; same walk as load_tile)
 
-  const int t_begin = strip * a.tiles_per_strip;
-  const int t_end = min(t_begin + a.tiles_per_strip, a.ntiles);
+  const int t_begin = __builtin_amdgcn_readfirstlane(strip * a.tiles_per_strip);
+  const int t_end = __builtin_amdgcn_readfirstlane(min(t_begin + a.tiles_per_strip, a.ntiles));
   // ---- producer waves: stage tile mt+1 while the consumers work on tile mt; they take part in
   //      every barrier of the consumer path below (tile loop + K-split fold) and nothing else
   if (producer) {
@@ -727,7 +755,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   for (int mt = t_begin; mt < t_end; ++mt) {
     const int cur = (mt - t_begin) & 1;
     if constexpr (RINGX) {
-      if (mt != t_begin) cxbase = (cxbase + ((mt % a.tiles_y == 0) ? THh : TRW)) % RING;
+      if (mt != t_begin) cxbase = __builtin_amdgcn_readfirstlane((cxbase + ((mt % a.tiles_y == 0) ? THh : TRW)) % RING);
     }
     {
     const unsigned short* s_x = RINGX ? s_base : s_base + cur * BUF;
@@ -762,39 +790,60 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     };
     bf16x8 ap[TG][CI_T][NP];
     bf16x8 bp[JG][NP];
-    auto stage_rows = [&](int st, int& Rd, int& Rx0) {
+    // Fragment addresses as (uniform byte offset) + (per-lane constant).  The row index of a fragment is U + lp with U uniform;
+    // where U is a multiple of 4 (no halo: U = row * 32 + 16 * (ks & 1); always for dz) or the rows are unswizzled (one
+    // 64-byte segment per row: the 32-channel cin slices of every nine-tap instance) the swizzled offset of lane (lp, c)
+    // does not depend on U, and the per-tile / per-tap part is scalar arithmetic.
+    constexpr bool A_SPLIT = HALO == 0 || NSX == 1;
+    const unsigned lds_x = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned short*)s_x;
+    const unsigned lds_d = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned short*)s_dz;
+    unsigned lane_a[CI_T], lane_b[CO_T];
+#pragma unroll
+    for (int i = 0; i < CI_T; ++i) lane_a[i] = 2u * (unsigned)tr_swz<NSX>(lp, (wci * CI_T + i) * 32 + lc);
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j) lane_b[j] = 2u * (unsigned)tr_swz<NSD>(lp, (wco * CO_T + j) * 32 + lc);
+    // (uniform parts of the fragments' pixel rows; the lane adds lp)
+    auto stage_rows = [&](int st, int& Ud, int& Ux0) {
       const int kk = st / (NJ0 * NT0);
       const int ks = wk * KPW + kk;
       const int row = ks >> 1, px0 = (ks & 1) * 16;
-      Rd = row * 32 + px0 + lp;
-      Rx0 = (row + HALO) * TWh + HALO + px0 + lp;
+      Ud = row * 32 + px0;
+      Ux0 = (row + HALO) * TWh + HALO + px0;
     };
     auto read_a = [&](int st, int p) {
-      int Rd, Rx0;
-      stage_rows(st, Rd, Rx0);
+      int Ud, Ux0;
+      stage_rows(st, Ud, Ux0);
       const int t0 = (st % NT0) * TG;
 #pragma unroll
       for (int tg = 0; tg < TG; ++tg) {
-        int Rx = Rx0 + tapoff[t0 + tg];
+        int Ux = Ux0 + tapoff[t0 + tg];
         if constexpr (RINGX) {
           // window row of this tap's fragment -> ring slot (uniform arithmetic; the 8 pixels of a fragment share a row)
           const int kk = st / (NJ0 * NT0), ks = wk * KPW + kk;
           int slot = cxbase + (ks >> 1) + HALO + a.dy[t0 + tg];
           slot = slot >= RING ? slot - RING : slot;
-          Rx = slot * TWh + HALO + (ks & 1) * 16 + lp + a.dx[t0 + tg];
+          Ux = slot * TWh + HALO + (ks & 1) * 16 + a.dx[t0 + tg];
         }
+        if constexpr (A_SPLIT) {
+          const unsigned ub = lds_x + 2u * (unsigned)(p * XPLANE + Ux * (32 * NSX));      // uniform
 #pragma unroll
-        for (int i = 0; i < CI_T; ++i)
-          ap[tg][i][p] = tr_frag<NSX>(s_x + p * XPLANE, Rx, (wci * CI_T + i) * 32 + lc);
+          for (int i = 0; i < CI_T; ++i) ap[tg][i][p] = tr_frag_u<NSX>(ub, lane_a[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < CI_T; ++i)
+            ap[tg][i][p] = tr_frag<NSX>(s_x + p * XPLANE, Ux + lp, (wci * CI_T + i) * 32 + lc);
+        }
       }
     };
     auto read_b = [&](int st, int p) {
-      int Rd, Rx0;
-      stage_rows(st, Rd, Rx0);
+      int Ud, Ux0;
+      stage_rows(st, Ud, Ux0);
       const int j0 = ((st / NT0) % NJ0) * JG;
+      const unsigned ub = lds_d + 2u * (unsigned)(p * DROWS * CO + Ud * (32 * NSD));        // uniform
 #pragma unroll
-      for (int jg = 0; jg < JG; ++jg) bp[jg][p] = tr_frag<NSD>(s_dz + p * DROWS * CO, Rd, (wco * CO_T + j0 + jg) * 32 + lc);
+      for (int jg = 0; jg < JG; ++jg) bp[jg][p] = tr_frag_u<NSD>(ub, lane_b[j0 + jg]);
     };
+    if (!(a.variant & 8)) {       // (variant & 8, ablation runs only: the consumer waves skip their reads and MFMAs)
     // stage 0: every plane, in the order the products need them
     c3d_wg_static_for<0, NQ>([&](auto q_tag) {
       constexpr int q = decltype(q_tag)::value;
@@ -830,6 +879,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     });
+    }
     }
     __syncthreads();   // next buffer written, this one no longer read
   }
