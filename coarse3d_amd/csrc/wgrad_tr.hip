@@ -74,17 +74,21 @@ __device__ __forceinline__ void split_planes(f32x4 v, u32x2 (&out)[NP]) {
     }
     return;
   }
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  // Packed conversions and bit expansion (round 5): element-wise (__bf16) casts cost 14 v_cvt_pk_bf16_f32 + 10 shifts + 8
+  // subtractions per unit (one conversion per element plus the packing); this form 6 + 10 + 8.  Same RNE values, same bits.
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x4 r = v;
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
-    bf16x4 h;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) h[q] = (__bf16)r[q];
-    out[p] = __builtin_bit_cast(u32x2, h);
+    const unsigned w0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r[0], r[1]}, bf16x2));
+    const unsigned w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r[2], r[3]}, bf16x2));
+    out[p] = u32x2{w0, w1};
     if (p + 1 < NP) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) r[q] -= (float)h[q];
+      r[0] -= __uint_as_float(w0 << 16);
+      r[1] -= __uint_as_float(w0 & 0xffff0000u);
+      r[2] -= __uint_as_float(w1 << 16);
+      r[3] -= __uint_as_float(w1 & 0xffff0000u);
     }
   }
 }
@@ -249,6 +253,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   struct Stage {
     SU px[X_PT], pd[D_PT];
     f32x4 pa[FA ? D_PT : 1];   // FA: the layer's stored output at the dz units (pd then holds dy)
+    bool allin;     // interior tile, full channel slices: every unit of the tile is inside the image (uniform) -- no masking
     unsigned inb;   // units of px that came from inside the image (the others are zero padding)
     unsigned dmask; // same for pd
     int dt;         // FA: element offset of the tile's first pixel in its image (uniform), for the dz store
@@ -346,8 +351,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     lb = mt / (a.tiles_x * a.tiles_y);
   };
   // (always_inline: with four register sets there are ~18 call sites, and a call that is not inlined puts the sets in scratch)
-  const bool abl_l2 = (a.variant & 32) != 0, abl_nolds = (a.variant & 64) != 0;      // finer ablations of the producer waves
-  const bool abl_prod = (a.variant & 16) != 0;      // (variant & 16, ablation runs only: the producer waves only keep the barriers)
+  // every thread's channel quad inside the tensors (uniform): with an interior tile on top no staged unit needs a mask
+  const bool full_slices = (ci0 + CI <= a.x.C) && (co0 + CO <= a.dz_cstride);
+  // Ablation switches (tools/ablate_wgrad.py; c3d_wgrad_desc.variant & 8: consumer waves idle, & 16: producer waves idle, & 32:
+  // every load an L2 hit, & 64: no LDS stores).  ONLY in a build with -DC3D_WGRAD_ABLATE: a uniform branch around the
+  // loads of load_tile is enough for the compiler to give up its counted vmcnt waits (6-11 full drains per instance instead
+  // of 3) -- measured in the round-5 step: every 1x1 instance 8-26 % slower with the switches compiled in.
+#ifdef C3D_WGRAD_ABLATE
+  const bool abl_l2 = (a.variant & 32) != 0, abl_nolds = (a.variant & 64) != 0, abl_prod = (a.variant & 16) != 0;
+  const bool abl_cons = (a.variant & 8) != 0;
+#else
+  constexpr bool abl_l2 = false, abl_nolds = false, abl_prod = false, abl_cons = false;
+#endif
   auto load_tile = [&](Stage& sg) __attribute__((always_inline)) {
     if (abl_prod) return;
     const int x0 = ltx * 32, y0 = lty * TRW, b = lb;
@@ -401,6 +416,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     }
     sg.inb = xmask;
     sg.dmask = dmask;
+    sg.allin = interior && full_slices;
     // EVERY unit issues its load (invalid ones read element 0 of the image and are zeroed in
     // store_tile): with a fixed number of loads per tile the compiler can wait for the older of
     // the two tiles in flight with s_waitcnt vmcnt(N); loads under per-unit branches made it
@@ -537,7 +553,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q], a.slope);
         }
-        if (!((sg.inb >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!sg.allin && !((sg.inb >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
         u32x2 pl[NP];
         split_planes<NP>(v, pl);
         int R = u / (CI / 4);                 // pixel of the staged rectangle: row R / TWh, column R % TWh
@@ -566,7 +582,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
           const bool in = (sg.dmask >> i) & 1u;
           pl[0] = u32x2{in ? sg.pd[i][0] : 0u, in ? sg.pd[i][1] : 0u};
         } else if constexpr (FA) {
-          const bool in = (sg.dmask >> i) & 1u;
+          const bool in = sg.allin || ((sg.dmask >> i) & 1u);
           f32x4 t;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -589,7 +605,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
             const bool in = (sg.dmask >> i) & 1u;
             pl[0] = u32x2{in ? __float_as_uint(sg.pd[i][0]) : 0u, in ? __float_as_uint(sg.pd[i][1]) : 0u};
           } else {
-            split_planes<NP>(((sg.dmask >> i) & 1u) ? (NP == 2 ? sg.pd[i] * dsc : sg.pd[i]) : f32x4{0.f, 0.f, 0.f, 0.f}, pl);
+            split_planes<NP>((sg.allin || ((sg.dmask >> i) & 1u)) ? (NP == 2 ? sg.pd[i] * dsc : sg.pd[i]) : f32x4{0.f, 0.f, 0.f, 0.f}, pl);
           }
         }
         const int o = tr_swz<NSD>(u / (CO / 4), (u % (CO / 4)) * 4);
@@ -843,7 +859,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
 #pragma unroll
       for (int jg = 0; jg < JG; ++jg) bp[jg][p] = tr_frag_u<NSD>(ub, lane_b[j0 + jg]);
     };
-    if (!(a.variant & 8)) {       // (variant & 8, ablation runs only: the consumer waves skip their reads and MFMAs)
+    if (!abl_cons) {
     // stage 0: every plane, in the order the products need them
     c3d_wg_static_for<0, NQ>([&](auto q_tag) {
       constexpr int q = decltype(q_tag)::value;

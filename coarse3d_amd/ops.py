@@ -367,7 +367,8 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         # EXPERIMENT (C3D_F16X2_FWD=1; DESIGN.md round-4 list): forward convs over large BatchNorm populations -- where the
         # exact split already runs six products -- on two fp16 planes / three products, generic kernel
         d.mfma_bf16 = 4
-    if use_mul and not L.lib().c3d_conv_stat_mul_supported(C.byref(d)):
+    _sup = getattr(L.lib(), "c3d_conv_stat_mul_supported", None)      # (absent from an older build loaded through C3D_LIB)
+    if use_mul and not (_sup(C.byref(d)) if _sup is not None else (MFMA_MODE == 2 and not d.out_bf16)):
         # the kernel this launch selects has no such epilogue (bf16x3 engine: fp32 tensors; bf16 engine: 8-row tiles over bf16
         # tensors): the caller runs the separate c3d_bn_bwd_reduce pass
         if not stat_mul_optional:

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Producer / consumer ablation of wgrad_tr (c3d_wgrad_desc.variant & 8: consumer waves idle, & 16: producer waves idle).
+Needs a library built with the switches compiled in (they cost the product kernels their counted waits):
+    make -C coarse3d_amd/csrc clean && make -C coarse3d_amd/csrc -j8 EXTRA=-DC3D_WGRAD_ABLATE
 usage (GPU box): python tools/ablate_wgrad.py [fuse]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
