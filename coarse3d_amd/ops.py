@@ -270,7 +270,7 @@ def _pw3_kernel_name(nt, k, cout, bf16_srcs=False):
     (short K, couts a multiple of 128) -- the "bf16" mode conv_pw1_kernel<NT> over bf16 tensors (four chunks in flight),
     else round 2's conv_pw3_kernel<NT, 1>."""
     if MFMA_MODE != 2:
-        return f"conv_pw1_kernel<{nt}>" if (bf16_srcs and (CONV_VARIANT & 3) != 3) else f"conv_pw3_kernel<{nt}, 1>"
+        return f"conv_pw1_kernel<{nt}, false>" if (bf16_srcs and (CONV_VARIANT & 3) != 3) else f"conv_pw3_kernel<{nt}, 1>"
     mode = CONV_VARIANT & 3
     if mode == 3:
         return f"conv_pw3_kernel<{nt}, 3>"
@@ -321,6 +321,7 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
 
     def kernel_name():
         halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
+        sm_ = "true" if d.stat_mul else "false"      # (bf16 engine: the instance with the BatchNorm-backward epilogue)
         hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
         k32 = tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs)
         if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
@@ -330,10 +331,10 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
             #  sixth template arguments)
             six_ = grad or b * h * w >= SIX_FWD_MIN_PIXELS          # (the fourth template argument: six plane products)
             name = (f"conv_x3{'f' if fused_ else ''}_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, {nt_}, "
-                    f"{'true' if six_ else 'false'}{', 3, false' if fused_ else ''}>")
+                    f"{'true' if six_ else 'false'}{', 3, false, false' if fused_ else ''}>")
         elif (MFMA_MODE == 1 and tr == 8 and nt_ == 9 and d.wpack_planes and not (CONV_VARIANT & 4)
               and all(s.t.dtype == torch.bfloat16 for s in srcs)):      # the fused nine-tap kernel with one plane (csrc/conv_x3.hip)
-            name = f"conv_x3f_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, 9, true, 1, true>"
+            name = f"conv_x3f_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, 9, true, 1, true, {sm_}>"
         elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
             name = _pw3_kernel_name(_pw3_tile(b, h, w, cout), sum(s.C for s in srcs), cout,
                                     bf16_srcs=all(s.t.dtype == torch.bfloat16 for s in srcs))
@@ -344,10 +345,10 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
             if bfs_:        # launch_bfp_bf16_sources(): deeper K chunks where every source's width allows
                 c32_, c64_ = all(s.C % 32 == 0 for s in srcs), all(s.C % 64 == 0 for s in srcs)
                 ck_ = (64 if c64_ else 32 if c32_ else 16) if nt_ == 1 else (32 if c32_ else 16)
-                name = f"conv_bfp_kernel<8, {2 if wide_ else 1}, {ck_}, {hh}, {nt_}, 1, true>"
+                name = f"conv_bfp_kernel<8, {2 if wide_ else 1}, {ck_}, {hh}, {nt_}, 1, true, {sm_}>"
             else:
-                name = (f"conv_bfp_kernel<8, {2 if wide_ else 1}, 32, 0, 1, {np_}, false>" if k32 else
-                        f"conv_bfp_kernel<{tr}, {2 if (wide_ or tr == 2) else 1}, 16, {hh}, {nt_}, {np_}, false>")
+                name = (f"conv_bfp_kernel<8, {2 if wide_ else 1}, 32, 0, 1, {np_}, false, false>" if k32 else
+                        f"conv_bfp_kernel<{tr}, {2 if (wide_ or tr == 2) else 1}, 16, {hh}, {nt_}, {np_}, false, false>")
         elif k32:         # mirrors c3d_conv_forward / launch_taps() in csrc/conv_mfma.hip
             wide = cout > 64 and (cout + 127) // 128 * 128 <= (cout + 63) // 64 * 64
             name = f"conv_mfma_kernel<8, {4 if wide else (2 if cout > 32 else 1)}, 32, 0, 1>"
