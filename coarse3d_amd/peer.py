@@ -28,10 +28,10 @@ class PeerDesc(C.Structure):
 
 
 class PeerExchange:
-    def __init__(self, group=None, timeout_s=20.0, cap_doubles=CAP_DOUBLES):
+    def __init__(self, group=None, timeout_s=20.0, cap_doubles=CAP_DOUBLES, selftest=True):
         """Collective: every rank of ``group`` (default: the world) must construct it at the same point.  Raises
-        RuntimeError -- on EVERY rank -- if any rank could not allocate, share or map a mailbox, or if the ranks are not
-        on one host."""
+        RuntimeError -- on EVERY rank -- if any rank could not allocate, share or map a mailbox, if the ranks are not on one
+        host, or if the self-test exchanges (``selftest``) did not return the right sums on every rank within two seconds."""
         if not torch.cuda.is_available():
             raise RuntimeError("PeerExchange needs a GPU")
         self.group = group
@@ -76,9 +76,33 @@ class PeerExchange:
             except Exception as e:      # noqa: BLE001
                 err = f"rank {self.rank}: {e}"
             errs = [e for e in self._gather(err) if e]       # (also the barrier: every mailbox is mapped before its first use)
+        if not errs and selftest:
+            # First use on this set of devices: a few exchanges of known vectors with a short timeout, checked on every rank.
+            # A transport that does not deliver (or delivers stale data) shows here, in two seconds and with an exception
+            # on EVERY rank, instead of as a hung or silently wrong training step -- the cross-GPU path has not run on
+            # hardware in this repository's tests (one-GPU boxes), only the two-processes-one-device path has.
+            err = self._selftest()
+            errs = [e for e in self._gather(err) if e]
         if errs:
             self.close()
             raise RuntimeError("PeerExchange setup failed: " + "; ".join(errs))
+
+    def _selftest(self):
+        keep = self.desc.timeout_s
+        self.desc.timeout_s = 2.0
+        try:
+            for it, n in enumerate((257, 1, 4096, 64, self.desc.cap_doubles)):
+                t = torch.arange(n, dtype=torch.float64, device="cuda") * (self.rank + 1) + 0.25 * it
+                self.allreduce_(t)
+                want = torch.arange(n, dtype=torch.float64) * sum(r + 1 for r in range(self.world)) + 0.25 * it * self.world
+                if not torch.equal(t.cpu(), want):
+                    return f"rank {self.rank}: self-test exchange {it} ({n} values) returned a wrong sum"
+            self.check()
+            return None
+        except Exception as e:      # noqa: BLE001 -- every rank must reach the gather below
+            return f"rank {self.rank}: {e}"
+        finally:
+            self.desc.timeout_s = keep
 
     def _gather(self, obj):
         if self.world == 1:
