@@ -394,9 +394,12 @@ class Backbone:
         rec.out.grad = None
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, train=True, dropout_masks=None, return_feat=True, update_running=True, lazy_feat=False):
+    def forward(self, x, train=True, dropout_masks=None, return_feat=True, update_running=True, lazy_feat=False,
+                encoder_only=False):
         """x [B,Cin,H,W] fp32 (NCHW, as the reference feeds it).  Returns dict with NHWC tensors:
-        prob [B,Ho,Wo,C], logits [B,H,W,32], feat [B,Ho,Wo,256] (if return_feat)."""
+        prob [B,Ho,Wo,C], logits [B,H,W,32], feat [B,Ho,Wo,256] (if return_feat).
+        encoder_only: stop behind resBlock5 and return {"enc": [B,H/16,W/16,256]} -- the reference's ``classification=True``
+        mode (salsanext_proto.py:445-447); ``backward_encoder`` is its backward pass."""
         self.train, self.masks, self.update_running = train, dropout_masks, update_running
         self.packs.refresh()             # every weight repack of this step in one launch
         self.tape = OrderedDict()
@@ -415,6 +418,13 @@ class Backbone:
         d2c, d2b = self._res_block("resBlock3", d1c)
         d3c, d3b = self._res_block("resBlock4", d2c)
         d5c, _ = self._res_block("resBlock5", d3c, pooling=False)
+        if encoder_only:
+            self.enc_out = d5c
+            if train and update_running:
+                torch._foreach_add_([self.P[f"{n}.num_batches_tracked"] for n in self.bn_seen], 1)
+            enc = d5c.t if d5c.scale is None else None
+            assert enc is not None
+            return {"enc": enc}
         self.skips = (d0b, d1b, d2b, d3b)
         self.out_hw = (ho, wo)
         self.return_feat = return_feat
@@ -717,6 +727,27 @@ class Backbone:
         prev, ops.WGRAD_FOLDS = ops.WGRAD_FOLDS, (ops.WgradFolds() if DEFER_WGRAD_FOLDS else None)
         try:
             return self._backward(d_prob, d_feat, grads)
+        finally:
+            ops.WGRAD_FOLDS = prev
+
+    def backward_encoder(self, d_enc, grads):
+        """Backward of ``forward(..., encoder_only=True)``: d_enc [B,H/16,W/16,256] NHWC, the gradient at resBlock5's output;
+        ``grads``: name -> preallocated gradient tensor of the ENCODER parameters (downCntx*, resBlock*)."""
+        prev, ops.WGRAD_FOLDS = ops.WGRAD_FOLDS, (ops.WgradFolds() if DEFER_WGRAD_FOLDS else None)
+        try:
+            self.grads = grads
+            self.enc_out.grad = d_enc.contiguous()
+            for name in ("resBlock5", "resBlock4", "resBlock3", "resBlock2", "resBlock1"):
+                self._res_backward(name)
+            self._ctx_backward("downCntx3")
+            self._ctx_backward("downCntx2")
+            self._ctx_backward("downCntx", first=True)
+            if ops.WGRAD_FOLDS is not None:
+                with self._fork():
+                    ops.WGRAD_FOLDS.flush()
+            self._join()
+            self.tape = None
+            return grads
         finally:
             ops.WGRAD_FOLDS = prev
 

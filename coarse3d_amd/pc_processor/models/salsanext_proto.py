@@ -79,6 +79,42 @@ _DROP_SITES = (("resBlock2.dropout", 4), ("resBlock3.dropout", 8), ("resBlock4.d
                ("upBlock3.dropout1", 1), ("upBlock3.dropout2", 5), ("upBlock3.dropout3", 2))
 
 
+class FC(nn.Module):
+    """The classifier of the reference's ImageNet pre-training mode (salsanext_proto.py:216-231): global average pool +
+    Linear(base_channels, 1000).  Same names (``fc.linear.*``) and construction as the reference's FC."""
+
+    def __init__(self, base_channels):
+        super().__init__()
+        self.base_channels = base_channels
+        self.pool = nn.AdaptiveAvgPool2d((1, 1))
+        self.linear = nn.Linear(in_features=base_channels, out_features=1000, bias=True)
+
+    def forward(self, x):
+        return self.linear(self.pool(x).view(-1, self.base_channels))
+
+
+class _EncoderFn(torch.autograd.Function):
+    """x, encoder parameters -> resBlock5's output [B,256,H/16,W/16] (``classification=True``, salsanext_proto.py:445-447);
+    backward = the explicit HIP backward plan of the encoder."""
+
+    @staticmethod
+    def forward(ctx, model, x, masks, names, *tensors):
+        bb = model._make_backbone(model._tensor_dict())
+        out = bb.forward(x.detach().float(), model.training, masks, False, encoder_only=True)
+        ctx.bb, ctx.names, ctx.model = bb, names, model
+        return out["enc"].permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, d_enc):
+        model, bb = ctx.model, ctx.bb
+        P = dict(model._cached()[0])
+        grads = {n: torch.zeros_like(P[n]) for n in ctx.names}
+        enc_dtype = bb.enc_out.t.dtype
+        bb.backward_encoder(d_enc.permute(0, 2, 3, 1).contiguous().to(enc_dtype), grads)
+        ctx.bb = None
+        return (None, None, None, None) + tuple(grads[n] for n in ctx.names)
+
+
 class _BackboneFn(torch.autograd.Function):
     """x, parameters -> (pred_2d, feat_2d); backward = the explicit HIP backward plan."""
 
@@ -180,8 +216,6 @@ class SalsaNextProto(nn.Module):
                  softmax=True, proj_dim=256, projection="v1", classification=False, proto_mom=0.999,
                  dataset="SemanticKitti"):
         super().__init__()
-        if classification:
-            raise ValueError("classification=True (ImageNet pre-training head) is outside the accelerated path")
         # ``softmax`` is accepted and stored like the reference does (:261, :279) -- and, like the
         # reference, never read again: forward applies F.softmax unconditionally (:460)
         self.nclasses = nclasses
@@ -205,6 +239,8 @@ class SalsaNextProto(nn.Module):
         self.resBlock3 = ResBlock(4 * bc, 8 * bc, DROP_P, pooling=True)
         self.resBlock4 = ResBlock(8 * bc, 8 * bc, DROP_P, pooling=True)
         self.resBlock5 = ResBlock(8 * bc, 8 * bc, DROP_P, pooling=False)
+        if self.classification:            # ImageNet pre-training head (salsanext_proto.py:308-309), registered where the reference does
+            self.fc = FC(8 * bc)
         self.upBlock1 = UpBlock(8 * bc, 4 * bc, DROP_P)
         self.upBlock2 = UpBlock(4 * bc, 4 * bc, DROP_P)
         self.upBlock3 = UpBlock(4 * bc, 2 * bc, DROP_P)
@@ -298,7 +334,8 @@ class SalsaNextProto(nn.Module):
         hp, wp = (h + 8, w + 8) if self.dataset == "SemanticPOSS" else (h, w)
         assert hp % 16 == 0 and wp % 16 == 0, "input height and width must be multiples of 16"
 
-    _SKIP = ("prototypes", "feat_norm.weight", "feat_norm.bias", "mask_norm.weight", "mask_norm.bias")
+    _SKIP = ("prototypes", "feat_norm.weight", "feat_norm.bias", "mask_norm.weight", "mask_norm.bias",
+             "fc.linear.weight", "fc.linear.bias")
     # class-level defaults (subclasses with their own __init__ inherit them)
     _bind_grads = False
     _grads_live = True
@@ -411,6 +448,11 @@ class SalsaNextProto(nn.Module):
         self._check_input(h, w)
         masks = self._draw_masks(b, x.device) if self.training else None
         named, names, _ = self._cached()
+        if self.classification:
+            # salsanext_proto.py:445-447: the encoder, then the classifier -- the decoder, the heads and the bank are not run
+            enc_named = [(n, p) for n, p in named if n.startswith(("downCntx", "resBlock"))]
+            enc = _EncoderFn.apply(self, x, masks, tuple(n for n, _ in enc_named), *[p for _, p in enc_named])
+            return self.fc(enc.float())
         pred, feat = _BackboneFn.apply(self, x, masks, bool(return_feat), names, *[p for _, p in named])
         out = proto_ops.LazyOutputs({"pred_2d": pred})
         labelled, self._labelled_hint = self._labelled_hint, None

@@ -43,6 +43,14 @@ def closed_form_state(in_channel=5, nclasses=20, sub_proto=20, proj_dim=256, sal
     return st
 
 
+def fc_state(features=256, classes=1000, salt=0):
+    """Closed-form parameters of the ImageNet pre-training head FC (salsanext_proto.py:216-231): fc.linear.{weight, bias}."""
+    g = _gen("fc.linear", salt)
+    bound = 1.0 / math.sqrt(features)
+    return OrderedDict([("fc.linear.weight", torch.from_numpy(g.uniform(-bound, bound, (classes, features)).astype(np.float32))),
+                        ("fc.linear.bias", torch.from_numpy(g.uniform(-bound, bound, classes).astype(np.float32)))])
+
+
 def block_state(kind, cin, cout, name="blk", salt=0):
     """Closed-form parameters of ONE block (kind in ctx/res/up) under prefix ``name``."""
     convs, bns = OrderedDict(), OrderedDict()

@@ -76,10 +76,19 @@ def test_state_dict_surface_matches_reference_names():
     assert len(enc) == 198
 
 
-def test_constructor_rejects_unsupported_modes():
+def test_classification_mode_has_the_reference_state_dict_surface():
+    """``classification=True`` (salsanext_proto.py:216-231, 308-309; built in round 5): the FC head's parameters appear
+    where the reference registers them -- behind resBlock5, ahead of upBlock1 -- under the reference's names."""
     from coarse3d_amd.pc_processor.models import SalsaNextProto
-    with pytest.raises(ValueError):
-        SalsaNextProto(classification=True)
+    m = SalsaNextProto(classification=True)
+    keys = list(m.state_dict().keys())
+    i = keys.index("fc.linear.weight")
+    assert keys[i - 1] == "resBlock5.bn4.num_batches_tracked" and keys[i + 1] == "fc.linear.bias" and keys[i + 2] == "upBlock1.conv1.weight"
+    assert tuple(m.fc.linear.weight.shape) == (1000, 256)
+    import weights as W
+    sd = W.closed_form_state()
+    sd.update(W.fc_state())
+    m.load_state_dict(sd)
 
 
 def test_taps_and_select_ratio():
