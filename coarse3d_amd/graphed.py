@@ -58,6 +58,8 @@ class GraphedBackbone:
         import coarse3d_amd
         if not x.is_cuda:
             return "CPU tensor"
+        if type(model).__name__ != "SalsaNextProto" or getattr(model, "classification", False):
+            return "only SalsaNextProto's segmentation forward is captured (the other backbones run launch by launch)"
         if not coarse3d_amd.GRAPH_REPLAY_SAFE and os.environ.get("C3D_GRAPH_UNSAFE") != "1":
             return "the HIP runtime was initialised without DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (coarse3d_amd/__init__.py)"
         if model._bn_exchange()[0] is not None or model._flat_grads is not None or model._block_done is not None or model._grad_ready is not None:
