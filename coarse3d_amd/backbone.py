@@ -30,10 +30,10 @@ BN_MOMENTUM = 0.1
 # separate reduce pass (module flag for tests / A-B runs)
 FUSE_BN_REDUCE = os.environ.get("C3D_FUSE_BN_REDUCE", "1") != "0"      # (the environment switch: same-box A/B runs)
 # The same on the bf16 engine (round 5: ConvArgs::stat_mul over bf16 tensors, tests/test_gpu_bf16_storage.py).  OFF by default:
-# measured on BASELINE configs[2] it removes 29 of the 43 reduce passes (1.13 -> 0.45 ms) but the launches that carry the
-# epilogue more than double (conv_x3f<2,2,9,..> 79 -> 180 us, conv_bfp<8,2,32,1,4,..> 56 -> 145 us: the multiplier tile is read
-# with sixteen 2-byte loads per lane and sub-tile, and these kernels are bound by requests in flight) -- 19.07 vs 17.66 ms of
-# kernels per step.  What it needs is the multiplier tile staged through LDS with 16-byte loads; until then the separate pass stays.
+# measured on BASELINE configs[2] it removes 29 of the 43 reduce passes (1.12 -> 0.44 ms) but the launches that carry the
+# epilogue cost more than the passes they replace -- first form (sixteen 2-byte multiplier loads per lane and sub-tile)
+# conv_x3f<2,2,9,..> 79 -> 180 us, with the multiplier tile staged through LDS by 16-byte loads 79 -> 130 us, against ~24 us for
+# the separate pass it replaces (which already runs at 4.9 TB/s): 18.20 vs 17.83 ms of kernels per step, 469 vs 478 img/s.
 FUSE_BN_REDUCE_BF16 = os.environ.get("C3D_FUSE_BN_REDUCE_BF16", "0") == "1"
 # BatchNorm / LeakyReLU backward applied ON LOAD by the layer's first weight-gradient launch (round 4; ops.conv_wgrad(fuse=...)):
 # the apply pass (dy, a -> dz: three tensor passes at HBM speed, 53 launches and the largest kernel of the round-3 step)

@@ -83,6 +83,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
   const float* mulp = (STATMUL && a.stat_partial) ? a.stat_mul : nullptr;
   const bool mbf = STATMUL && BF16_OUT && a.stat_mul_bf16 != 0;      // bf16 multiplier tensor; the sums use the values as stored
   const float asc = a.acc_scale_dev ? a.acc_scale * *a.acc_scale_dev : a.acc_scale;
+  // bf16 multiplier tile through LDS (round 5): read per accumulator element it is sixteen 2-byte loads per lane and sub-tile,
+  // and the bf16 engine's kernels are bound by requests in flight -- the launches that carried the epilogue more than
+  // doubled (conv_x3f<2,2,9,..> 79 -> 180 us).  The workgroup copies the tile's [TR * 32 pixels][TN channels] with 16-byte
+  // loads into the (now dead) staging buffers and the lanes pick their elements from there.
+  constexpr int MROW = TN + 8;                       // bf16 per LDS row: the two half-waves of a read (4 rows apart) hit different banks
+  unsigned short* s_mul = reinterpret_cast<unsigned short*>(smem);
+  bool stage_mul = false;
+  if constexpr (STATMUL && BF16_OUT) {
+    stage_mul = mulp != nullptr && mbf && full_pix && n0 + TN <= a.Cout && (a.stat_mul_cs & 7) == 0;     // workgroup-uniform
+    if (stage_mul) {
+      __syncthreads();                               // every wave is done with the K loop's buffers
+      constexpr int UPP = TN / 8;                    // 16-byte units per pixel
+      typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+      for (int u = tid; u < TR * 32 * UPP; u += NTHR) {
+        const int p = u / UPP, cu = u % UPP;
+        const size_t g = (tile_pix + (size_t)(p >> 5) * a.W + (p & 31)) * a.stat_mul_cs + n0 + cu * 8;
+        *reinterpret_cast<u32x4_t*>(s_mul + p * MROW + cu * 8) =
+            *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const unsigned short*>(mulp) + g);
+      }
+      __syncthreads();
+    }
+  }
   // one 32-wide cout sub-tile, any position: per-element predicates
   auto slow_sub = [&](int j) {
     const int co = n0 + (ILV ? j * WN + wn : wn * NPW + j) * 32 + l31;
@@ -178,9 +200,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         // BatchNorm-backward sums (stat_mul): the multiplier tile is requested with the old values, one round trip
         float mul[STATMUL ? 16 : 1];
         if constexpr (STATMUL) if (mulp) {
-          const size_t mbase = (tile_pix + (size_t)((wm + i * WM) * a.W + 4 * half)) * a.stat_mul_cs + n0 + cl + l31;
+          if (stage_mul) {
+            const unsigned short* mr = s_mul + ((wm + i * WM) * 32 + 4 * half) * MROW + cl + l31;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) mul[r] = c3d_ld1(mulp, mbase + (size_t)((r & 3) + 8 * (r >> 2)) * a.stat_mul_cs, mbf);
+            for (int r = 0; r < 16; ++r) mul[r] = __uint_as_float((unsigned)mr[((r & 3) + 8 * (r >> 2)) * MROW] << 16);
+          } else {
+            const size_t mbase = (tile_pix + (size_t)((wm + i * WM) * a.W + 4 * half)) * a.stat_mul_cs + n0 + cl + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mul[r] = c3d_ld1(mulp, mbase + (size_t)((r & 3) + 8 * (r >> 2)) * a.stat_mul_cs, mbf);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
