@@ -30,6 +30,7 @@ struct WgradArgs {
   int ci_slices, co_slices;
   float slope;
   int variant = 0;                   // c3d_wgrad_desc.variant
+  int npw = 4;                       // producer waves of the wgrad_tr workgroup (c3d_wgrad_producer_waves)
 };
 
 // A workgroup owns a (CI cin, CO cout) slice and TRW x 32 pixel tiles.
@@ -56,6 +57,12 @@ inline WgCfg c3d_wgrad_cfg(int T, int Cin, int Cout, int planes, int halo = 1) {
   if (T <= 4 && planes == 3 && Cout > 32 && Cin % 64 == 0 && halo <= 1) return WgCfg{8, 64, 64, 2};
   if (T <= 4) return Cout > 32 ? WgCfg{4, 32, 64, planes == 3 ? 2 : 4} : WgCfg{5, 32, 32, 4};
   return Cout > 32 ? WgCfg{6, 32, 64, planes == 1 ? 4 : 2} : WgCfg{7, 32, 32, 4};
+}
+
+// Producer waves of the wgrad_tr workgroup: eight (two per SIMD, 768 threads) for the three-plane 1x1 instances with small
+// accumulators (ids 1-3), four elsewhere.  c3d_wgrad_desc.variant & 128: four everywhere (the bit-identity test, A/B runs).
+inline int c3d_wgrad_producer_waves(int planes, int id, int variant) {
+  return (planes == 3 && id >= 1 && id <= 3 && !(variant & 128)) ? 8 : 4;
 }
 
 // wgrad_tr.hip

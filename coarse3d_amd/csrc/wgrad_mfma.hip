@@ -415,6 +415,7 @@ void plan(const c3d_wgrad_desc* d, WgradArgs& a, WgCfg& c) {
   if (strips < 1) strips = 1;
   a.tiles_per_strip = (a.ntiles + strips - 1) / strips;
   a.strips = (a.ntiles + a.tiles_per_strip - 1) / a.tiles_per_strip;
+  a.npw = c3d_wgrad_producer_waves(planes_for(d), c.id, d->variant);
 }
 
 template <int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool BF>
@@ -458,7 +459,7 @@ extern "C" int c3d_wgrad_fused_sum_n(const c3d_wgrad_desc* d) {
   WgradArgs a;
   WgCfg c;
   plan(d, a, c);
-  return a.strips * (256 / (c.CO / 4));
+  return a.strips * (64 * a.npw / (c.CO / 4));
 }
 
 extern "C" int64_t c3d_wgrad_partial_floats(const c3d_wgrad_desc* d) {
@@ -505,7 +506,7 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
     C3D_REQUIRE((d->fuse_pre_scale == nullptr) == (d->fuse_pre_shift == nullptr) && (!d->fuse_pre_scale || d->fuse_k1),
                 "wgrad: fuse_pre_scale / fuse_pre_shift come together and need the BatchNorm coefficients");
     a.f_ps = d->fuse_pre_scale; a.f_psh = d->fuse_pre_shift;
-    a.f_sum_n = a.strips * (256 / (c.CO / 4));
+    a.f_sum_n = a.strips * (64 * a.npw / (c.CO / 4));
   }
   hipStream_t st = (hipStream_t)stream;
   const int planes = planes_for(d);

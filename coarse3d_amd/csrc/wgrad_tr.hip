@@ -181,8 +181,15 @@ __device__ __forceinline__ void c3d_wg_static_for(F&& f) {
 // in the unfused ones; the fused 32 -> 32 3x3 weight gradient ran at 110 TF against 197 unfused).  The 2 * HALO rows that
 // only a column's first tile needs are now loaded inside store_tile of that tile, into the registers its x units have just
 // left, and converted after the dz units (whose conversion hides most of their latency).
-template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool FA = false, bool RAW = false, bool LEAN = false>
-__global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
+// NPW (round 5, the 1x1 instances of the three-plane engine): EIGHT producer waves, two per SIMD, in a 768-thread workgroup.  A
+// 1x1 weight gradient has next to no matrix work per staged byte (matrix pipe busy 0.05-0.16): its time is the producer waves'
+// -- one wave per SIMD issuing a dependent VALU chain per staged unit with nothing to fill its stalls, and two tiles of
+// loads in flight per CU.  Its accumulators are small (16-64 registers), so the 168 registers of a twelve-wave workgroup
+// are enough; a wave stages half the units per tile and the CU keeps twice the waves' worth of loads in flight.
+template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool FA = false, bool RAW = false, bool LEAN = false,
+          int NPW = 4>
+__global__ __launch_bounds__(256 + 64 * NPW, 1) void wgrad_tr_kernel(WgradArgs a) {
+  constexpr int NPT = 64 * NPW;        // producer threads
   static_assert(!RAW || (NP == 1 && !FA), "raw bf16 stages belong to the one-plane engine without the fused apply");
   constexpr int DEPTH = RAW ? 4 : 2;   // tiles the producer waves keep in flight (register sets)
   using SU = std::conditional_t<RAW, u32x2, f32x4>;   // a staged unit in flight: four bf16 as loaded, or four floats
@@ -228,7 +235,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   //  add, compare, select, a quarter-rate v_mul_lo_u32 by the window width -- per lane: 218 VALU instructions per 108 MFMAs
   //  of the 32 x 32 nine-tap instance, in a kernel whose MFMA and VALU streams share the SIMD's issue port -- PMC: 39 % of
   //  the wave cycles were issue stalls.)
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & 255) >> 6);
+  // (consumer threads 0 .. 255, producer threads 0 .. NPT - 1)
+  const int tid = producer ? (int)threadIdx.x - 256 : (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int wci = wave % WCI, wco = (wave / WCI) % WCO, wk = wave / (WCI * WCO);
   // transposed-read source of this lane: group g = lane>>4 covers channels 16*(g&1).. of pixels 8*(g>>1)..
@@ -244,10 +252,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
 
   // ---- register staging (prefetch) of the next pixel tile while the current one is consumed
   constexpr int X_UNITS = LEANX ? NEWROWS_UNITS : XROWS * (CI / 4);      // x units of a register set in flight
-  constexpr int X_PT = (X_UNITS + 255) / 256;
-  constexpr int E_PT = LEANX ? (EXTRA_UNITS + 255) / 256 : 0;
+  constexpr int X_PT = (X_UNITS + NPT - 1) / NPT;
+  constexpr int E_PT = LEANX ? (EXTRA_UNITS + NPT - 1) / NPT : 0;
   constexpr int D_UNITS = DROWS * (CO / 4);
-  constexpr int D_PT = (D_UNITS + 255) / 256;
+  constexpr int D_PT = (D_UNITS + NPT - 1) / NPT;
   // one register set per tile in flight; the producers keep TWO tiles of loads outstanding (one
   // tile per CU in flight left the kernel bound by memory latency)
   struct Stage {
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     int ex0, ey0;   // LEANX: image column / row of the window's first pixel (uniform; may be negative)
     size_t ximg;    // LEANX: element offset of the image in x (uniform)
   };
-  const int xc4 = tid % (CI / 4);          // 256 % (CI/4) == 0: fixed channel quad per thread
+  const int xc4 = tid % (CI / 4);          // NPT % (CI/4) == 0: fixed channel quad per thread
   const int xc = ci0 + xc4 * 4;
   const bool xc_ok = xc < a.x.C;
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
@@ -285,9 +293,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   // per-unit index arithmetic or bounds tests.  Without a halo a pass of 256 threads advances by
   // a uniform pixel offset, so one offset per thread is enough.
   const int xp0 = tid / (CI / 4);
-  constexpr int XSTEP = 256 / (CI / 4);    // pixels per pass of the workgroup
+  constexpr int XSTEP = NPT / (CI / 4);    // pixels per pass of the producer waves
   const int dc4 = tid % (CO / 4), dp0 = tid / (CO / 4);
-  constexpr int DSTEP = 256 / (CO / 4);
+  constexpr int DSTEP = NPT / (CO / 4);
   static_assert(XSTEP % 32 == 0 || 32 % XSTEP == 0, "pass size must tile the 32-pixel rows");
   static_assert(DSTEP % 32 == 0 || 32 % DSTEP == 0, "pass size must tile the 32-pixel rows");
   const int dc = co0 + dc4 * 4;
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     xoff[0] = (unsigned)(((xp0 / 32) * a.W + xp0 % 32) * a.x.cstride + a.x.coff + xc);
   }
   const unsigned doff0 = (unsigned)(((dp0 / 32) * a.W + dp0 % 32) * a.dz_cstride + dc);
-  const unsigned x_all = xc_ok ? ((X_UNITS % 256 == 0 || tid < X_UNITS % 256) ? ((1u << X_PT) - 1u) : ((1u << (X_PT - 1)) - 1u)) : 0u;
+  const unsigned x_all = xc_ok ? ((X_UNITS % NPT == 0 || tid < X_UNITS % NPT) ? ((1u << X_PT) - 1u) : ((1u << (X_PT - 1)) - 1u)) : 0u;
   unsigned x_new = 0;        // RINGX: this thread's units that lie in the first TRW rows of the staged rectangle
 #pragma unroll
   for (int i = 0; i < X_PT; ++i)
@@ -499,7 +507,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
         emask = 0;
 #pragma unroll
         for (int j = 0; j < X_PT; ++j) {
-          const int u = tid + (j0 + j) * 256;
+          const int u = tid + (j0 + j) * NPT;
           const int pp = u / (CI / 4);
           const int r = pp / TWh, col = pp - r * TWh;
           const int gx = sg.ex0 + col, gy = sg.ey0 + r;
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
       if constexpr (LEANX) {
 #pragma unroll
         for (int j = 0; j < X_PT; ++j) {
-          const int u = tid + (j0 + j) * 256;
+          const int u = tid + (j0 + j) * NPT;
           if ((j0 + j) < E_PT && u < EXTRA_UNITS) {
             f32x4 v = pe[j];
             if (aff) v = v * psc + psh;
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     };
 #pragma unroll
     for (int i = 0; i < X_PT; ++i) {
-      const int u = tid + i * 256;
+      const int u = tid + i * NPT;
       if (u < xunits) {
         f32x4 v;
         if constexpr (RAW) {
@@ -575,7 +583,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < D_PT; ++i) {
-      const int u = tid + i * 256;
+      const int u = tid + i * NPT;
       if (u < D_UNITS) {
         u32x2 pl[NP];
         if constexpr (RAW) {
@@ -941,8 +949,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(WgradArgs a) {
   }
 }
 
-template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool LEAN_FA = false>
+template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool LEAN_FA = false, int NPW = 4>
 int launch_tr(const WgradArgs& a, hipStream_t st) {
+  constexpr int NPT = 64 * NPW;
+  static_assert(NPW == 4 || (NP == 3 && HALO == 0 && !LEAN_FA), "eight producer waves: the three-plane 1x1 instances");
   constexpr int WK = 4 / (WCI * WCO);
   constexpr int CI = 32 * CI_T * WCI, CO = 32 * CO_T * WCO;
   size_t lds = 2 * (size_t)NP * ((size_t)(TRW + 2 * HALO) * (32 + 2 * HALO) * CI + (size_t)TRW * 32 * CO) * 2;   // two tile buffers
@@ -951,7 +961,7 @@ int launch_tr(const WgradArgs& a, hipStream_t st) {
   dim3 grid(a.strips * a.ci_slices * a.co_slices);
   if constexpr (NP == 3) {
     if (a.f_dy) {       // BatchNorm / LeakyReLU backward on load
-      if (a.f_sum_n != a.strips * (256 / (CO / 4))) {
+      if (a.f_sum_n != a.strips * (NPT / (CO / 4))) {
         c3d_set_error("wgrad: fuse_sum was not sized with c3d_wgrad_fused_sum_n()");
         return 1;
       }
@@ -970,8 +980,8 @@ int launch_tr(const WgradArgs& a, hipStream_t st) {
           return 0;
         }
       }
-      c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true>>();
-      hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true>), grid, dim3(512), lds, st, a);
+      c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true, false, false, NPW>>();
+      hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true, false, false, NPW>), grid, dim3(256 + NPT), lds, st, a);
       C3D_CHECK_LAUNCH();
       return 0;
     }
@@ -984,8 +994,8 @@ int launch_tr(const WgradArgs& a, hipStream_t st) {
       return 0;
     }
   }
-  c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO>>();
-  hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO>), grid, dim3(512), lds, st, a);
+  c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, false, false, NPW>>();
+  hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, false, false, NPW>), grid, dim3(256 + NPT), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -996,9 +1006,15 @@ int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
   switch (id) {
     //                         TMAX CI_T CO_T WCI WCO TRW HALO
     case 0: return launch_tr<NP, 1, 2, 4, 2, 2, 1, 0>(a, st);
-    case 1: return launch_tr<NP, 1, 2, 2, 2, 2, 1, 0>(a, st);
-    case 2: return launch_tr<NP, 1, 2, 2, 1, 1, 2, 0>(a, st);
-    case 3: return launch_tr<NP, 1, 1, 1, 1, 1, 4, 0>(a, st);
+    case 1:
+      if constexpr (NP == 3) if (a.npw == 8) return launch_tr<NP, 1, 2, 2, 2, 2, 1, 0, false, 8>(a, st);
+      return launch_tr<NP, 1, 2, 2, 2, 2, 1, 0>(a, st);
+    case 2:
+      if constexpr (NP == 3) if (a.npw == 8) return launch_tr<NP, 1, 2, 2, 1, 1, 2, 0, false, 8>(a, st);
+      return launch_tr<NP, 1, 2, 2, 1, 1, 2, 0>(a, st);
+    case 3:
+      if constexpr (NP == 3) if (a.npw == 8) return launch_tr<NP, 1, 1, 1, 1, 1, 4, 0, false, 8>(a, st);
+      return launch_tr<NP, 1, 1, 1, 1, 1, 4, 0>(a, st);
     case 4: return halo <= 1 ? launch_tr<NP, 4, 1, 2, 1, 1, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 4, 1, 2, 1, 1, (NP == 1 ? 4 : 2), 2>(a, st);
     case 5: return halo <= 1 ? launch_tr<NP, 4, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 4, 1, 1, 1, 1, 4, 2, NP == 3>(a, st);
     case 8:

@@ -84,8 +84,9 @@ def _bf(*tensors):
 # bit 2 = round 2's phased kernel for nine-tap convs.  Same bits out of every variant (tests/test_gpu_conv.py).
 CONV_VARIANT = 0
 # c3d_wgrad_desc.variant (fused weight-gradient launches): 0 = the library's choice, 1 = whole-window register sets, 2 = lean
-# ones (same bits), +4 = a fused 1x1 launch keeps the unfused tile configuration
-WGRAD_VARIANT = 0
+# ones (same bits), +4 = a fused 1x1 launch keeps the unfused tile configuration, +128 = four producer waves in every
+# instance (the three-plane 1x1 instances with small accumulators run eight)
+WGRAD_VARIANT = int(os.environ.get("C3D_WGRAD_VARIANT", "0"))
 F16X2_FWD = os.environ.get("C3D_F16X2_FWD", "0") == "1"
 F16X2_BWD = os.environ.get("C3D_F16X2_BWD", "0") == "1"     # EXPERIMENT: multi-tap input gradients too (per-tensor exponent)
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -387,7 +388,8 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
 
 def _wgrad_kernel_name(ci, co, nt, halo, fused=False, raw=False, h=0):
     """Mirrors c3d_wgrad_cfg() (csrc/wgrad_common.h), plan() (wgrad_mfma.hip) and the launch tables of wgrad_mfma.hip /
-    wgrad_tr.hip (names as rocprofv3 prints them; the eleventh template argument: lean register sets, round 5)."""
+    wgrad_tr.hip (names as rocprofv3 prints them; the eleventh template argument: lean register sets, the twelfth: producer
+    waves, round 5)."""
     tr = MFMA_MODE != 0
     hl = 1 if halo <= 1 else 2
     x3 = tr and MFMA_MODE == 2          # three planes: the smaller pixel tiles of c3d_wgrad_cfg
@@ -412,8 +414,9 @@ def _wgrad_kernel_name(ci, co, nt, halo, fused=False, raw=False, h=0):
     if tr:       # (ninth template argument: BatchNorm backward applied on load, conv_wgrad(fuse=...); tenth: raw bf16 stages, four
         # tiles in flight -- the bf16 engine with bf16 tensors on both sides; eleventh: lean register sets)
         lean = bool(fused and x3 and lean_ok and (h + trw - 1) // trw >= 8)
+        npw = 8 if (x3 and nt == 1 and not cfg.startswith("1, 2, 4") and not (WGRAD_VARIANT & 128)) else 4      # c3d_wgrad_producer_waves()
         return (f"wgrad_tr_kernel<{3 if MFMA_MODE == 2 else 1}, {cfg}, {'true' if fused else 'false'}, "
-                f"{'true' if (raw and MFMA_MODE == 1 and not fused) else 'false'}, {'true' if lean else 'false'}>")
+                f"{'true' if (raw and MFMA_MODE == 1 and not fused) else 'false'}, {'true' if lean else 'false'}, {npw}>")
     return f"wgrad_mfma_kernel<{cfg}, {'true' if MFMA_MODE == 1 else 'false'}>"
 
 

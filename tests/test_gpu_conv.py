@@ -250,6 +250,10 @@ def _random_shape_cases(ops, rnd, dev):
     (1, 64, 2048, 64, 48, 3, 2, 2),      # dilation-2 halo, ragged cout
     (4, 32, 1024, 160, 224, 1, 1, 0),    # 128x256 slices (ragged in both), 32 tiles per strip
     (1, 64, 2040, 32, 64, 2, 2, 1),      # 2x2 taps, W % 32 != 0: border tiles inside long strips
+    # round 5: the 1x1 instances whose workgroup has eight producer waves (bf16x3: ids 3, 2, 1), ragged W / channels
+    (2, 64, 2040, 32, 24, 1, 1, 0),
+    (2, 64, 2048, 48, 64, 1, 1, 0),
+    (4, 32, 1000, 128, 100, 1, 1, 0),
 ])
 def test_weight_gradient_long_strips(mode, B, H, W, Cin, Cout, k, dil, pad):
     """Weight gradients at sizes where every workgroup walks many pixel tiles (the unit cases above
@@ -270,6 +274,14 @@ def test_weight_gradient_long_strips(mode, B, H, W, Cin, Cout, k, dil, pad):
         dw = torch.zeros(Cout, Cin, k, k, device=dev)
         ops.conv_wgrad(ops.Source(x, sc, sh, lrelu=True), dz, dw, taps)
         torch.cuda.synchronize()
+        if k == 1 and mode == "bf16x3":      # four producer waves instead of eight: the same LDS image, the same bits
+            dw4 = torch.zeros_like(dw)
+            ops.WGRAD_VARIANT = 128
+            try:
+                ops.conv_wgrad(ops.Source(x, sc, sh, lrelu=True), dz, dw4, taps)
+            finally:
+                ops.WGRAD_VARIANT = 0
+            assert torch.equal(dw, dw4)
     finally:
         ops.set_matrix_precision(*_PREV.pop())
     xt = F.leaky_relu((x.double() * sc.double() + sh.double()).float(), 0.01)          # one fused multiply-add, as the kernel
@@ -372,7 +384,8 @@ def test_batchnorm_backward_applied_on_load_by_the_weight_gradient(B, H, W, Cin,
         # +4 = a fused 1x1 launch over >= 96 x 192 channels keeps the unfused launch's 128 x 256 slice (the library's
         # choice is the 128 x 128 one, which does not spill: another strip layout, i.e. another fp32 summation order)
         wide = k == 1 and Cin >= 96 and Cout >= 192
-        for variant in (0, 1 | 4, 2 | 4):
+        # +128 (round 5): four producer waves where the library runs eight (the three-plane 1x1 instances) -- the same bits
+        for variant in (0, 1 | 4, 2 | 4, 128, 128 | 4):
             dz = torch.full_like(act, float("nan"))
             dw = torch.zeros_like(dw_ref)
             db = torch.zeros_like(db_ref)
@@ -383,7 +396,7 @@ def test_batchnorm_backward_applied_on_load_by_the_weight_gradient(B, H, W, Cin,
                 ops.WGRAD_VARIANT = 0
             torch.cuda.synchronize()
             assert torch.equal(dz, dz_ref), variant
-            if variant == 0 and wide:
+            if wide and not (variant & 4):
                 assert float((dw - dw_ref).abs().max()) <= 2e-6 * float(dw_ref.abs().max()), variant
             else:
                 assert torch.equal(dw, dw_ref), variant

@@ -1,9 +1,8 @@
 #!/bin/bash
-# A/B of environment-variable settings on the GPU box: tools/ab_env.sh "VAR=a VAR2=b" "VAR=c" ...  (each arg = one setting)
-for setting in "$@"; do
-  for rep in 1 2; do
-    env $setting python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-second-engine --graph off 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$setting', d['value'], d['ms_per_step'], d['roofline']['all_mfma_kernels']['ms_per_step'])"
-  done
+# Same-box A/B of one environment switch on the captured headline step: tools/ab_env.sh VAR=value [H W classes batch]
+# (alternates default / switched, three times; prints ms per step)
+SW=$1; shift
+for rep in 1 2 3; do
+  python tools/ab_step.py "$@"
+  env "$SW" python tools/ab_step.py "$@"
 done

@@ -4,28 +4,6 @@
 OTHER=$1; shift
 for rep in 1 2; do
   for lib in "" "$OTHER"; do
-    C3D_LIB=$lib python - "$@" <<'PY'
-import os, sys, time
-sys.path.insert(0, os.getcwd())
-import coarse3d_amd, torch, bench
-from coarse3d_amd import trainer
-from coarse3d_amd.pc_processor.models import SalsaNextProto
-H, W, C, B = (int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (64, 2048, 20, 8)))
-dev = torch.device("cuda", 0)
-batches = [bench.synth_batch(B, H, W, C, 1000 + s, dev, 1e-3) for s in range(8)]
-torch.manual_seed(1)
-model = SalsaNextProto(5, C, 20, 0, use_prototype=True, dataset="SemanticPOSS" if H == 40 else "SemanticKitti").to(dev).train()
-ts = trainer.TrainStep(model, C, lr=1e-3, n_epochs=100, temperature=0.07, num_anchor=512, loss_w_contrast=0.1,
-                       feature_mean=bench.FEATURE_MEAN, feature_std=bench.FEATURE_STD, proto_loss=True, inputs_resident=True, graph=True)
-for s in range(6):
-    res = ts.step(*batches[s % 8], epoch=10)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for s in range(20):
-    res = ts.step(*batches[s % 8], epoch=10)
-torch.cuda.synchronize()
-el = (time.perf_counter() - t0) / 20
-print(f"{os.environ.get('C3D_LIB') or 'default build'}: {el * 1e3:.3f} ms/step ({B / el:.1f} img/s), loss {float(res['loss']):.6f}", flush=True)
-PY
+    C3D_LIB=$lib python tools/ab_step.py "$@"
   done
 done
