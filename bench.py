@@ -290,6 +290,10 @@ HBM_KERNELS = ("bn_bwd_kernel", "bilinear_kernel", "bilinear_bwd_kernel", "bilin
 MATRIX_KERNELS = ("conv_", "wgrad_")
 
 
+class PeerExchangeFailed(RuntimeError):
+    pass
+
+
 class Bench:
     """One workload on the current process' GPU: model + TrainStep construction, the timed passes, the roofline object."""
 
@@ -421,6 +425,16 @@ class Bench:
                 t = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 elapsed = float(t)
+            px = getattr(ts.model, "peer", None) if self.dp else None
+            if px is not None:
+                # the SyncBatchNorm sums travelled through peer memory (coarse3d_amd/peer.py): did every exchange of every rank
+                # complete?  (A rank that gave up waiting computed with partial sums: the pass is void -- the caller repeats
+                # it over torch.distributed collectives.)  Decided together: every rank raises or none does.
+                bad = torch.tensor([float(px.failed())], device=self.dev)
+                if self.world > 1:
+                    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                if float(bad) > 0:
+                    raise PeerExchangeFailed("an exchange through peer memory timed out on at least one rank")
             timed = None
             if ops.KERNEL_EVENTS:
                 timed = self.summarise(ops.KERNEL_EVENTS)
@@ -437,6 +451,8 @@ class Bench:
                     D.EXPOSED = None
                     coll["comm_exposed_ms"] = {k: round(v / steps, 3) for k, v in ex.items()}
                     coll["comm_exposed_ms"]["total"] = round(sum(ex.values()) / steps, 3)
+                coll["syncbn_exchange"] = ("peer-memory kernel (coarse3d_amd/peer.py, csrc/peer_ops.hip)" if px is not None
+                                           else "torch.distributed all_reduce")
                 out["collectives"] = coll
             out["n_ranks"] = n_ranks
             out["value"] = round(self.wl["batch"] * n_ranks * steps / elapsed, 3)
@@ -708,8 +724,17 @@ def main():
             out["config"]["launch"] = launch_note
         return out
 
+    peer_note = None
     if want_eager:
-        eager = b.run(False, args.steps, args.warmup, args.prewarm, events, exposed=dp)
+        try:
+            eager = b.run(False, args.steps, args.warmup, args.prewarm, events, exposed=dp)
+        except PeerExchangeFailed as e:
+            # first run of the peer-memory exchange on this node's transport did not hold: every rank (the check is a
+            # consensus) switches the SyncBatchNorm sums back to torch.distributed collectives and repeats the pass
+            os.environ["C3D_SYNCBN_EXCHANGE"] = "collective"
+            peer_note = f"collective ({e}; the pass was repeated with torch.distributed all-reduces)"
+            print(f"bench.py: rank {rank}: {peer_note}", file=sys.stderr, flush=True)
+            eager = b.run(False, args.steps, args.warmup, args.prewarm, events, exposed=dp)
     if want_graph:
         guard = None
         if dp and eager is not None:
@@ -747,6 +772,8 @@ def main():
             if guard is not None:
                 guard.cancel()
     out = headline(eager, cap, launch_note)
+    if peer_note:
+        out["syncbn_exchange_fallback"] = peer_note
     if rank == 0:
         extra = world == 1 and not single_rank_group
         if extra and args.matrix_dtype == "bf16x3" and not args.no_second_engine:

@@ -54,9 +54,12 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs a) {
   unsigned int* status = reinterpret_cast<unsigned int*>(own + 8);
   if (tid == 0) {
     s_seq = *calls + 1ull;
-    s_fail = 0;
+    s_fail = (int)*status;
   }
   __syncthreads();
+  // an earlier exchange gave up: the ranks' sequence numbers no longer agree and every further wait would run into its
+  // timeout too -- do nothing (the host raises at its next check; a step with 86 exchanges costs ONE timeout, not 86)
+  if (s_fail) return;
   const unsigned long long seq = s_seq;
   const int parity = (int)(seq & 1ull);
   // 1. my vector into my slot of every mailbox

@@ -346,6 +346,7 @@ class SalsaNextProto(nn.Module):
     graph_backbone = False
     _gb = None
     _last_keep = None
+    classification = False           # (class-level defaults: the other backbones' constructors do not run this class' __init__)
 
     def _graphed_backbone(self):
         if self._gb is None:

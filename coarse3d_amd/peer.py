@@ -19,6 +19,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 
+SELFTEST_EXCHANGES = 5 + 96   # what PeerExchange(selftest=True) adds to the exchange counter
 CAP_DOUBLES = 8192          # slot capacity: SalsaNext's largest grouped exchange is 2 x (704 + 128) doubles, SqueezeSegV3's 2 x 2304
 
 
@@ -31,7 +32,8 @@ class PeerExchange:
     def __init__(self, group=None, timeout_s=20.0, cap_doubles=CAP_DOUBLES, selftest=True):
         """Collective: every rank of ``group`` (default: the world) must construct it at the same point.  Raises
         RuntimeError -- on EVERY rank -- if any rank could not allocate, share or map a mailbox, if the ranks are not on one
-        host, or if the self-test exchanges (``selftest``) did not return the right sums on every rank within two seconds."""
+        host, or if the self-test exchanges (``selftest``: five of known vectors, then 96 queued back to back with one rank
+        late at a time, as in a training step) did not return the right sums on every rank within two seconds each."""
         if not torch.cuda.is_available():
             raise RuntimeError("PeerExchange needs a GPU")
         self.group = group
@@ -97,6 +99,21 @@ class PeerExchange:
                 want = torch.arange(n, dtype=torch.float64) * sum(r + 1 for r in range(self.world)) + 0.25 * it * self.world
                 if not torch.equal(t.cpu(), want):
                     return f"rank {self.rank}: self-test exchange {it} ({n} values) returned a wrong sum"
+            # the pattern of a training step: many exchanges queued back to back with no host synchronisation in between
+            # (both parities reused ~50 times), one rank arriving late at some of them, sizes of the BatchNorm layers
+            sizes = (64, 128, 256, 512, 1408, 64, 64, 1664)
+            ts = []
+            for it in range(96):
+                n = sizes[it % len(sizes)]
+                t = torch.full((n,), float(it), dtype=torch.float64, device="cuda") + self.rank
+                if it % 16 == self.rank % 16:
+                    torch.cuda._sleep(200_000)          # ~0.1 ms: this rank is the late one
+                self.allreduce_(t)
+                ts.append((it, t))
+            base = sum(range(self.world))
+            for it, t in ts:
+                if not bool((t == float(it) * self.world + base).all()):
+                    return f"rank {self.rank}: self-test exchange {it} of the back-to-back series returned a wrong sum"
             self.check()
             return None
         except Exception as e:      # noqa: BLE001 -- every rank must reach the gather below
@@ -133,6 +150,13 @@ class PeerExchange:
     @staticmethod
     def end(stream):
         torch.cuda.current_stream().wait_stream(stream)
+
+    def failed(self):
+        """True if an exchange of this rank gave up waiting for a peer (synchronises; does not raise)."""
+        st = C.c_int32(0)
+        torch.cuda.synchronize()
+        L.check(L.lib().c3d_peer_status(C.byref(self.desc), C.byref(st), None), "c3d_peer_status")
+        return bool(st.value)
 
     def check(self):
         """Host check (synchronises): raises if an exchange gave up waiting for a peer -- its result was not a sum, and

@@ -91,6 +91,19 @@ def test_classification_mode_has_the_reference_state_dict_surface():
     m.load_state_dict(sd)
 
 
+def test_the_other_backbones_carry_the_attributes_the_shared_forward_reads():
+    """RangeNetProto / SqueezeSegV3Proto reuse SalsaNextProto.forward but run their own constructors: every attribute that
+    forward reads must exist on them (a missing ``classification`` broke their data-parallel step once)."""
+    from coarse3d_amd.pc_processor.models import RangeNetProto, SalsaNextProto, SqueezeSegV3Proto
+    base = SalsaNextProto()
+    for m in (RangeNetProto(layers=21, nclasses=20, use_prototype=True), SqueezeSegV3Proto(nclasses=20, layers=21, use_prototype=True)):
+        assert m.classification is False and m.graph_backbone is False and m._gb is None
+        missing = [k for k in vars(base) if not k.startswith("_") and not hasattr(m, k)
+                   and k not in base._modules and k not in base._parameters and k not in base._buffers
+                   and k not in ("softmax", "base_channels")]      # (stored as the reference does / read by SalsaNext's own mask draw only)
+        assert not missing, missing
+
+
 def test_taps_and_select_ratio():
     from coarse3d_amd import ops
     from coarse3d_amd.trainer import select_ratio_for

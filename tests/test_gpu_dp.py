@@ -2,6 +2,7 @@
 single-process run on the full batch: SyncBatchNorm statistics, gradient mean over ranks and the
 prototype-bank mean must reproduce the full-batch result (SURVEY.md section 8e semantics)."""
 import os
+import time
 
 import pytest
 import torch
@@ -54,7 +55,8 @@ def _run(rank, world, port, q, b, h, w, ncls, proto_sync="bank_mean", wrap="c3d"
         # torch.distributed -- here between two processes that share the box's one GPU
         assert model.peer is not None and D.COUNTS["syncbn"] > 0
         peer_calls = model.peer.check()
-        assert peer_calls == D.COUNTS["syncbn"] + 5          # (+ the constructor's self-test exchanges)
+        from coarse3d_amd.peer import SELFTEST_EXCHANGES
+        assert peer_calls == D.COUNTS["syncbn"] + SELFTEST_EXCHANGES          # (+ the constructor's self-test exchanges)
     res = {"peer_calls": peer_calls,
            "grads": {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None},
            "protos": m.prototypes.detach().cpu().numpy(),
@@ -150,6 +152,12 @@ def _peer_worker(rank, world, port, q, skip_last):
                 px.check()
             except RuntimeError as e:
                 timed_out = "timed out" in str(e)
+            # ... and every exchange after that returns at once (one timeout per failure, not one per exchange of the step)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                px.allreduce_(t)
+            torch.cuda.synchronize()
+            timed_out = timed_out and (time.perf_counter() - t0) < 1.0
         dist.barrier()
     q.put((rank, ok, calls, timed_out))
     dist.barrier()
@@ -174,7 +182,8 @@ def test_peer_exchange_between_two_processes_on_one_device(skip_last):
         pr.join(60)
         assert pr.exitcode == 0
     assert res[0][0] and res[1][0]
-    assert res[0][1] == res[1][1] == 303 + 5                 # (+ the five self-test exchanges of the constructor)
+    from coarse3d_amd.peer import SELFTEST_EXCHANGES
+    assert res[0][1] == res[1][1] == 303 + SELFTEST_EXCHANGES      # (+ the self-test exchanges of the constructor)
     assert res[0][2] == bool(skip_last) and not res[1][2]
 
 
