@@ -68,7 +68,7 @@ __device__ __forceinline__ void split4(f32x4 v, u32x2 (&out)[NP]) {
 // workgroups per CU: compiled into the common instance the epilogue's multiplier tile pushed it past its register cap (303
 // spilled registers at three workgroups per CU) for EVERY launch, with or without stat_mul.
 template <int TR, int NT, int CK, int HALO, int TT, int NP, bool BFS = false, bool SM = false>
-__global__ __launch_bounds__(256, (!SM && NP == 1 && !(TT == 9 && NT == 2 && TR == 8) && !(BFS && NT == 2 && (CK == 64 || (TT == 4 && CK == 32)))) ? 3 : 2)
+__global__ __launch_bounds__(256, (!SM && NP == 1 && !(TT >= 6 && NT == 2 && TR == 8) && !(BFS && NT == 2 && (CK == 64 || (TT == 4 && CK == 32)))) ? 3 : 2)
     void conv_bfp_kernel(ConvArgs a) {
   static_assert(!BFS || NP == 1, "raw bf16 staging belongs to the one-plane engine");
   static_assert(!SM || BFS, "the separate stat_mul instance exists for the raw-bf16 kernels");
@@ -340,6 +340,10 @@ template <int TR, int NT, int NP>
 int launch_bfp_taps(ConvArgs& a, int halo, hipStream_t st) {
   if (a.T == 1) return launch_bfp<TR, NT, 16, 0, 1, NP>(a, st);
   if (a.T == 4) return halo <= 1 ? launch_bfp<TR, NT, 16, 1, 4, NP>(a, st) : launch_bfp<TR, NT, 16, 2, 4, NP>(a, st);
+  if constexpr (NP != 2) {      // (3 / 6 taps, halo 1: RangeNet's strided / transposed convs over column-pair views)
+    if (a.T == 3) return launch_bfp<TR, NT, 16, 1, 3, NP>(a, st);
+    if (a.T == 6) return launch_bfp<TR, NT, 16, 1, 6, NP>(a, st);
+  }
   if (halo <= 1) return launch_bfp<TR, NT, 16, 1, 9, NP>(a, st);
   return launch_bfp<TR, NT, 16, 2, 9, NP>(a, st);
 }

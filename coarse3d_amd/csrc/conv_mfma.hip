@@ -27,7 +27,7 @@ namespace {
 
 
 template <int TR, int NT, int CK, int HALO, int TT>
-__global__ __launch_bounds__(256, (NT >= 4 || (TT == 9 && NT == 2 && TR == 8)) ? 2 : 3) void conv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (NT >= 4 || (TT >= 6 && NT == 2 && TR == 8)) ? 2 : 3) void conv_mfma_kernel(ConvArgs a) {
   constexpr int CS = CK + 4;
   constexpr int TWh = 32 + 2 * HALO;
   constexpr int THh = TR + 2 * HALO;
@@ -224,6 +224,8 @@ template <int TR, int NT>
 int launch_taps(ConvArgs& a, int halo, hipStream_t st) {
   if (a.T == 1) return launch_cfg<TR, NT, 16, 0, 1>(a, st);
   if (a.T == 4) return halo <= 1 ? launch_cfg<TR, NT, 16, 1, 4>(a, st) : launch_cfg<TR, NT, 16, 2, 4>(a, st);
+  if (a.T == 3) return launch_cfg<TR, NT, 16, 1, 3>(a, st);      // (3 / 6 taps: halo 1, c3d_conv_forward checked)
+  if (a.T == 6) return launch_cfg<TR, NT, 16, 1, 6>(a, st);
   if (halo <= 1) return launch_cfg<TR, NT, 16, 1, 9>(a, st);
   return launch_cfg<TR, NT, 16, 2, 9>(a, st);
 }
@@ -272,7 +274,8 @@ static bool c3d_stat_mul_kernel(const c3d_conv_desc* d) {
 
 extern "C" int c3d_conv_stat_mul_supported(const c3d_conv_desc* d) {
   if (!d || !d->stat_mul || !d->stat_partial || d->nsrc < 1 || d->nsrc > C3D_MAX_SRC || d->H <= 0) return 0;
-  if (d->ntaps != 1 && d->ntaps != 4 && d->ntaps != 9) return 0;
+  if (d->ntaps != 1 && d->ntaps != 3 && d->ntaps != 4 && d->ntaps != 6 && d->ntaps != 9) return 0;
+  if ((d->ntaps == 3 || d->ntaps == 6) && d->mfma_bf16 < 2) return 0;      // (the generic kernels; bf16x3: every kernel has the epilogue)
   return c3d_stat_mul_kernel(d) ? 1 : 0;
 }
 
@@ -281,7 +284,10 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   C3D_REQUIRE(d->nsrc >= 1 && d->nsrc <= C3D_MAX_SRC, "conv: nsrc must be 1..3");
   C3D_REQUIRE(d->wpack && d->out, "conv: wpack and out must not be null");
   C3D_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "conv: empty problem");
-  C3D_REQUIRE(d->ntaps == 1 || d->ntaps == 4 || d->ntaps == 9, "conv: ntaps must be 1, 4 or 9");
+  // 3 and 6 taps (round 5): the column taps of RangeNet's transposed conv and the 3 x 2 taps of its stride-(1, 2) conv over
+  // column-pair views (coarse3d_amd/rangenet.py) -- the generic kernels of every engine, offsets within +-1
+  C3D_REQUIRE(d->ntaps == 1 || d->ntaps == 3 || d->ntaps == 4 || d->ntaps == 6 || d->ntaps == 9, "conv: ntaps must be 1, 3, 4, 6 or 9");
+  const bool odd_taps = d->ntaps == 3 || d->ntaps == 6;
   ConvArgs a;
   int K = 0, halo = 0;
   for (int s = 0; s < d->nsrc; ++s) {
@@ -300,6 +306,7 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
   }
   C3D_REQUIRE(halo <= 2, "conv: tap offsets beyond +-2 are not supported");
   C3D_REQUIRE(d->ntaps != 1 || halo == 0, "conv: a single tap must have zero offset");
+  C3D_REQUIRE(!odd_taps || (halo <= 1 && d->mfma_bf16 != 4), "conv: 3 / 6 taps: offsets within +-1, not in the f16x2 experiment");
   a.nsrc = d->nsrc;
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
   a.T = d->ntaps;
@@ -346,6 +353,8 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
     for (int s = 0; s < d->nsrc; ++s) k32 = k32 && (d->src[s].C % 32 == 0);
     const bool x3 = d->mfma_bf16 >= 2;      // 3 = the exact-split engine with six plane products (input gradients)
     a.six = d->mfma_bf16 == 3;
+    // (3 / 6 taps: the fused multi-tap kernel of the bf16x3 engine on 8-row tiles -- variant & 4: the generic kernel, as everywhere else)
+    if (odd_taps && !(x3 && tr == 8 && d->wpack_planes && !(d->variant & 4))) return c3d_conv_forward_bfp(a, x3 ? 3 : 1, tr, halo, false, st);
     if (!x3 && tr == 8 && d->ntaps == 9 && d->wpack_planes && !(d->variant & 4)) {
       // bf16 engine, nine taps, every source a bf16 tensor: the fused kernel with one plane (conv_x3.hip); variant & 4 keeps
       // the phased conv_bfp kernel (bit-identity test)

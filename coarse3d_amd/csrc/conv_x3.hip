@@ -321,6 +321,10 @@ struct c3d_x3_products_one {
 
 // SM (round 5, the one-plane kernel over bf16 tensors): the instance with the BatchNorm-backward epilogue (ConvArgs::stat_mul);
 // the common instance stays without it (34 spilled registers otherwise, for every launch)
+// taps per staged weight group of the fused kernel: nine taps = three rows of three, four = two rows of two; round 5: six (the
+// stride-(1, 2) conv of RangeNet over a column-pair view: three rows of two) and three (its transposed conv: three "rows" of one)
+constexpr int c3d_x3f_group(int tt) { return tt == 9 ? 3 : ((tt == 4 || tt == 6) ? 2 : (tt == 3 ? 1 : tt)); }
+
 template <int NT, int HALO, int TT, bool SIX, int NPL = 3, bool BFS = false, bool SM = false>
 __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   static_assert(!BFS || NPL == 1, "bf16 sources belong to the one-plane engine");
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   constexpr int TWh = 32 + 2 * HALO, THh = TR + 2 * HALO;
   constexpr int TN = 32 * NT;
   constexpr int WM = 4, WN = 1, RPW = 2, NPW = NT;
-  constexpr int G = (TT == 9) ? 3 : (TT == 4 ? 2 : TT);            // taps per staged weight group (tap row)
+  constexpr int G = c3d_x3f_group(TT);            // taps per staged weight group (tap row)
   constexpr int NG = TT / G;
   constexpr int IN_ROWS = THh * TWh;
   constexpr int IN_UNITS = IN_ROWS * CQ;
@@ -709,7 +713,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
 
 template <int NT, int HALO, int TT, bool SIX, int NPL = 3, bool BFS = false>
 int launch_x3f_s(ConvArgs& a, hipStream_t st) {
-  constexpr int G = (TT == 9) ? 3 : (TT == 4 ? 2 : TT);
+  constexpr int G = c3d_x3f_group(TT);
   constexpr int IN_PT = ((8 + 2 * HALO) * (32 + 2 * HALO) * 4 + 255) / 256, W_PT = (G * 32 * NT * 4 + 255) / 256;
   size_t lds = (size_t)NPL * (IN_PT * 64 + 2 * W_PT * 64) * 16 * 2;      // rows padded to whole staging units
   const size_t red = (size_t)4 * 32 * NT * 2 * sizeof(float);   // statistics scratch of the epilogue
@@ -766,6 +770,8 @@ int launch_x3(ConvArgs& a, hipStream_t st) {
 
 template <int NT>
 int launch_x3_taps(ConvArgs& a, int halo, hipStream_t st) {
+  if (a.T == 6) return a.six ? launch_x3f_s<NT, 1, 6, true>(a, st) : launch_x3f_s<NT, 1, 6, false>(a, st);      // (halo 1: c3d_conv_forward)
+  if (a.T == 3) return a.six ? launch_x3f_s<NT, 1, 3, true>(a, st) : launch_x3f_s<NT, 1, 3, false>(a, st);
   if (a.T == 4) return halo <= 1 ? launch_x3<NT, 1, 4>(a, st) : launch_x3<NT, 2, 4>(a, st);
   return halo <= 1 ? launch_x3<NT, 1, 9>(a, st) : launch_x3<NT, 2, 9>(a, st);
 }

@@ -471,7 +471,9 @@ extern "C" int64_t c3d_wgrad_partial_floats(const c3d_wgrad_desc* d) {
 
 extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   C3D_REQUIRE(d != nullptr && d->x.ptr && d->dz && d->dw && d->partial, "wgrad: null pointer");
-  C3D_REQUIRE(d->ntaps == 1 || d->ntaps == 4 || d->ntaps == 9, "wgrad: ntaps must be 1, 4 or 9");
+  // 3 and 6 taps (round 5: RangeNet's strided / transposed convs over column-pair views, coarse3d_amd/rangenet.py) run in the
+  // four- / nine-tap instances with the surplus taps at offset zero: their products are computed and never written
+  C3D_REQUIRE(d->ntaps == 1 || d->ntaps == 3 || d->ntaps == 4 || d->ntaps == 6 || d->ntaps == 9, "wgrad: ntaps must be 1, 3, 4, 6 or 9");
   C3D_REQUIRE(d->x.C % 4 == 0, "wgrad: source channels must be a multiple of 4");
   C3D_REQUIRE(d->dz_cstride % 4 == 0 && d->x.cstride % 4 == 0 && d->x.coff % 4 == 0, "wgrad: strides must be multiples of 4");
   WgradArgs a;
@@ -479,6 +481,7 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
   C3D_REQUIRE((!d->dz_bf16 && !d->x.bf16) || d->mfma_bf16 == 1, "wgrad: bf16 activation storage needs mfma_bf16 == 1");
   a.B = d->B; a.H = d->H; a.W = d->W; a.Cout = d->Cout; a.T = d->ntaps;
   int halo = 0;
+  for (int t = 0; t < 9; ++t) a.dy[t] = a.dx[t] = 0;
   for (int t = 0; t < d->ntaps; ++t) {
     a.dy[t] = d->tap_dy[t];
     a.dx[t] = d->tap_dx[t];

@@ -325,9 +325,9 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         sm_ = "true" if d.stat_mul else "false"      # (bf16 engine: the instance with the BatchNorm-backward epilogue)
         hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
         k32 = tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs)
-        if MFMA_MODE == 2 and tr == 8 and nt_ > 1:      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
+        if MFMA_MODE == 2 and tr == 8 and nt_ > 1 and not (nt_ in (3, 6) and (CONV_VARIANT & 4)):      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
             # nine taps: the fused kernel (round 3); four taps: fused too since round 5; CONV_VARIANT & 4 forces the phased one
-            fused_ = nt_ in (4, 9) and not (CONV_VARIANT & 4)      # (four taps: fused since round 5)
+            fused_ = not (CONV_VARIANT & 4)      # (four taps: fused since round 5; three / six: fused only)
             # (names as rocprofv3 prints them: the fused kernel carries its plane count and its bf16-source flag as fifth and
             #  sixth template arguments)
             six_ = grad or b * h * w >= SIX_FWD_MIN_PIXELS          # (the fourth template argument: six plane products)
@@ -399,7 +399,7 @@ def _wgrad_kernel_name(ci, co, nt, halo, fused=False, raw=False, h=0):
         cfg = ("1, 2, 4, 2, 2, 1, 0" if wide else "1, 2, 2, 2, 2, 1, 0" if (ci >= 96 and co >= 96)
                else f"1, 2, 2, 1, 1, {2 if tr else 4}, 0" if co > 32 else "1, 1, 1, 1, 1, 4, 0")
         trw = 1
-    elif nt == 4:
+    elif nt in (3, 4):        # (three taps run in the four-tap instances, six in the nine-tap ones)
         if x3 and co > 32 and ci % 64 == 0 and halo <= 1:
             cfg, trw, lean_ok = f"4, 1, 2, 2, 1, 2, {hl}", 2, True
         elif co > 32:

@@ -9,8 +9,9 @@ adds:
 * conv -> BatchNorm -> LeakyReLU(0.1) order: the conv epilogue emits raw outputs + statistics,
   consumers apply affine + activation while staging (``src_lrelu`` with slope 0.1) and the
   BatchNorm backward runs in its "BN then activation" mode;
-* stride-(1,2) 3x3 convs = stride-1 conv + even-column subsampling, ConvTranspose2d([1,4],[1,2],
-  [0,1]) = zero-column insertion + 4-tap conv (``c3d_cols_resample`` is its own adjoint);
+* stride-(1,2) 3x3 convs and ConvTranspose2d([1,4],[1,2],[0,1]) as stride-1 convs over COLUMN-PAIR VIEWS of their input /
+  output ([B,H,W,C] read as [B,H,W/2,2C]: the same memory) with six / three taps -- no resampling pass, no zero-filled or
+  full-width intermediate (``_down`` / ``_up`` below);
 * skip connections are DETACHED in the reference (``skips[os] = x.detach()`` :217, ``skips[os]
   .detach()`` :353, and the 480-channel embedding input): no gradient flows through them.
 """
@@ -24,7 +25,8 @@ from .backbone import Act, Backbone
 SLOPE = 0.1                      # nn.LeakyReLU(0.1)
 BN_MOM = 0.01                    # Backbone.bn_d / Decoder.bn_d
 MODEL_BLOCKS = {21: [1, 1, 2, 2, 1], 53: [1, 2, 8, 8, 4]}
-UP_TAPS = [(0, 1 - k) for k in range(4)]     # out[x] = sum_k u[x + 1 - k] * w[:, :, 0, k]
+DOWN_TAPS = [(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0)]      # stride-(1, 2) 3x3 conv over the column-pair view of its input
+UP_TAPS = [(0, -1), (0, 0), (0, 1)]                                # ConvTranspose2d([1, 4], [1, 2], [0, 1]) onto the pair view of its output
 DROP_SITES = ("enc1", "enc2", "enc3", "enc4", "enc5", "decoder", "head")
 
 
@@ -57,62 +59,118 @@ class RangeNetBackbone(Backbone):
         self._conv_backward(f"{name}.conv1", a1.grad)
         a1.grad = None
 
+    # ---- stride-(1, 2) / transposed convs over COLUMN-PAIR VIEWS (round 5).  An NHWC tensor [B, H, W, C] read as
+    # [B, H, W/2, 2C] is the same memory: pair x' holds column 2x' in channels 0 .. C-1 and column 2x'+1 in C .. 2C-1.
+    #   * Conv2d(3x3, stride (1, 2), padding 1): out[y, x'] reads columns 2x'-1, 2x', 2x'+1 = (pair x'-1, odd half),
+    #     (pair x', even half), (pair x', odd half): a stride-1 conv with the SIX taps (dy, dx') in {-1,0,1} x {-1,0} over 2C
+    #     channels, whose weight [Cout, 2C, 3, 2] is the 3x3 weight re-indexed (a quarter of it zero).  12 C products per
+    #     output instead of the 18 C of "stride-1 conv, then drop every other column", no full-width intermediate, no resampling.
+    #   * ConvTranspose2d([1, 4], stride [1, 2], padding [0, 1]): out[2m] = in[m] w1 + in[m-1] w3, out[2m+1] = in[m+1] w0 +
+    #     in[m] w2: the output's pair view [B, H, W, 2 Cout] is a stride-1 conv of the INPUT with the three column taps
+    #     -1, 0, +1 and the weight [2 Cout, Cin, 1, 3] = ((w3 | 0), (w1 | w2), (0 | w0)); no zero-filled input.
+    # Input and weight gradients are the engine's ordinary ones in view space (the gradient of a view is the view of the
+    # gradient); the parameter's gradient is the same re-indexing read backwards.  The re-indexing is one gather per
+    # layer and direction over an index built once (``_pair_index``).
+    def _pair_index(self, name, kind, w):
+        cache = self.packs.__dict__.setdefault("pair_idx", {})      # (the pack cache outlives the per-step backbone object)
+        key = (name, kind, tuple(w.shape))
+        if key not in cache:
+            n = w.numel()
+            src = torch.arange(n, dtype=torch.int64).view(w.shape)          # flat index of every parameter element
+            if kind == "down":                                              # [Cout, C, 3, 3] -> [Cout, 2C, 3, 2]
+                co, c = w.shape[:2]
+                idx = torch.full((co, 2 * c, 3, 2), n, dtype=torch.int64)   # n = the zero appended behind the parameter
+                idx[:, c:, :, 0] = src[:, :, :, 0]
+                idx[:, :c, :, 1] = src[:, :, :, 1]
+                idx[:, c:, :, 1] = src[:, :, :, 2]
+            else:                                                           # [Cin, Cout, 1, 4] -> [2 Cout, Cin, 1, 3]
+                ci, co = w.shape[:2]
+                k = src[:, :, 0, :].permute(1, 0, 2)                        # [Cout, Cin, 4]
+                idx = torch.full((2 * co, ci, 1, 3), n, dtype=torch.int64)
+                idx[:co, :, 0, 0] = k[:, :, 3]
+                idx[:co, :, 0, 1] = k[:, :, 1]
+                idx[co:, :, 0, 1] = k[:, :, 2]
+                idx[co:, :, 0, 2] = k[:, :, 0]
+            flat = idx.reshape(-1)
+            inv = torch.empty(n, dtype=torch.int64)                         # where each parameter element sits in the view weight
+            sel = flat < n
+            inv[flat[sel]] = torch.nonzero(sel).reshape(-1)
+            cache[key] = (tuple(idx.shape), flat.to(w.device), inv.to(w.device))
+        return cache[key]
+
+    def _pair_weight(self, name, kind, w):
+        shape, flat, _ = self._pair_index(name, kind, w)
+        return torch.cat([w.reshape(-1), w.new_zeros(1)])[flat].view(shape)
+
+    def _pair_weight_grad(self, name, kind, w, dw_view, out):
+        _, _, inv = self._pair_index(name, kind, w)
+        torch.index_select(dw_view.reshape(-1), 0, inv, out=out.view(-1))
+
     def _down(self, name, src, src_pending):
         """stride-(1,2) 3x3 conv (no bias) -> BN -> LReLU, materialised (rangenet_proto.py:194-206)."""
         w = self.P[f"{name}.conv.weight"]
-        cout = w.shape[0]
-        taps = ops.conv_taps(3, 3, 1, 1)
-        full, _ = ops.conv_forward([src.src(src_pending)], self.packs.get(w, 0), None, cout, taps, slope=SLOPE)
-        y = ops.cols_resample(full, up=False)
-        b, h, wd, _ = y.shape
-        bn = None
-        if self.train:
-            part = ops.bn_bwd_reduce(y, y, cout, 0)          # (sum y, sum y*y) per channel
-            bn = self._bn_forward(f"{name}.bn", part, cout, b * h * wd, BN_MOM)
-        else:
-            bn = self._bn_forward(f"{name}.bn", None, cout, b * h * wd, BN_MOM)
-        out = Act(ops.affine_add(None, y, bn.scale, bn.shift, slope=SLOPE))
-        self.tape[f"{name}.down"] = (src, src_pending, y, bn, out, taps)
+        b, h, wd, c = src.t.shape
+        v = Act(src.t.view(b, h, wd // 2, 2 * c))
+        if src_pending:
+            v.scale, v.shift = src.scale.repeat(2), src.shift.repeat(2)
+        v.no_grad = src.no_grad
+        w2 = self._pair_weight(name, "down", w)
+        dw2 = torch.empty_like(w2) if self.train else None
+        z = self._conv(f"{name}.conv", [v], 3, 1, 1, lrelu=False, bn=f"{name}.bn", src_lrelu=src_pending, taps=DOWN_TAPS,
+                       slope=SLOPE, bn_momentum=BN_MOM, weight=w2, dweight=dw2)
+        out = self._materialise(z)
+        self.tape[f"{name}.down"] = (src, v, out, dw2)
         return out
 
     def _down_backward(self, name):
-        src, src_pending, y, bn, out, taps = self.tape[f"{name}.down"]
-        cout = y.shape[3]
-        dz_sub, _ = self._bn_backward(bn, out.grad, y, cout, 1, SLOPE)
+        src, v, out, dw2 = self.tape[f"{name}.down"]
+        self._conv_backward(f"{name}.conv", out.grad)
         out.grad = None
-        dz = ops.cols_resample(dz_sub, up=True)
-        w = self.P[f"{name}.conv.weight"]
-        dw = self.grads[f"{name}.conv.weight"]
-        cin = src.t.shape[3]
-        with self._fork(dz):                                 # weight-gradient chain: side stream (Backbone._conv_backward)
-            ops.conv_wgrad(src.src(src_pending), dz, dw, taps, slope=SLOPE)
-        if not src.no_grad:
-            wd = self.packs.get(w, 1, c_off=0, c_cnt=cin, kpad=(cout + 15) // 16 * 16)
-            acc = src.grad is not None
-            if not acc:
-                src.grad = torch.empty_like(src.t)
-            ops.conv_forward([ops.Source(dz)], wd, None, cin, ops.negate_taps(taps), out=src.grad, accumulate=acc, grad=True)
+        with self._fork():                                   # after the weight-gradient launch that fills dw2
+            self._pair_weight_grad(name, "down", self.P[f"{name}.conv.weight"], dw2, self.grads[f"{name}.conv.weight"])
+        if v.grad is not None:
+            g = v.grad.view(src.t.shape)
+            src.grad = g if src.grad is None else src.grad.add_(g)
+            v.grad = None
 
     def _up(self, name, t):
         """ConvTranspose2d([1,4], stride [1,2], padding [0,1]) + bias -> BN -> LReLU, materialised."""
-        u = Act(ops.cols_resample(t.t, up=True))
         w_t = self.P[f"{name}.upconv.weight"]               # [Cin, Cout, 1, 4]
-        w_conv = w_t.permute(1, 0, 2, 3).contiguous()       # OIHW of the equivalent 4-tap conv
-        dw_conv = torch.empty_like(w_conv) if self.train else None
-        z = self._conv(f"{name}.upconv", [u], 1, 1, 0, lrelu=False, bn=f"{name}.bn", taps=UP_TAPS, slope=SLOPE,
-                       bn_momentum=BN_MOM, weight=w_conv, dweight=dw_conv)
-        out = self._materialise(z)
-        self.tape[f"{name}.up"] = (t, u, z, out, dw_conv)
+        cin, cout = w_t.shape[:2]
+        b, h, wd, _ = t.t.shape
+        w3 = self._pair_weight(name, "up", w_t)             # [2 Cout, Cin, 1, 3]
+        z2, part = ops.conv_forward([t.src()], ops.pack_weights(w3, 0), self.P[f"{name}.upconv.bias"].repeat(2), 2 * cout, UP_TAPS,
+                                    lrelu=False, stats=self.train, slope=SLOPE)
+        z = z2.view(b, h, 2 * wd, cout)
+        if self.train:       # the statistics of channel c are those of view channels c and Cout + c: [2 Cout, 2, n] -> [Cout, 2, 2n]
+            n = part.shape[2]
+            part = part.view(2, cout, 2, n).permute(1, 2, 0, 3).reshape(cout, 2, 2 * n).contiguous()    # (n = 1: reshape returns a strided view)
+        bn = self._bn_forward(f"{name}.bn", part if self.train else None, cout, b * h * 2 * wd, BN_MOM)
+        out = Act(ops.affine_add(None, z, bn.scale, bn.shift, slope=SLOPE))
+        if t.first_consumer is None:
+            t.first_consumer = f"{name}.upconv"
+        self.tape[f"{name}.up"] = (t, z, bn, out, w3)
         return out
 
     def _up_backward(self, name):
-        t, u, z, out, dw_conv = self.tape[f"{name}.up"]
-        self._conv_backward(f"{name}.upconv", out.grad)
+        t, z, bn, out, w3 = self.tape[f"{name}.up"]
+        cout = z.shape[3]
+        cin = t.t.shape[3]
+        b, h, wd, _ = t.t.shape
+        dz, pz = self._bn_backward(bn, out.grad, z, cout, 1, SLOPE)
         out.grad = None
-        with self._fork():                                   # after the wgrad that fills dw_conv
-            self.grads[f"{name}.upconv.weight"].copy_(dw_conv.permute(1, 0, 2, 3))
-        t.grad = ops.cols_resample(u.grad, up=False)
-        u.grad = None
+        dz2 = dz.view(b, h, wd, 2 * cout)
+        dw3 = torch.empty_like(w3)
+        with self._fork(dz, pz):                             # weight-gradient chain: side stream (Backbone._conv_backward)
+            ops.bias_from_partials(pz, self.grads[f"{name}.upconv.bias"])
+            ops.conv_wgrad(t.src(), dz2, dw3, UP_TAPS, slope=SLOPE)
+            self._pair_weight_grad(name, "up", self.P[f"{name}.upconv.weight"], dw3, self.grads[f"{name}.upconv.weight"])
+        if not t.no_grad:
+            wd_ = ops.pack_weights(w3, 1, c_off=0, c_cnt=cin, kpad=(2 * cout + 15) // 16 * 16)
+            acc = t.grad is not None
+            if not acc:
+                t.grad = torch.empty_like(t.t)
+            ops.conv_forward([ops.Source(dz2)], wd_, None, cin, ops.negate_taps(UP_TAPS), out=t.grad, accumulate=acc, grad=True)
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, train=True, dropout_masks=None, return_feat=True, update_running=True):
