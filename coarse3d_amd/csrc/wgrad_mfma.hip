@@ -415,7 +415,8 @@ void plan(const c3d_wgrad_desc* d, WgradArgs& a, WgCfg& c) {
   if (strips < 1) strips = 1;
   a.tiles_per_strip = (a.ntiles + strips - 1) / strips;
   a.strips = (a.ntiles + a.tiles_per_strip - 1) / a.tiles_per_strip;
-  a.npw = c3d_wgrad_producer_waves(planes_for(d), c.id, d->variant);
+  a.npw = c3d_wgrad_producer_waves(planes_for(d), c.id, d->variant, d->ntaps);
+  if (c.id >= 6 && d->fuse_dy) a.npw = 4;      // (nine taps with the BatchNorm backward on load: the four + four wave form, wgrad_tr.hip)
 }
 
 template <int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool BF>

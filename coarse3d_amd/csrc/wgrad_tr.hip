@@ -186,10 +186,23 @@ __device__ __forceinline__ void c3d_wg_static_for(F&& f) {
 // -- one wave per SIMD issuing a dependent VALU chain per staged unit with nothing to fill its stalls, and two tiles of
 // loads in flight per CU.  Its accumulators are small (16-64 registers), so the 168 registers of a twelve-wave workgroup
 // are enough; a wave stages half the units per tile and the CU keeps twice the waves' worth of loads in flight.
+// NCW = 8 (round 5, the nine-tap instances of the three-plane engine; with NPW = 8: a 1024-thread workgroup, four waves per SIMD
+// at 128 registers): the TAPS are split across two consumer waves per SIMD so that a second producer wave per SIMD fits.  The
+// ablation (tools/ablate_wgrad.py) says these kernels are bound by their producer waves -- one per SIMD, a dependent VALU
+// chain per staged unit, nothing to fill its stalls -- while a consumer wave holds 9 x 16 accumulator registers and leaves
+// no room for more waves.  Consumer wave (w, half h) of SIMD w: taps 0-4 (h = 0) or 5-8 (h = 1) on every K step of w's pixel
+// share -- five accumulators = 80 registers.  The two halves share the SIMD's matrix pipe, so that five against four taps is
+// no imbalance of the pipe (half 0 runs its last sixth alone).  One tap per stage: the six products of a tap are a dependent
+// MFMA chain, and the two consumer waves of a SIMD interleave theirs (a chain alone issues at 41 cycles per MFMA, the matrix
+// pipe takes one every 32).  Every tap sees its K steps and products in the order of the four-wave form: the same bits.
 template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool FA = false, bool RAW = false, bool LEAN = false,
-          int NPW = 4>
-__global__ __launch_bounds__(256 + 64 * NPW, 1) void wgrad_tr_kernel(WgradArgs a) {
+          int NPW = 4, int NCW = 4>
+__global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs a) {
   constexpr int NPT = 64 * NPW;        // producer threads
+  constexpr int NCT = 64 * NCW;        // consumer threads
+  constexpr bool SPL = NCW == 8;       // taps split across two consumer waves per SIMD
+  static_assert(NCW == 4 || (NCW == 8 && NPW == 8 && TMAX == 9 && CI_T == 1 && CO_T == 1 && WCI == 1 && NP == 3),
+                "split consumers: the nine-tap instances of the three-plane engine, eight producer waves");
   static_assert(!RAW || (NP == 1 && !FA), "raw bf16 stages belong to the one-plane engine without the fused apply");
   constexpr int DEPTH = RAW ? 4 : 2;   // tiles the producer waves keep in flight (register sets)
   using SU = std::conditional_t<RAW, u32x2, f32x4>;   // a staged unit in flight: four bf16 as loaded, or four floats
@@ -229,14 +242,17 @@ __global__ __launch_bounds__(256 + 64 * NPW, 1) void wgrad_tr_kernel(WgradArgs a
   // waves doing both jobs in turn (the first version of this kernel) the staging and matrix
   // phases of the two resident workgroups fell into lock-step and simply added up
   // (704x704 layer: 0.96 ms staging + 1.50 ms matrix phase -> 2.16 ms).
-  const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 256;   // wave-uniform, in an SGPR
+  const bool producer = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= NCT;   // wave-uniform, in an SGPR
   // (wave-uniform values pinned in SGPRs, round 5: the compiler cannot prove that threadIdx.x >> 6 or the result of an
   //  integer division of blockIdx-derived numbers is uniform, so the consumer waves computed every fragment's ring slot --
   //  add, compare, select, a quarter-rate v_mul_lo_u32 by the window width -- per lane: 218 VALU instructions per 108 MFMAs
   //  of the 32 x 32 nine-tap instance, in a kernel whose MFMA and VALU streams share the SIMD's issue port -- PMC: 39 % of
   //  the wave cycles were issue stalls.)
-  // (consumer threads 0 .. 255, producer threads 0 .. NPT - 1)
-  const int tid = producer ? (int)threadIdx.x - 256 : (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // (consumer threads 0 .. NCT - 1, producer threads 0 .. NPT - 1)
+  const int tid = producer ? (int)threadIdx.x - NCT : (int)threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = SPL ? (wave8 & 3) : wave8;       // SPL: consumer wave (wave, th); producers never use it
+  const int th = SPL ? ((wave8 >> 2) & 1) : 0;
   const int half = lane >> 5, l31 = lane & 31;
   const int wci = wave % WCI, wco = (wave / WCI) % WCO, wk = wave / (WCI * WCO);
   // transposed-read source of this lane: group g = lane>>4 covers channels 16*(g&1).. of pixels 8*(g>>1)..
@@ -305,7 +321,8 @@ __global__ __launch_bounds__(256 + 64 * NPW, 1) void wgrad_tr_kernel(WgradArgs a
   }
   // FA: BatchNorm-backward coefficients of this thread's four channels (channels beyond Cout give dz = 0), running sums of dz
   f32x4 fk1 = {0.f, 0.f, 0.f, 0.f}, fk2 = fk1, fk3 = fk1, fsum = fk1, fps = fk1, fpsh = fk1;
-  const bool fpre = FA && a.f_ps != nullptr;          // conv -> BatchNorm -> LeakyReLU layer: activation derivative at BN(act) (uniform)
+  // (SPL: the launcher keeps layers with a pre-activation affine on the four-wave form -- eight registers the 128 do not have)
+  const bool fpre = FA && !SPL && a.f_ps != nullptr;  // conv -> BatchNorm -> LeakyReLU layer: activation derivative at BN(act) (uniform)
   const bool fwrite = FA && ci0 == 0;                 // one cin slice per cout slice writes dz and the sums (uniform)
   if constexpr (FA) {
     if (dc + 3 < a.Cout) {
@@ -322,6 +339,34 @@ __global__ __launch_bounds__(256 + 64 * NPW, 1) void wgrad_tr_kernel(WgradArgs a
       }
     }
   }
+  // SPL (1024 threads, 128 registers): the per-channel constants of the staging code -- the on-load affine of x, the three
+  // BatchNorm-backward coefficients -- live in LDS behind the tile buffers and are read where a phase of store_tile needs
+  // them (20 registers that are not held across the tile loop; every thread of a channel quad reads the same 16 bytes)
+  constexpr int CONST_OFF = 2 * NP * ((TRW + 2 * HALO) * (32 + 2 * HALO) * CI + TRW * 32 * CO) * 2;     // bytes: both tile buffers
+  float* s_const = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + CONST_OFF);                  // [2][CI], then [3][CO]
+  if constexpr (SPL) {
+    if (producer) {
+      if (tid < CI / 4) {
+        *reinterpret_cast<f32x4*>(s_const + tid * 4) = psc;
+        *reinterpret_cast<f32x4*>(s_const + CI + tid * 4) = psh;
+      }
+      if (FA && tid < CO / 4) {
+        *reinterpret_cast<f32x4*>(s_const + 2 * CI + tid * 4) = fk1;
+        *reinterpret_cast<f32x4*>(s_const + 2 * CI + CO + tid * 4) = fk2;
+        *reinterpret_cast<f32x4*>(s_const + 2 * CI + 2 * CO + tid * 4) = fk3;
+      }
+    }
+    __syncthreads();
+  }
+  auto x_affine = [&](f32x4& sc, f32x4& sh) __attribute__((always_inline)) {
+    if constexpr (SPL) {
+      sc = *reinterpret_cast<const f32x4*>(s_const + xc4 * 4);
+      sh = *reinterpret_cast<const f32x4*>(s_const + CI + xc4 * 4);
+    } else {
+      sc = psc;
+      sh = psh;
+    }
+  };
   unsigned xoff[HALO > 0 ? X_PT : 1];
   if constexpr (HALO > 0) {
 #pragma unroll
@@ -519,12 +564,14 @@ __global__ __launch_bounds__(256 + 64 * NPW, 1) void wgrad_tr_kernel(WgradArgs a
     };
     auto extra_store = [&](int j0) __attribute__((always_inline)) {
       if constexpr (LEANX) {
+        f32x4 esc, esh;
+        x_affine(esc, esh);
 #pragma unroll
         for (int j = 0; j < X_PT; ++j) {
           const int u = tid + (j0 + j) * NPT;
           if ((j0 + j) < E_PT && u < EXTRA_UNITS) {
             f32x4 v = pe[j];
-            if (aff) v = v * psc + psh;
+            if (aff) v = v * esc + esh;
             if (lr) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q], a.slope);
@@ -545,6 +592,8 @@ __global__ __launch_bounds__(256 + 64 * NPW, 1) void wgrad_tr_kernel(WgradArgs a
         }
       }
     };
+    f32x4 xsc, xsh;
+    x_affine(xsc, xsh);
 #pragma unroll
     for (int i = 0; i < X_PT; ++i) {
       const int u = tid + i * NPT;
@@ -556,7 +605,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, 1) void wgrad_tr_kernel(WgradArgs a
         } else {
           v = sg.px[i];
         }
-        if (aff) v = v * psc + psh;
+        if (aff) v = v * xsc + xsh;
         if (lr) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = c3d_lrelu(v[q], a.slope);
@@ -581,6 +630,12 @@ __global__ __launch_bounds__(256 + 64 * NPW, 1) void wgrad_tr_kernel(WgradArgs a
     if constexpr (LEANX) {
       if (sg.xfresh) extra_load(0);          // into the registers the x units above have left; converted behind the dz units
     }
+    f32x4 k1 = fk1, k2 = fk2, k3 = fk3;
+    if constexpr (SPL && FA) {
+      k1 = *reinterpret_cast<const f32x4*>(s_const + 2 * CI + dc4 * 4);
+      k2 = *reinterpret_cast<const f32x4*>(s_const + 2 * CI + CO + dc4 * 4);
+      k3 = *reinterpret_cast<const f32x4*>(s_const + 2 * CI + 2 * CO + dc4 * 4);
+    }
 #pragma unroll
     for (int i = 0; i < D_PT; ++i) {
       const int u = tid + i * NPT;
@@ -597,7 +652,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, 1) void wgrad_tr_kernel(WgradArgs a
             // the arithmetic of bn_bwd_kernel<true> (bn_ops.hip), same operation order: bit-identical dz
             float dyq = sg.pd[i][q];
             if (fpre) dyq *= (fmaf(sg.pa[i][q], fps[q], fpsh[q]) > 0.f) ? 1.f : a.slope;
-            float da = fmaf(fk2[q], sg.pa[i][q], fmaf(fk1[q], dyq, fk3[q]));
+            float da = fmaf(k2[q], sg.pa[i][q], fmaf(k1[q], dyq, k3[q]));
             if (!fpre) da *= (sg.pa[i][q] > 0.f) ? 1.f : a.slope;
             t[q] = in ? da : 0.f;
           }
@@ -750,10 +805,133 @@ __global__ __launch_bounds__(256 + 64 * NPW, 1) void wgrad_tr_kernel(WgradArgs a
           if (dc + q < a.Cout) a.f_sum[((size_t)(dc + q) * 2) * a.f_sum_n + strip * DSTEP + dp0] = fsum[q];
       }
     }
-    if (WK > 1) {
+    if constexpr (SPL) {
+      for (int t = 0; t < 5; ++t) {
+        __syncthreads();
+        __syncthreads();
+      }
+    } else if (WK > 1) {
       for (int t = 0; t < a.T; ++t) {
         __syncthreads();
         __syncthreads();
+      }
+    }
+    return;
+  }
+
+  if constexpr (SPL) {
+    // ---- consumer waves, taps split (see NCW at the head of the kernel): half 0 owns taps 0-4, half 1 taps 5-8
+    constexpr int TL = 5;
+    f32x16 acc[TL];
+#pragma unroll
+    for (int t = 0; t < TL; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    int ldy[TL], ldx[TL];                    // (uniform: two scalar loads and a select each; half 1 never uses its fifth)
+#pragma unroll
+    for (int t = 0; t < TL; ++t) {
+      ldy[t] = (th && t < 4) ? a.dy[5 + t] : a.dy[t];
+      ldx[t] = (th && t < 4) ? a.dx[5 + t] : a.dx[t];
+    }
+    constexpr int NQ = 6;
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};      // as below: smallest products first
+    auto last_use = [](const int (&pl)[6], int plane) constexpr {
+      int l = -1;
+      for (int q = 0; q < NQ; ++q)
+        if (pl[q] == plane) l = q;
+      return l;
+    };
+    constexpr int NSTAGE = KPW * TL;         // stage = (K step, local tap); half 1 skips the fifth tap of every K step
+    const unsigned lane_a = 2u * (unsigned)tr_swz<NSX>(lp, lc);
+    const unsigned lane_b = 2u * (unsigned)tr_swz<NSD>(lp, wco * 32 + lc);
+    __syncthreads();
+    for (int mt = t_begin; mt < t_end; ++mt) {
+      const int cur = (mt - t_begin) & 1;
+      if constexpr (RINGX) {
+        if (mt != t_begin) cxbase = __builtin_amdgcn_readfirstlane((cxbase + ((mt % a.tiles_y == 0) ? THh : TRW)) % RING);
+      }
+      const unsigned short* s_x = RINGX ? s_base : s_base + cur * BUF;
+      const unsigned short* s_dz = RINGX ? s_base + NP * XPLANE + cur * (NP * DROWS * CO) : s_x + NP * XROWS * CI;
+      const unsigned lds_x = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned short*)s_x;
+      const unsigned lds_d = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned short*)s_dz;
+      bf16x8 ap[NP], bp[NP];
+      auto read_a = [&](int st, int p) {
+        const int ks = wk * KPW + st / TL, tl = st % TL;
+        int Ux;
+        if constexpr (RINGX) {
+          int slot = cxbase + (ks >> 1) + HALO + ldy[tl];
+          slot = slot >= RING ? slot - RING : slot;
+          Ux = slot * TWh + HALO + (ks & 1) * 16 + ldx[tl];
+        } else {
+          Ux = ((ks >> 1) + HALO + ldy[tl]) * TWh + HALO + (ks & 1) * 16 + ldx[tl];
+        }
+        ap[p] = tr_frag_u<NSX>(lds_x + 2u * (unsigned)(p * XPLANE + Ux * (32 * NSX)), lane_a);
+      };
+      auto read_b = [&](int st, int p) {
+        const int ks = wk * KPW + st / TL;
+        const int Ud = (ks >> 1) * 32 + (ks & 1) * 16;
+        bp[p] = tr_frag_u<NSD>(lds_d + 2u * (unsigned)(p * DROWS * CO + Ud * (32 * NSD)), lane_b);
+      };
+      c3d_wg_static_for<0, NQ>([&](auto q_tag) {
+        constexpr int q = decltype(q_tag)::value;
+        bool fa = true, fb = true;
+        for (int r = 0; r < q; ++r) {
+          if (PA[r] == PA[q]) fa = false;
+          if (PB[r] == PB[q]) fb = false;
+        }
+        if (fa) read_a(0, PA[q]);
+        if (fb) read_b(0, PB[q]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      // The same accumulation order per tap as the four-wave form (K steps ascending, the six products in this order): the
+      // same bits.  Operand planes of the next stage are read right after their last product of this one.
+      c3d_wg_static_for<0, NSTAGE * NQ>([&](auto s_tag) {
+        constexpr int sq = decltype(s_tag)::value, st = sq / NQ, q = sq % NQ, tl = st % TL;
+        if (tl < 4 || th == 0) {             // (uniform; a real branch for the fifth tap only)
+          acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA[q]], bp[PB[q]], acc[tl], 0, 0, 0);
+          if constexpr (st + 1 < NSTAGE) {
+            constexpr int n1 = st + 1;
+            if constexpr (n1 % TL == 4) {    // the fifth tap comes next: half 0 runs it, half 1 goes on to the next K step
+              if constexpr (last_use(PA, PA[q]) == q) {
+                if (!th) read_a(n1, PA[q]);
+                else if constexpr (st + 2 < NSTAGE) read_a(st + 2, PA[q]);
+              }
+              if constexpr (last_use(PB, PB[q]) == q && st + 2 < NSTAGE) {
+                if (th) read_b(st + 2, PB[q]);
+              }
+            } else {
+              if constexpr (last_use(PA, PA[q]) == q) read_a(n1, PA[q]);
+              if constexpr (n1 % TL == 0 && last_use(PB, PB[q]) == q) read_b(n1, PB[q]);      // the K step changes
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      __syncthreads();   // next buffer written, this one no longer read
+    }
+    // ---- fold the WK pixel groups of every tap through LDS (rank order, as below); partial layout as below
+    const size_t slice_floats = (size_t)a.T * CI * CO;
+    float* pout = a.partial + ((size_t)(sl * a.strips + strip)) * slice_floats;
+    float* red = smem;   // [consumer wave 0..7][16][64]
+#pragma unroll
+    for (int tl = 0; tl < TL; ++tl) {
+      const int t = th ? 5 + tl : tl;        // (half 1, tl = 4: no such tap -- it only keeps the barriers)
+      __syncthreads();
+      if (wk > 0 && t < 9) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave8 * 16 + r) * 64 + lane] = acc[tl][r];
+      }
+      __syncthreads();
+      if (wk == 0 && t < 9) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[tl][r];
+#pragma unroll
+          for (int k = 1; k < WK; ++k) v += red[((th * 4 + k * WCO + wco) * 16 + r) * 64 + lane];
+          const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int co = wco * 32 + l31;
+          pout[((size_t)t * CI + ci) * CO + co] = v;
+        }
       }
     }
     return;
@@ -949,17 +1127,19 @@ __global__ __launch_bounds__(256 + 64 * NPW, 1) void wgrad_tr_kernel(WgradArgs a
   }
 }
 
-template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool LEAN_FA = false, int NPW = 4>
+template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool LEAN_FA = false, int NPW = 4, int NCW = 4>
 int launch_tr(const WgradArgs& a, hipStream_t st) {
   constexpr int NPT = 64 * NPW;
-  static_assert(NPW == 4 || (NP == 3 && HALO == 0 && !LEAN_FA), "eight producer waves: the three-plane 1x1 instances");
+  static_assert(NPW == 4 || (NP == 3 && ((HALO == 0 && !LEAN_FA && NCW == 4) || (TMAX == 9 && NCW == 8))),
+                "eight producer waves: the three-plane 1x1 instances, and the nine-tap ones with split consumers");
   constexpr int WK = 4 / (WCI * WCO);
   constexpr int CI = 32 * CI_T * WCI, CO = 32 * CO_T * WCO;
   size_t lds = 2 * (size_t)NP * ((size_t)(TRW + 2 * HALO) * (32 + 2 * HALO) * CI + (size_t)TRW * 32 * CO) * 2;   // two tile buffers
-  const size_t red = (size_t)(WK - 1) * WCI * WCO * CI_T * CO_T * 1024 * sizeof(float);
+  const size_t red = NCW == 8 ? (size_t)8 * 1024 * sizeof(float) : (size_t)(WK - 1) * WCI * WCO * CI_T * CO_T * 1024 * sizeof(float);
+  if (NCW == 8) lds += (size_t)(2 * CI + 3 * CO) * sizeof(float);      // the staging constants behind the tile buffers
   if (red > lds) lds = red;
   dim3 grid(a.strips * a.ci_slices * a.co_slices);
-  if constexpr (NP == 3) {
+  if constexpr (NP == 3 && NCW == 4) {      // (split consumers: unfused launches only, see launch_tr_id)
     if (a.f_dy) {       // BatchNorm / LeakyReLU backward on load
       if (a.f_sum_n != a.strips * (NPT / (CO / 4))) {
         c3d_set_error("wgrad: fuse_sum was not sized with c3d_wgrad_fused_sum_n()");
@@ -974,14 +1154,14 @@ int launch_tr(const WgradArgs& a, hipStream_t st) {
         // (c3d_wgrad_desc.variant & 3: 1 / 2 force one form -- tests/test_gpu_conv.py holds the two to the same bits.)
         const int force = a.variant & 3;
         if (force ? force == 2 : a.tiles_y >= C3D_WGRAD_LEAN_MIN_TILES_Y) {
-          c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true, false, true>>();
-          hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true, false, true>), grid, dim3(512), lds, st, a);
+          c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true, false, true, NPW, NCW>>();
+          hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true, false, true, NPW, NCW>), grid, dim3(64 * (NCW + NPW)), lds, st, a);
           C3D_CHECK_LAUNCH();
           return 0;
         }
       }
-      c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true, false, false, NPW>>();
-      hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true, false, false, NPW>), grid, dim3(256 + NPT), lds, st, a);
+      c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true, false, false, NPW, NCW>>();
+      hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true, false, false, NPW, NCW>), grid, dim3(64 * (NCW + NPW)), lds, st, a);
       C3D_CHECK_LAUNCH();
       return 0;
     }
@@ -994,8 +1174,8 @@ int launch_tr(const WgradArgs& a, hipStream_t st) {
       return 0;
     }
   }
-  c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, false, false, NPW>>();
-  hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, false, false, NPW>), grid, dim3(256 + NPT), lds, st, a);
+  c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, false, false, NPW, NCW>>();
+  hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, false, false, NPW, NCW>), grid, dim3(64 * (NCW + NPW)), lds, st, a);
   C3D_CHECK_LAUNCH();
   return 0;
 }
@@ -1020,8 +1200,18 @@ int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
     case 8:
       if constexpr (NP >= 2) return halo <= 1 ? launch_tr<NP, 4, 1, 2, 2, 1, 2, 1, NP == 3>(a, st) : launch_tr<NP, 4, 1, 2, 2, 1, 2, 2, NP == 3>(a, st);
       else return -1;
-    case 6: return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 2>(a, st);
-    default: return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, 4, 2, NP == 3>(a, st);
+    case 6:
+      // Nine taps, unfused (every weight gradient of a data-parallel step, whose BatchNorm backward is a pass of its own): taps split
+      // across eight consumer waves + eight producer waves (NCW at the kernel).  Measured at 8 x 64 x 2048 / 32 x 1024 / 16 x 512:
+      // 64 -> 64 0.438 -> 0.403 ms, 32 -> 32 0.125 -> 0.117, 128 -> 128 0.439 -> 0.417, 256 -> 256 0.405 -> 0.365.  NOT the launches
+      // with the BatchNorm backward on load: dy, the stored output and x in flight twice do not fit the 128 registers of a
+      // sixteen-wave workgroup even with the per-channel constants in LDS (9-45 spilled registers, every reload a full drain of
+      // the loads in flight: 64 -> 64 d2 0.467 -> 0.554 ms); those keep the four + four wave form.
+      if constexpr (NP == 3) if (a.npw == 8 && a.T == 9 && !a.f_dy) return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 2, 2, 1, false, 8, 8>(a, st) : launch_tr<NP, 9, 1, 1, 1, 2, 2, 2, false, 8, 8>(a, st);
+      return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 2>(a, st);
+    default:
+      if constexpr (NP == 3) if (a.npw == 8 && a.T == 9 && !a.f_dy) return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, 4, 1, false, 8, 8>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, 4, 2, false, 8, 8>(a, st);
+      return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, 4, 2, NP == 3>(a, st);
   }
 }
 

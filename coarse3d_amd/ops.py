@@ -388,8 +388,8 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
 
 def _wgrad_kernel_name(ci, co, nt, halo, fused=False, raw=False, h=0):
     """Mirrors c3d_wgrad_cfg() (csrc/wgrad_common.h), plan() (wgrad_mfma.hip) and the launch tables of wgrad_mfma.hip /
-    wgrad_tr.hip (names as rocprofv3 prints them; the eleventh template argument: lean register sets, the twelfth: producer
-    waves, round 5)."""
+    wgrad_tr.hip (names as rocprofv3 prints them; the eleventh template argument: lean register sets, the twelfth and thirteenth: producer
+    and consumer waves, round 5)."""
     tr = MFMA_MODE != 0
     hl = 1 if halo <= 1 else 2
     x3 = tr and MFMA_MODE == 2          # three planes: the smaller pixel tiles of c3d_wgrad_cfg
@@ -414,9 +414,12 @@ def _wgrad_kernel_name(ci, co, nt, halo, fused=False, raw=False, h=0):
     if tr:       # (ninth template argument: BatchNorm backward applied on load, conv_wgrad(fuse=...); tenth: raw bf16 stages, four
         # tiles in flight -- the bf16 engine with bf16 tensors on both sides; eleventh: lean register sets)
         lean = bool(fused and x3 and lean_ok and (h + trw - 1) // trw >= 8)
-        npw = 8 if (x3 and nt == 1 and not cfg.startswith("1, 2, 4") and not (WGRAD_VARIANT & 128)) else 4      # c3d_wgrad_producer_waves()
+        # c3d_wgrad_producer_waves(): eight producer waves in the small 1x1 instances; unfused nine-tap launches: eight + eight
+        # consumer waves with the taps split (launch_tr_id in csrc/wgrad_tr.hip)
+        ncw = 8 if (x3 and nt == 9 and not fused and not (WGRAD_VARIANT & 128)) else 4
+        npw = 8 if (ncw == 8 or (x3 and nt == 1 and not cfg.startswith("1, 2, 4") and not (WGRAD_VARIANT & 128))) else 4
         return (f"wgrad_tr_kernel<{3 if MFMA_MODE == 2 else 1}, {cfg}, {'true' if fused else 'false'}, "
-                f"{'true' if (raw and MFMA_MODE == 1 and not fused) else 'false'}, {'true' if lean else 'false'}, {npw}>")
+                f"{'true' if (raw and MFMA_MODE == 1 and not fused) else 'false'}, {'true' if lean else 'false'}, {npw}, {ncw}>")
     return f"wgrad_mfma_kernel<{cfg}, {'true' if MFMA_MODE == 1 else 'false'}>"
 
 

@@ -67,7 +67,8 @@ typedef struct {
   int32_t nsrc;
   int32_t B, H, W;
   int32_t Cout;
-  int32_t ntaps;            /* 1, 4 or 9                                                 */
+  int32_t ntaps;            /* 1, 4 or 9; 3 or 6 (offsets within +-1): strided / transposed convs over column-pair views
+                             * (rangenet_proto.py:192-200, 328-334; coarse3d_amd/rangenet.py)      */
   int32_t tap_dy[9];        /* input offset of tap t relative to the output pixel        */
   int32_t tap_dx[9];
   const float* wpack;       /* packed by c3d_pack_weights: [tap][K/4][Cout][4]           */
@@ -182,7 +183,7 @@ typedef struct {
   const float* dz;          /* NHWC [B,H,W,Cout] gradient w.r.t. the conv output (pre-act) */
   int32_t dz_cstride;
   int32_t B, H, W, Cout;   /* Cout = rows of dw; dz channels beyond it must be zero       */
-  int32_t ntaps;
+  int32_t ntaps;            /* 1, 3, 4, 6 or 9 (as in c3d_conv_desc)                       */
   int32_t tap_dy[9];
   int32_t tap_dx[9];
   int32_t Cin_total;        /* Cin of the OIHW weight tensor                              */
@@ -196,7 +197,8 @@ typedef struct {
   int32_t variant;          /* schedule selector of the bit-identity tests / A-B runs: 0 = the library's choice.  Fused launches
                              * (fuse_dy) of the kernels with a rolling window: 1 = whole-window register sets (round 4), 2 = lean
                              * register sets (round 5) -- the same bits either way.  Bit 2 (4): a fused 1x1 launch keeps the
-                             * 128 x 256 slice of the unfused one (another summation order)                                */
+                             * 128 x 256 slice of the unfused one (another summation order).  Bit 7 (128): four producer waves
+                             * in the 1x1 instances of the three-plane engine that run eight (round 5) -- the same bits     */
   /* optional: fold the layer's bias-gradient partials in the same launch that folds the weight-gradient strips
    * (saves one tiny launch per conv layer): dbias[c] = sum_k bias_partial[c][0][k], k < bias_n, the
    * [Cout][2][bias_n] partials c3d_bn_bwd_apply wrote (what c3d_bias_from_partials computes).  NULL = off. */

@@ -11,7 +11,8 @@ ops.set_matrix_precision("bf16x3")
 dev = "cuda"
 fuse = len(sys.argv) > 1 and sys.argv[1] == "fuse"
 shapes = [(8, 64, 2048, 32, 32, 3, 2, 2), (8, 64, 2048, 32, 32, 3, 1, 1), (8, 64, 2048, 64, 64, 3, 2, 2), (8, 64, 2048, 64, 64, 2, 2, 1),
-          (8, 32, 1024, 128, 128, 3, 2, 2), (8, 32, 1024, 704, 256, 1, 1, 0), (8, 64, 2048, 64, 64, 1, 1, 0)]
+          (8, 32, 1024, 128, 128, 3, 2, 2), (8, 32, 1024, 704, 256, 1, 1, 0), (8, 64, 2048, 64, 64, 1, 1, 0),
+          (8, 64, 2048, 32, 32, 1, 1, 0), (8, 32, 1024, 128, 128, 1, 1, 0)]
 for (B, H, W, Ci, Co, k, dil, pad) in shapes:
     x = torch.randn(B, H, W, Ci, device=dev); dz = torch.randn(B, H, W, Co, device=dev)
     sc = torch.rand(Ci, device=dev) + 0.5; sh = torch.randn(Ci, device=dev) * 0.1
@@ -21,7 +22,7 @@ for (B, H, W, Ci, Co, k, dil, pad) in shapes:
     act = torch.randn(B, H, W, Co, device=dev); kk = torch.randn(3, Co, device=dev) * 0.1
     dzo = torch.empty_like(dz); db = torch.zeros(Co, device=dev)
     out = {}
-    for name, var in (("full", 0), ("producer_only", 8), ("consumer_only", 16), ("barriers_only", 24),
+    for name, var in (("full", 0), ("full_4_producer_waves", 128), ("consumer_only_4pw", 16 | 128), ("producer_only_4pw", 8 | 128), ("producer_only", 8), ("consumer_only", 16), ("barriers_only", 24),
                       ("prod_only_l2_loads", 8 | 32), ("prod_only_no_lds_stores", 8 | 64), ("prod_only_l2_no_lds", 8 | 32 | 64)):
         ops.WGRAD_VARIANT = var
         fn = (lambda: ops.conv_wgrad(src, dzo, dw, taps, dbias=db, fuse=(dz, act, kk))) if fuse else (lambda: ops.conv_wgrad(src, dz, dw, taps))
