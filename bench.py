@@ -788,9 +788,9 @@ def main():
             engines["bf16x3_wgrad_on_second_stream"] = {
                 "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": k2, "launch": "one hipGraph replay per step",
                 "note": "the headline step with the weight-gradient chain of the backward pass on a second HIP stream (C3D_WGRAD_STREAM=1; what "
-                        "data-parallel runs use to hide the SyncBatchNorm exchanges).  The BatchNorm-backward apply pass is then a pass of its own "
-                        "again (on one stream the first weight-gradient launch of a layer applies it on load).  Not the default on one GPU: the "
-                        "kernels of two streams share the CUs, nothing is gained"}
+                        "data-parallel runs used through round 4 to hide the SyncBatchNorm exchanges).  The BatchNorm-backward apply pass is then a "
+                        "pass of its own again (on one stream the first weight-gradient launch of a layer applies it on load).  Not the default: "
+                        "the kernels of two streams share the CUs, nothing is gained"}
             # the module API as the reference's own trainer loop uses it (model(x), loss modules, loss.backward(), optimiser),
             # with the backbone's forward / backward replayed as two hipGraphs behind it (coarse3d_amd/graphed.py)
             try:
@@ -894,8 +894,8 @@ def dp_single_rank(wl, dev, steps, warmup):
         else:
             os.environ["C3D_SINGLE_RANK_COLLECTIVES"] = prev
     return {"value": cap["value"], "ms_per_step": cap["ms_per_step"], "steps": steps,
-            "launch": "one hipGraph replay per step, RCCL exchanges inside the graph (coarse3d_amd.dist.DataParallel, weight gradients "
-                      "on the second stream)",
+            "launch": "one hipGraph replay per step, RCCL exchanges inside the graph (coarse3d_amd.dist.DataParallel; one stream since "
+                      "round 5, C3D_WGRAD_STREAM=1 puts the weight gradients on a second one)",
             "collectives_per_step": eager["collectives"], "collectives_in_captured_step": cap["collectives"]["total"],
             "launch_by_launch": {"value": eager["value"], "ms_per_step": eager["ms_per_step"]},
             "note": "n_gpus = 1: what N > 1 adds on top is the latency / bandwidth of the collectives themselves"}

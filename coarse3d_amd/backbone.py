@@ -77,12 +77,14 @@ class Backbone:
         """params: mapping name -> CUDA tensor (the module's parameters and buffers).
         side_stream: second HIP stream for the weight-gradient chain of the backward pass."""
         self.P = params
-        # The weight-gradient chain moves to the side stream when there is exchange latency to hide
-        # under it (data parallel: SyncBN statistics, gradient buckets).  On one GPU it measured
-        # 54.4 vs 55.5 ms/step (-1.8 %) while inflating every per-kernel duration (kernels of the two
-        # streams share the CUs), so there it is opt-in: C3D_WGRAD_STREAM=1 forces it, =0 forbids it.
+        # The weight-gradient chain can run on a side stream, under the exchange latency of a data-parallel step (SyncBN
+        # statistics: 43 blocking exchanges in backward).  Opt-in (C3D_WGRAD_STREAM=1) since round 5, data parallel too:
+        # kernels of two streams share the CUs and the BatchNorm backward cannot ride on the weight gradient's loads then --
+        # the 1-rank data-parallel step measured 32.6 ms with it and 31.5 without (same box; the plain step 34.9 vs 31.4 when
+        # forced on), i.e. it pays only where an exchange costs more than ~25 us, and the peer-memory exchange
+        # (coarse3d_amd/peer.py) is a 4 us kernel plus the link latency.
         mode = os.environ.get("C3D_WGRAD_STREAM", "auto")
-        use_side = mode == "1" or (mode != "0" and reduce_fn is not None)
+        use_side = mode == "1"
         self.side = side_stream if use_side else None
         self.ncls = nclasses
         self.dataset = dataset
