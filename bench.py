@@ -451,8 +451,11 @@ class Bench:
                     D.EXPOSED = None
                     coll["comm_exposed_ms"] = {k: round(v / steps, 3) for k, v in ex.items()}
                     coll["comm_exposed_ms"]["total"] = round(sum(ex.values()) / steps, 3)
-                coll["syncbn_exchange"] = ("peer-memory kernel (coarse3d_amd/peer.py, csrc/peer_ops.hip)" if px is not None
-                                           else "torch.distributed all_reduce")
+                fused_bn = px is not None and os.environ.get("C3D_PEER_FUSED_BN", "1") != "0"
+                coll["syncbn_exchange"] = (("peer-memory kernels (coarse3d_amd/peer.py, csrc/peer_ops.hip)"
+                                            + ("; a layer that exchanges alone folds its partials, exchanges and finishes in ONE launch -- "
+                                               "comm_exposed_ms.syncbn then times that whole launch (fold and finalize included), not the "
+                                               "exchange alone" if fused_bn else "")) if px is not None else "torch.distributed all_reduce")
                 out["collectives"] = coll
             out["n_ranks"] = n_ranks
             out["value"] = round(self.wl["batch"] * n_ranks * steps / elapsed, 3)

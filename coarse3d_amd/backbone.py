@@ -107,6 +107,11 @@ class Backbone:
             if self.reduce_fn is None:      # single rank: fold + finalize in one launch
                 rec.scale, rec.shift, rec.mean, rec.invstd = ops.bn_finalize_partials(
                     partial, count, P[f"{name}.weight"], P[f"{name}.bias"], rm, rv, momentum, BN_EPS)
+            elif getattr(self.reduce_fn, "bn_forward", None) is not None and self.reduce_fn.fits_channels(c) and partial.dtype == torch.float32:
+                # SyncBN through peer memory: fold + exchange + finalize in one launch (coarse3d_amd/peer.py)
+                count = count * self.world
+                rec.scale, rec.shift, rec.mean, rec.invstd = self.reduce_fn.bn_forward(
+                    partial, count, P[f"{name}.weight"], P[f"{name}.bias"], rm, rv, momentum, BN_EPS)
             else:                           # SyncBN: all-reduce the fp64 sums in between
                 sums = ops.stat_reduce(partial, c)
                 self.reduce_fn(sums)
@@ -492,6 +497,9 @@ class Backbone:
                 part = ops.bn_bwd_reduce(dy, a, c, mode, pre_s, pre_h, slope=slope)
             if self.reduce_fn is None:
                 k = ops.bn_bwd_coeffs_partials(part, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
+                                               G[f"{bn.name}.weight"], G[f"{bn.name}.bias"])
+            elif getattr(self.reduce_fn, "bn_backward", None) is not None and self.reduce_fn.fits_channels(c) and part.dtype == torch.float32:
+                k = self.reduce_fn.bn_backward(part, bn.count, bn.mean, bn.invstd, self.P[f"{bn.name}.weight"],
                                                G[f"{bn.name}.weight"], G[f"{bn.name}.bias"])
             else:
                 sums, local = ops.stat_reduce(part, c, copy=True)      # dgamma/dbeta stay rank-local (averaged with the other grads)

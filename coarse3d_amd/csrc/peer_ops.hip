@@ -45,7 +45,11 @@ __device__ __forceinline__ double* peer_slot(unsigned char* box, int cap, int pa
   return reinterpret_cast<double*>(box + PEER_HEADER_BYTES + 2 * PEER_W * sizeof(unsigned long long)) + ((size_t)parity * PEER_W + r) * cap;
 }
 
-__global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs a) {
+// The exchange, by one 256-thread block: a.buf[0 .. n) becomes the rank-ordered sum over ranks.  COHERENT: a.buf was written by
+// other blocks of this launch (the fused kernels below) -- read it past this CU's L1.  Returns false if a peer never arrived
+// (status word set, a.buf untouched from the protocol's side).
+template <bool COHERENT>
+__device__ __forceinline__ bool peer_exchange_block(const PeerArgs& a) {
   __shared__ unsigned long long s_seq;
   __shared__ int s_fail;
   const int tid = threadIdx.x;
@@ -59,13 +63,16 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs a) {
   __syncthreads();
   // an earlier exchange gave up: the ranks' sequence numbers no longer agree and every further wait would run into its
   // timeout too -- do nothing (the host raises at its next check; a step with 86 exchanges costs ONE timeout, not 86)
-  if (s_fail) return;
+  if (s_fail) return false;
   const unsigned long long seq = s_seq;
   const int parity = (int)(seq & 1ull);
   // 1. my vector into my slot of every mailbox
   for (int p = 0; p < a.world; ++p) {
     double* dst = peer_slot(a.box[p], a.cap, parity, a.rank);
-    for (int i = tid; i < a.n; i += 256) __hip_atomic_store(dst + i, a.buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int i = tid; i < a.n; i += 256) {
+      const double v = COHERENT ? __hip_atomic_load(a.buf + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : a.buf[i];
+      __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   // 2. publish: the stores above must be visible system-wide before the sequence number is.  They are write-through
   //    (system-scope sc0 sc1 stores) and every storing wave drains them; across DEVICES a system-scope release fence is
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs a) {
       *status = 1u;
       *calls = seq;
     }
-    return;
+    return false;
   }
   // 4. the sum, in rank order
   for (int i = tid; i < a.n; i += 256) {
@@ -103,6 +110,123 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs a) {
     a.buf[i] = s;
   }
   if (tid == 0) *calls = seq;
+  __syncthreads();       // (the fused kernels read a.buf across threads next)
+  return true;
+}
+
+__global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs a) { (void)peer_exchange_block<false>(a); }
+
+// block-wide fold of one channel's partials [2][n] -> (s1, s2) in fp64 (as fold_channel in bn_ops.hip: the same order, the same bits)
+__device__ __forceinline__ void peer_fold_channel(const float* __restrict__ p, int n, double& s1, double& s2) {
+  __shared__ double red[2][4];
+  s1 = 0.0;
+  s2 = 0.0;
+  for (int t = threadIdx.x; t < n; t += 256) {
+    s1 += (double)p[t];
+    s2 += (double)p[n + t];
+  }
+  s1 = c3d_wave_sum_d(s1);
+  s2 = c3d_wave_sum_d(s2);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s1;
+    red[1][threadIdx.x >> 6] = s2;
+  }
+  __syncthreads();
+  s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+}
+
+// One block per channel folds; the block that draws the last ticket of the launch is alone from then on.  No fences: on this
+// chip an agent-scope release / acquire is a write-back / invalidate of an XCD's whole L2 (one per block: the first version of
+// these kernels took 23 us a launch, more than the three launches they replace).  The sums are write-through stores, drained
+// before thread 0 draws its ticket, and the last block reads them past its caches -- the discipline of the exchange itself.
+__device__ __forceinline__ void peer_publish(double* dst, double v) { __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ bool peer_last_block(unsigned int* ticket) {
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this block's sums (thread 0 wrote them) before its ticket
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == gridDim.x - 1;
+    if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (everybody has drawn)
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+
+struct PeerBnFwd {
+  const float* partial; int npart; int C; double count;
+  const float *gamma, *beta; float *rm, *rv; float momentum, eps;
+  float *scale, *shift, *mean, *invstd;
+  unsigned int* ticket;
+};
+
+// SyncBatchNorm forward statistics in ONE launch (data parallel): fold the conv epilogue's partials, exchange the fp64 sums
+// through the mailboxes, finish (scale, shift, mean, invstd, running statistics) -- stat_reduce + the exchange kernel +
+// bn_finalize of the three-launch path, the same arithmetic in the same order.  a.buf: scratch [C][2] doubles.
+__global__ __launch_bounds__(256) void peer_bn_forward_kernel(PeerArgs a, PeerBnFwd f) {
+  const int c = blockIdx.x;
+  double s1, s2;
+  peer_fold_channel(f.partial + (size_t)c * 2 * f.npart, f.npart, s1, s2);
+  if (threadIdx.x == 0) {
+    peer_publish(a.buf + c * 2 + 0, s1);
+    peer_publish(a.buf + c * 2 + 1, s2);
+  }
+  if (!peer_last_block(f.ticket)) return;
+  if (!peer_exchange_block<true>(a)) return;
+  for (int ch = threadIdx.x; ch < f.C; ch += 256) {        // bn_finalize_kernel (bn_ops.hip)
+    const double mean = a.buf[ch * 2] / f.count;
+    double var = a.buf[ch * 2 + 1] / f.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float sc = f.gamma[ch] * invstd;
+    f.scale[ch] = sc;
+    f.shift[ch] = f.beta[ch] - (float)mean * sc;
+    f.mean[ch] = (float)mean;
+    f.invstd[ch] = invstd;
+    if (f.rm) {
+      const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+      f.rm[ch] = (1.f - f.momentum) * f.rm[ch] + f.momentum * (float)mean;
+      f.rv[ch] = (1.f - f.momentum) * f.rv[ch] + f.momentum * (float)unbiased;
+    }
+  }
+}
+
+struct PeerBnBwd {
+  const float* partial; int npart; int C; double count;
+  const float *mean, *invstd, *gamma;
+  float *k1, *k2, *k3, *dgamma, *dbeta;
+  double* local;          // scratch [C][2]: this rank's sums (the parameter gradients stay rank-local, as torch.nn.SyncBatchNorm's)
+  unsigned int* ticket;
+};
+
+// ... and the backward sums (sum dy, sum dy * a): stat_reduce2 + the exchange kernel + bn_bwd_coeffs in one launch
+__global__ __launch_bounds__(256) void peer_bn_backward_kernel(PeerArgs a, PeerBnBwd f) {
+  const int c = blockIdx.x;
+  double s1, s2;
+  peer_fold_channel(f.partial + (size_t)c * 2 * f.npart, f.npart, s1, s2);
+  if (threadIdx.x == 0) {
+    peer_publish(a.buf + c * 2 + 0, s1);
+    peer_publish(a.buf + c * 2 + 1, s2);
+    peer_publish(f.local + c * 2 + 0, s1);
+    peer_publish(f.local + c * 2 + 1, s2);
+  }
+  if (!peer_last_block(f.ticket)) return;
+  if (!peer_exchange_block<true>(a)) return;
+  for (int ch = threadIdx.x; ch < f.C; ch += 256) {        // bn_bwd_coeffs_kernel (bn_ops.hip)
+    const double sdy = a.buf[ch * 2], sdya = a.buf[ch * 2 + 1];
+    const double mu = f.mean[ch], is = f.invstd[ch], g = f.gamma[ch];
+    const double sdyx = is * (sdya - mu * sdy);
+    const double kk1 = g * is;
+    const double kk2 = -g * is * is * sdyx / f.count;
+    const double kk3 = -g * is * sdy / f.count - kk2 * mu;
+    f.k1[ch] = (float)kk1;
+    f.k2[ch] = (float)kk2;
+    f.k3[ch] = (float)kk3;
+    const double ldy = __hip_atomic_load(f.local + ch * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const double ldya = __hip_atomic_load(f.local + ch * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    f.dgamma[ch] = (float)(is * (ldya - mu * ldy));
+    f.dbeta[ch] = (float)ldy;
+  }
 }
 
 }  // namespace
@@ -167,19 +291,51 @@ extern "C" int c3d_peer_free(void* ptr) {
   return 0;
 }
 
-extern "C" int c3d_peer_allreduce_f64(const c3d_peer_desc* d, double* buf, int n, c3d_stream stream) {
-  C3D_REQUIRE(d != nullptr && buf != nullptr, "peer_allreduce: null pointer");
-  C3D_REQUIRE(d->world >= 1 && d->world <= PEER_W && d->rank >= 0 && d->rank < d->world, "peer_allreduce: bad rank / world");
-  C3D_REQUIRE(n >= 0 && n <= d->cap_doubles, "peer_allreduce: the vector does not fit the mailbox slot");
-  if (n == 0) return 0;
-  PeerArgs a;
+static int peer_args(const c3d_peer_desc* d, double* buf, int n, PeerArgs& a) {
+  C3D_REQUIRE(d != nullptr && buf != nullptr, "peer exchange: null pointer");
+  C3D_REQUIRE(d->world >= 1 && d->world <= PEER_W && d->rank >= 0 && d->rank < d->world, "peer exchange: bad rank / world");
+  C3D_REQUIRE(n >= 0 && n <= d->cap_doubles, "peer exchange: the vector does not fit the mailbox slot");
   for (int p = 0; p < PEER_W; ++p) a.box[p] = p < d->world ? static_cast<unsigned char*>(d->mailbox[p]) : nullptr;
-  for (int p = 0; p < d->world; ++p) C3D_REQUIRE(a.box[p] != nullptr, "peer_allreduce: a peer mailbox is not mapped");
+  for (int p = 0; p < d->world; ++p) C3D_REQUIRE(a.box[p] != nullptr, "peer exchange: a peer mailbox is not mapped");
   a.rank = d->rank; a.world = d->world; a.cap = d->cap_doubles; a.buf = buf; a.n = n;
   a.fences = (d->one_device || d->world == 1) ? 0 : 1;
   const double secs = d->timeout_s > 0.f ? d->timeout_s : 20.f;
   a.timeout_ticks = (unsigned long long)(secs * 100e6);
+  return 0;
+}
+
+extern "C" int c3d_peer_allreduce_f64(const c3d_peer_desc* d, double* buf, int n, c3d_stream stream) {
+  PeerArgs a;
+  if (peer_args(d, buf, n, a)) return 1;
+  if (n == 0) return 0;
   hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_peer_bn_finalize_partials(const c3d_peer_desc* d, const float* partial, int n, double count, const float* gamma,
+                                             const float* beta, float* running_mean, float* running_var, float momentum, float eps, int C,
+                                             float* scale, float* shift, float* save_mean, float* save_invstd, double* scratch,
+                                             uint32_t* ticket, c3d_stream stream) {
+  C3D_REQUIRE(partial && gamma && beta && scale && shift && save_mean && save_invstd && scratch && ticket && C > 0 && n > 0,
+              "peer_bn_finalize_partials: null pointer or empty problem");
+  PeerArgs a;
+  if (peer_args(d, scratch, 2 * C, a)) return 1;
+  PeerBnFwd f{partial, n, C, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd, ticket};
+  hipLaunchKernelGGL(peer_bn_forward_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, a, f);
+  C3D_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int c3d_peer_bn_bwd_coeffs_partials(const c3d_peer_desc* d, const float* partial, int n, double count, const float* mean,
+                                               const float* invstd, const float* gamma, int C, float* k1, float* k2, float* k3,
+                                               float* dgamma, float* dbeta, double* scratch, uint32_t* ticket, c3d_stream stream) {
+  C3D_REQUIRE(partial && mean && invstd && gamma && k1 && k2 && k3 && dgamma && dbeta && scratch && ticket && C > 0 && n > 0,
+              "peer_bn_bwd_coeffs_partials: null pointer or empty problem");
+  PeerArgs a;
+  if (peer_args(d, scratch, 2 * C, a)) return 1;
+  PeerBnBwd f{partial, n, C, count, mean, invstd, gamma, k1, k2, k3, dgamma, dbeta, scratch + 2 * C, ticket};
+  hipLaunchKernelGGL(peer_bn_backward_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, a, f);
   C3D_CHECK_LAUNCH();
   return 0;
 }

@@ -120,7 +120,25 @@ def peer_syncbn_reduce(px):
         if work is not None:
             with _exposed("syncbn"):
                 px.end(work)
+    # one launch per BatchNorm layer and direction: fold + exchange + finish (coarse3d_amd/backbone.py takes these where a layer
+    # exchanges alone; C3D_PEER_FUSED_BN=0: the three-launch path -- same bits, tests/test_gpu_dp.py)
+    def bn_forward(partial, count, gamma, beta, rm, rv, momentum, eps):
+        with _exposed("syncbn"):
+            out = px.bn_finalize_partials(partial, count, gamma, beta, rm, rv, momentum, eps)
+        COUNTS["syncbn"] += 1
+        return out
+
+    def bn_backward(partial, count, mean, invstd, gamma, dgamma, dbeta):
+        with _exposed("syncbn"):
+            k = px.bn_bwd_coeffs_partials(partial, count, mean, invstd, gamma, dgamma, dbeta)
+        COUNTS["syncbn"] += 1
+        return k
+
+    def fits_channels(c):
+        return 2 * c <= px.desc.cap_doubles
     reduce_.begin, reduce_.end, reduce_.peer = begin, end, px
+    if os.environ.get("C3D_PEER_FUSED_BN", "1") != "0":
+        reduce_.bn_forward, reduce_.bn_backward, reduce_.fits_channels = bn_forward, bn_backward, fits_channels
     return reduce_
 
 

@@ -48,13 +48,18 @@ class PeerExchange:
         self.desc = PeerDesc()
         self.desc.rank, self.desc.world, self.desc.cap_doubles, self.desc.timeout_s = self.rank, self.world, cap_doubles, timeout_s
         self.stream = torch.cuda.Stream()       # for the asynchronous form (begin / end)
+        self._scratch = self._ticket = None
         err = None
         handle = (C.c_ubyte * 64)()
         try:
-            nbytes = lib.c3d_peer_mailbox_bytes(cap_doubles)
+            nbytes = (lib.c3d_peer_mailbox_bytes(cap_doubles) + 255) // 256 * 256
             ptr = C.c_void_p()
-            L.check(lib.c3d_peer_alloc(nbytes, C.byref(ptr), handle), "c3d_peer_alloc")
+            # behind the mailbox, in the same fine-grained allocation (zeroed): the sums scratch (4 x cap doubles) and the ticket
+            # word of the fused BatchNorm launches -- their blocks talk through write-through stores, like the exchange itself
+            L.check(lib.c3d_peer_alloc(nbytes + 4 * cap_doubles * 8 + 256, C.byref(ptr), handle), "c3d_peer_alloc")
             self._own = ptr.value
+            self._scratch = self._own + nbytes
+            self._ticket = self._scratch + 4 * cap_doubles * 8
         except Exception as e:      # noqa: BLE001 -- the other ranks must learn about it below
             err = f"rank {self.rank}: {e}"
         props = torch.cuda.get_device_properties(torch.cuda.current_device())
@@ -138,6 +143,36 @@ class PeerExchange:
         L.check(L.lib().c3d_peer_allreduce_f64(C.byref(self.desc), t.data_ptr(), t.numel(), C.c_void_p(s.cuda_stream)),
                 "c3d_peer_allreduce_f64")
         return t
+
+    def bn_finalize_partials(self, partial, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
+        """SyncBatchNorm forward statistics of one layer in ONE launch on the current stream: fold the partials [C, 2, n],
+        exchange the fp64 sums, finish -> (scale, shift, mean, invstd) and the running statistics.  ``count``: elements per
+        channel over all ranks.  One exchange in every rank's call sequence (csrc/peer_ops.hip)."""
+        c = gamma.shape[0]
+        if 2 * c > self.desc.cap_doubles:
+            raise ValueError(f"PeerExchange.bn_finalize_partials: {c} channels exceed the mailbox slot")
+        buf = torch.empty(4, c, device=gamma.device, dtype=torch.float32)
+        s = torch.cuda.current_stream()
+        L.check(L.lib().c3d_peer_bn_finalize_partials(
+            C.byref(self.desc), partial.data_ptr(), partial.shape[2], float(count), gamma.data_ptr(), beta.data_ptr(),
+            running_mean.data_ptr() if running_mean is not None else None, running_var.data_ptr() if running_var is not None else None,
+            momentum, eps, c, buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr(), C.c_void_p(self._scratch),
+            C.c_void_p(self._ticket), C.c_void_p(s.cuda_stream)), "c3d_peer_bn_finalize_partials")
+        return buf[0], buf[1], buf[2], buf[3]
+
+    def bn_bwd_coeffs_partials(self, partial, count, mean, invstd, gamma, dgamma, dbeta):
+        """... and the backward sums (sum dy, sum dy * a): -> the three input-gradient coefficients [3, C] from the global sums,
+        dgamma / dbeta from this rank's (as torch.nn.SyncBatchNorm: parameter gradients are averaged with the others)."""
+        c = gamma.shape[0]
+        if 2 * c > self.desc.cap_doubles:
+            raise ValueError(f"PeerExchange.bn_bwd_coeffs_partials: {c} channels exceed the mailbox slot")
+        k = torch.empty(3, c, device=gamma.device, dtype=torch.float32)
+        s = torch.cuda.current_stream()
+        L.check(L.lib().c3d_peer_bn_bwd_coeffs_partials(
+            C.byref(self.desc), partial.data_ptr(), partial.shape[2], float(count), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+            c, k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), C.c_void_p(self._scratch),
+            C.c_void_p(self._ticket), C.c_void_p(s.cuda_stream)), "c3d_peer_bn_bwd_coeffs_partials")
+        return k
 
     def begin(self, t):
         """Asynchronous form: the exchange runs on this object's side stream, ordered after what the current stream has

@@ -651,6 +651,19 @@ int c3d_peer_free(void* ptr);
 int c3d_peer_allreduce_f64(const c3d_peer_desc* d, double* buf, int n, c3d_stream stream);
 /* host read of the rank's status word (0 = fine, 1 = an exchange timed out: its result was not a sum) and call counter */
 int c3d_peer_status(const c3d_peer_desc* d, int32_t* status_out, int64_t* calls_out);
+/* SyncBatchNorm in ONE launch per layer and direction (torch.nn.SyncBatchNorm's forward / backward all-reduce,
+ * tasks/weak_segmentation/trainer.py:54): fold the per-tile partials [C][2][n] (conv epilogue / c3d_bn_bwd_reduce), exchange the
+ * fp64 sums through the mailboxes, finish -- c3d_stat_reduce(2) + c3d_peer_allreduce_f64 + c3d_bn_finalize / c3d_bn_bwd_coeffs of
+ * the three-launch path, the same arithmetic in the same order (the same bits).  count = elements per channel over ALL ranks.
+ * scratch: device doubles, 2 C (forward) / 4 C (backward), 2 C <= cap_doubles; ticket: one device word, zero before the first
+ * call (the kernel leaves it zero).  Counts as one exchange in every rank's call sequence. */
+int c3d_peer_bn_finalize_partials(const c3d_peer_desc* d, const float* partial, int n, double count, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var, float momentum, float eps, int C,
+                                  float* scale, float* shift, float* save_mean, float* save_invstd, double* scratch,
+                                  uint32_t* ticket, c3d_stream stream);
+int c3d_peer_bn_bwd_coeffs_partials(const c3d_peer_desc* d, const float* partial, int n, double count, const float* mean,
+                                    const float* invstd, const float* gamma, int C, float* k1, float* k2, float* k3,
+                                    float* dgamma, float* dbeta, double* scratch, uint32_t* ticket, c3d_stream stream);
 
 #ifdef __cplusplus
 }

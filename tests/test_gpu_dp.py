@@ -164,6 +164,42 @@ def _peer_worker(rank, world, port, q, skip_last):
     dist.destroy_process_group()
 
 
+def test_syncbn_in_one_launch_per_layer_has_the_bits_of_the_three_launch_path():
+    """Round 5: under the peer-memory exchange a BatchNorm layer's statistics take ONE launch per direction -- fold of the
+    partials, exchange, finalize / coefficients (csrc/peer_ops.hip: peer_bn_forward_kernel, peer_bn_backward_kernel) -- instead
+    of c3d_stat_reduce + the exchange kernel + c3d_bn_finalize / c3d_bn_bwd_coeffs (C3D_PEER_FUSED_BN=0).  Two processes on
+    this box's GPU, both ways: predictions, running statistics, every gradient and the bank bit for bit, and the same number of
+    exchanges in the mailboxes' call counters."""
+    b, h, w, ncls = 2, 32, 64, 20
+    ctx = mp.get_context("spawn")
+    out = {}
+    prev = os.environ.get("C3D_PEER_FUSED_BN")
+    try:
+        for i, mode in enumerate(("1", "0")):
+            os.environ["C3D_PEER_FUSED_BN"] = mode          # (the spawned ranks inherit it; read when DataParallel is built)
+            q = ctx.Queue()
+            port = 29450 + os.getpid() % 400 + 11 * i
+            procs = [ctx.Process(target=_run, args=(r, 2, port, q, b, h, w, ncls)) for r in range(2)]
+            for pr in procs:
+                pr.start()
+            out[mode] = dict(q.get(timeout=300) for _ in range(2))
+            for pr in procs:
+                pr.join(60)
+                assert pr.exitcode == 0
+    finally:
+        if prev is None:
+            os.environ.pop("C3D_PEER_FUSED_BN", None)
+        else:
+            os.environ["C3D_PEER_FUSED_BN"] = prev
+    for r in range(2):
+        one, three = out["1"][r], out["0"][r]
+        assert one["peer_calls"] == three["peer_calls"] >= 40
+        assert (one["pred"] == three["pred"]).all() and (one["rm"] == three["rm"]).all() and (one["protos"] == three["protos"]).all()
+        assert set(one["grads"]) == set(three["grads"])
+        for k in one["grads"]:
+            assert (one["grads"][k] == three["grads"][k]).all(), k
+
+
 @pytest.mark.parametrize("skip_last", [False, True])
 def test_peer_exchange_between_two_processes_on_one_device(skip_last):
     """coarse3d_amd/peer.py + csrc/peer_ops.hip: the SyncBatchNorm sums of trainer.py:54 through
