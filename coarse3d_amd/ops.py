@@ -321,41 +321,8 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     timed = KERNEL_EVENTS is not None        # the kernel-name mirror below only serves the per-kernel event timers
 
     def kernel_name():
-        halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
-        sm_ = "true" if d.stat_mul else "false"      # (bf16 engine: the instance with the BatchNorm-backward epilogue)
-        hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
-        k32 = tr == 8 and nt_ == 1 and all(s.C % 32 == 0 for s in srcs)
-        if MFMA_MODE == 2 and tr == 8 and nt_ > 1 and not (nt_ in (3, 6) and (CONV_VARIANT & 4)):      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
-            # nine taps: the fused kernel (round 3); four taps: fused too since round 5; CONV_VARIANT & 4 forces the phased one
-            fused_ = not (CONV_VARIANT & 4)      # (four taps: fused since round 5; three / six: fused only)
-            # (names as rocprofv3 prints them: the fused kernel carries its plane count and its bf16-source flag as fifth and
-            #  sixth template arguments)
-            six_ = grad or b * h * w >= SIX_FWD_MIN_PIXELS          # (the fourth template argument: six plane products)
-            name = (f"conv_x3{'f' if fused_ else ''}_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, {nt_}, "
-                    f"{'true' if six_ else 'false'}{', 3, false, false' if fused_ else ''}>")
-        elif (MFMA_MODE == 1 and tr == 8 and nt_ == 9 and d.wpack_planes and not (CONV_VARIANT & 4)
-              and all(s.t.dtype == torch.bfloat16 for s in srcs)):      # the fused nine-tap kernel with one plane (csrc/conv_x3.hip)
-            name = f"conv_x3f_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, 9, true, 1, true, {sm_}>"
-        elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and d.wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
-            name = _pw3_kernel_name(_pw3_tile(b, h, w, cout), sum(s.C for s in srcs), cout,
-                                    bf16_srcs=all(s.t.dtype == torch.bfloat16 for s in srcs))
-        elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip (the trailing template argument: raw bf16 staging)
-            np_ = 3 if MFMA_MODE == 2 else 1
-            wide_ = _wide_cout_tiles(b, h, w, cout, tr)
-            bfs_ = (np_ == 1 and tr == 8 and nt_ in (1, 4) and not (CONV_VARIANT & 8) and all(s.t.dtype == torch.bfloat16 for s in srcs))
-            if bfs_:        # launch_bfp_bf16_sources(): deeper K chunks where every source's width allows
-                c32_, c64_ = all(s.C % 32 == 0 for s in srcs), all(s.C % 64 == 0 for s in srcs)
-                ck_ = (64 if c64_ else 32 if c32_ else 16) if nt_ == 1 else (32 if c32_ else 16)
-                name = f"conv_bfp_kernel<8, {2 if wide_ else 1}, {ck_}, {hh}, {nt_}, 1, true, {sm_}>"
-            else:
-                name = (f"conv_bfp_kernel<8, {2 if wide_ else 1}, 32, 0, 1, {np_}, false, false>" if k32 else
-                        f"conv_bfp_kernel<{tr}, {2 if (wide_ or tr == 2) else 1}, 16, {hh}, {nt_}, {np_}, false, false>")
-        elif k32:         # mirrors c3d_conv_forward / launch_taps() in csrc/conv_mfma.hip
-            wide = cout > 64 and (cout + 127) // 128 * 128 <= (cout + 63) // 64 * 64
-            name = f"conv_mfma_kernel<8, {4 if wide else (2 if cout > 32 else 1)}, 32, 0, 1>"
-        else:
-            name = f"conv_mfma_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}>"
-        return name, halo
+        return _conv_kernel_name(b, h, w, [s.C for s in srcs], [s.t.dtype == torch.bfloat16 for s in srcs], cout, taps, grad,
+                                 bool(d.wpack_planes), bool(d.stat_mul))
     # six plane products: every input gradient, and forward multi-tap convs whose BatchNorm population is large
     # (SIX_FWD_MIN_PIXELS).  conv_pw3 runs six in every launch (the flag is ignored there).
     six = MFMA_MODE == 2 and (grad or (nt_ > 1 and tr == 8 and b * h * w >= SIX_FWD_MIN_PIXELS))
@@ -384,6 +351,49 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
                 (h, w, sum(s.C for s in srcs), cout, nt_, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_forward(C.byref(d), _stream()), "c3d_conv_forward")
     return out, stat_partial
+
+
+def _conv_kernel_name(b, h, w, src_c, src_bf16, cout, taps, grad, wpack_planes, stat_mul):
+    """The kernel instance c3d_conv_forward launches for this problem, as rocprofv3 prints it -- a mirror of the dispatch in
+    csrc/conv_mfma.hip, conv_x3.hip, conv_pw3.hip and conv_bfp.hip for the per-kernel event timers of bench.py
+    (tests/test_cpu_kernel_names.py holds every name it can produce against the symbols of the built library)."""
+    tr = _tile_rows(h)
+    nt_ = len(taps)
+    halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
+    sm_ = "true" if stat_mul else "false"      # (bf16 engine: the instance with the BatchNorm-backward epilogue)
+    hh = 0 if nt_ == 1 else (1 if (nt_ == 4 or halo <= 1) else 2)
+    k32 = tr == 8 and nt_ == 1 and all(c % 32 == 0 for c in src_c)
+    if MFMA_MODE == 2 and tr == 8 and nt_ > 1 and not (nt_ in (3, 6) and (CONV_VARIANT & 4)):      # mirrors c3d_conv_forward_x3() in csrc/conv_x3.hip
+        # nine taps: the fused kernel (round 3); four taps: fused too since round 5; CONV_VARIANT & 4 forces the phased one
+        fused_ = not (CONV_VARIANT & 4)      # (four taps: fused since round 5; three / six: fused only)
+        # (names as rocprofv3 prints them: the fused kernel carries its plane count and its bf16-source flag as fifth and
+        #  sixth template arguments)
+        six_ = grad or b * h * w >= SIX_FWD_MIN_PIXELS          # (the fourth template argument: six plane products)
+        name = (f"conv_x3{'f' if fused_ else ''}_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, {nt_}, "
+                f"{'true' if six_ else 'false'}{', 3, false, false' if fused_ else ''}>")
+    elif (MFMA_MODE == 1 and tr == 8 and nt_ == 9 and wpack_planes and not (CONV_VARIANT & 4)
+          and all(src_bf16)):      # the fused nine-tap kernel with one plane (csrc/conv_x3.hip)
+        name = f"conv_x3f_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, 9, true, 1, true, {sm_}>"
+    elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
+        name = _pw3_kernel_name(_pw3_tile(b, h, w, cout), sum(src_c), cout,
+                                bf16_srcs=all(src_bf16))
+    elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip (the trailing template argument: raw bf16 staging)
+        np_ = 3 if MFMA_MODE == 2 else 1
+        wide_ = _wide_cout_tiles(b, h, w, cout, tr)
+        bfs_ = (np_ == 1 and tr == 8 and nt_ in (1, 4) and not (CONV_VARIANT & 8) and all(src_bf16))
+        if bfs_:        # launch_bfp_bf16_sources(): deeper K chunks where every source's width allows
+            c32_, c64_ = all(c % 32 == 0 for c in src_c), all(c % 64 == 0 for c in src_c)
+            ck_ = (64 if c64_ else 32 if c32_ else 16) if nt_ == 1 else (32 if c32_ else 16)
+            name = f"conv_bfp_kernel<8, {2 if wide_ else 1}, {ck_}, {hh}, {nt_}, 1, true, {sm_}>"
+        else:
+            name = (f"conv_bfp_kernel<8, {2 if wide_ else 1}, 32, 0, 1, {np_}, false, false>" if k32 else
+                    f"conv_bfp_kernel<{tr}, {2 if (wide_ or tr == 2) else 1}, 16, {hh}, {nt_}, {np_}, false, false>")
+    elif k32:         # mirrors c3d_conv_forward / launch_taps() in csrc/conv_mfma.hip
+        wide = cout > 64 and (cout + 127) // 128 * 128 <= (cout + 63) // 64 * 64
+        name = f"conv_mfma_kernel<8, {4 if wide else (2 if cout > 32 else 1)}, 32, 0, 1>"
+    else:
+        name = f"conv_mfma_kernel<{tr}, {2 if (cout > 32 or tr == 2) else 1}, 16, {hh}, {nt_}>"
+    return name, halo
 
 
 def _wgrad_kernel_name(ci, co, nt, halo, fused=False, raw=False, h=0):
