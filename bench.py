@@ -430,7 +430,8 @@ class Bench:
                 # the SyncBatchNorm sums travelled through peer memory (coarse3d_amd/peer.py): did every exchange of every rank
                 # complete?  (A rank that gave up waiting computed with partial sums: the pass is void -- the caller repeats
                 # it over torch.distributed collectives.)  Decided together: every rank raises or none does.
-                bad = torch.tensor([float(px.failed())], device=self.dev)
+                # (C3D_BENCH_INJECT_PEER_FAILURE=1: the test of this fallback -- the first pass of every rank reports a timeout)
+                bad = torch.tensor([float(px.failed() or os.environ.pop("C3D_BENCH_INJECT_PEER_FAILURE", None) == "1")], device=self.dev)
                 if self.world > 1:
                     dist.all_reduce(bad, op=dist.ReduceOp.MAX)
                 if float(bad) > 0:

@@ -283,6 +283,29 @@ def test_bench_launches_two_ranks():
     assert out["value"] > 0
 
 
+def test_bench_repeats_a_pass_over_collectives_when_the_peer_exchange_reports_a_timeout():
+    """bench.py asks every rank after a data-parallel pass whether an exchange through peer memory timed out (consensus) and, if
+    one did, repeats the pass with the SyncBatchNorm sums over torch.distributed -- the guard around the first multi-GPU use of
+    the mailboxes.  Two ranks on this box's GPU with an injected report: the line says so and names the collective exchange."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--height", "32", "--width", "256", "--no-cpu-baseline", "--no-kernel-events", "--no-second-engine", "--graph", "off"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "C3D_SYNCBN_EXCHANGE")}
+    env.update(C3D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", C3D_BENCH_INJECT_PEER_FAILURE="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and "collective" in out["syncbn_exchange_fallback"]
+    coll = out["config"]["collectives_per_step"]
+    assert coll["syncbn_exchange"] == "torch.distributed all_reduce" and 0 < coll["syncbn"] < 86
+    assert "repeated" in r.stderr
+
+
 def test_two_ranks_prototype_sums_exchange():
     """DataParallel(proto_sync="sums"): the per-class feature sums + counts are all-reduced before ONE
     momentum update -- both ranks end with the identical, unit-norm bank, which differs from the
