@@ -385,19 +385,28 @@ class Backbone:
             for (sk, o, c), d in zip(lo, dzs):
                 ops.conv_wgrad(sk.src(), d, dw, rec.taps, cin_off=o)
         kp = (cout + 15) // 16 * 16
+        # (each skip's gradient is initialised here, or -- embedding branch behind the up blocks, backward(d_feat_ready=...) --
+        #  added to what the decoder has written: one fp32 addition of the same two numbers either way)
         for src, o, c, orig in hi:
             wd = self.packs.get(w, 1, c_off=o, c_cnt=c, kpad=kp)
+            if orig is None and src.grad is not None:               # the skip itself, already holding the decoder's share
+                ops.conv_forward([ops.Source(dz)], wd, None, c, rec.taps, out=src.grad, accumulate=True, grad=True)
+                continue
             g = torch.empty_like(src.t)
             ops.conv_forward([ops.Source(dz)], wd, None, c, rec.taps, out=g, grad=True)
             if orig is None:
                 src.grad = g                                        # the skip itself
             else:
-                orig.grad = torch.empty_like(orig.t)
-                ops.bilinear_bwd(orig.grad, g)
+                acc = orig.grad is not None
+                if not acc:
+                    orig.grad = torch.empty_like(orig.t)
+                ops.bilinear_bwd(orig.grad, g, accumulate=acc)
         for (sk, o, c), d in zip(lo, dzs):
             wd = self.packs.get(w, 1, c_off=o, c_cnt=c, kpad=kp)
-            sk.grad = torch.empty_like(sk.t)
-            ops.conv_forward([ops.Source(d)], wd, None, c, rec.taps, out=sk.grad, grad=True)
+            acc = sk.grad is not None
+            if not acc:
+                sk.grad = torch.empty_like(sk.t)
+            ops.conv_forward([ops.Source(d)], wd, None, c, rec.taps, out=sk.grad, accumulate=acc, grad=True)
         rec.out.grad = None
 
     # ------------------------------------------------------------------ forward
@@ -729,14 +738,19 @@ class Backbone:
         self._accum(xin, dxa)
 
     # ------------------------------------------------------------------ backward
-    def backward(self, d_prob=None, d_feat=None, grads=None):
+    def backward(self, d_prob=None, d_feat=None, grads=None, d_feat_ready=None):
         """d_prob [B,Ho,Wo,C], d_feat [B,Ho,Wo,256] (NHWC, either may be None).  ``grads``: optional
-        dict name -> preallocated gradient tensor (reference layout); returned filled."""
+        dict name -> preallocated gradient tensor (reference layout); returned filled.
+        ``d_feat_ready`` (round 5; single process only): a callable that returns ``d_feat`` -- and makes the current stream wait
+        for it -- as late as the pass can take it: the embedding branch then runs BEHIND the four up blocks instead of in front
+        of them, so that whoever computes that gradient (the contrast loss on a second stream, coarse3d_amd.trainer.TrainStep)
+        runs under the decoder's backward.  The skip gradients see their contributions in another order (u + p instead of
+        p + u per element: the same bits)."""
         # the strips -> dw folds of the weight gradients are queued and run in batches (ops.WgradFolds): at the end of the
         # pass, or -- data parallel -- whenever a block's gradients are about to be sent
         prev, ops.WGRAD_FOLDS = ops.WGRAD_FOLDS, (ops.WgradFolds() if DEFER_WGRAD_FOLDS else None)
         try:
-            return self._backward(d_prob, d_feat, grads)
+            return self._backward(d_prob, d_feat, grads, d_feat_ready)
         finally:
             ops.WGRAD_FOLDS = prev
 
@@ -761,8 +775,11 @@ class Backbone:
         finally:
             ops.WGRAD_FOLDS = prev
 
-    def _backward(self, d_prob, d_feat, grads):
+    def _backward(self, d_prob, d_feat, grads, d_feat_ready=None):
         P = self.P
+        late = d_feat_ready is not None
+        if late and (d_feat is not None or self.reduce_fn is not None or self.on_block_done is not None or not self.return_feat):
+            raise ValueError("backward(d_feat_ready=...): single process, an embedding branch in the forward, no d_feat next to it")
         if grads is None:
             grads = {k: torch.empty_like(v) for k, v in P.items()
                      if v.is_floating_point() and v.dim() > 0 and not k.endswith(("running_mean", "running_var"))
@@ -783,10 +800,10 @@ class Backbone:
 
         if d_prob is None:
             raise ValueError("backward needs d_prob (the segmentation losses always produce it)")
-        embed = d_feat is not None and self.return_feat
+        embed = (d_feat is not None or late) and self.return_feat
         self.embed_ran = embed
-        # ---- both heads down to their first BatchNorm: projector.proj.3 and cls_head
-        if embed:
+
+        def embed_head(d_feat):
             feat_a, z0, emb, embn, norm = self.tape["embed"]
             if self.lazy_feat:
                 d_embn = d_feat.contiguous()
@@ -799,26 +816,40 @@ class Backbone:
                 ops.bilinear_bwd(d_embn, d_feat, rowmask=contrast.take_row_hint(d_feat))
             d_emb = ops.l2norm_bwd(embn, norm, d_embn, 1e-12)
             self._conv_backward("projector.proj.3", d_emb)
+
+        def embed_rest(ks):
+            """the rest of the embedding branch: gather-form transposes into the skip gradients (initialised here, or -- late
+            -- added to what the up blocks have written)"""
+            feat_a, z0 = self.tape["embed"][0], self.tape["embed"][1]
+            if "proj0.split" in self.tape:
+                self._proj0_backward(z0.grad, ks.get("projector.proj.0"))
+                z0.grad = None
+                return
+            self._conv_backward("projector.proj.0", z0.grad, ks.get("projector.proj.0"))
+            z0.grad = None
+            off = 0
+            for s in self.skips:
+                acc = s.grad is not None
+                if not acc:
+                    s.grad = torch.empty_like(s.t)
+                ops.bilinear_bwd(s.grad, feat_a.grad, dcoff=off, c=s.t.shape[3], accumulate=acc)
+                off += s.t.shape[3]
+            feat_a.grad = None
+
+        # ---- both heads down to their first BatchNorm: projector.proj.3 and cls_head
+        if embed and not late:
+            embed_head(d_feat)
         logits = self.tape["cls_head"].out
         dl = ops.softmax_bwd(self._prob, d_prob.contiguous(), tuple(logits.t.shape))
         self._conv_backward("cls_head", dl)
         a4 = self.tape["upBlock4.conv4"].out
         # ---- the two BatchNorm backwards that are ready now share one statistics exchange
-        ks = self._bn_backward_group(([("projector.proj.0", z0.grad)] if embed else []) + [("upBlock4.conv4", a4.grad)])
+        ks = self._bn_backward_group(([("projector.proj.0", self.tape["embed"][1].grad)] if (embed and not late) else [])
+                                     + [("upBlock4.conv4", a4.grad)])
         # ---- rest of the embedding branch: it initialises the skip gradients (gather-form transposes)
-        if embed and "proj0.split" in self.tape:
-            self._proj0_backward(z0.grad, ks.get("projector.proj.0"))
-            z0.grad = None
-        elif embed:
-            self._conv_backward("projector.proj.0", z0.grad, ks.get("projector.proj.0"))
-            z0.grad = None
-            off = 0
-            for s in self.skips:
-                s.grad = torch.empty_like(s.t)
-                ops.bilinear_bwd(s.grad, feat_a.grad, dcoff=off, c=s.t.shape[3])
-                off += s.t.shape[3]
-            feat_a.grad = None
-        else:
+        if embed and not late:
+            embed_rest(ks)
+        elif not embed:
             for n in ("projector.proj.0", "projector.proj.1", "projector.proj.3"):
                 for suffix in ("weight", "bias"):
                     grads[f"{n}.{suffix}"].zero_()
@@ -827,6 +858,9 @@ class Backbone:
         for name in ("upBlock4", "upBlock3", "upBlock2", "upBlock1"):
             self._up_backward(name, ks.get(f"{name}.conv4"))
             done(name)
+        if late:         # the embedding branch behind the decoder: its gradient has had the decoder's backward to arrive
+            embed_head(d_feat_ready())
+            embed_rest({})
         for name in ("resBlock5", "resBlock4", "resBlock3", "resBlock2", "resBlock1"):
             self._res_backward(name)
             done(name)

@@ -136,39 +136,46 @@ class _ContrastFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        st = ctx.state
-        b, h, w, d = st["bhwd"]
-        n = h * w
-        tmax, a = st["tmax"], st["a"]
-        # d(anchor rows, normalised) = dlogits x queue ; then through the l2 normalisation
-        da = ops.gemm_rows(st["dlogits"], st["wq_t"], d)
-        dx = ops.l2norm_bwd(st["anchors"], st["norm"], da)
-        gs = g.reshape(1).to(torch.float32).contiguous()
-        if st["low"] is not None:
-            # gradient of the half-resolution embedding straight from the anchor rows: owner sums in a compact buffer,
-            # then the same gather-form adjoint the dense path runs over a zero-filled [B,H,W,D] tensor
-            low = st["low"]
-            drows, cmap, rowmask = ops.scatter_rows_compact(dx, st["img"], st["idx"], st["T"], tmax, a, n, b, gs)
-            d_low = torch.empty(b, low.shape[2], low.shape[3], d, device=dx.device, dtype=low.dtype)
-            ops.bilinear_bwd_rows(d_low, drows, cmap, rowmask, h, w)
-            return d_low.permute(0, 3, 1, 2), None
-        dfeat = torch.zeros(b, h, w, d, device=dx.device, dtype=torch.float32)
-        # one bit per pixel that received a row: a hint for whoever consumes this (dense, complete) gradient next
-        rowmask = torch.zeros((b * n + 31) // 32, device=dx.device, dtype=torch.int32) if SPARSE_HINT_ON else None
-        ops.scatter_add_rows(dx, st["img"], st["idx"], st["T"], tmax, a, n, dfeat, gs, rowmask=rowmask)
-        if rowmask is not None:
-            _publish_row_hint(dfeat, rowmask)
-        return dfeat.permute(0, 3, 1, 2), None
+        return _contrast_backward(ctx.state, g).permute(0, 3, 1, 2), None
+
+
+def _contrast_backward(st, g):
+    """d(loss * g) / d(feats) as an NHWC tensor: of the half-resolution embedding (``st["low"]``: lazy form) or dense."""
+    b, h, w, d = st["bhwd"]
+    n = h * w
+    tmax, a = st["tmax"], st["a"]
+    # d(anchor rows, normalised) = dlogits x queue ; then through the l2 normalisation
+    da = ops.gemm_rows(st["dlogits"], st["wq_t"], d)
+    dx = ops.l2norm_bwd(st["anchors"], st["norm"], da)
+    gs = g.reshape(1).to(torch.float32).contiguous()
+    if st["low"] is not None:
+        # gradient of the half-resolution embedding straight from the anchor rows: owner sums in a compact buffer,
+        # then the same gather-form adjoint the dense path runs over a zero-filled [B,H,W,D] tensor
+        low = st["low"]
+        drows, cmap, rowmask = ops.scatter_rows_compact(dx, st["img"], st["idx"], st["T"], tmax, a, n, b, gs)
+        d_low = torch.empty(b, low.shape[2], low.shape[3], d, device=dx.device, dtype=low.dtype)
+        ops.bilinear_bwd_rows(d_low, drows, cmap, rowmask, h, w)
+        return d_low
+    dfeat = torch.zeros(b, h, w, d, device=dx.device, dtype=torch.float32)
+    # one bit per pixel that received a row: a hint for whoever consumes this (dense, complete) gradient next
+    rowmask = torch.zeros((b * n + 31) // 32, device=dx.device, dtype=torch.int32) if SPARSE_HINT_ON else None
+    ops.scatter_add_rows(dx, st["img"], st["idx"], st["T"], tmax, a, n, dfeat, gs, rowmask=rowmask)
+    if rowmask is not None:
+        _publish_row_hint(dfeat, rowmask)
+    return dfeat
 
 
 def contrast_mem_loss(feats, prob, labels, keep_mask, proto_queue, temperature=0.1, base_temperature=0.07,
-                      num_anchor=50, ignore_label=0, uniforms=None, perms=None, return_debug=False):
+                      num_anchor=50, ignore_label=0, uniforms=None, perms=None, return_debug=False, explicit_grad_scale=None):
     """feats [B,D,H,W]-shaped (channels-last memory preferred) or a LowResFeat, prob [B,C,H,W]-shaped, labels
     [B,H,W] int64, keep_mask [B,H,W] bool or None, proto_queue [C,M,D].
 
     uniforms: float64 [B*C, A] draws (row t feeds the t-th present (image,class) pair, exactly
     the stream torch.multinomial would consume); perms: int64 [C-1, M] queue row orders.
-    Returns the 0-dim loss (autograd-connected to ``feats``)."""
+    Returns the 0-dim loss (autograd-connected to ``feats``).
+    explicit_grad_scale (a LowResFeat only): no autograd node -- returns (loss, d(explicit_grad_scale * loss) / d(feats.low) as an
+    NHWC tensor), the same kernels the autograd path runs in its backward (coarse3d_amd.trainer.TrainStep hands that
+    gradient to the backbone's backward itself, from a second stream)."""
     b, d, h, w = feats.shape
     c = prob.shape[1]
     n = h * w
@@ -212,6 +219,11 @@ def contrast_mem_loss(feats, prob, labels, keep_mask, proto_queue, temperature=0
     loss, row_loss = ops.infonce_rows(logits, a_cls, t, tmax, a, m, ncols, temperature, base_temperature)
     state = dict(bhwd=(b, h, w, d), low=feats.low if lazy else None, anchors=anchors, norm=norm, dlogits=logits,
                  wq_t=ops.pack_weights(w_q, 1), img=a_img, idx=a_idx, T=t, tmax=tmax, a=a, loss=loss)
+    if explicit_grad_scale is not None:
+        if not lazy or return_debug:
+            raise ValueError("contrast_mem_loss(explicit_grad_scale=...): a LowResFeat embedding, no debug output")
+        gs = torch.full((1,), float(explicit_grad_scale), device=dev, dtype=torch.float32)
+        return loss.reshape(()), _contrast_backward(state, gs)
     out = _ContrastFn.apply(feats.low if lazy else feats, state)
     if return_debug:
         return out, dict(idx=a_idx, img=a_img, cls=a_cls, T=t, row_loss=row_loss, weights=w_anchor, counts=counts,

@@ -22,7 +22,7 @@ class ContrastMEMLoss(nn.Module):
         self.keep_debug = False
         self.last_debug = None
 
-    def forward(self, feats=None, output=None, labels=None, keep_mask=None, proto_queue=None):
+    def forward(self, feats=None, output=None, labels=None, keep_mask=None, proto_queue=None, explicit_grad_scale=None):
         assert proto_queue is not None
         assert output is not None, "entropy weights need the class probabilities"
         assert labels.shape[-1] == feats.shape[-1], "{} {}".format(labels.shape, feats.shape)
@@ -31,7 +31,7 @@ class ContrastMEMLoss(nn.Module):
             print("queue size, max views : ", queue.shape)
         res = contrast.contrast_mem_loss(feats, output, labels, keep_mask, queue, self.temperature,
                                          self.base_temperature, self.num_anchor, self.ignore_label,
-                                         self.uniforms, self.perms, return_debug=self.keep_debug)
+                                         self.uniforms, self.perms, return_debug=self.keep_debug, explicit_grad_scale=explicit_grad_scale)
         if self.keep_debug:
             res, self.last_debug = res
         return res

@@ -38,6 +38,7 @@ def _basic_block(inplanes, planes, bn_d):
 
 
 class RangeNetProto(SalsaNextProto):
+    _late_dfeat_ok = False           # (this backbone's backward has no late embedding branch: coarse3d_amd/backbone.py)
     def __init__(self, layers=21, nclasses=20, dataset="", path=None, path_append="", proj_dim=256, projection="v1",
                  proj_feat="mix", l2_norm=False, proto_mom=0.999, ignore_label=0, sub_proto_size=20,
                  use_prototype=False):

@@ -184,7 +184,21 @@ class _BackboneFn(torch.autograd.Function):
                   else torch.zeros_like(prob))
         d_f = d_feat.permute(0, 2, 3, 1).contiguous() if (ctx.return_feat and d_feat is not None) else None
         bound = model._bound_grad_views(ctx.names)
-        grads = bb.backward(d_prob, d_f, grads=bound if bound is not None else model._grad_buffers(ctx.names))
+        # coarse3d_amd.trainer.TrainStep computes the embedding's gradient itself, on a second stream (the contrast loss is
+        # not in autograd's graph then): (event, NHWC gradient of the half-resolution embedding).  The backbone takes it
+        # behind its decoder blocks (Backbone.backward(d_feat_ready=...)).
+        late, model._late_dfeat = model._late_dfeat, None
+        ready = None
+        if late is not None and ctx.return_feat:
+            # (autograd hands this Function a materialised ZERO gradient for the embedding nobody in its graph read: TrainStep
+            #  kept the contrast loss out of the graph, the gradient is the one it computed)
+            ev, d_low = late
+            d_f = None
+
+            def ready():
+                torch.cuda.current_stream().wait_event(ev)
+                return d_low
+        grads = bb.backward(d_prob, d_f, grads=bound if bound is not None else model._grad_buffers(ctx.names), d_feat_ready=ready)
         ctx.bb = None
         # Without the embedding branch in the graph (contrast warm-up epochs: return_feat=False, trainer.py:625-630; or a
         # loss that never read feat_2d) the reference's projector parameters get NO gradient (autograd leaves .grad at
@@ -347,6 +361,8 @@ class SalsaNextProto(nn.Module):
     _gb = None
     _last_keep = None
     classification = False           # (class-level defaults: the other backbones' constructors do not run this class' __init__)
+    _late_dfeat = None               # (event, gradient): see _BackboneFn.backward
+    _late_dfeat_ok = True            # this class' backbone takes the embedding's gradient behind its decoder blocks
 
     def _graphed_backbone(self):
         if self._gb is None:

@@ -50,6 +50,7 @@ def _basic_block(inplanes, planes, bn_d):
 
 
 class SqueezeSegV3Proto(SalsaNextProto):
+    _late_dfeat_ok = False           # (this backbone's backward has no late embedding branch: coarse3d_amd/backbone.py)
     def __init__(self, nclasses, dataset="SemanticKitti", path=None, path_append="", strict=False, layers=21,
                  proj_dim=256, projection="v1", proj_feat="mix", l2_norm=True, proto_mom=0.999, ignore_label=0,
                  sub_proto_size=20, use_prototype=False, pred_3d=False):

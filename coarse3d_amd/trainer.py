@@ -90,6 +90,16 @@ class TrainStep:
         self.optimizer = optimizer
         self.scheduler = scheduler
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        # Round 5, OFF by default (C3D_OVERLAP_CONTRAST=1 / overlap_contrast = True): pseudo-label selection + contrast loss + its
+        # gradient on a SECOND stream, under the segmentation losses and the decoder's backward; the backbone takes the
+        # embedding's gradient behind its up blocks.  Same kernels, same values: bit-identical to the sequential step
+        # (tests/test_gpu_step.py), and the replayed graph does run the two branches on two queues (tools/trace_overlap.py) --
+        # but the step is not faster (30.71 / 30.80 / 30.85 vs 30.75 / 30.82 / 30.75 ms, same box, alternating): the branch's
+        # ~0.8 ms are HBM-bound streams over the 1M-pixel maps (entropy statistics 22 us alone, 390 us next to the backward's
+        # kernels), not idle latency.  Plain (unwrapped) SalsaNextProto with the rows-on-demand embedding only.
+        self.overlap_contrast = os.environ.get("C3D_OVERLAP_CONTRAST", "0") == "1"
+        self._side2 = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.late_steps = 0          # steps (eager bodies / captures) that took the second-stream form
         # True: the caller guarantees that the label tensors handed to step() are complete in HBM
         # (e.g. delivered by a prefetcher on its own copy stream and synchronised) -- the side
         # stream may then read them without waiting for the main stream.
@@ -177,6 +187,25 @@ class TrainStep:
         pred = out["pred_2d"]
         total = pred.new_zeros(())
         res = {}
+        late_c = None
+        feats_rows = getattr(out, "feat_rows", None) if (self.w_con > 0 and return_feat) else None
+        if (self.overlap_contrast and self._side2 is not None and isinstance(feats_rows, contrast.LowResFeat) and net is self.model
+                and getattr(net, "_late_dfeat_ok", False) and not getattr(net, "graph_backbone", False) and feats_rows.low.requires_grad
+                and not self.contrast.keep_debug and not self.contrast.is_debug):
+            cur = torch.cuda.current_stream()
+            s2 = self._side2
+            s2.wait_stream(cur)
+            with torch.cuda.stream(s2), torch.no_grad():
+                lab_c, mask_c = self._contra_labels(pred, train_label, eval_label, wss_mask, epoch, ratio)
+                loss_c, d_low = self.contrast(feats=feats_rows, output=pred, labels=lab_c, keep_mask=mask_c,
+                                              proto_queue=net.prototypes.detach().unsqueeze(0), explicit_grad_scale=self.w_con)
+                ev = torch.cuda.Event()
+                ev.record(s2)
+            for t_ in (lab_c, mask_c, loss_c, d_low):       # allocated on the second stream, read on this one from here on
+                t_.record_stream(cur)
+            net._late_dfeat = (ev, d_low)
+            late_c = (ev, loss_c, lab_c, mask_c)
+            self.late_steps += 1
         fused = (self.fused_loss_head and lov_valid is not None and self.ignore_cls == 0
                  and (lov_count is not None or loss_head.fused_available(lov_valid.numel())))
         if fused:      # focal + Lovasz forward/backward on the HIP loss-head kernels
@@ -196,16 +225,10 @@ class TrainStep:
             if self.w_lov > 0:
                 res["lov"] = self.lovasz(pred, train_label, valid=lov_valid)
                 total = total + self.w_lov * res["lov"]
-        if self.w_con > 0 and return_feat:
-            if self.entropy_selection:
-                with torch.no_grad():
-                    if ratio is None:       # (captured / shape-static step: the device scalar TrainStep._sync_ratio keeps)
-                        ratio = select_ratio_for(epoch, self.n_epochs)
-                    lab_c, mask_c = contrast.entropy_selection(
-                        pred.detach().permute(0, 2, 3, 1).contiguous(), train_label, eval_label, ratio,
-                        noise=self.pl_noise, ignore_cls=self.ignore_cls)
-            else:
-                lab_c, mask_c = train_label, wss_mask
+        if late_c is not None:
+            res["labels_contra"], res["mask_contra"] = late_c[2], late_c[3]
+        elif self.w_con > 0 and return_feat:
+            lab_c, mask_c = self._contra_labels(pred, train_label, eval_label, wss_mask, epoch, ratio)
             res["labels_contra"], res["mask_contra"] = lab_c, mask_c
             queue = net.prototypes.detach().unsqueeze(0)
             # (the embedding as rows-on-demand where the model offers it: the anchors are interpolated from the
@@ -216,12 +239,27 @@ class TrainStep:
             total = total + self.w_con * res["contrast"]
         self.optimizer.zero_grad(set_to_none=True)
         total.backward()
+        if late_c is not None:
+            net._late_dfeat = None
+            torch.cuda.current_stream().wait_event(late_c[0])       # (the backbone has waited for it already)
+            res["contrast"] = late_c[1]
+            total = total.detach() + self.w_con * late_c[1]
         if hasattr(self.model, "finish_gradients"):
             self.model.finish_gradients()
         self.optimizer.step()
         res["loss"] = total.detach()
         res["pred_2d"] = pred.detach()
         return res
+
+    def _contra_labels(self, pred, train_label, eval_label, wss_mask, epoch, ratio):
+        """Labels / keep mask of the contrast loss: entropy-selected pseudo labels (trainer.py:656-662) or the weak labels."""
+        if not self.entropy_selection:                  # SURVEY appendix C, Q3
+            return train_label, wss_mask
+        with torch.no_grad():
+            if ratio is None:       # (captured / shape-static step: the device scalar TrainStep._sync_ratio keeps)
+                ratio = select_ratio_for(epoch, self.n_epochs)
+            return contrast.entropy_selection(pred.detach().permute(0, 2, 3, 1).contiguous(), train_label, eval_label, ratio,
+                                              noise=self.pl_noise, ignore_cls=self.ignore_cls)
 
     # ------------------------------------------------------------------ captured step
     def _graph_supported(self):

@@ -838,6 +838,43 @@ def test_prototype_sums_exchange_mode():
     assert float((banks["fused"][1] - l2).abs().max()) > 1e-6
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_contrast_branch_on_a_second_stream_changes_nothing(graph):
+    """Round 5: TrainStep runs pseudo-label selection, the contrast loss and its gradient on a SECOND stream, under the
+    segmentation losses and the decoder's backward; the backbone takes the embedding's gradient behind its up blocks
+    (Backbone.backward(d_feat_ready=...)).  Against the sequential step (overlap_contrast = False), launch by launch and
+    captured: losses, pseudo-label maps, every parameter and the prototype bank after four steps, bit for bit."""
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    from coarse3d_amd.trainer import TrainStep
+    b, h, w, ncls = 2, 32, 128, 20
+    batches = [W.synthetic_batch(b, h, w, ncls, 5 + i, 0.02, gh=8, gw=16) for i in range(4)]
+    results = []
+    for overlap in (True, False):
+        torch.manual_seed(3)
+        m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True)
+        m.load_state_dict(W.closed_form_state(nclasses=ncls))
+        m.to(DEV).train()
+        ts = TrainStep(m, ncls, proto_loss=True, lr=1e-3, num_anchor=64, loss_w_contrast=0.5, n_epochs=20, graph=graph,
+                       inputs_resident=True)
+        ts.overlap_contrast = overlap
+        torch.manual_seed(11)
+        out = []
+        for i, (x, tr, ev) in enumerate(batches):
+            res = ts.step(x.to(DEV), tr.to(DEV), ev.to(DEV), epoch=10)
+            out.append((float(res["loss"]), float(res["contrast"]), res["labels_contra"].clone(), res["mask_contra"].clone()))
+        if graph:
+            assert ts._replays >= 1
+        assert (ts.late_steps > 0) == overlap
+        results.append((out, {k: p.detach().clone() for k, p in m.named_parameters()}, m.prototypes.detach().clone()))
+    (o1, p1, b1), (o0, p0, b0) = results
+    for s1, s0 in zip(o1, o0):
+        assert s1[0] == s0[0] and s1[1] == s0[1] and s1[1] > 0
+        assert torch.equal(s1[2], s0[2]) and torch.equal(s1[3], s0[3])
+    for k in p0:
+        assert torch.equal(p1[k], p0[k]), k
+    assert torch.equal(b1, b0)
+
+
 def test_fast_paths_of_the_training_step_change_nothing(monkeypatch):
     """Five shortcuts of TrainStep on a plain model -- param.grad bound to one persistent buffer instead of going through
     AccumulateGrad, the contrast loss' row bitmap letting the bilinear adjoint skip known-zero rows of the dense

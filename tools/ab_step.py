@@ -23,4 +23,5 @@ for s in range(20):
 torch.cuda.synchronize()
 el = (time.perf_counter() - t0) / 20
 tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("C3D_") and v) or "default build"
+tag += f" [late_steps {getattr(ts, 'late_steps', '-')}]"
 print(f"{tag}: {el * 1e3:.3f} ms/step ({B / el:.1f} img/s), loss {float(res['loss']):.6f}", flush=True)
