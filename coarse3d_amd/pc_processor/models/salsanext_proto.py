@@ -198,7 +198,9 @@ class _BackboneFn(torch.autograd.Function):
             def ready():
                 torch.cuda.current_stream().wait_event(ev)
                 return d_low
-        grads = bb.backward(d_prob, d_f, grads=bound if bound is not None else model._grad_buffers(ctx.names), d_feat_ready=ready)
+        gbuf = bound if bound is not None else model._grad_buffers(ctx.names)
+        # (the other backbones' backward passes have no such argument: TrainStep only offers it to this class' own)
+        grads = bb.backward(d_prob, d_f, grads=gbuf, d_feat_ready=ready) if ready is not None else bb.backward(d_prob, d_f, grads=gbuf)
         ctx.bb = None
         # Without the embedding branch in the graph (contrast warm-up epochs: return_feat=False, trainer.py:625-630; or a
         # loss that never read feat_2d) the reference's projector parameters get NO gradient (autograd leaves .grad at

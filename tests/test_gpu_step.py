@@ -861,7 +861,7 @@ def test_contrast_branch_on_a_second_stream_changes_nothing(graph):
         out = []
         for i, (x, tr, ev) in enumerate(batches):
             res = ts.step(x.to(DEV), tr.to(DEV), ev.to(DEV), epoch=10)
-            out.append((float(res["loss"]), float(res["contrast"]), res["labels_contra"].clone(), res["mask_contra"].clone()))
+            out.append((float(res["loss"]), float(res["contrast"].detach()), res["labels_contra"].clone(), res["mask_contra"].clone()))
         if graph:
             assert ts._replays >= 1
         assert (ts.late_steps > 0) == overlap
