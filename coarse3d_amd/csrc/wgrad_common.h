@@ -62,8 +62,9 @@ inline WgCfg c3d_wgrad_cfg(int T, int Cin, int Cout, int planes, int halo = 1) {
 // Producer waves of the wgrad_tr workgroup: eight (two per SIMD, 768 threads) for the three-plane 1x1 instances with small
 // accumulators (ids 1-3), four elsewhere.  c3d_wgrad_desc.variant & 128: four everywhere (the bit-identity test, A/B runs).
 inline int c3d_wgrad_producer_waves(int planes, int id, int variant, int ntaps = 1) {
-  if (planes != 3 || (variant & 128)) return 4;
-  if (id >= 1 && id <= 3) return 8;
+  if ((planes != 3 && planes != 1) || (variant & 128)) return 4;
+  if (id >= 1 && id <= 3) return 8;      // (one plane: the bf16 engine's 1x1 weight gradients are bound by requests in flight alike)
+  if (planes != 3) return 4;
   return (id >= 6 && ntaps == 9) ? 8 : 4;      // nine taps: with the taps split across eight consumer waves (wgrad_tr.hip, NCW)
 }
 

@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
 template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool LEAN_FA = false, int NPW = 4, int NCW = 4>
 int launch_tr(const WgradArgs& a, hipStream_t st) {
   constexpr int NPT = 64 * NPW;
-  static_assert(NPW == 4 || (NP == 3 && ((HALO == 0 && !LEAN_FA && NCW == 4) || (TMAX == 9 && NCW == 8))),
+  static_assert(NPW == 4 || (((NP == 3 || NP == 1) && HALO == 0 && !LEAN_FA && NCW == 4) || (NP == 3 && TMAX == 9 && NCW == 8)),
                 "eight producer waves: the three-plane 1x1 instances, and the nine-tap ones with split consumers");
   constexpr int WK = 4 / (WCI * WCO);
   constexpr int CI = 32 * CI_T * WCI, CO = 32 * CO_T * WCO;
@@ -1168,8 +1168,8 @@ int launch_tr(const WgradArgs& a, hipStream_t st) {
   }
   if constexpr (NP == 1) {
     if (a.x.bf16 && a.dz_bf16 && !a.f_dy) {       // bf16 tensors on both sides: raw stages, four tiles in flight
-      c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, true>>();
-      hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, true>), grid, dim3(512), lds, st, a);
+      c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, true, false, NPW, NCW>>();
+      hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, true, false, NPW, NCW>), grid, dim3(64 * (NCW + NPW)), lds, st, a);
       C3D_CHECK_LAUNCH();
       return 0;
     }
@@ -1187,13 +1187,13 @@ int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
     //                         TMAX CI_T CO_T WCI WCO TRW HALO
     case 0: return launch_tr<NP, 1, 2, 4, 2, 2, 1, 0>(a, st);
     case 1:
-      if constexpr (NP == 3) if (a.npw == 8) return launch_tr<NP, 1, 2, 2, 2, 2, 1, 0, false, 8>(a, st);
+      if constexpr (NP == 3 || NP == 1) if (a.npw == 8) return launch_tr<NP, 1, 2, 2, 2, 2, 1, 0, false, 8>(a, st);
       return launch_tr<NP, 1, 2, 2, 2, 2, 1, 0>(a, st);
     case 2:
-      if constexpr (NP == 3) if (a.npw == 8) return launch_tr<NP, 1, 2, 2, 1, 1, 2, 0, false, 8>(a, st);
+      if constexpr (NP == 3 || NP == 1) if (a.npw == 8) return launch_tr<NP, 1, 2, 2, 1, 1, 2, 0, false, 8>(a, st);
       return launch_tr<NP, 1, 2, 2, 1, 1, 2, 0>(a, st);
     case 3:
-      if constexpr (NP == 3) if (a.npw == 8) return launch_tr<NP, 1, 1, 1, 1, 1, 4, 0, false, 8>(a, st);
+      if constexpr (NP == 3 || NP == 1) if (a.npw == 8) return launch_tr<NP, 1, 1, 1, 1, 1, 4, 0, false, 8>(a, st);
       return launch_tr<NP, 1, 1, 1, 1, 1, 4, 0>(a, st);
     case 4: return halo <= 1 ? launch_tr<NP, 4, 1, 2, 1, 1, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 4, 1, 2, 1, 1, (NP == 1 ? 4 : 2), 2>(a, st);
     case 5: return halo <= 1 ? launch_tr<NP, 4, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 4, 1, 1, 1, 1, 4, 2, NP == 3>(a, st);

@@ -287,6 +287,14 @@ def test_weight_gradient_with_four_raw_tiles_in_flight_equals_the_two_deep_kerne
         ops.conv_wgrad(ops.Source(x.bfloat16(), sc, sh, lrelu=True), dz.bfloat16(), dw16, taps)
         assert torch.equal(dw16, dw32), ((b, h, w), float((dw16 - dw32).abs().max() / dw32.abs().max()))
         assert float(dw32.abs().max()) > 0
+        if k == 1:       # round 5: eight producer waves in the small 1x1 instances; c3d_wgrad_desc.variant & 128 keeps four: same bits
+            dw4 = torch.zeros_like(dw32)
+            ops.WGRAD_VARIANT = 128
+            try:
+                ops.conv_wgrad(ops.Source(x.bfloat16(), sc, sh, lrelu=True), dz.bfloat16(), dw4, taps)
+            finally:
+                ops.WGRAD_VARIANT = 0
+            assert torch.equal(dw4, dw16)
 
 
 @pytest.mark.parametrize("k,dil,pad,srcs,cout,acc", [
