@@ -64,8 +64,8 @@ inline WgCfg c3d_wgrad_cfg(int T, int Cin, int Cout, int planes, int halo = 1) {
 inline int c3d_wgrad_producer_waves(int planes, int id, int variant, int ntaps = 1) {
   if ((planes != 3 && planes != 1) || (variant & 128)) return 4;
   if (id >= 1 && id <= 3) return 8;      // (one plane: the bf16 engine's 1x1 weight gradients are bound by requests in flight alike)
-  if (planes != 3) return 4;
-  return (id >= 6 && ntaps == 9) ? 8 : 4;      // nine taps: with the taps split across eight consumer waves (wgrad_tr.hip, NCW)
+  // nine taps: with the taps split across eight consumer waves (wgrad_tr.hip, NCW); one plane: the 32-cout instance only
+  return (id >= 6 && ntaps == 9 && (planes == 3 || id == 7)) ? 8 : 4;
 }
 
 // wgrad_tr.hip

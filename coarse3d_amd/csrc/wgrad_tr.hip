@@ -201,8 +201,8 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
   constexpr int NPT = 64 * NPW;        // producer threads
   constexpr int NCT = 64 * NCW;        // consumer threads
   constexpr bool SPL = NCW == 8;       // taps split across two consumer waves per SIMD
-  static_assert(NCW == 4 || (NCW == 8 && NPW == 8 && TMAX == 9 && CI_T == 1 && CO_T == 1 && WCI == 1 && NP == 3),
-                "split consumers: the nine-tap instances of the three-plane engine, eight producer waves");
+  static_assert(NCW == 4 || (NCW == 8 && NPW == 8 && TMAX == 9 && CI_T == 1 && CO_T == 1 && WCI == 1 && (NP == 3 || NP == 1)),
+                "split consumers: the nine-tap instances of the three-plane and one-plane engines, eight producer waves");
   static_assert(!RAW || (NP == 1 && !FA), "raw bf16 stages belong to the one-plane engine without the fused apply");
   constexpr int DEPTH = RAW ? 4 : 2;   // tiles the producer waves keep in flight (register sets)
   using SU = std::conditional_t<RAW, u32x2, f32x4>;   // a staged unit in flight: four bf16 as loaded, or four floats
@@ -833,8 +833,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
       ldy[t] = (th && t < 4) ? a.dy[5 + t] : a.dy[t];
       ldx[t] = (th && t < 4) ? a.dx[5 + t] : a.dx[t];
     }
-    constexpr int NQ = 6;
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};      // as below: smallest products first
+    constexpr int NQ = NP == 3 ? 6 : 1;      // (one plane: the one product)
+    constexpr int PA[6] = {NP == 3 ? 1 : 0, NP == 3 ? 2 : 0, 0, NP == 3 ? 1 : 0, 0, 0};      // as below: smallest products first
+    constexpr int PB[6] = {NP == 3 ? 1 : 0, 0, NP == 3 ? 2 : 0, 0, NP == 3 ? 1 : 0, 0};
     auto last_use = [](const int (&pl)[6], int plane) constexpr {
       int l = -1;
       for (int q = 0; q < NQ; ++q)
@@ -1130,7 +1131,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
 template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool LEAN_FA = false, int NPW = 4, int NCW = 4>
 int launch_tr(const WgradArgs& a, hipStream_t st) {
   constexpr int NPT = 64 * NPW;
-  static_assert(NPW == 4 || (((NP == 3 || NP == 1) && HALO == 0 && !LEAN_FA && NCW == 4) || (NP == 3 && TMAX == 9 && NCW == 8)),
+  static_assert(NPW == 4 || (((NP == 3 || NP == 1) && HALO == 0 && !LEAN_FA && NCW == 4) || ((NP == 3 || NP == 1) && TMAX == 9 && NCW == 8)),
                 "eight producer waves: the three-plane 1x1 instances, and the nine-tap ones with split consumers");
   constexpr int WK = 4 / (WCI * WCO);
   constexpr int CI = 32 * CI_T * WCI, CO = 32 * CO_T * WCO;
@@ -1207,10 +1208,11 @@ int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
       // with the BatchNorm backward on load: dy, the stored output and x in flight twice do not fit the 128 registers of a
       // sixteen-wave workgroup even with the per-channel constants in LDS (9-45 spilled registers, every reload a full drain of
       // the loads in flight: 64 -> 64 d2 0.467 -> 0.554 ms); those keep the four + four wave form.
+      // (one plane: its four-row tiles of 64 couts with four raw tiles in flight spill at 128 registers -- the four + four wave form)
       if constexpr (NP == 3) if (a.npw == 8 && a.T == 9 && !a.f_dy) return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 2, 2, 1, false, 8, 8>(a, st) : launch_tr<NP, 9, 1, 1, 1, 2, 2, 2, false, 8, 8>(a, st);
       return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 2>(a, st);
     default:
-      if constexpr (NP == 3) if (a.npw == 8 && a.T == 9 && !a.f_dy) return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, 4, 1, false, 8, 8>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, 4, 2, false, 8, 8>(a, st);
+      if constexpr (NP == 3 || NP == 1) if (a.npw == 8 && a.T == 9 && !a.f_dy) return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, 4, 1, false, 8, 8>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, 4, 2, false, 8, 8>(a, st);
       return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, 4, 2, NP == 3>(a, st);
   }
 }

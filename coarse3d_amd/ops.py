@@ -426,7 +426,7 @@ def _wgrad_kernel_name(ci, co, nt, halo, fused=False, raw=False, h=0):
         lean = bool(fused and x3 and lean_ok and (h + trw - 1) // trw >= 8)
         # c3d_wgrad_producer_waves(): eight producer waves in the small 1x1 instances; unfused nine-tap launches: eight + eight
         # consumer waves with the taps split (launch_tr_id in csrc/wgrad_tr.hip)
-        ncw = 8 if (x3 and nt == 9 and not fused and not (WGRAD_VARIANT & 128)) else 4
+        ncw = 8 if (nt == 9 and not fused and not (WGRAD_VARIANT & 128) and (x3 or co <= 32)) else 4
         npw = 8 if (ncw == 8 or (nt == 1 and not cfg.startswith("1, 2, 4") and not (WGRAD_VARIANT & 128))) else 4
         return (f"wgrad_tr_kernel<{3 if MFMA_MODE == 2 else 1}, {cfg}, {'true' if fused else 'false'}, "
                 f"{'true' if (raw and MFMA_MODE == 1 and not fused) else 'false'}, {'true' if lean else 'false'}, {npw}, {ncw}>")

@@ -267,7 +267,8 @@ def test_bf16_output_stores_match_the_fp32_output_of_the_same_kernel(k, dil, src
         assert torch.equal(o16[..., :16].float(), o0[..., :16])                     # nothing written beside the slice
 
 
-@pytest.mark.parametrize("k,dil,pad,cin,cout", [(1, 1, 0, 64, 64), (3, 2, 2, 32, 64), (2, 2, 1, 64, 64), (1, 1, 0, 192, 256)])
+@pytest.mark.parametrize("k,dil,pad,cin,cout", [(1, 1, 0, 64, 64), (3, 2, 2, 32, 64), (2, 2, 1, 64, 64), (1, 1, 0, 192, 256), (3, 1, 1, 32, 32),
+                                                (3, 2, 2, 64, 32)])
 def test_weight_gradient_with_four_raw_tiles_in_flight_equals_the_two_deep_kernel(k, dil, pad, cin, cout):
     """bf16 tensors on both sides: wgrad_tr_kernel<1, ..., RAW = true> (round 4: the staged units stay the 8 bytes they are loaded
     as, four tiles in flight).  fp32 tensors holding the same bf16 values take the two-deep kernel, which rounds them to the same
@@ -287,7 +288,8 @@ def test_weight_gradient_with_four_raw_tiles_in_flight_equals_the_two_deep_kerne
         ops.conv_wgrad(ops.Source(x.bfloat16(), sc, sh, lrelu=True), dz.bfloat16(), dw16, taps)
         assert torch.equal(dw16, dw32), ((b, h, w), float((dw16 - dw32).abs().max() / dw32.abs().max()))
         assert float(dw32.abs().max()) > 0
-        if k == 1:       # round 5: eight producer waves in the small 1x1 instances; c3d_wgrad_desc.variant & 128 keeps four: same bits
+        if k in (1, 3):  # round 5: eight producer waves in the small 1x1 instances (and, nine taps onto <= 32 couts, eight + eight waves with the
+            # taps split across the consumers); c3d_wgrad_desc.variant & 128 keeps four + four: same bits
             dw4 = torch.zeros_like(dw32)
             ops.WGRAD_VARIANT = 128
             try:

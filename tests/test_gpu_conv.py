@@ -274,7 +274,7 @@ def test_weight_gradient_long_strips(mode, B, H, W, Cin, Cout, k, dil, pad):
         dw = torch.zeros(Cout, Cin, k, k, device=dev)
         ops.conv_wgrad(ops.Source(x, sc, sh, lrelu=True), dz, dw, taps)
         torch.cuda.synchronize()
-        if (k in (1, 3) and mode == "bf16x3") or (k == 1 and mode == "bf16"):
+        if k in (1, 3) and mode in ("bf16x3", "bf16"):
             # the library's forms with eight producer waves (1x1) / eight + eight waves with the taps split across the consumers
             # (nine taps, unfused) against the four + four wave form: the same LDS image, the same accumulation order, the same bits
             dw4 = torch.zeros_like(dw)
