@@ -12,6 +12,7 @@ lives in device memory), so a captured data-parallel step keeps only the gradien
 One process per GPU, all ranks on one node (IPC), at most ``C3D_PEER_MAX_RANKS`` = 8 of them.  Any transport works for the
 control plane (nccl, gloo); two ranks may share one device (tests/test_gpu_dp.py runs exactly that on the one-GPU box)."""
 import ctypes as C
+import os
 import socket
 
 import torch
@@ -70,6 +71,10 @@ class PeerExchange:
             errs = [f"the ranks run on different hosts ({sorted({i[0] for i in infos})}): IPC needs one node"]
         # every rank on one device (the one-GPU test box; world == 1): no system-scope fences around the write-through payload
         self.desc.one_device = int(len({i[3] for i in infos}) == 1)
+        if os.environ.get("C3D_PEER_FORCE_FENCES") == "1":
+            # test hook: ranks that share one device take the multi-device form of the kernels (system-scope release / acquire
+            # fences around the payload) -- the code path a node with several GPUs runs, exercised on a one-GPU box
+            self.desc.one_device = 0
         if not errs:
             try:
                 for r, (_, h, _, _) in enumerate(infos):

@@ -164,6 +164,40 @@ def _peer_worker(rank, world, port, q, skip_last):
     dist.destroy_process_group()
 
 
+def test_two_ranks_with_the_multi_device_form_of_the_exchange_kernels():
+    """Across GPUs the exchange kernels put system-scope release / acquire fences around their payload (c3d_peer_desc.one_device
+    = 0); two ranks that share a device leave them out.  No multi-GPU node has run this code yet: C3D_PEER_FORCE_FENCES=1 makes
+    the two ranks on this box's one GPU take that form -- exchange alone and the fused BatchNorm launches -- and the step must
+    come out as with the one-device form, bit for bit."""
+    b, h, w, ncls = 2, 32, 64, 20
+    ctx = mp.get_context("spawn")
+    out = {}
+    prev = os.environ.get("C3D_PEER_FORCE_FENCES")
+    try:
+        for i, mode in enumerate(("1", "0")):
+            os.environ["C3D_PEER_FORCE_FENCES"] = mode
+            q = ctx.Queue()
+            port = 29350 + os.getpid() % 400 + 13 * i
+            procs = [ctx.Process(target=_run, args=(r, 2, port, q, b, h, w, ncls)) for r in range(2)]
+            for pr in procs:
+                pr.start()
+            out[mode] = dict(q.get(timeout=300) for _ in range(2))
+            for pr in procs:
+                pr.join(60)
+                assert pr.exitcode == 0
+    finally:
+        if prev is None:
+            os.environ.pop("C3D_PEER_FORCE_FENCES", None)
+        else:
+            os.environ["C3D_PEER_FORCE_FENCES"] = prev
+    for r in range(2):
+        fenced, plain = out["1"][r], out["0"][r]
+        assert fenced["peer_calls"] == plain["peer_calls"] >= 40
+        assert (fenced["pred"] == plain["pred"]).all() and (fenced["rm"] == plain["rm"]).all() and (fenced["protos"] == plain["protos"]).all()
+        for k in plain["grads"]:
+            assert (fenced["grads"][k] == plain["grads"][k]).all(), k
+
+
 def test_syncbn_in_one_launch_per_layer_has_the_bits_of_the_three_launch_path():
     """Round 5: under the peer-memory exchange a BatchNorm layer's statistics take ONE launch per direction -- fold of the
     partials, exchange, finalize / coefficients (csrc/peer_ops.hip: peer_bn_forward_kernel, peer_bn_backward_kernel) -- instead
