@@ -64,7 +64,12 @@ class PeerExchange:
         except Exception as e:      # noqa: BLE001 -- the other ranks must learn about it below
             err = f"rank {self.rank}: {e}"
         props = torch.cuda.get_device_properties(torch.cuda.current_device())
-        dev_id = (getattr(props, "uuid", None) and str(props.uuid)) or getattr(props, "pci_bus_id", None) or torch.cuda.current_device()
+        # which physical device: its UUID (or PCI address).  A device INDEX says nothing when every rank sees only its own GPU, so
+        # without either the ranks count as being on different devices (the conservative, fenced form of the kernels)
+        dev_id = ((getattr(props, "uuid", None) and str(props.uuid))
+                  or (getattr(props, "pci_bus_id", None) is not None
+                      and f"pci {getattr(props, 'pci_domain_id', 0)}:{props.pci_bus_id}:{getattr(props, 'pci_device_id', 0)}")
+                  or f"unknown device of rank {self.rank}")
         infos = self._gather((socket.gethostname(), bytes(handle), err, str(dev_id)))
         errs = [i[2] for i in infos if i[2]]
         if not errs and len({i[0] for i in infos}) != 1:
