@@ -376,6 +376,7 @@ class Bench:
         from coarse3d_amd import dist as D
         from coarse3d_amd import ops
         model, ts = self.build(graph, wgrad_stream, graph_backbone)
+        completed = False
         try:
             if graph:
                 warmup = max(warmup, 3)            # two eager steps + the capture
@@ -461,12 +462,17 @@ class Bench:
             out["n_ranks"] = n_ranks
             out["value"] = round(self.wl["batch"] * n_ranks * steps / elapsed, 3)
             out["ms_per_step"] = round(elapsed / steps * 1e3, 3)
+            completed = True
             return out
         finally:
             D.EXPOSED = None
             ops.KERNEL_EVENTS = None
             ops.KERNEL_EVENT_FILTER = None
             self.done()
+            if self.dp and completed and hasattr(ts.model, "close"):
+                # the peer mailboxes: unmapped everywhere before anybody frees (collective -- only behind a pass every rank has
+                # finished; a pass that raised leaves each rank to free on its own: no barrier inside error handling)
+                ts.model.close()
             del ts, model
             torch.cuda.empty_cache()
 

@@ -310,6 +310,13 @@ class DataParallel(torch.nn.Module):
             for b in module.buffers():
                 dist.broadcast(b.data, 0)
 
+    def close(self):
+        """Collective: release the peer mailboxes (every rank, same point); the module goes back to rank-local statistics
+        hooks only if wrapped again.  Dropping the wrapper without it is fine too (each rank then frees on its own)."""
+        if self.peer is not None:
+            self.peer.close(collective=True)
+            self.peer = None
+
     def forward(self, *a, **k):
         self.flat.begin()
         return self.module(*a, **k)

@@ -214,13 +214,17 @@ class PeerExchange:
                                "(a rank died, or the ranks' call sequences diverged); results since then are invalid")
         return calls.value
 
-    def close(self):
+    def close(self, collective=False):
+        """Unmap the peers' mailboxes, free the own one.  ``collective`` (every rank calls it at the same point, the process
+        group is alive): a barrier in between, so that no rank frees a mailbox another rank still has mapped."""
         lib = L.lib()
+        torch.cuda.synchronize()
         for p in self._mapped:
             lib.c3d_peer_close(C.c_void_p(p))
         self._mapped = []
+        if collective and self.world > 1 and dist.is_available() and dist.is_initialized():
+            dist.barrier(group=self.group)
         if self._own is not None:
-            torch.cuda.synchronize()
             lib.c3d_peer_free(C.c_void_p(self._own))
             self._own = None
 
