@@ -1199,8 +1199,15 @@ int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
     case 4: return halo <= 1 ? launch_tr<NP, 4, 1, 2, 1, 1, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 4, 1, 2, 1, 1, (NP == 1 ? 4 : 2), 2>(a, st);
     case 5: return halo <= 1 ? launch_tr<NP, 4, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 4, 1, 1, 1, 1, 4, 2, NP == 3>(a, st);
     case 8:
-      if constexpr (NP >= 2) return halo <= 1 ? launch_tr<NP, 4, 1, 2, 2, 1, 2, 1, NP == 3>(a, st) : launch_tr<NP, 4, 1, 2, 2, 1, 2, 2, NP == 3>(a, st);
-      else return -1;
+      // (halo <= 1 only: c3d_wgrad_cfg never hands this slice a two-pixel halo -- its two tile buffers would exceed the LDS; the
+      //  instances that existed for it until round 5 were dead code, and the library's worst spillers)
+      if constexpr (NP >= 2) {
+        if (halo <= 1) return launch_tr<NP, 4, 1, 2, 2, 1, 2, 1, NP == 3>(a, st);
+        c3d_set_error("wgrad: the 64 x 64 four-tap slice has no two-pixel-halo form (c3d_wgrad_cfg)");
+        return 1;
+      } else {
+        return -1;
+      }
     case 6:
       // Nine taps, unfused (every weight gradient of a data-parallel step, whose BatchNorm backward is a pass of its own): taps split
       // across eight consumer waves + eight producer waves (NCW at the kernel).  Measured at 8 x 64 x 2048 / 32 x 1024 / 16 x 512:

@@ -30,9 +30,8 @@ ALLOWED = {
     # the BatchNorm-backward epilogue over bf16 tensors: built, measured slower, off by default (C3D_FUSE_BN_REDUCE_BF16)
     r"conv_bfp_kernel<8, 2, \d+, \d, \d, 1, true, true>": "stat_mul instances of the bf16 engine (off)",
     r"conv_x3f_kernel<2, [12], 9, true, 1, true, true>": "stat_mul instances of the bf16 engine (off)",
-    # weight gradients: instances the launcher never picks (kept for c3d_wgrad_desc.variant / a two-pixel halo that the 64 x 64
-    # slice does not support), and the whole-window fused forms that short columns (< 8 tiles) still take
-    r"wgrad_tr_kernel<[23], 4, 1, 2, 2, 1, 2, 2, (true|false), false, false, 4, 4>": "64 x 64 four-tap slice with a two-pixel halo: never selected (c3d_wgrad_cfg)",
+    # weight gradients: an instance the launcher only picks for c3d_wgrad_desc.variant, and the whole-window fused forms that
+    # short columns (< 8 tiles) still take
     r"wgrad_tr_kernel<3, 1, 2, 4, 2, 2, 1, 0, true, false, false, 4, 4>": "fused 128 x 256 slice: variant & 4 only (the launcher takes 128 x 128)",
     r"wgrad_tr_kernel<3, 4, 1, 1, 1, 1, 4, 2, true, false, false, 4, 4>": "whole-window fused form: columns of < 8 tiles / variant 1",
     r"wgrad_tr_kernel<3, 4, 1, 2, 2, 1, 2, 1, true, false, false, 4, 4>": "whole-window fused form: columns of < 8 tiles / variant 1",
