@@ -17,6 +17,7 @@ Parameter tensors are taken by *reference-compatible names* (``downCntx.conv1.we
 in OIHW layout, gradients are produced in the same layout.
 """
 import contextlib
+import weakref
 import os
 from collections import OrderedDict
 
@@ -53,7 +54,9 @@ class Act:
         self.grad = None      # gradient w.r.t. the affine-transformed value (NHWC, same shape)
         self.mask = mask      # Dropout2d multiplier [B,C] applied by the consumer (UpBlock out)
         self.no_grad = False  # True: nothing upstream needs d(loss)/d(this) (network input, detached skips)
-        self.producer = None        # the conv record whose output this is
+        self.producer = None        # weakref to the conv record whose output this is (the tape holds the record: a strong
+                                    # reference here made record <-> activation cycles, and EVERY activation of a launch-by-launch
+                                    # step waited for Python's cyclic collector -- 285 GB after a few dozen full-size steps)
         self.first_consumer = None  # name of the first conv (forward order) that reads it = the LAST one to add to its gradient
         self.bwd_partial = None     # (sum dy, sum dy*a) partials taken in the epilogue of that last input-gradient launch
         self.bn_alias = None        # a residual sum x + BN(a): the Act of a -- its gradient IS the gradient at that BatchNorm's output
@@ -64,7 +67,7 @@ class Act:
 
 class _ConvRec:
     __slots__ = ("name", "srcs", "src_lrelu", "taps", "cout", "mode", "bn", "out", "stats", "slope", "weight",
-                 "dweight")
+                 "dweight", "__weakref__")
 
 
 class _BNRec:
@@ -205,7 +208,7 @@ class Backbone:
         else:
             rec.bn = self._bn_forward(bn, partial, cout, b * h * wd, bn_momentum) if bn is not None else None
             rec.out = Act(y, rec.bn.scale if rec.bn else None, rec.bn.shift if rec.bn else None)
-        rec.out.producer = rec
+        rec.out.producer = weakref.ref(rec)
         self.tape[name] = rec
         return rec.out
 
@@ -660,7 +663,7 @@ class Backbone:
                 part = None
                 # (a residual sum x + BN(a) passes its gradient on unchanged: the same sums, multiplied with a, for that layer)
                 tgt = s if s.bn_alias is None else s.bn_alias
-                p_ = tgt.producer
+                p_ = tgt.producer() if tgt.producer is not None else None
                 # (round 5: the bf16 engine too, over bf16 tensors -- its BatchNorm-backward reduce pass was the second
                 #  largest kernel of BASELINE configs[2]; kernels without the epilogue answer part = None)
                 if (FUSE_BN_REDUCE and (ops.MFMA_MODE == 2 or (ops.MFMA_MODE == 1 and FUSE_BN_REDUCE_BF16)) and self.train

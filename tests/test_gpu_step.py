@@ -838,6 +838,50 @@ def test_prototype_sums_exchange_mode():
     assert float((banks["fused"][1] - l2).abs().max()) > 1e-6
 
 
+@pytest.mark.parametrize("api", ["trainstep", "module"])
+def test_launch_by_launch_steps_do_not_wait_for_the_cyclic_collector(api):
+    """Every activation of a step hangs off the backward plan's tape.  Round 5 found a reference cycle there (conv record <->
+    its output activation): nothing of a launch-by-launch step was freed until Python's CYCLIC collector happened to run, and a
+    few dozen full-size steps filled 288 GB (tools/step_soak.py eager).  With the collector switched off the footprint after
+    every step must be the footprint after the first -- through TrainStep and through the plain module API."""
+    import gc
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    from coarse3d_amd.trainer import TrainStep
+    b, h, w, ncls = 2, 32, 256, 20
+    x, tr, ev = W.synthetic_batch(b, h, w, ncls, 5, 0.02, gh=8, gw=16)
+    x, tr, ev = x.to(DEV), tr.to(DEV), ev.to(DEV)
+    torch.manual_seed(3)
+    m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True).to(DEV).train()
+    if api == "trainstep":
+        ts = TrainStep(m, ncls, proto_loss=True, lr=1e-3, num_anchor=64, loss_w_contrast=0.5, n_epochs=20, graph=False, inputs_resident=True)
+        step = lambda: ts.step(x, tr, ev, epoch=10)["loss"]           # noqa: E731
+    else:
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            out = m(x, label=tr, eval_mask=tr > 0, return_feat=True, proto_loss=True)
+            loss = out["pred_2d"].mean() + out["feat_2d"].mean()
+            loss.backward()
+            opt.step()
+            return loss
+    for _ in range(3):
+        step()
+    gc.collect()
+    torch.cuda.synchronize()
+    gc.disable()
+    try:
+        seen = []
+        for _ in range(6):
+            loss = step()
+            del loss
+            torch.cuda.synchronize()
+            seen.append(torch.cuda.memory_allocated())
+    finally:
+        gc.enable()
+    assert max(seen) - min(seen) <= (1 << 20), [round(v / 2**20, 1) for v in seen]
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_contrast_branch_on_a_second_stream_changes_nothing(graph):
     """Round 5: TrainStep runs pseudo-label selection, the contrast loss and its gradient on a SECOND stream, under the
