@@ -882,6 +882,18 @@ def test_launch_by_launch_steps_do_not_wait_for_the_cyclic_collector(api):
     assert max(seen) - min(seen) <= (1 << 20), [round(v / 2**20, 1) for v in seen]
 
 
+def test_no_usage_mode_holds_its_activations_in_a_reference_cycle():
+    """tools/footprint_modes.py: TrainStep launch by launch / captured, the module API with and without the graphed backbone,
+    eval forwards, a training-mode forward whose graph is dropped, RangeNet and SqueezeSegV3 -- the allocator footprint after
+    every step with Python's cyclic collector off."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "footprint_modes.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1500:])
+    assert r.stdout.count("FLAT") == 8 and "GROWS" not in r.stdout, r.stdout
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_contrast_branch_on_a_second_stream_changes_nothing(graph):
     """Round 5: TrainStep runs pseudo-label selection, the contrast loss and its gradient on a SECOND stream, under the
