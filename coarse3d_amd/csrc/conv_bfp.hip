@@ -324,6 +324,7 @@ int launch_bfp(ConvArgs& a, hipStream_t st) {
   if constexpr (BFS) {
     if (a.stat_mul && a.stat_partial) {      // BatchNorm-backward sums in the epilogue: the instance that has it
       if (lds < (size_t)TR * 32 * (32 * NT + 8) * 2) lds = (size_t)TR * 32 * (32 * NT + 8) * 2;      // the multiplier tile of the epilogue
+      a.lds_bytes = (unsigned)lds;
       c3d_opt_in_lds<&conv_bfp_kernel<TR, NT, CK, HALO, TT, NP, BFS, true>>();
       hipLaunchKernelGGL((conv_bfp_kernel<TR, NT, CK, HALO, TT, NP, BFS, true>), grid, dim3(256), lds, st, a);
       C3D_CHECK_LAUNCH();

@@ -30,6 +30,8 @@ struct ConvArgs {
   bool one_plane = false;  // conv_x3.hip: the bf16 engine's fused nine-tap kernel (one plane, bf16 tensors)
   bool f16x2 = false;      // EXPERIMENT (mfma_bf16 == 4): two fp16 planes / three products where a kernel has the variant
   const float* acc_scale_dev = nullptr;   // times this device scalar, if any (per-tensor gradient exponent)
+  unsigned lds_bytes = 0;  // dynamic LDS of THIS launch, set by the launchers whose kernels stage the epilogue's multiplier tile there
+                           // (conv_epilogue only stages when the tile fits: 0 = never, the per-element loads take over)
   float acc_scale = 1.f;   // the accumulators are multiplied by this before bias / activation (1: fma(acc, 1, bias) == acc + bias);
                            // the f16x2 experiment stages its operands times 2^6 / 2^10 and hands 2^-16 back here
 };
@@ -91,7 +93,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
   unsigned short* s_mul = reinterpret_cast<unsigned short*>(smem);
   bool stage_mul = false;
   if constexpr (STATMUL && BF16_OUT) {
-    stage_mul = mulp != nullptr && mbf && full_pix && n0 + TN <= a.Cout && (a.stat_mul_cs & 7) == 0;     // workgroup-uniform
+    // (the tile lands in the K loop's dynamic LDS: only if THIS launch allocated enough of it -- the launcher says how much)
+    stage_mul = mulp != nullptr && mbf && full_pix && n0 + TN <= a.Cout && (a.stat_mul_cs & 7) == 0 &&
+                a.lds_bytes >= (unsigned)(TR * 32 * MROW * 2);     // workgroup-uniform
     if (stage_mul) {
       __syncthreads();                               // every wave is done with the K loop's buffers
       constexpr int UPP = TN / 8;                    // 16-byte units per pixel

@@ -789,6 +789,7 @@ int launch_pw1(ConvArgs& a, hipStream_t st) {
   // four sub-tiles per wave end up in scratch, 4 326 scratch instructions -- c3d_conv_stat_mul_supported() answers 0 there)
   if constexpr (NT == 4) if (a.stat_mul && a.stat_partial) {
     if (lds < (size_t)8 * 32 * (32 * NT + 8) * 2) lds = (size_t)8 * 32 * (32 * NT + 8) * 2;      // the multiplier tile of the epilogue
+    a.lds_bytes = (unsigned)lds;
     c3d_opt_in_lds<&conv_pw1_kernel<NT, true>>();
     hipLaunchKernelGGL((conv_pw1_kernel<NT, true>), grid, dim3(512), lds, st, a);
     C3D_CHECK_LAUNCH();

@@ -724,6 +724,7 @@ int launch_x3f_s(ConvArgs& a, hipStream_t st) {
   if constexpr (BFS) {
     if (a.stat_mul && a.stat_partial) {      // BatchNorm-backward sums in the epilogue: the instance that has it
       if (lds < (size_t)8 * 32 * (32 * NT + 8) * 2) lds = (size_t)8 * 32 * (32 * NT + 8) * 2;      // the multiplier tile of the epilogue
+      a.lds_bytes = (unsigned)lds;
       c3d_opt_in_lds<&conv_x3f_kernel<NT, HALO, TT, SIX, NPL, BFS, true>>();
       hipLaunchKernelGGL((conv_x3f_kernel<NT, HALO, TT, SIX, NPL, BFS, true>), grid, dim3(256), lds, st, a);
       C3D_CHECK_LAUNCH();

@@ -189,7 +189,14 @@ class FlatGradients:
         self.names = [n for n, _ in named]
         total = sum(p.numel() for _, p in named)
         dev = device if device is not None else named[0][1].device
-        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        # one element behind the gradients: the health word of the step (0 = fine).  It travels with the LAST gradient bucket,
+        # so every rank learns of any rank's failed SyncBatchNorm exchange from an all-reduce the step makes anyway -- no extra
+        # collective (DataParallel.watch_status / check_status).  ``flat`` -- what the optimiser and everybody else sees -- is
+        # the gradients alone.
+        self._storage = torch.zeros(total + 1, device=dev, dtype=torch.float32)
+        self.flat = self._storage[:total]
+        self.status = self._storage[total:]
+        self.status_src = None        # callable(dst: fp32[1]) writing this rank's health word on the current stream, or None
         self.views, off = {}, 0
         self.block_end = {}           # block tag -> end offset of its parameters in the flat buffer
         for n, p in named:
@@ -229,6 +236,10 @@ class FlatGradients:
         if end <= self._sent:
             return
         seg = self.flat[self._sent:end]
+        if end == self.flat.numel():
+            if self.status_src is not None:
+                self.status_src(self.status)
+            seg = self._storage[self._sent:end + 1]       # ... + the health word: mean over ranks, > 0 = some rank failed
         seg.div_(dist.get_world_size())
         self._works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
         self.collectives += 1
@@ -270,21 +281,32 @@ class DataParallel(torch.nn.Module):
     backward); ``finish_gradients()`` waits for them and re-binds ``param.grad`` to the
     reduced flat views."""
 
-    def __init__(self, module, sync_bn=True, proto_sync="bank_mean", syncbn_exchange="auto"):
+    STATUS_LAG = 2      # a step's health word is checked this many steps later (its copy has long arrived: no stall)
+
+    def __init__(self, module, sync_bn=True, proto_sync="bank_mean", syncbn_exchange="auto", peer_timeout_s=None):
         """proto_sync: "bank_mean" = reference semantics (mean over ranks of each rank's updated,
         l2-normalised bank, salsanext_proto.py:397-400); "sums" = all-reduce the per-class masked
         feature sums and counts and apply ONE momentum update with the global statistics (what a
         single process on the global batch would compute, up to the per-rank Sinkhorn).
-        syncbn_exchange: how the 43 + 43 fp64 statistics vectors of a step travel.  "peer" = IPC-mapped mailboxes, one
-        small kernel per exchange (coarse3d_amd/peer.py; one node, <= 8 ranks); "collective" = one torch.distributed
-        all-reduce each (RCCL / gloo); "auto" (default; C3D_SYNCBN_EXCHANGE overrides) = "peer" when the model lives on
-        a GPU and every rank could set its mailboxes up, else "collective" -- decided together, the ranks never split."""
+        syncbn_exchange: how the 43 + 43 fp64 statistics vectors of a step travel (C3D_SYNCBN_EXCHANGE overrides).
+        "collective" = one torch.distributed all-reduce each (RCCL / gloo).  "peer" = IPC-mapped mailboxes, one small
+        kernel per exchange (coarse3d_amd/peer.py; one node, <= 8 ranks); raises if they cannot be set up.  "try_peer" =
+        "peer" when every rank could set its mailboxes up and the self-test exchanges held, else "collective" -- decided
+        together, the ranks never split (bench.py runs this one, behind its own consensus check and fallback).  "auto"
+        (default) = "try_peer" ONLY in the placements whose kernels have run on hardware -- a 1-rank group, or every rank on
+        one device (the fence-free form) -- and "collective" for ranks on different GPUs: the fenced cross-device form of
+        the exchange kernels has not met an xGMI link yet, and a library default must not be the first run.
+        peer_timeout_s: how long an exchange waits for a peer (default: C3D_PEER_TIMEOUT_S or 600 s -- the order of the
+        process-group timeout of the collective it replaces; coarse3d_amd/peer.py).
+        A failed exchange does not go unnoticed: its results are NaN, and the rank's status word travels with the last
+        gradient bucket of every step, so ``finish_gradients()`` / ``TrainStep`` raise on EVERY rank, at the same step,
+        ``STATUS_LAG`` steps later at most (``check_status(final=True)`` / ``TrainStep.flush()``: at once)."""
         super().__init__()
         if proto_sync not in ("bank_mean", "sums"):
             raise ValueError(f"proto_sync must be 'bank_mean' or 'sums', got {proto_sync!r}")
         syncbn_exchange = os.environ.get("C3D_SYNCBN_EXCHANGE", syncbn_exchange)
-        if syncbn_exchange not in ("auto", "peer", "collective"):
-            raise ValueError(f"syncbn_exchange must be 'auto', 'peer' or 'collective', got {syncbn_exchange!r}")
+        if syncbn_exchange not in ("auto", "peer", "try_peer", "collective"):
+            raise ValueError(f"syncbn_exchange must be 'auto', 'peer', 'try_peer' or 'collective', got {syncbn_exchange!r}")
         self.module = module
         world = dist.get_world_size() if is_dist() else 1
         module._world = world if sync_bn else 1
@@ -294,7 +316,8 @@ class DataParallel(torch.nn.Module):
         if module._bn_reduce is not None and syncbn_exchange != "collective" and (on_gpu or syncbn_exchange == "peer"):
             from .peer import PeerExchange
             try:
-                self.peer = PeerExchange()          # collective: raises on every rank or on none
+                # collective: raises on every rank or on none
+                self.peer = PeerExchange(timeout_s=peer_timeout_s, only_one_device=(syncbn_exchange == "auto"))
                 module._bn_reduce = peer_syncbn_reduce(self.peer)
             except RuntimeError:
                 if syncbn_exchange == "peer":
@@ -302,6 +325,11 @@ class DataParallel(torch.nn.Module):
         module._proto_mean = world_mean if (is_dist() and proto_sync == "bank_mean") else None
         module._proto_sums_reduce = allreduce_proto_sums_ if (is_dist() and proto_sync == "sums") else None
         self.flat = FlatGradients(module._trainable())
+        if self.peer is not None:
+            self.flat.status_src = self.peer.status_to
+        self._status_ring = []            # (step, event, slot) of the health words on their way to the host
+        self._status_host = None
+        self._steps = 0
         module._flat_grads = self.flat.views
         module._block_done = self.flat.block_done
         if is_dist():                      # identical initial weights on every rank
@@ -321,8 +349,44 @@ class DataParallel(torch.nn.Module):
         self.flat.begin()
         return self.module(*a, **k)
 
+    def watch_status(self):
+        """Queue an asynchronous read-back of this step's health word (FlatGradients.status after the last bucket: the mean
+        over ranks of the ranks' peer-exchange status words) and check the one of ``STATUS_LAG`` steps ago -- the same step on
+        every rank, so the ranks raise together instead of one of them leaving the others in a collective.  Called by
+        ``finish_gradients()``; a captured step cannot (host code does not replay): ``TrainStep`` calls it after each replay."""
+        if self.flat.status_src is None or not self.flat.status.is_cuda:
+            return
+        if self._status_host is None:
+            self._status_host = torch.zeros(8, dtype=torch.float32).pin_memory()
+        self._steps += 1
+        slot = self._steps % 8
+        self._status_host[slot:slot + 1].copy_(self.flat.status, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._status_ring.append((self._steps, ev, slot))
+        self.check_status()
+
+    def check_status(self, final=False):
+        """Raises RuntimeError if the health word of a step says that some rank's SyncBatchNorm exchange through peer memory
+        failed (timed out).  ``final``: every queued step (synchronises) -- before a checkpoint, at the end of an epoch."""
+        while self._status_ring and (final or self._status_ring[0][0] <= self._steps - self.STATUS_LAG):
+            step, ev, slot = self._status_ring.pop(0)
+            ev.synchronize()
+            if float(self._status_host[slot]) != 0.0:      # (NaN included)
+                self._status_ring = []
+                raise RuntimeError(
+                    f"coarse3d_amd.dist.DataParallel: a SyncBatchNorm exchange through peer memory failed on at least one rank in "
+                    f"data-parallel step {step} (a peer did not arrive within the exchange timeout: a rank died, stalled longer "
+                    f"than C3D_PEER_TIMEOUT_S, or the ranks' call sequences diverged).  The statistics of that step and "
+                    f"everything computed since are invalid (NaN by construction) on every rank: restore the last checkpoint; "
+                    f"C3D_SYNCBN_EXCHANGE=collective takes the mailboxes out of the picture")
+        if final and self.peer is not None and self.flat.status_src is not None and self.peer.failed():
+            raise RuntimeError("coarse3d_amd.dist.DataParallel: this rank's peer-memory exchange reports a timeout (status word set)")
+
     def finish_gradients(self):
         self.flat.finish()
+        if not (self.flat.flat.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self.watch_status()
         live = getattr(self.module, "_grads_live", True)
         for n, p in self.module._trainable():      # autograd may have cloned the views
             # (no embedding branch in this step -- contrast warm-up --: the projector has no gradient, on any rank)

@@ -157,13 +157,16 @@ class GraphedBackbone:
             ent.sdprob.zero_()
         else:
             ent.sdprob.copy_(d_prob_nhwc)
-        live = True
+        # the rule of the launch-by-launch path (Backbone.embed_ran): the projector's parameters have a gradient only if the
+        # embedding branch is in this graph (return_feat) AND somebody read feat_2d.  With return_feat=False -- the contrast
+        # warm-up epochs, trainer.py:625-630 -- the graph has no embedding branch and projector.* must stay at grad None
+        # (AdamW then skips them: no weight decay, no step count), as under the reference
+        live = bool(ent.embed) and ent.sdfeat is not None and d_feat_nhwc is not None
         if ent.sdfeat is not None:
             if d_feat_nhwc is None:
                 # nobody read feat_2d: the reference's projector then has NO gradient (None, AdamW skips it).  The graph has the
                 # embedding branch in it: fed zeros it adds exact zeros to the skips' gradients; the projector's are not bound
                 ent.sdfeat.zero_()
-                live = False
             else:
                 ent.sdfeat.copy_(d_feat_nhwc)
         ent.g_bwd.replay()

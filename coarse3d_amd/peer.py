@@ -29,12 +29,23 @@ class PeerDesc(C.Structure):
                 ("timeout_s", C.c_float), ("one_device", C.c_int32), ("reserved", C.c_int32)]
 
 
+def default_timeout_s():
+    """How long an exchange waits for a peer before it gives up (status word set, NaN results, every later exchange a no-op).
+    The collective it replaces waits for the process group's timeout (RCCL / NCCL: 10-30 minutes); ranks legitimately
+    drift by more than seconds -- a checkpoint written by rank 0, a data-loader stall, first-touch compilation -- and this
+    package's trainer has no per-step barrier (coarse3d_amd/trainer.py).  Hence minutes, not seconds: ``C3D_PEER_TIMEOUT_S``
+    (default 600).  After rank-local work longer than that, barrier before the next step."""
+    return float(os.environ.get("C3D_PEER_TIMEOUT_S", "600"))
+
+
 class PeerExchange:
-    def __init__(self, group=None, timeout_s=20.0, cap_doubles=CAP_DOUBLES, selftest=True):
+    def __init__(self, group=None, timeout_s=None, cap_doubles=CAP_DOUBLES, selftest=True, only_one_device=False):
         """Collective: every rank of ``group`` (default: the world) must construct it at the same point.  Raises
         RuntimeError -- on EVERY rank -- if any rank could not allocate, share or map a mailbox, if the ranks are not on one
         host, or if the self-test exchanges (``selftest``: five of known vectors, then 96 queued back to back with one rank
-        late at a time, as in a training step) did not return the right sums on every rank within two seconds each."""
+        late at a time, as in a training step) did not return the right sums on every rank within two seconds each.
+        ``only_one_device``: also raise (everywhere) when the ranks sit on different devices -- the placement whose fenced
+        form of the kernels has not run over xGMI yet; a library default takes the collectives there (dist.DataParallel)."""
         if not torch.cuda.is_available():
             raise RuntimeError("PeerExchange needs a GPU")
         self.group = group
@@ -46,9 +57,15 @@ class PeerExchange:
         lib = L.lib()
         self._own = None
         self._mapped = []
+        if timeout_s is None:
+            timeout_s = default_timeout_s()
         self.desc = PeerDesc()
         self.desc.rank, self.desc.world, self.desc.cap_doubles, self.desc.timeout_s = self.rank, self.world, cap_doubles, timeout_s
         self.stream = torch.cuda.Stream()       # for the asynchronous form (begin / end)
+        # One exchange of a rank at a time: every launch shares the sequence counter, the parity slots, the scratch and the
+        # ticket word.  begin() puts an exchange on the side stream; until its end() nothing else of this object may be
+        # launched (it would run on ANOTHER stream, unordered against the one in flight) -- enforced below, not assumed.
+        self._in_flight = False
         self._scratch = self._ticket = None
         err = None
         handle = (C.c_ubyte * 64)()
@@ -76,10 +93,13 @@ class PeerExchange:
             errs = [f"the ranks run on different hosts ({sorted({i[0] for i in infos})}): IPC needs one node"]
         # every rank on one device (the one-GPU test box; world == 1): no system-scope fences around the write-through payload
         self.desc.one_device = int(len({i[3] for i in infos}) == 1)
+        same_device = bool(self.desc.one_device)
         if os.environ.get("C3D_PEER_FORCE_FENCES") == "1":
             # test hook: ranks that share one device take the multi-device form of the kernels (system-scope release / acquire
             # fences around the payload) -- the code path a node with several GPUs runs, exercised on a one-GPU box
             self.desc.one_device = 0
+        if not errs and only_one_device and not same_device and self.world > 1:
+            errs = ["the ranks run on different devices and the caller asked for the one-device form only"]
         if not errs:
             try:
                 for r, (_, h, _, _) in enumerate(infos):
@@ -149,10 +169,18 @@ class PeerExchange:
             raise ValueError("PeerExchange.allreduce_: contiguous fp64 CUDA tensor expected")
         if t.numel() > self.desc.cap_doubles:
             raise ValueError(f"PeerExchange.allreduce_: {t.numel()} values exceed the mailbox slot ({self.desc.cap_doubles})")
+        if stream is None:
+            self._require_idle("allreduce_")
         s = stream if stream is not None else torch.cuda.current_stream()
         L.check(L.lib().c3d_peer_allreduce_f64(C.byref(self.desc), t.data_ptr(), t.numel(), C.c_void_p(s.cuda_stream)),
                 "c3d_peer_allreduce_f64")
         return t
+
+    def _require_idle(self, what):
+        if self._in_flight:
+            raise RuntimeError(f"PeerExchange.{what}: an exchange started with begin() is still in flight on the side stream; the "
+                               "exchanges of a rank share one sequence counter, parity slots and ticket word and must not overlap "
+                               "-- call end() first (and never mix begin/end with the blocking calls inside one window)")
 
     def bn_finalize_partials(self, partial, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
         """SyncBatchNorm forward statistics of one layer in ONE launch on the current stream: fold the partials [C, 2, n],
@@ -161,6 +189,7 @@ class PeerExchange:
         c = gamma.shape[0]
         if 2 * c > self.desc.cap_doubles:
             raise ValueError(f"PeerExchange.bn_finalize_partials: {c} channels exceed the mailbox slot")
+        self._require_idle("bn_finalize_partials")
         buf = torch.empty(4, c, device=gamma.device, dtype=torch.float32)
         s = torch.cuda.current_stream()
         L.check(L.lib().c3d_peer_bn_finalize_partials(
@@ -176,6 +205,7 @@ class PeerExchange:
         c = gamma.shape[0]
         if 2 * c > self.desc.cap_doubles:
             raise ValueError(f"PeerExchange.bn_bwd_coeffs_partials: {c} channels exceed the mailbox slot")
+        self._require_idle("bn_bwd_coeffs_partials")
         k = torch.empty(3, c, device=gamma.device, dtype=torch.float32)
         s = torch.cuda.current_stream()
         L.check(L.lib().c3d_peer_bn_bwd_coeffs_partials(
@@ -187,14 +217,22 @@ class PeerExchange:
     def begin(self, t):
         """Asynchronous form: the exchange runs on this object's side stream, ordered after what the current stream has
         queued; ``end`` makes the current stream wait for it.  Independent kernels queued in between run under the wait."""
+        self._require_idle("begin")
         self.stream.wait_stream(torch.cuda.current_stream())
         t.record_stream(self.stream)
         self.allreduce_(t, self.stream)
+        self._in_flight = True
         return self.stream
 
-    @staticmethod
-    def end(stream):
+    def end(self, stream):
         torch.cuda.current_stream().wait_stream(stream)
+        self._in_flight = False
+
+    def status_to(self, dst, stream=None):
+        """This rank's status word as a device float (0 / 1) into ``dst`` (one fp32 element) on the current stream -- no host
+        synchronisation; coarse3d_amd.dist.DataParallel appends it to its last gradient bucket."""
+        s = stream if stream is not None else torch.cuda.current_stream()
+        L.check(L.lib().c3d_peer_status_to(C.byref(self.desc), dst.data_ptr(), C.c_void_p(s.cuda_stream)), "c3d_peer_status_to")
 
     def failed(self):
         """True if an exchange of this rank gave up waiting for a peer (synchronises; does not raise)."""

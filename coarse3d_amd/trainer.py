@@ -372,6 +372,9 @@ class TrainStep:
             for k, v in ent["collectives"].items():
                 c3d_dist.COUNTS[k] += v
         self._watch_capacity(ent["res"]["lov_count"])
+        if hasattr(self.model, "watch_status"):
+            # data parallel: the health word of this replay's exchanges (coarse3d_amd/dist.py) -- host code does not replay
+            self.model.watch_status()
         if self.scheduler is not None:
             self.scheduler.step()
         return ent["res"]
@@ -439,6 +442,8 @@ class TrainStep:
             ev.synchronize()
             self._cnt_free.append(slot)
             self._check_capacity(int(self._cnt_host[slot]))
+        if hasattr(self.model, "check_status"):
+            self.model.check_status(final=True)
 
     def _poll_capacity(self):
         while self._cnt_ring and self._cnt_ring[0][0].query():

@@ -635,7 +635,8 @@ typedef struct {
   void* mailbox[C3D_PEER_MAX_RANKS];   /* mailbox[r]: rank r's mailbox as mapped in THIS process (mailbox[rank] = own allocation) */
   int32_t rank, world;
   int32_t cap_doubles;                 /* slot capacity the mailboxes were sized for (c3d_peer_mailbox_bytes)                  */
-  float timeout_s;                     /* an exchange gives up waiting for a peer after this long (<= 0: 20 s)                */
+  float timeout_s;                     /* an exchange gives up waiting for a peer after this long (<= 0: 600 s, the order of a
+                                        * process group's collective timeout -- what the all-reduce it replaces would wait)     */
   int32_t one_device;                  /* 1: every rank of the group runs on THIS device (or world == 1): the payload's
                                         * write-through stores + drained flag need no system-scope fences around them           */
   int32_t reserved;
@@ -647,16 +648,24 @@ int c3d_peer_alloc(int64_t bytes, void** ptr, void* handle64);
 int c3d_peer_open(const void* handle64, void** ptr);
 int c3d_peer_close(void* ptr);
 int c3d_peer_free(void* ptr);
-/* buf[0 .. n) (fp64, device) <- sum over ranks, in place; every rank of the group must make the same sequence of calls */
+/* buf[0 .. n) (fp64, device) <- sum over ranks, in place; every rank of the group must make the same sequence of calls.
+ * A failed exchange (a peer never arrived within timeout_s, or an earlier exchange of this rank failed: the status word is
+ * sticky) leaves NaN in buf -- the dist.all_reduce it replaces (torch.nn.SyncBatchNorm, trainer.py:54) would block or raise;
+ * a kernel cannot raise, so it poisons: whatever is computed from the result cannot pass for a statistic. */
 int c3d_peer_allreduce_f64(const c3d_peer_desc* d, double* buf, int n, c3d_stream stream);
 /* host read of the rank's status word (0 = fine, 1 = an exchange timed out: its result was not a sum) and call counter */
 int c3d_peer_status(const c3d_peer_desc* d, int32_t* status_out, int64_t* calls_out);
+/* the same status word as a device float (0.f / 1.f) written to *dst on `stream`, no host synchronisation: the data-parallel
+ * wrapper appends it to its last gradient bucket, so that every rank learns of ANY rank's failure from the all-reduce it
+ * makes anyway (coarse3d_amd/dist.py; the reference's DistributedDataParallel + NCCL watchdog, trainer.py:55-60) */
+int c3d_peer_status_to(const c3d_peer_desc* d, float* dst, c3d_stream stream);
 /* SyncBatchNorm in ONE launch per layer and direction (torch.nn.SyncBatchNorm's forward / backward all-reduce,
  * tasks/weak_segmentation/trainer.py:54): fold the per-tile partials [C][2][n] (conv epilogue / c3d_bn_bwd_reduce), exchange the
  * fp64 sums through the mailboxes, finish -- c3d_stat_reduce(2) + c3d_peer_allreduce_f64 + c3d_bn_finalize / c3d_bn_bwd_coeffs of
  * the three-launch path, the same arithmetic in the same order (the same bits).  count = elements per channel over ALL ranks.
  * scratch: device doubles, 2 C (forward) / 4 C (backward), 2 C <= cap_doubles; ticket: one device word, zero before the first
- * call (the kernel leaves it zero).  Counts as one exchange in every rank's call sequence. */
+ * call (the kernel leaves it zero).  Counts as one exchange in every rank's call sequence.  A failed exchange writes NaN into
+ * every output vector (scale .. save_invstd / k1 .. dbeta; the running statistics are left alone). */
 int c3d_peer_bn_finalize_partials(const c3d_peer_desc* d, const float* partial, int n, double count, const float* gamma,
                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps, int C,
                                   float* scale, float* shift, float* save_mean, float* save_invstd, double* scratch,

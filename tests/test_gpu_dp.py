@@ -152,6 +152,11 @@ def _peer_worker(rank, world, port, q, skip_last):
                 px.check()
             except RuntimeError as e:
                 timed_out = "timed out" in str(e)
+            # ... its result is poisoned, not a partial sum that could pass for a statistic, and the status
+            # word is there for the device too (what DataParallel appends to its last gradient bucket)
+            flag = torch.zeros(1, device="cuda")
+            px.status_to(flag)
+            timed_out = timed_out and bool(torch.isnan(t).all()) and float(flag) == 1.0
             # ... and every exchange after that returns at once (one timeout per failure, not one per exchange of the step)
             t0 = time.perf_counter()
             for _ in range(20):
@@ -255,6 +260,105 @@ def test_peer_exchange_between_two_processes_on_one_device(skip_last):
     from coarse3d_amd.peer import SELFTEST_EXCHANGES
     assert res[0][1] == res[1][1] == 303 + SELFTEST_EXCHANGES      # (+ the self-test exchanges of the constructor)
     assert res[0][2] == bool(skip_last) and not res[1][2]
+
+
+def _status_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coarse3d_amd import dist as D
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    dev = "cuda:0"
+    b, h, w, ncls = 2, 32, 64, 20
+    x, tr, ev = W.synthetic_batch(b, h, w, ncls, 11, 0.05, gh=8, gw=16)
+    sl = slice(rank, rank + 1)
+    torch.manual_seed(3)
+    m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True).to(dev).train()
+    model = D.DataParallel(m, peer_timeout_s=1.5)
+    assert model.peer is not None and abs(model.peer.desc.timeout_s - 1.5) < 1e-6
+
+    def step():
+        out = model(x[sl].to(dev), label=tr[sl].to(dev), eval_mask=(tr[sl] > 0).to(dev), return_feat=True, proto_loss=True)
+        (out["pred_2d"].square().sum() + out["feat_2d"].sum()).backward()
+        model.finish_gradients()
+    step()
+    model.check_status(final=True)                 # a healthy step: nothing to report
+    healthy = all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
+    dist.barrier()
+    if rank == 0:
+        # one exchange too many on rank 0: it times out (1.5 s), its status word sticks, its later exchanges are no-ops with
+        # NaN results; rank 1's first exchange of the next step then waits for a sequence number that never comes
+        model.peer.allreduce_(torch.ones(4, dtype=torch.float64, device=dev))
+    raised_at, msg = None, ""
+    try:
+        for i in range(1, 6):
+            step()                                  # (finish_gradients checks the word of step i - STATUS_LAG)
+    except RuntimeError as e:
+        raised_at, msg = i, str(e)
+    late = None
+    if raised_at is None:
+        try:
+            model.check_status(final=True)
+        except RuntimeError as e:
+            late = str(e)
+    # the statistics of the failed step are NaN by construction: they cannot pass for a result
+    poisoned = not all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
+    q.put((rank, healthy, raised_at, "failed on at least one rank" in msg, late, poisoned))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failed_peer_exchange_raises_on_every_rank_at_the_same_step():
+    """nothing in the training path looked at the peer exchange's status word -- after one timeout the
+    step went on with partial sums.  Now (i) a failed exchange leaves NaN, (ii) every rank's status word rides on the last
+    gradient bucket of each step (one extra element of an all-reduce the step makes anyway: FlatGradients.status), so that
+    (iii) DataParallel.finish_gradients() raises on EVERY rank, the one that did not time out included, at the SAME step
+    (STATUS_LAG steps after the failure: the read-back is asynchronous) -- the ranks leave together instead of one of them
+    stranding the others in a collective.  Two processes on this box's GPU, rank 0 made to time out."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 400
+    procs = [ctx.Process(target=_status_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=600) for _ in range(2))}
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    for r in range(2):
+        healthy, raised_at, right_message, late, poisoned = res[r]
+        assert healthy and raised_at is not None and right_message and late is None, res
+        assert poisoned
+    from coarse3d_amd.dist import DataParallel
+    assert res[0][1] == res[1][1] == 1 + DataParallel.STATUS_LAG, res      # the failed step is step 1 after the healthy one
+
+
+def test_bench_two_ranks_on_one_gpu_through_the_full_data_parallel_path():
+    """``bench.py --gpus 2`` on the one GPU through the FULL path a multi-GPU node runs -- gloo
+    control plane for the IPC handles, the peer exchange in its fenced (multi-device) form (C3D_PEER_FORCE_FENCES=1), the
+    bucket-order checks of the flat gradient buffer, the health word on the last bucket, and the guard of the captured step
+    (a gloo group cannot be captured: the line is the launch-by-launch pass and says why).  The line carries the exchange
+    counts of the real thing: 84 SyncBatchNorm exchanges (43 + 43, two batched away), the gradient buckets, one bank mean --
+    90 collectives per step -- and n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--height", "32", "--width", "256", "--no-cpu-baseline", "--no-kernel-events", "--no-second-engine"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "C3D_SYNCBN_EXCHANGE")}
+    env.update(C3D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", C3D_PEER_FORCE_FENCES="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and "captured_pass_abandoned" not in out
+    assert "syncbn_exchange_fallback" not in out
+    coll = out["config"]["collectives_per_step"]
+    assert "peer-memory" in coll["syncbn_exchange"], coll
+    assert coll["syncbn"] == 84 and coll["prototype_bank"] == 1, coll
+    assert coll["total"] == 90, coll
+    assert out["value"] > 0
 
 
 def test_reference_wrap_syncbn_and_stock_ddp_match_full_batch():

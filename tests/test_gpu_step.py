@@ -1062,3 +1062,42 @@ def test_graphed_backbone_behind_the_module_api_is_bit_identical_to_launch_by_la
     for k in grads[0]:
         assert torch.equal(grads[0][k], grads[1][k]), k
 
+
+
+def test_graphed_backbone_without_the_embedding_branch_leaves_the_projector_without_a_gradient():
+    """ADVICE round 5 (coarse3d_amd/graphed.py): the reference's loop calls the model with ``return_feat=False`` in the
+    contrast warm-up epochs (trainer.py:625-630); autograd then leaves ``projector.*`` at ``.grad is None`` and AdamW skips
+    them -- no weight decay, no step count, no moment decay.  The graphed backbone has to follow the launch-by-launch
+    rule (``Backbone.embed_ran``): five steps of the same loop, graphed and not -- ``projector.*`` keep ``grad is None``
+    and their initial values on both, the optimiser holds no state for them, everything else agrees bit for bit."""
+    from coarse3d_amd.pc_processor.models import SalsaNextProto
+    b, h, w, ncls = 2, 32, 128, 20
+    batches = [W.synthetic_batch(b, h, w, ncls, 700 + i, 0.03, gh=8, gw=16) for i in range(5)]
+    gen = torch.Generator().manual_seed(19)
+    wp = [torch.randn(b, ncls, h, w, generator=gen).to(DEV) for _ in range(5)]
+    runs = []
+    for graphed in (False, True):
+        torch.manual_seed(61)
+        m = SalsaNextProto(5, ncls, 20, 0, use_prototype=True).to(DEV).train()
+        m.graph_backbone = graphed
+        init = {k: p.detach().clone() for k, p in m.named_parameters() if k.startswith("projector.")}
+        opt = torch.optim.AdamW(m.parameters(), lr=2e-3, weight_decay=0.05)
+        torch.manual_seed(62)
+        for i, (x, tr, ev) in enumerate(batches):
+            out = m(x.to(DEV), label=tr.to(DEV), eval_mask=(tr > 0).to(DEV), return_feat=False)
+            assert "feat_2d" not in out
+            opt.zero_grad(set_to_none=True)
+            ((out["pred_2d"] * wp[i]).sum() * 1e-2).backward()
+            for k, p in m.named_parameters():
+                assert (p.grad is None) == k.startswith("projector."), (graphed, i, k)
+            opt.step()
+        torch.cuda.synchronize()
+        for k, p in m.named_parameters():
+            if k.startswith("projector."):
+                assert torch.equal(p.detach(), init[k]), (graphed, k)        # no weight decay reached them
+                assert p not in opt.state or len(opt.state[p]) == 0, (graphed, k)
+        runs.append(({k: v.detach().clone() for k, v in m.state_dict().items()}, m))
+    gb = runs[1][1]._gb
+    assert gb is not None and gb.captures == 1 and gb.replays == 3 and gb.fallbacks == 0
+    for k, v in runs[0][0].items():
+        assert torch.equal(v, runs[1][0][k]), k
