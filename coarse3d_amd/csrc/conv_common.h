@@ -49,6 +49,9 @@ inline bool c3d_wide_cout_tiles(const ConvArgs& a) {
 int c3d_conv_forward_bfp(ConvArgs& a, int planes, int tr, int halo, bool k32, hipStream_t st);
 // second-generation bf16x3 engine for 8-row tiles with 4 or 9 taps (conv_x3.hip); needs a mode | 2 pack
 int c3d_conv_forward_x3(ConvArgs& a, int halo, hipStream_t st);
+// Winograd F(2x2, 3x3) on the exact-split engine (conv_wino.hip; c3d_conv_desc.variant & 16): nine taps on the 3 x 3 grid of
+// dilation `dil` (1 or 2); a.wpack is a c3d_pack_weights_wino pack
+int c3d_conv_forward_wino(ConvArgs& a, int dil, hipStream_t st);
 // wide pointwise engine on the bf16 pipe, 8-row tiles, Cout > 64 (conv_pw3.hip; planes = 1 or 3); needs a mode | 2 pack
 int c3d_conv_forward_pw3(ConvArgs& a, int planes, bool wide, hipStream_t st);   // wide: 256-cout tiles, else 128
 

@@ -353,6 +353,16 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
     for (int s = 0; s < d->nsrc; ++s) k32 = k32 && (d->src[s].C % 32 == 0);
     const bool x3 = d->mfma_bf16 >= 2;      // 3 = the exact-split engine with six plane products (input gradients)
     a.six = d->mfma_bf16 == 3;
+    if (d->variant & 16) {
+      // Winograd F(2x2, 3x3) (conv_wino.hip, round 6): the caller packed the weights with c3d_pack_weights_wino and sized
+      // stat_partial with c3d_conv_wino_num_tiles
+      C3D_REQUIRE(x3 && d->ntaps == 9 && (halo == 1 || halo == 2), "conv: the Winograd variant takes nine-tap convs of the bf16x3 engine");
+      C3D_REQUIRE(d->Cout % 4 == 0 && d->out_cstride % 4 == 0 && d->out_coff % 4 == 0 && (!d->stat_mul || d->stat_mul_cstride % 4 == 0),
+                  "conv (Winograd): output channels, stride and offset must be multiples of 4");
+      for (int t = 0; t < 9; ++t)
+        C3D_REQUIRE(d->tap_dy[t] % halo == 0 && d->tap_dx[t] % halo == 0, "conv (Winograd): the taps must be the 3 x 3 grid of one dilation");
+      return c3d_conv_forward_wino(a, halo, st);
+    }
     // (3 / 6 taps: the fused multi-tap kernel of the bf16x3 engine on 8-row tiles -- variant & 4: the generic kernel, as everywhere else)
     if (odd_taps && !(x3 && tr == 8 && d->wpack_planes && !(d->variant & 4))) return c3d_conv_forward_bfp(a, x3 ? 3 : 1, tr, halo, false, st);
     if (!x3 && tr == 8 && d->ntaps == 9 && d->wpack_planes && !(d->variant & 4)) {

@@ -183,6 +183,24 @@ def pack_weights(w, mode=0, c_off=0, c_cnt=None, kpad=None):
     return dst
 
 
+def pack_weights_wino(wpack, kpad, n, taps):
+    """Winograd F(2x2, 3x3) weights U = G g G^T (three bf16 planes) from the fp32 image of a ``pack_weights`` pack of a
+    nine-tap conv (either mode) and the launch's tap offsets -- csrc/conv_wino.hip, c3d_pack_weights_wino."""
+    assert len(taps) == 9
+    dil = max(max(abs(dy), abs(dx)) for dy, dx in taps)
+    nbytes = L.lib().c3d_wino_pack_bytes(kpad, n)
+    dst = torch.empty(nbytes // 2, device=wpack.device, dtype=torch.int16)
+    dy = (C.c_int32 * 9)(*[t[0] for t in taps])
+    dx = (C.c_int32 * 9)(*[t[1] for t in taps])
+    L.check(L.lib().c3d_pack_weights_wino(_p(wpack), kpad, n, dy, dx, dil, _p(dst), _stream()), "c3d_pack_weights_wino")
+    dst.c3d_wino = dil
+    return dst
+
+
+def wino_num_tiles(b, h, w, dil):
+    return L.lib().c3d_conv_wino_num_tiles(b, h, w, dil)
+
+
 class PackCache:
     """All weight repacks of a model in ONE launch per step.
 
@@ -295,10 +313,11 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     d.ntaps = len(taps)
     for i, (dy, dx) in enumerate(taps):
         d.tap_dy[i], d.tap_dx[i] = dy, dx
-    if MFMA_MODE == 2 and len(taps) > 1 and not getattr(wpack, "c3d_planes", False):
+    if MFMA_MODE == 2 and len(taps) > 1 and not getattr(wpack, "c3d_planes", False) and not getattr(wpack, "c3d_wino", 0):
         raise RuntimeError("bf16x3 mode needs weight packs made after ops.set_matrix_precision('bf16x3')")
+    wino = getattr(wpack, "c3d_wino", 0)          # a pack_weights_wino pack: Winograd F(2x2, 3x3), csrc/conv_wino.hip
     d.wpack = wpack.data_ptr()
-    d.wpack_planes = int(bool(getattr(wpack, "c3d_planes", False)))
+    d.wpack_planes = int(bool(getattr(wpack, "c3d_planes", False)) or bool(wino))
     d.bias = bias.data_ptr() if bias is not None else None
     d.epi_lrelu = int(lrelu)
     d.lrelu_slope = slope            # 0 = the SalsaNext default 0.01
@@ -306,9 +325,10 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
         out = torch.empty(b, h, w, cout, device=wpack.device, dtype=srcs[0].t.dtype)
     d.out, d.out_cstride, d.out_coff, d.accumulate = out.data_ptr(), out.shape[3], out_coff, int(accumulate)
     d.out_bf16 = int(out.dtype == torch.bfloat16)
-    d.variant = CONV_VARIANT
+    d.variant = CONV_VARIANT | (16 if wino else 0)
     if stats and stat_partial is None:
-        stat_partial = torch.empty(cout, 2, num_mtiles(b, h, w), device=wpack.device, dtype=torch.float32)
+        stat_partial = torch.empty(cout, 2, wino_num_tiles(b, h, w, wino) if wino else num_mtiles(b, h, w), device=wpack.device,
+                                   dtype=torch.float32)
     d.stat_partial = stat_partial.data_ptr() if stat_partial is not None else None
     use_mul = stat_mul is not None
     if use_mul:      # (sum v, sum v * stat_mul) instead of (sum v, sum v^2): BatchNorm-backward sums in the epilogue

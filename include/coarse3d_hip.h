@@ -138,6 +138,18 @@ int c3d_conv_stat_mul_supported(const c3d_conv_desc* d);
  * and, with transposed weights, their input gradients.                                      */
 int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream);
 
+/* Winograd F(2x2, 3x3) for the nine-tap convolutions (and input gradients) of the exact-split engine, dilation 1 or 2
+ * (salsanext_proto.py:46-52, 87-105, 172-186: every 3x3 Conv2d of ResContextBlock / ResBlock / UpBlock; csrc/conv_wino.hip).
+ * c3d_conv_forward takes it with c3d_conv_desc.variant & 16, mfma_bf16 == 2 / 3, ntaps == 9 on the 3 x 3 grid of one dilation:
+ * wpack is then a c3d_pack_weights_wino pack and stat_partial holds [Cout][2][c3d_conv_wino_num_tiles] partials (4 x 32-pixel
+ * tiles per dilation sub-grid instead of 8 x 32).  The weight transform U = G g G^T is taken from the fp32 image of an ordinary
+ * c3d_pack_weights pack (either mode: forward or transposed) + the launch's tap offsets, in float64, rounded once to fp32 and
+ * split exactly into three bf16 planes: dst [Kpad / 16][16][3][roundup(N, 64)][16] bf16, c3d_wino_pack_bytes bytes. */
+int c3d_conv_wino_num_tiles(int B, int H, int W, int dil);
+int64_t c3d_wino_pack_bytes(int Kpad, int N);
+int c3d_pack_weights_wino(const float* pack_f32, int Kpad, int N, const int32_t* tap_dy, const int32_t* tap_dx, int dil,
+                          void* dst, c3d_stream stream);
+
 /* Weight repack from the reference's OIHW layout [Cout][Cin][T] (T = kh*kw):
  *   mode 0 (forward):  dst[t][k/4][n][k%4] = W[n][k0 + k][t],  k < K=Cin_cnt,  n < Cout
  *   mode 1 (dgrad):    dst[t][k/4][n][k%4] = W[k][n0 + n][t],  k < Cout,       n < N=Cin_cnt

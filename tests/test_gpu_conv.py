@@ -595,3 +595,98 @@ def test_f16x2_forward_experiment_against_float64(k, dil, pad, cin, cout, monkey
     s1 = part[:, 0].double().sum(1)
     assert float((s1 - got.double().sum((0, 1, 2))).abs().max() / got.double().abs().sum((0, 1, 2)).max()) < 1e-6
     assert torch.equal(on_small, off_small)
+
+
+def test_winograd_variant_matches_the_direct_kernel_and_float64():
+    """Round 6 gate experiment (csrc/conv_wino.hip; c3d_conv_desc.variant & 16): Winograd F(2x2, 3x3) on the exact-split engine.
+    It FAILED its time gate (profiles/round6_wino_gate.md: 1.07x the fused nine-tap kernel on 64 -> 64 at 8 x 64 x 2048) and is
+    off; this test keeps the measurement honest -- the kernel computes the same convolution.  Twenty seeded random launches:
+    both dilations (the four parity sub-grids at dilation 2), 1-3 sources at channel offsets with / without BatchNorm affine and
+    LeakyReLU, ragged H / W (odd sizes: sub-grids of different sizes), ragged couts, output at a channel offset, accumulate,
+    bias, statistics, BatchNorm-backward sums (stat_mul), forward (eight / six products) and transposed packs: within 2e-6 of
+    max|ref| of the direct kernel's result, and no further from float64 than 1.5x the direct kernel."""
+    import random
+    from coarse3d_amd import ops
+    rnd = random.Random(606)
+    dev = "cuda"
+    prev = ops.matrix_precision_state()
+    ops.set_matrix_precision("bf16x3")
+    try:
+        worst = 0.0
+        for case in range(20):
+            g = torch.Generator().manual_seed(6000 + case)
+            dil = rnd.choice([1, 2])
+            B, H, W = rnd.choice([(2, 16, 256), (1, 24, 200), (3, 9, 97), (1, 64, 160), (2, 7, 131), (8, 8, 256)])
+            nsrc = rnd.choice([1, 1, 2, 3])
+            srcC = [rnd.choice([16, 32, 64]) for _ in range(nsrc)]
+            Cout = rnd.choice([32, 48, 64, 80, 128])
+            grad = rnd.random() < 0.4
+            srcs, dense = [], []
+            for c in srcC:
+                wide = c + rnd.choice([0, 16])
+                coff = rnd.choice([0, wide - c])
+                x = torch.randn(B, H, W, wide, generator=g).to(dev)
+                aff = rnd.random() < 0.6
+                lr = rnd.random() < 0.5
+                sc = (torch.rand(c, generator=g) + 0.5).to(dev) if aff else None
+                sh = (torch.randn(c, generator=g) * 0.3).to(dev) if aff else None
+                srcs.append(ops.Source(x, sc, sh, C=c, coff=coff, lrelu=lr))
+                v = x[..., coff:coff + c].double()
+                if aff:
+                    v = v * sc.double() + sh.double()
+                if lr:
+                    v = torch.where(v > 0, v, 0.01 * v)
+                dense.append(v)
+            K = sum(srcC)
+            # (a transposed pack is what an input-gradient launch reads: weight [K, Cout] read as [Cout <- K], taps negated)
+            w = (torch.randn(K, Cout, 3, 3, generator=g) if grad else torch.randn(Cout, K, 3, 3, generator=g)).to(dev) / (K * 9) ** 0.5
+            wp = ops.pack_weights(w, mode=1 if grad else 0)
+            taps = ops.conv_taps(3, 3, dil, dil)
+            if grad:
+                taps = ops.negate_taps(taps)
+            wu = ops.pack_weights_wino(wp, K, Cout, taps)
+            bias = (torch.randn(Cout, generator=g) * 0.1).to(dev) if rnd.random() < 0.5 else None
+            ocoff = rnd.choice([0, 4, 32])
+            base = torch.randn(B, H, W, Cout + ocoff + rnd.choice([0, 4]), generator=g).to(dev)
+            acc, stats, lrelu = rnd.random() < 0.4, rnd.random() < 0.6, rnd.random() < 0.5
+            mul = torch.randn(B, H, W, Cout + 4, generator=g).to(dev) if (stats and rnd.random() < 0.5) else None
+            outs = {}
+            for name, pack in (("direct", wp), ("wino", wu)):
+                out = base.clone()
+                _, part = ops.conv_forward(srcs, pack, bias, Cout, taps, lrelu=lrelu, stats=stats, out=out, out_coff=ocoff,
+                                           accumulate=acc, grad=grad, stat_mul=mul)
+                torch.cuda.synchronize()
+                outs[name] = (out, part)
+            xin = torch.cat(dense, -1).permute(0, 3, 1, 2)
+            if grad:
+                ref = F.conv_transpose2d(xin, w.double(), padding=dil, dilation=dil)
+            else:
+                ref = F.conv2d(xin, w.double(), padding=dil, dilation=dil)
+            if bias is not None:
+                ref = ref + bias.double()[None, :, None, None]
+            if lrelu:
+                ref = torch.where(ref > 0, ref, 0.01 * ref)
+            ref = ref.permute(0, 2, 3, 1)
+            if acc:
+                ref = ref + base[..., ocoff:ocoff + Cout].double()
+            tag = (case, dil, B, H, W, srcC, Cout, ocoff, acc, stats, grad)
+            scale = float(ref.abs().max())
+            got_d = outs["direct"][0][..., ocoff:ocoff + Cout].double()
+            got_w = outs["wino"][0][..., ocoff:ocoff + Cout].double()
+            e_d = float((got_d - ref).abs().max()) / scale
+            e_w = float((got_w - ref).abs().max()) / scale
+            worst = max(worst, e_w)
+            assert e_w < 2e-6 and e_w <= 1.5 * e_d + 2e-7, (tag, e_w, e_d)
+            # channels outside [ocoff, ocoff + Cout) are untouched
+            keep = torch.ones(base.shape[-1], dtype=torch.bool)
+            keep[ocoff:ocoff + Cout] = False
+            assert torch.equal(outs["wino"][0][..., keep], base[..., keep]), tag
+            if stats:
+                s_d = outs["direct"][1].double().sum(-1)
+                s_w = outs["wino"][1].double().sum(-1)
+                n = B * H * W
+                assert float((s_d - s_w).abs().max()) <= 1e-5 * (float(s_d.abs().max()) + n ** 0.5), tag
+        from _measure import record
+        record("conv_wino/max_err_vs_float64", worst)
+    finally:
+        ops.set_matrix_precision(*prev)
