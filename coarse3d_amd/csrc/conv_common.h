@@ -52,6 +52,9 @@ int c3d_conv_forward_x3(ConvArgs& a, int halo, hipStream_t st);
 // Winograd F(2x2, 3x3) on the exact-split engine (conv_wino.hip; c3d_conv_desc.variant & 16): nine taps on the 3 x 3 grid of
 // dilation `dil` (1 or 2); a.wpack is a c3d_pack_weights_wino pack
 int c3d_conv_forward_wino(ConvArgs& a, int dil, hipStream_t st);
+// narrow pointwise convs of the exact-split engine as a streaming kernel (conv_pws.hip, round 6): Cout <= 64, K <= 192, six products
+bool c3d_conv_pws_takes(const ConvArgs& a);
+int c3d_conv_forward_pws(ConvArgs& a, hipStream_t st);
 // wide pointwise engine on the bf16 pipe, 8-row tiles, Cout > 64 (conv_pw3.hip; planes = 1 or 3); needs a mode | 2 pack
 int c3d_conv_forward_pw3(ConvArgs& a, int planes, bool wide, hipStream_t st);   // wide: 256-cout tiles, else 128
 

@@ -389,6 +389,9 @@ extern "C" int c3d_conv_forward(const c3d_conv_desc* d, c3d_stream stream) {
       if (wide && px_tiles * ((d->Cout + 255) / 256) < fill) wide = false;
       if (wide || px_tiles * ((d->Cout + 127) / 128) >= fill) return c3d_conv_forward_pw3(a, x3 ? 3 : 1, wide, st);
     }
+    // narrow 1x1 convs (Cout <= 64) of the exact-split engine with six plane products: the streaming kernel (conv_pws.hip, round 6);
+    // variant & 32 keeps conv_bfp's staged tile (A/B runs, tests)
+    if (x3 && a.six && tr == 8 && d->ntaps == 1 && !(d->variant & 32) && c3d_conv_pws_takes(a)) return c3d_conv_forward_pws(a, st);
     return c3d_conv_forward_bfp(a, x3 ? 3 : 1, tr, halo, k32, st);
   }
   if (tr == 8 && d->ntaps == 1) {

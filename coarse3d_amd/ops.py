@@ -342,7 +342,8 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
 
     def kernel_name():
         return _conv_kernel_name(b, h, w, [s.C for s in srcs], [s.t.dtype == torch.bfloat16 for s in srcs], cout, taps, grad,
-                                 bool(d.wpack_planes), bool(d.stat_mul))
+                                 bool(d.wpack_planes), bool(d.stat_mul), has_stats=bool(d.stat_partial), accumulate=bool(accumulate),
+                                 out_room=(out.shape[3] - out_coff) if (out.shape[3] % 4 == 0 and out_coff % 4 == 0) else 0)
     # six plane products: every input gradient, and forward multi-tap convs whose BatchNorm population is large
     # (SIX_FWD_MIN_PIXELS).  conv_pw3 runs six in every launch (the flag is ignored there).
     six = MFMA_MODE == 2 and (grad or (nt_ > 1 and tr == 8 and b * h * w >= SIX_FWD_MIN_PIXELS))
@@ -373,7 +374,7 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     return out, stat_partial
 
 
-def _conv_kernel_name(b, h, w, src_c, src_bf16, cout, taps, grad, wpack_planes, stat_mul):
+def _conv_kernel_name(b, h, w, src_c, src_bf16, cout, taps, grad, wpack_planes, stat_mul, has_stats=False, accumulate=False, out_room=None):
     """The kernel instance c3d_conv_forward launches for this problem, as rocprofv3 prints it -- a mirror of the dispatch in
     csrc/conv_mfma.hip, conv_x3.hip, conv_pw3.hip and conv_bfp.hip for the per-kernel event timers of bench.py
     (tests/test_cpu_kernel_names.py holds every name it can produce against the symbols of the built library)."""
@@ -397,6 +398,12 @@ def _conv_kernel_name(b, h, w, src_c, src_bf16, cout, taps, grad, wpack_planes, 
     elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
         name = _pw3_kernel_name(_pw3_tile(b, h, w, cout), sum(src_c), cout,
                                 bf16_srcs=all(src_bf16))
+    elif (MFMA_MODE == 2 and tr == 8 and nt_ == 1 and cout <= 32 and not has_stats and not (CONV_VARIANT & 32)
+          and (grad or b * h * w >= SIX_FWD_MIN_PIXELS) and not any(src_bf16) and sum(src_c) == 32
+          and not (cout % 4 and accumulate) and (out_room is None or (cout + 3) // 4 * 4 <= out_room)):
+        # 32-channel 1x1 convs without statistics (and the class head) with six plane products: the streaming kernel
+        # (csrc/conv_pws.hip, round 6; c3d_conv_pws_takes)
+        name = "conv_pws_kernel<1, 2, false>"
     elif MFMA_MODE:     # mirrors dispatch_bfp() in csrc/conv_bfp.hip (the trailing template argument: raw bf16 staging)
         np_ = 3 if MFMA_MODE == 2 else 1
         wide_ = _wide_cout_tiles(b, h, w, cout, tr)

@@ -690,3 +690,76 @@ def test_winograd_variant_matches_the_direct_kernel_and_float64():
         record("conv_wino/max_err_vs_float64", worst)
     finally:
         ops.set_matrix_precision(*prev)
+
+
+def test_streaming_pointwise_kernel_matches_the_staged_one():
+    """csrc/conv_pws.hip (round 6): the 32-channel 1x1 convs without statistics and the class head as a per-wave stream (weights as
+    the A operand, a lane = a pixel, 16-byte stores) instead of conv_bfp's staged tile (c3d_conv_desc.variant & 32).  Same
+    arithmetic -- three exact planes, six plane products, fp32 accumulation -- in another order of the twelve products of a
+    pixel (conv_bfp walks its 32-channel chunk plane pair by plane pair): within 5e-7 of max of each other (measured 1.6e-7).
+    Twenty-four seeded launches: one or two sources at channel
+    offsets, BatchNorm affine / LeakyReLU on load, bias, LeakyReLU in the epilogue, accumulate, ragged H / W, ragged couts
+    (20 / 17 / 14 classes into the padded 32-channel logits buffer: the pad channels stay exact zeros), output at a channel
+    offset; and against float64 at 1e-6 of max."""
+    import random
+    from coarse3d_amd import ops
+    rnd = random.Random(77)
+    dev = "cuda"
+    prev = ops.matrix_precision_state()
+    ops.set_matrix_precision("bf16x3")
+    saved = ops.CONV_VARIANT
+    try:
+        for case in range(24):
+            g = torch.Generator().manual_seed(7000 + case)
+            B, H, W = rnd.choice([(2, 16, 256), (1, 24, 200), (3, 9, 97), (1, 64, 160), (2, 7, 131), (8, 8, 256)])
+            srcC = rnd.choice([[32], [32], [16, 16]])
+            Cout = rnd.choice([32, 32, 20, 17, 14, 16, 8])
+            srcs, dense = [], []
+            for c in srcC:
+                wide = c + rnd.choice([0, 16])
+                coff = rnd.choice([0, wide - c])
+                x = torch.randn(B, H, W, wide, generator=g).to(dev)
+                aff, lr = rnd.random() < 0.6, rnd.random() < 0.5
+                sc = (torch.rand(c, generator=g) + 0.5).to(dev) if aff else None
+                sh = (torch.randn(c, generator=g) * 0.3).to(dev) if aff else None
+                srcs.append(ops.Source(x, sc, sh, C=c, coff=coff, lrelu=lr))
+                v = x[..., coff:coff + c].double()
+                if aff:
+                    v = v * sc.double() + sh.double()
+                if lr:
+                    v = torch.where(v > 0, v, 0.01 * v)
+                dense.append(v)
+            w = (torch.randn(Cout, 32, 1, 1, generator=g) / 32 ** 0.5).to(dev)
+            wp = ops.pack_weights(w, mode=0)
+            bias = (torch.randn(Cout, generator=g) * 0.1).to(dev) if rnd.random() < 0.5 else None
+            ocoff = rnd.choice([0, 4, 32]) if Cout % 4 == 0 else 0
+            acc = Cout % 4 == 0 and rnd.random() < 0.4
+            lrelu = rnd.random() < 0.5
+            cpad = 32 if Cout % 4 else Cout + ocoff + rnd.choice([0, 4])
+            base = torch.randn(B, H, W, cpad, generator=g).to(dev) if Cout % 4 == 0 else torch.zeros(B, H, W, cpad, device=dev)
+            outs = {}
+            for name, var in (("staged", 32), ("stream", 0)):
+                ops.CONV_VARIANT = var
+                out = base.clone()
+                ops.conv_forward(srcs, wp, bias, Cout, [(0, 0)], lrelu=lrelu, out=out, out_coff=ocoff, accumulate=acc, grad=True)
+                torch.cuda.synchronize()
+                outs[name] = out
+            tag = (case, B, H, W, srcC, Cout, ocoff, acc, lrelu)
+            scale_ = float(outs["staged"].abs().max())
+            assert float((outs["stream"] - outs["staged"]).abs().max()) <= 5e-7 * scale_, tag
+            xin = torch.cat(dense, -1)
+            ref = xin @ w.double().reshape(Cout, 32).t()
+            if bias is not None:
+                ref = ref + bias.double()
+            if lrelu:
+                ref = torch.where(ref > 0, ref, 0.01 * ref)
+            if acc:
+                ref = ref + base[..., ocoff:ocoff + Cout].double()
+            got = outs["stream"][..., ocoff:ocoff + Cout].double()
+            assert float((got - ref).abs().max()) < 1e-6 * float(ref.abs().max()), tag
+            keep = torch.ones(cpad, dtype=torch.bool)
+            keep[ocoff:ocoff + Cout] = False
+            assert torch.equal(outs["stream"][..., keep], base[..., keep]), tag       # pad channels / neighbours untouched (zeros stay zeros)
+    finally:
+        ops.CONV_VARIANT = saved
+        ops.set_matrix_precision(*prev)
