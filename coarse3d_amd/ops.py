@@ -21,7 +21,7 @@ KERNEL_EVENT_FILTER = None       # None = every MFMA launch; else only launches 
 #              step on the bf16 matrix pipe, fp32 accumulate: fp32-class results (csrc/conv_x3.hip, conv_pw3.hip,
 #              conv_bfp.hip, wgrad_tr.hip); every `pytest -m gpu` test runs on it
 #   0 "f32"    v_mfma_f32_32x32x2_f32 everywhere (== an fmaf chain): the strict-IEEE engine; the whole GPU suite is
-#              re-run on it by tests/test_gpu_configs.py::test_whole_gpu_suite_passes_on_the_strict_fp32_engine
+#              re-run on it by tests/test_gpu_configs.py::test_parity_suite_passes_on_the_strict_fp32_engine
 #   1 "bf16"   operands rounded to bf16 inside the kernels, fp32 accumulate; activations stored as bf16
 #              (STORAGE_BF16) or fp32 -- opt-in mixed precision, BASELINE configs[2]
 _MODES = {"f32": 0, "bf16": 1, "bf16x3": 2}
