@@ -45,7 +45,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md chip-
 PEAK_BF16_MFMA_TFLOPS = 2500.0                       # dense bf16 (no sparsity), same guide
 # committed per-kernel HBM-traffic captures (tools/profile_round.sh <tag> <bench args>): profiles/round<N>_<workload>_<engine>_hbm.json,
 # newest round first
-PMC_ROUNDS = (5, 4, 3)
+PMC_ROUNDS = (6, 5, 4, 3)
 
 
 def synth_batch(b, h, w, ncls, seed, device, label_rate=1e-3):

@@ -20,5 +20,9 @@ S=$(find /tmp/p_stats -name '*kernel_stats.csv' | head -1)
 F=$(find /tmp/p_fetch -name '*counter_collection.csv' | head -1)
 W=$(find /tmp/p_write -name '*counter_collection.csv' | head -1)
 cp $S $OUT/${TAG}_kernel_stats.csv
+# steady state: the last two of the four steps only (the --stats summary above also counts what happens once: weight upload,
+# first-step packs, optimiser state allocation)
+T=$(find /tmp/p_stats -name '*kernel_trace.csv' | head -1)
+python3 tools/steady_stats.py $T $OUT/${TAG}_kernel_stats_steady.csv 2 > $OUT/${TAG}_steady.txt
 python3 tools/hbm_report.py $F $W $S 4 $OUT/${TAG}_hbm.md $OUT/${TAG}_hbm.json
 tail -1 $OUT/${TAG}_stats.log
