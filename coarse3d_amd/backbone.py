@@ -35,6 +35,11 @@ FUSE_BN_REDUCE = os.environ.get("C3D_FUSE_BN_REDUCE", "1") != "0"      # (the en
 # epilogue cost more than the passes they replace -- first form (sixteen 2-byte multiplier loads per lane and sub-tile)
 # conv_x3f<2,2,9,..> 79 -> 180 us, with the multiplier tile staged through LDS by 16-byte loads 79 -> 130 us, against ~24 us for
 # the separate pass it replaces (which already runs at 4.9 TB/s): 18.20 vs 17.83 ms of kernels per step, 469 vs 478 img/s.
+# Round 6: the multiplier tile now arrives by LDS-DMA under the last K chunk (conv_common.h: conv_mul_dma_issue) and the
+# 64-cout launches keep their line-contiguous store order: conv_x3f<2,2,9,..> 130 -> 115 us (78 without the epilogue), 17.06 vs
+# 16.84 ms of kernels per step, 473.8 vs 479.4 img/s (same box, alternating) -- still a loss, still off.  What the epilogue costs
+# is not latency any more but the read of the multiplier tensor itself (134 MB per 64-channel full-resolution layer) plus a
+# workgroup per CU where the tile's 16-32 KB of LDS cost one: the separate pass only re-reads dy on top, much of it from L2 / MALL.
 FUSE_BN_REDUCE_BF16 = os.environ.get("C3D_FUSE_BN_REDUCE_BF16", "0") == "1"
 # BatchNorm / LeakyReLU backward applied ON LOAD by the layer's first weight-gradient launch (round 4; ops.conv_wgrad(fuse=...)):
 # the apply pass (dy, a -> dz: three tensor passes at HBM speed, 53 launches and the largest kernel of the round-3 step)

@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256, (!SM && NP == 1 && !(TT >= 6 && NT == 2 && TR 
 
   const int nj = min(NPW, (a.Cout - n0 - wn * NPW * 32 + 31) / 32);   // live 32-wide cout sub-tiles (conv_mfma.hip)
   int s = 0, c0 = 0, kbase = 0;
+  bool mul_dma = false;
   load_chunk(s, c0, kbase);
   while (true) {
     __syncthreads();
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256, (!SM && NP == 1 && !(TT >= 6 && NT == 2 && TR 
     }
     const bool more = s2 < a.nsrc;
     if (more) load_chunk(s2, c2, kb2);
+    if constexpr (SM) if (!more) mul_dma = conv_mul_dma_issue<TR, TN, 256>(a, smem, tid, x0, y0, n0, tile_pix);      // (round 6: under the last chunk)
     __builtin_amdgcn_s_setprio(1);
     // NJ = live 32-wide cout sub-tiles of this wave, a compile-time constant per code path: a
     // per-MFMA predicate (as the fp32 kernel uses) broke the bf16 MFMA schedule (68 vs 53 ms/step)
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256, (!SM && NP == 1 && !(TT >= 6 && NT == 2 && TR 
     kbase = kb2;
   }
   conv_epilogue<TR, NT, WM, WN, NP == 1, false, 256, false, (NP >= 2 || SM)>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
-                                                                     tile_pix);
+                                                                     tile_pix, mul_dma);
 }
 
 template <int TR, int NT, int CK, int HALO, int TT, int NP, bool BFS = false>
@@ -324,6 +326,12 @@ int launch_bfp(ConvArgs& a, hipStream_t st) {
   if constexpr (BFS) {
     if (a.stat_mul && a.stat_partial) {      // BatchNorm-backward sums in the epilogue: the instance that has it
       if (lds < (size_t)TR * 32 * (32 * NT + 8) * 2) lds = (size_t)TR * 32 * (32 * NT + 8) * 2;      // the multiplier tile of the epilogue
+      if (!(a.variant & 64) && (lds + 15) / 16 * 16 + (size_t)TR * 32 * (32 * NT) * 2 <= 80 * 1024) {
+        // round 6: a region of its own behind the K loop's buffers, filled by LDS-DMA under the last chunk (two workgroups per CU kept)
+        lds = (lds + 15) / 16 * 16;
+        a.mul_lds_off = (unsigned)lds;
+        lds += (size_t)TR * 32 * (32 * NT) * 2;
+      }
       a.lds_bytes = (unsigned)lds;
       c3d_opt_in_lds<&conv_bfp_kernel<TR, NT, CK, HALO, TT, NP, BFS, true>>();
       hipLaunchKernelGGL((conv_bfp_kernel<TR, NT, CK, HALO, TT, NP, BFS, true>), grid, dim3(256), lds, st, a);

@@ -30,6 +30,8 @@ struct ConvArgs {
   bool one_plane = false;  // conv_x3.hip: the bf16 engine's fused nine-tap kernel (one plane, bf16 tensors)
   bool f16x2 = false;      // EXPERIMENT (mfma_bf16 == 4): two fp16 planes / three products where a kernel has the variant
   const float* acc_scale_dev = nullptr;   // times this device scalar, if any (per-tensor gradient exponent)
+  unsigned mul_lds_off = 0;  // byte offset of a DEDICATED multiplier-tile region behind the K loop's LDS (0 = none): the kernels that have
+                           // it fetch the tile with LDS-DMA loads under their last K chunk (conv_mul_dma_issue, round 6)
   unsigned lds_bytes = 0;  // dynamic LDS of THIS launch, set by the launchers whose kernels stage the epilogue's multiplier tile there
                            // (conv_epilogue only stages when the tile fits: 0 = never, the per-element loads take over)
   float acc_scale = 1.f;   // the accumulators are multiplied by this before bias / activation (1: fma(acc, 1, bias) == acc + bias);
@@ -65,6 +67,36 @@ struct c3d_type_tag {
   using type = T;
 };
 
+// Round 6 (the bf16 engine's BatchNorm-backward sums in the input-gradient epilogue, ConvArgs::stat_mul over bf16 tensors): round 5
+// copied the multiplier tile into LDS at the START of the epilogue -- 32 KB of loads per workgroup with nothing left to hide
+// them under: the launches that carried the epilogue lost more (79 -> 130 us) than the separate reduce pass costs (24 us).
+// LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction straight into LDS, no registers) lets the tile be REQUESTED while
+// the last K chunk is still being multiplied and merely waited for in the epilogue.  The region is the launch's own
+// (ConvArgs::mul_lds_off), [TR * 32 pixels][TN channels] bf16, unpadded: a wave instruction covers 64 consecutive 16-byte units.
+// Returns whether the tile was requested (workgroup-uniform).
+template <int TR, int TN, int NTHR>
+__device__ __forceinline__ bool conv_mul_dma_issue(const ConvArgs& a, float* smem, int tid, int x0, int y0, int n0, size_t tile_pix) {
+  const bool ok = a.mul_lds_off != 0 && a.stat_mul != nullptr && a.stat_partial != nullptr && a.stat_mul_bf16 != 0 &&
+                  x0 + 32 <= a.W && y0 + TR <= a.H && n0 + TN <= a.Cout && (a.stat_mul_cs & 7) == 0;
+  if (!ok) return false;
+  constexpr int UPP = TN / 8;                        // 16-byte units per pixel
+  constexpr int UNITS = TR * 32 * UPP;
+  static_assert(UNITS % NTHR == 0, "whole wave instructions");
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const unsigned short* mp = reinterpret_cast<const unsigned short*>(a.stat_mul);
+  char* lbase = reinterpret_cast<char*>(smem) + a.mul_lds_off;
+#pragma unroll
+  for (int k = 0; k < UNITS / NTHR; ++k) {
+    const int u0 = k * NTHR + wave * 64;             // wave-uniform: the LDS address of a DMA load is M0 + 16 * lane
+    const int u = u0 + lane;
+    const int p = u / UPP, cu = u % UPP;
+    const unsigned short* g = mp + (tile_pix + (size_t)(p >> 5) * a.W + (p & 31)) * a.stat_mul_cs + n0 + cu * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(lbase + (size_t)u0 * 16), 16, 0, 0);
+  }
+  return true;
+}
+
 // Epilogue of one workgroup tile: bias, LeakyReLU, (accumulating) store, per-tile channel
 // statistics [C][2][ntile].  acc[i][j] is the 32x32 MFMA accumulator of tile row wm + i*WM and
 // cout tile wn*NPW + j (lane l: cout l&31, pixels (r&3) + 8*(r>>2) + 4*(l>>5)).
@@ -79,7 +111,7 @@ template <int TR, int NT, int WM, int WN, bool BF16_OUT = false, bool ILV = fals
           bool STATMUL = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TR / WM][NT / WN], float* smem, int tid,
                                               int lane, int half, int l31, int wm, int wn, int b, int x0, int y0,
-                                              int n0, int mt, int ntile, size_t tile_pix) {
+                                              int n0, int mt, int ntile, size_t tile_pix, bool mul_dma = false) {
   constexpr int RPW = TR / WM;
   constexpr int NPW = NT / WN;
   constexpr int TN = 32 * NT;
@@ -95,10 +127,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
   // and the bf16 engine's kernels are bound by requests in flight -- the launches that carried the epilogue more than
   // doubled (conv_x3f<2,2,9,..> 79 -> 180 us).  The workgroup copies the tile's [TR * 32 pixels][TN channels] with 16-byte
   // loads into the (now dead) staging buffers and the lanes pick their elements from there.
-  constexpr int MROW = TN + 8;                       // bf16 per LDS row: the two half-waves of a read (4 rows apart) hit different banks
+  int MROW = TN + 8;                                 // bf16 per LDS row: the two half-waves of a read (4 rows apart) hit different banks
   unsigned short* s_mul = reinterpret_cast<unsigned short*>(smem);
   bool stage_mul = false;
-  if constexpr (STATMUL && BF16_OUT) {
+  if constexpr (STATMUL && BF16_OUT) if (mul_dma) {
+    // the tile was requested under the last K chunk (conv_mul_dma_issue): wait for it, nothing to copy
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    s_mul = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(smem) + a.mul_lds_off);
+    MROW = TN;
+    stage_mul = true;
+  }
+  if constexpr (STATMUL && BF16_OUT) if (!mul_dma) {
     // (the tile lands in the K loop's dynamic LDS: only if THIS launch allocated enough of it -- the launcher says how much)
     stage_mul = mulp != nullptr && mbf && full_pix && n0 + TN <= a.Cout && (a.stat_mul_cs & 7) == 0 &&
                 a.lds_bytes >= (unsigned)(TR * 32 * MROW * 2);     // workgroup-uniform
@@ -138,6 +178,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
           s1[j] += v;
           s2v[j] += v * (mulp ? c3d_ld1(mulp, ((size_t)(b * a.H + gy) * a.W + gx) * a.stat_mul_cs + co, mbf) : v);
         }
+        // (edge tiles only: keep the scheduler from batching four elements' loads and predicates -- registers, see fast_epilogue)
+        if constexpr (STATMUL && BF16_OUT) if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
@@ -150,7 +192,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     constexpr bool ACC = decltype(accumulate_tag)::value;
     using OT = typename decltype(type_tag)::type;
     OT* obase = reinterpret_cast<OT*>(a.out) + obase_i;
-    if constexpr (std::is_same_v<OT, __bf16> && !ACC && !ILV && (NT / WN) > 1) if (!mulp) {
+    if constexpr (std::is_same_v<OT, __bf16> && !ACC && !ILV && (NT / WN) > 1) if (!mulp || stage_mul) {
       // bf16 output, several ADJACENT cout sub-tiles per wave: a sub-tile is 64 bytes of a pixel, half a cache line, and a
       // launch that mostly writes (192 -> 704) took as long as over fp32 tensors.  With the sub-tiles innermost the wave's
       // consecutive stores cover NPW x 64 contiguous bytes of the same pixel.
@@ -169,6 +211,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
           OT* orow = obase + (ptrdiff_t)((wm + i * WM) * a.W + 4 * half) * ocs + wn * NPW * 32;
+          // (round 6: with the multiplier tile in LDS the BatchNorm-backward sums ride on this store order too -- the per-sub-tile
+          //  order below writes 64-byte halves of a line: the 64-cout launches that carried the sums took 120 us instead of 78)
+          const unsigned short* mr = s_mul + ((wm + i * WM) * 32 + 4 * half) * MROW + wn * NPW * 32 + l31;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
 #pragma unroll
@@ -176,9 +221,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
               float v = __builtin_fmaf(acc[i][j][r], asc, bj[j]);
               if (a.epi_lrelu) v = c3d_lrelu(v, a.slope);
               __builtin_nontemporal_store((OT)v, &orow[(ptrdiff_t)((r & 3) + 8 * (r >> 2)) * ocs + j * 32]);
-              s1[j] += v;
-              s2v[j] += v * v;
+              if constexpr (STATMUL) {
+                if (mulp) {
+                  v = (float)(OT)v;                                      // the value as stored
+                  s1[j] += v;
+                  s2v[j] += v * __uint_as_float((unsigned)mr[((r & 3) + 8 * (r >> 2)) * MROW + j * 32] << 16);
+                } else {
+                  s1[j] += v;
+                  s2v[j] += v * v;
+                }
+              } else {
+                s1[j] += v;
+                s2v[j] += v * v;
+              }
             }
+            if constexpr (STATMUL) if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
           }
         }
         return;
@@ -234,6 +291,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
           if constexpr (STATMUL) s2v[j] += v * (mulp ? mul[r] : v);
           else s2v[j] += v * v;
         }
+        // (one (row pair, sub-tile) at a time: without the fence the scheduler hoists the multiplier reads of every sub-tile to the
+        //  top of the epilogue -- 64 registers on top of the accumulators in the 64-cout kernels, which spilled 36-67 of them
+        //  INTO THE K LOOP's allocation: tools/obj_resources.py, round 6)
+        if constexpr (STATMUL && BF16_OUT) __builtin_amdgcn_sched_barrier(0);
       }
     }
   };

@@ -431,6 +431,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw1_kernel(ConvArgs a) {
     }
   };
 
+  const bool mul_dma = false;      // (see launch_pw1: no LDS-DMA prefetch in this kernel)
   // ---- prologue: chunks 0 .. DEPTH - 1 requested, chunk 0 staged, chunk DEPTH requested into its set
   c3d_pw_static_for<0, DEPTH>([&](auto d_tag) { load_chunk(d_tag); });
   __syncthreads();                         // the affine table is complete
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw1_kernel(ConvArgs a) {
       __syncthreads();                     // the other buffer is complete, this one is free again
     });
   }
-  conv_epilogue<TR, NT, WM, WN, true, false, 512, true, SM>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix);
+  conv_epilogue<TR, NT, WM, WN, true, false, 512, true, SM>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile, tile_pix, mul_dma);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -789,6 +790,9 @@ int launch_pw1(ConvArgs& a, hipStream_t st) {
   // four sub-tiles per wave end up in scratch, 4 326 scratch instructions -- c3d_conv_stat_mul_supported() answers 0 there)
   if constexpr (NT == 4) if (a.stat_mul && a.stat_partial) {
     if (lds < (size_t)8 * 32 * (32 * NT + 8) * 2) lds = (size_t)8 * 32 * (32 * NT + 8) * 2;      // the multiplier tile of the epilogue
+    // (round 6: the LDS-DMA form of the multiplier tile -- conv_mul_dma_issue, which conv_x3f and conv_bfp use -- measured 34 -> 73 us
+    //  here: the only place to request it without a branch around the ring's counted loads is the prologue, and 32 KB of in-order
+    //  DMA in front of the first chunks delays the whole ring.  This kernel keeps the copy at the start of its epilogue.)
     a.lds_bytes = (unsigned)lds;
     c3d_opt_in_lds<&conv_pw1_kernel<NT, true>>();
     hipLaunchKernelGGL((conv_pw1_kernel<NT, true>), grid, dim3(512), lds, st, a);

@@ -683,6 +683,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   ++wq;
   __syncthreads();
 
+  bool mul_dma = false;
   auto k_loop = [&](auto nj_tag) {
     int wb = 0;
     for (int c = 0; c + 1 < nchunks; ++c) {
@@ -698,6 +699,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
     }
     // last chunk: weight atoms only (round 3: its input atoms used to re-load and re-convert the last chunk -- half of
     // all staging work of a 32-channel layer)
+    if constexpr (SM) mul_dma = conv_mul_dma_issue<TR, TN, 256>(a, smem, tid, x0, y0, n0, tile_pix);      // (round 6: under this chunk)
     c3d_x3_static_for<0, NG>([&](auto g_tag) {
       group(g_tag, wb, nj_tag, std::true_type{});
       ++wq;
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   if (NPW == 1 || nj >= NPW) k_loop(std::integral_constant<int, NPW>{});
   else k_loop(std::integral_constant<int, 1>{});
   conv_epilogue<TR, NT, WM, WN, NPL == 1, false, 256, false, (NPL >= 2 || SM)>(a, acc, smem, tid, lane, half, l31, wm, wn, b, x0, y0, n0, mt, ntile,
-                                                                       tile_pix);
+                                                                       tile_pix, mul_dma);
 }
 
 template <int NT, int HALO, int TT, bool SIX, int NPL = 3, bool BFS = false>
@@ -724,6 +726,11 @@ int launch_x3f_s(ConvArgs& a, hipStream_t st) {
   if constexpr (BFS) {
     if (a.stat_mul && a.stat_partial) {      // BatchNorm-backward sums in the epilogue: the instance that has it
       if (lds < (size_t)8 * 32 * (32 * NT + 8) * 2) lds = (size_t)8 * 32 * (32 * NT + 8) * 2;      // the multiplier tile of the epilogue
+      if (!(a.variant & 64)) {      // round 6: a region of its own behind the K loop's buffers, filled by LDS-DMA under the last chunk
+        lds = (lds + 15) / 16 * 16;
+        a.mul_lds_off = (unsigned)lds;
+        lds += (size_t)8 * 32 * (32 * NT) * 2;
+      }
       a.lds_bytes = (unsigned)lds;
       c3d_opt_in_lds<&conv_x3f_kernel<NT, HALO, TT, SIX, NPL, BFS, true>>();
       hipLaunchKernelGGL((conv_x3f_kernel<NT, HALO, TT, SIX, NPL, BFS, true>), grid, dim3(256), lds, st, a);
