@@ -325,9 +325,16 @@ struct c3d_x3_products_one {
 // stride-(1, 2) conv of RangeNet over a column-pair view: three rows of two) and three (its transposed conv: three "rows" of one)
 constexpr int c3d_x3f_group(int tt) { return tt == 9 ? 3 : ((tt == 4 || tt == 6) ? 2 : (tt == 3 ? 1 : tt)); }
 
-template <int NT, int HALO, int TT, bool SIX, int NPL = 3, bool BFS = false, bool SM = false>
+// PLAIN (round 6, the three-plane engine): every source of the launch comes without BatchNorm affine and without LeakyReLU -- the
+// input-gradient launches, whose source is dz.  The on-load transform is then the identity (fma(x, 1, 0), max(v, 1 * v)) and
+// the zero padding needs no mask (an out-of-range buffer load returns 0 and there is no shift to undo): the XF atoms -- four
+// of the twelve VALU operations per staged value -- and the scale / shift loads are left out.  With 32 couts per workgroup
+// the fused schedule deals ~3 VALU + ~1.2 LDS operations into every MFMA gap, the edge of what hides there (guide: <= 5):
+// these launches ran at 0.37-0.43 matrix-pipe busy against 0.62-0.65 for the 64-cout ones.  Same values, same order: bit-identical.
+template <int NT, int HALO, int TT, bool SIX, int NPL = 3, bool BFS = false, bool SM = false, bool PLAIN = false>
 __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   static_assert(!BFS || NPL == 1, "bf16 sources belong to the one-plane engine");
+  static_assert(!PLAIN || (NPL == 3 && !BFS), "the transform-free instance exists for the three-plane engine over fp32 tensors");
   static_assert(!SM || BFS, "the separate stat_mul instance exists for the one-plane kernel over bf16 tensors");
   constexpr bool F16 = NPL == 2;
   constexpr unsigned EB = BFS ? 2u : 4u;           // bytes per stored activation element
@@ -495,8 +502,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   //      chunk earlier, spills at 64 couts per workgroup.  Round 5: four taps run as two rows of two, G = 2.)
   static_assert(NG > 1, "the fused schedule needs more than one tap row per chunk");
   f32x4 sv;
-  constexpr int LOAD_ATOMS = IN_PT + 1;            // + scale / shift
-  constexpr int CA_U = 2 + 2 * NPL;                // atoms per input unit: XF e0, XF e1, then two SPLIT halves per plane
+  constexpr int LOAD_ATOMS = IN_PT + (PLAIN ? 0 : 1);            // + scale / shift
+  constexpr int XFA = PLAIN ? 0 : 2;               // XF atoms per unit
+  constexpr int CA_U = XFA + 2 * NPL;              // atoms per input unit: XF e0, XF e1, then two SPLIT halves per plane
   constexpr int CONV_ATOMS = IN_PT * CA_U;
   constexpr int WA_U = NPL + 1;                    // atoms per weight unit: one store per plane, then the next load
   constexpr int W_ATOMS = W_PT * WA_U;
@@ -518,7 +526,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
   auto conv_atom = [&](auto k_tag) {
     constexpr int k = decltype(k_tag)::value;
     constexpr int i = k / CA_U, r = k % CA_U;
-    if constexpr (r < 2) {
+    if constexpr (PLAIN && r == 0) sv = pin[i];      // the raw unit IS the staged value
+    if constexpr (r < XFA) {
       // zero padding AFTER the transform, as a bit mask: written as `in ? f(v) : 0.f` the compiler built a branch per pair
       // of elements (s_and_saveexec / s_xor / s_andn2_saveexec / s_or around three VALU instructions each) in the
       // middle of the MFMA stream
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3f_kernel(ConvArgs a) {
         sv[q] = __uint_as_float(__float_as_uint(__builtin_fmaxf(v, v * pslope)) & keep);
       }
     } else {
-      constexpr int p = (r - 2) / 2, e = (r - 2) % 2;
+      constexpr int p = (r - XFA) / 2, e = (r - XFA) % 2;
       if constexpr (F16) {
         float r0, r1;
         npl[i][p][e] = split_f16(sv[2 * e], sv[2 * e + 1], r0, r1);
@@ -734,6 +743,18 @@ int launch_x3f_s(ConvArgs& a, hipStream_t st) {
       a.lds_bytes = (unsigned)lds;
       c3d_opt_in_lds<&conv_x3f_kernel<NT, HALO, TT, SIX, NPL, BFS, true>>();
       hipLaunchKernelGGL((conv_x3f_kernel<NT, HALO, TT, SIX, NPL, BFS, true>), grid, dim3(256), lds, st, a);
+      C3D_CHECK_LAUNCH();
+      return 0;
+    }
+  }
+  if constexpr (NPL == 3 && SIX && !BFS) {
+    // input-gradient launches (six products) whose sources carry no on-load transform: the transform-free instance
+    // (variant & 128 keeps the general one: bit-identity test)
+    bool plain = !(a.variant & 128);
+    for (int s = 0; s < a.nsrc; ++s) plain = plain && a.src[s].scale == nullptr && a.src[s].lrelu == 0;
+    if (plain) {
+      c3d_opt_in_lds<&conv_x3f_kernel<NT, HALO, TT, SIX, NPL, BFS, false, true>>();
+      hipLaunchKernelGGL((conv_x3f_kernel<NT, HALO, TT, SIX, NPL, BFS, false, true>), grid, dim3(256), lds, st, a);
       C3D_CHECK_LAUNCH();
       return 0;
     }

@@ -343,7 +343,8 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     def kernel_name():
         return _conv_kernel_name(b, h, w, [s.C for s in srcs], [s.t.dtype == torch.bfloat16 for s in srcs], cout, taps, grad,
                                  bool(d.wpack_planes), bool(d.stat_mul), has_stats=bool(d.stat_partial), accumulate=bool(accumulate),
-                                 out_room=(out.shape[3] - out_coff) if (out.shape[3] % 4 == 0 and out_coff % 4 == 0) else 0)
+                                 out_room=(out.shape[3] - out_coff) if (out.shape[3] % 4 == 0 and out_coff % 4 == 0) else 0,
+                                 plain=all(s_.scale is None and not s_.lrelu for s_ in srcs))
     # six plane products: every input gradient, and forward multi-tap convs whose BatchNorm population is large
     # (SIX_FWD_MIN_PIXELS).  conv_pw3 runs six in every launch (the flag is ignored there).
     six = MFMA_MODE == 2 and (grad or (nt_ > 1 and tr == 8 and b * h * w >= SIX_FWD_MIN_PIXELS))
@@ -374,7 +375,7 @@ def conv_forward(srcs, wpack, bias, cout, taps, lrelu=False, stats=False, out=No
     return out, stat_partial
 
 
-def _conv_kernel_name(b, h, w, src_c, src_bf16, cout, taps, grad, wpack_planes, stat_mul, has_stats=False, accumulate=False, out_room=None):
+def _conv_kernel_name(b, h, w, src_c, src_bf16, cout, taps, grad, wpack_planes, stat_mul, has_stats=False, accumulate=False, out_room=None, plain=False):
     """The kernel instance c3d_conv_forward launches for this problem, as rocprofv3 prints it -- a mirror of the dispatch in
     csrc/conv_mfma.hip, conv_x3.hip, conv_pw3.hip and conv_bfp.hip for the per-kernel event timers of bench.py
     (tests/test_cpu_kernel_names.py holds every name it can produce against the symbols of the built library)."""
@@ -390,11 +391,14 @@ def _conv_kernel_name(b, h, w, src_c, src_bf16, cout, taps, grad, wpack_planes, 
         # (names as rocprofv3 prints them: the fused kernel carries its plane count and its bf16-source flag as fifth and
         #  sixth template arguments)
         six_ = grad or b * h * w >= SIX_FWD_MIN_PIXELS          # (the fourth template argument: six plane products)
+        # (eighth argument, round 6: the transform-free instance -- six products, no source with an affine or a LeakyReLU on load:
+        #  the input-gradient launches; CONV_VARIANT & 128 keeps the general one)
+        plain_ = bool(fused_ and six_ and plain and not (CONV_VARIANT & 128))
         name = (f"conv_x3{'f' if fused_ else ''}_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, {nt_}, "
-                f"{'true' if six_ else 'false'}{', 3, false, false' if fused_ else ''}>")
+                f"{'true' if six_ else 'false'}{(', 3, false, false, ' + ('true' if plain_ else 'false')) if fused_ else ''}>")
     elif (MFMA_MODE == 1 and tr == 8 and nt_ == 9 and wpack_planes and not (CONV_VARIANT & 4)
           and all(src_bf16)):      # the fused nine-tap kernel with one plane (csrc/conv_x3.hip)
-        name = f"conv_x3f_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, 9, true, 1, true, {sm_}>"
+        name = f"conv_x3f_kernel<{2 if _wide_cout_tiles(b, h, w, cout, tr) else 1}, {hh}, 9, true, 1, true, {sm_}, false>"
     elif MFMA_MODE and tr == 8 and nt_ == 1 and cout > 64 and wpack_planes and _pw3_tile(b, h, w, cout):     # csrc/conv_pw3.hip
         name = _pw3_kernel_name(_pw3_tile(b, h, w, cout), sum(src_c), cout,
                                 bf16_srcs=all(src_bf16))

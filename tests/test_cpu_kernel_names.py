@@ -54,9 +54,10 @@ def test_conv_and_weight_gradient_name_mirrors_name_kernels_of_the_library(mode,
             for bf in ((False, True) if mode == 1 else (False,)):
                 planes = (mode == 2 and len(taps) > 1) or (mode == 1 and len(taps) == 9) or (mode != 0 and len(taps) == 1 and cout > 64)
                 for sm in ((False, True) if (mode == 1 and bf and grad) else (False,)):
-                    name, _ = ops._conv_kernel_name(B, H, W, srcs, [bf] * len(srcs), cout, taps, grad, planes, sm)
-                    if name not in have and not (sm and name.startswith("conv_pw1_kernel<8")):      # (no such instance: ops asks c3d_conv_stat_mul_supported first)
-                        missing.add(name)
+                    for plain in ((False, True) if grad else (False,)):       # (input-gradient launches: sources without an on-load transform)
+                        name, _ = ops._conv_kernel_name(B, H, W, srcs, [bf] * len(srcs), cout, taps, grad, planes, sm, plain=plain)
+                        if name not in have and not (sm and name.startswith("conv_pw1_kernel<8")):      # (no such instance: ops asks c3d_conv_stat_mul_supported first)
+                            missing.add(name)
         for fused in ((False, True) if mode == 2 else (False,)):
             for raw in ((False, True) if mode == 1 else (False,)):
                 for ci in srcs:

@@ -29,7 +29,7 @@ ALLOWED = {
     r"conv_bfp_kernel<[48], [12], 16, 2, 9, 1, false, false>": "bf16 engine over fp32 tensors, phased nine-tap",
     # the BatchNorm-backward epilogue over bf16 tensors: built, measured slower, off by default (C3D_FUSE_BN_REDUCE_BF16)
     r"conv_bfp_kernel<8, 2, \d+, \d, \d, 1, true, true>": "stat_mul instances of the bf16 engine (off)",
-    r"conv_x3f_kernel<2, [12], 9, true, 1, true, true>": "stat_mul instances of the bf16 engine (off)",
+    r"conv_x3f_kernel<2, [12], 9, true, 1, true, true, false>": "stat_mul instances of the bf16 engine (off); round 6: all 35 in the epilogue",
     # weight gradients: an instance the launcher only picks for c3d_wgrad_desc.variant, and the whole-window fused forms that
     # short columns (< 8 tiles) still take
     r"wgrad_tr_kernel<3, 1, 2, 4, 2, 2, 1, 0, true, false, false, 4, 4>": "fused 128 x 256 slice: variant & 4 only (the launcher takes 128 x 128)",
