@@ -251,7 +251,10 @@ extern "C" int c3d_conv_num_mtiles(int B, int H, int W) {
 }
 
 // smallest grid the wide pointwise kernel is launched with (see c3d_conv_forward); mirrored by ops._pw3_tile()
-static int c3d_pw3_min_workgroups() { return 128; }
+static int c3d_pw3_min_workgroups() {
+  static const int v = getenv("C3D_PW3_FILL") ? atoi(getenv("C3D_PW3_FILL")) : 128;      // (experiments)
+  return v;
+}
 
 // Whether the kernel a descriptor selects compiles the BatchNorm-backward epilogue in (conv_common.h, STATMUL).  Mirrors the
 // dispatch of c3d_conv_forward below and of conv_bfp.hip / conv_pw3.hip for the bf16 engine.

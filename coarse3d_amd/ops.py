@@ -273,7 +273,7 @@ def _wide_cout_tiles(b, h, w, cout, tr):
 def _pw3_tile(b, h, w, cout):
     """Cout sub-tiles (8 = 256 couts, 4 = 128) of the wide pointwise kernel for this launch, 0 = the grid would leave
     most CUs idle and conv_bfp's 64-wide workgroups run instead.  Mirrors c3d_conv_forward() in csrc/conv_mfma.hip."""
-    fill = 128
+    fill = int(os.environ.get("C3D_PW3_FILL", "128"))
     px_tiles = b * ((w + 31) // 32) * ((h + 7) // 8)
     wide = cout > 128
     if wide and px_tiles * ((cout + 255) // 256) < fill:
