@@ -599,14 +599,14 @@ def whole_step(roof, value_img_s):
 DTYPE_NOTE = {
     "f32": "f32 (v_mfma_f32_32x32x2_f32 everywhere)",
     "bf16": "bf16 activations in HBM + bf16 MFMA operands, f32 accumulate / statistics / master weights.  Held against the reference "
-            "side (profiles/round5_parity_measured_bf16.json): forward vs the fp32 CPU oracle |dp| max 0.13 / mean 4.3e-3 = 1.11x / 0.99x "
+            "side (profiles/round6_parity_measured_bf16.json): forward vs the fp32 CPU oracle |dp| max 0.13 / mean 4.3e-3 = 1.11x / 0.99x "
             "the distance of the SAME oracle with bf16-rounded conv operands; one training step vs the reference-generated golden "
             "step: ce 3.5e-3, Lovasz 4.7e-4, contrast 4.5e-5 relative",
     "bf16_f32storage": "bf16 MFMA operands, f32 accumulate/storage",
     "bf16x3": "f32 via 3xbf16 exact split on the bf16 matrix pipe (the library's default engine), f32 accumulate; 6 of 9 plane "
               "products (8 of 9 in forward 3x3 / 2x2 convs whose output has fewer than 32768 pixels, where a small BatchNorm "
               "population amplifies the difference); f32 storage everywhere.  Parity as measured on MI355X "
-              "(profiles/round5_parity_measured.json): forward / logits / prototypes <= 1e-4 of the reference on every golden; "
+              "(profiles/round6_parity_measured.json): forward / logits / prototypes <= 1e-4 of the reference on every golden; "
               "pseudo-label maps identical; anchor selection bit-exact on identical weights; END TO END against the reference's "
               "golden steps: {anchor_rate}; whole-network gradient error vs the reference golden: median 1.1e-2 (fp32-MFMA engine "
               "6.1e-3; per-layer float64 check 7e-7 on both)",
