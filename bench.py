@@ -235,6 +235,11 @@ BASELINE_CONFIGS = {
                        note="nuScenes 32x1024 range image, 16 classes + ignore, bs=16 (small-H path)"),
     "configs[4]": dict(height=40, width=1800, classes=14, dataset="SemanticPOSS", batch=8, matrix_dtype="bf16x3", storage=None,
                        note="SemanticPOSS 40x1800 (+8 pad), 0.01 % weak labels, entropy anchor sampling on (sparse-anchor path)"),
+    # not a BASELINE.json config: the shape of the REFERENCE's own nuScenes YAML (tasks/weak_segmentation/config_nuscenes.yaml:132-133;
+    # BASELINE configs[3] quotes 32 x 1024 -- SURVEY appendix C, Q11 "ship both"; parity case in tests/test_gpu_configs.py)
+    "nuscenes_reference_yaml_shape": dict(height=64, width=2048, classes=17, dataset="SemanticKitti", batch=8, matrix_dtype="bf16x3",
+                                          storage=None, note="nuScenes at the reference YAML's own range-image shape 64x2048, 16 classes + "
+                                                             "ignore, bs=8 (not a BASELINE.json config)"),
 }
 
 
