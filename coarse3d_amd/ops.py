@@ -82,6 +82,9 @@ def _bf(*tensors):
 # Schedule selector of the bit-identity tests (c3d_conv_desc.variant): 0 = the library's choice; bits 0-1 for 1x1 convs
 # with Cout > 64 on the bf16x3 engine (1 = fused kernel with eight waves, 2 = with four, 3 = round 2's phased kernel);
 # bit 2 = round 2's phased kernel for nine-tap convs.  Same bits out of every variant (tests/test_gpu_conv.py).
+# Round 6: 32 = conv_bfp's staged tile instead of the streaming 32-channel pointwise kernel (csrc/conv_pws.hip), 64 = no LDS-DMA
+# prefetch of the bf16 engine's multiplier tile, 128 = the general instance of conv_x3f for input-gradient launches (instead of the
+# transform-free one); a pack made by pack_weights_wino adds 16 by itself (Winograd variant, csrc/conv_wino.hip).
 CONV_VARIANT = 0
 # c3d_wgrad_desc.variant (fused weight-gradient launches): 0 = the library's choice, 1 = whole-window register sets, 2 = lean
 # ones (same bits), +4 = a fused 1x1 launch keeps the unfused tile configuration, +128 = four producer waves in every

@@ -117,7 +117,16 @@ typedef struct {
                                fused one;
                                bit 3, the bf16 engine's 1x1 / four-tap convs with <= 64 outputs over bf16 tensors
                                (conv_bfp.hip): 16 / 32-channel K chunks widened at load instead of the deeper chunks of
-                               raw bf16                                                                              */
+                               raw bf16;
+                               round 6 -- bit 4 (16): nine-tap convs of the bf16x3 engine as Winograd F(2x2, 3x3) (conv_wino.hip;
+                               wpack is then a c3d_pack_weights_wino pack, stat_partial sized by c3d_conv_wino_num_tiles): the
+                               gate experiment, NOT the same bits (another association of the same fp32-class arithmetic),
+                               measured slower, off;  bit 5 (32): the staged tile (conv_bfp) where the streaming kernel of the
+                               32-channel 1x1 convs would run (conv_pws.hip; agrees to 2e-7 of max: another product order);
+                               bit 6 (64): the bf16 engine's BatchNorm-backward epilogue copies its multiplier tile at the
+                               start of the epilogue instead of fetching it by LDS-DMA under the last K chunk (same bits);
+                               bit 7 (128): input-gradient launches of the fused multi-tap kernel keep the general instance
+                               instead of the transform-free one (same bits)                                          */
   const float* acc_scale_dev; /* EXPERIMENT (mfma_bf16 == 4): NULL, or a device scalar the accumulators are multiplied
                                with before bias / activation -- the inverse of a per-tensor gradient exponent
                                (c3d_grad_exponent)                                                            */
