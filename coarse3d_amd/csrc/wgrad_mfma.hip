@@ -416,7 +416,14 @@ void plan(const c3d_wgrad_desc* d, WgradArgs& a, WgCfg& c) {
   a.tiles_per_strip = (a.ntiles + strips - 1) / strips;
   a.strips = (a.ntiles + a.tiles_per_strip - 1) / a.tiles_per_strip;
   a.npw = c3d_wgrad_producer_waves(planes_for(d), c.id, d->variant, d->ntaps);
-  if (c.id >= 6 && d->fuse_dy) a.npw = 4;      // (nine taps with the BatchNorm backward on load: the four + four wave form, wgrad_tr.hip)
+  // nine taps with the BatchNorm backward on load: sixteen waves with the producer waves split by tensor (round 6, ROLES in
+  // wgrad_tr.hip); layers with a pre-activation affine, three / six taps and variant & 256 keep the four + four wave form
+  if (c.id >= 6 && d->fuse_dy && (a.npw != 8 || d->fuse_pre_scale || (d->variant & 256))) a.npw = 4;
+}
+
+// threads the dz units of a fused launch are dealt to (= entries per strip and channel of fuse_sum, times CO / 4)
+int fused_dz_threads(const c3d_wgrad_desc* d, const WgradArgs& a, const WgCfg& c) {
+  return (c.id >= 6 && d->fuse_dy && a.npw == 8) ? 256 : 64 * a.npw;
 }
 
 template <int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool BF>
@@ -460,7 +467,7 @@ extern "C" int c3d_wgrad_fused_sum_n(const c3d_wgrad_desc* d) {
   WgradArgs a;
   WgCfg c;
   plan(d, a, c);
-  return a.strips * (64 * a.npw / (c.CO / 4));
+  return a.strips * (fused_dz_threads(d, a, c) / (c.CO / 4));
 }
 
 extern "C" int64_t c3d_wgrad_partial_floats(const c3d_wgrad_desc* d) {
@@ -510,7 +517,7 @@ extern "C" int c3d_conv_wgrad(const c3d_wgrad_desc* d, c3d_stream stream) {
     C3D_REQUIRE((d->fuse_pre_scale == nullptr) == (d->fuse_pre_shift == nullptr) && (!d->fuse_pre_scale || d->fuse_k1),
                 "wgrad: fuse_pre_scale / fuse_pre_shift come together and need the BatchNorm coefficients");
     a.f_ps = d->fuse_pre_scale; a.f_psh = d->fuse_pre_shift;
-    a.f_sum_n = a.strips * (64 * a.npw / (c.CO / 4));
+    a.f_sum_n = a.strips * (fused_dz_threads(d, a, c) / (c.CO / 4));
   }
   hipStream_t st = (hipStream_t)stream;
   const int planes = planes_for(d);

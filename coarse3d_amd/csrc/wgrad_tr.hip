@@ -201,6 +201,15 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
   constexpr int NPT = 64 * NPW;        // producer threads
   constexpr int NCT = 64 * NCW;        // consumer threads
   constexpr bool SPL = NCW == 8;       // taps split across two consumer waves per SIMD
+  // ROLES (round 6, the nine-tap instances with the BatchNorm backward on load): the producer waves split by TENSOR -- waves
+  // 0 .. NPW/2 - 1 stage the x units of a tile, the others its dz units (dy and the stored output in flight, the fmaf chain, the
+  // dz store, the bias sums).  With both tensors in flight twice a producer wave did not fit the 128 registers of a sixteen-wave
+  // workgroup (9-45 spilled registers: the fused launches stayed on the four + four wave form, one producer wave per SIMD with
+  // nothing to fill its stalls).  Either role alone does.  XT / DT: the threads a tile's x / dz units are dealt to -- with
+  // ROLES each is the four + four form's 256, so every unit sits with the thread index it had there: same dz, same bias sums.
+  constexpr bool ROLES = FA && SPL;
+  constexpr int XT = ROLES ? NPT / 2 : NPT;
+  constexpr int DT = ROLES ? NPT - XT : NPT;
   static_assert(NCW == 4 || (NCW == 8 && NPW == 8 && TMAX == 9 && CI_T == 1 && CO_T == 1 && WCI == 1 && (NP == 3 || NP == 1)),
                 "split consumers: the nine-tap instances of the three-plane and one-plane engines, eight producer waves");
   static_assert(!RAW || (NP == 1 && !FA), "raw bf16 stages belong to the one-plane engine without the fused apply");
@@ -249,7 +258,8 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
   //  of the 32 x 32 nine-tap instance, in a kernel whose MFMA and VALU streams share the SIMD's issue port -- PMC: 39 % of
   //  the wave cycles were issue stalls.)
   // (consumer threads 0 .. NCT - 1, producer threads 0 .. NPT - 1)
-  const int tid = producer ? (int)threadIdx.x - NCT : (int)threadIdx.x, lane = tid & 63;
+  const bool xrole = !ROLES || __builtin_amdgcn_readfirstlane((int)threadIdx.x) < NCT + XT;          // (producers; wave-uniform)
+  const int tid = producer ? (int)threadIdx.x - NCT - (xrole ? 0 : XT) : (int)threadIdx.x, lane = tid & 63;   // index within the role
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = SPL ? (wave8 & 3) : wave8;       // SPL: consumer wave (wave, th); producers never use it
   const int th = SPL ? ((wave8 >> 2) & 1) : 0;
@@ -268,10 +278,10 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
 
   // ---- register staging (prefetch) of the next pixel tile while the current one is consumed
   constexpr int X_UNITS = LEANX ? NEWROWS_UNITS : XROWS * (CI / 4);      // x units of a register set in flight
-  constexpr int X_PT = (X_UNITS + NPT - 1) / NPT;
-  constexpr int E_PT = LEANX ? (EXTRA_UNITS + NPT - 1) / NPT : 0;
+  constexpr int X_PT = (X_UNITS + XT - 1) / XT;
+  constexpr int E_PT = LEANX ? (EXTRA_UNITS + XT - 1) / XT : 0;
   constexpr int D_UNITS = DROWS * (CO / 4);
-  constexpr int D_PT = (D_UNITS + NPT - 1) / NPT;
+  constexpr int D_PT = (D_UNITS + DT - 1) / DT;
   // one register set per tile in flight; the producers keep TWO tiles of loads outstanding (one
   // tile per CU in flight left the kernel bound by memory latency)
   struct Stage {
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
     int ex0, ey0;   // LEANX: image column / row of the window's first pixel (uniform; may be negative)
     size_t ximg;    // LEANX: element offset of the image in x (uniform)
   };
-  const int xc4 = tid % (CI / 4);          // NPT % (CI/4) == 0: fixed channel quad per thread
+  const int xc4 = tid % (CI / 4);          // XT % (CI/4) == 0: fixed channel quad per thread
   const int xc = ci0 + xc4 * 4;
   const bool xc_ok = xc < a.x.C;
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
@@ -309,9 +319,9 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
   // per-unit index arithmetic or bounds tests.  Without a halo a pass of 256 threads advances by
   // a uniform pixel offset, so one offset per thread is enough.
   const int xp0 = tid / (CI / 4);
-  constexpr int XSTEP = NPT / (CI / 4);    // pixels per pass of the producer waves
+  constexpr int XSTEP = XT / (CI / 4);    // pixels per pass of the producer waves
   const int dc4 = tid % (CO / 4), dp0 = tid / (CO / 4);
-  constexpr int DSTEP = NPT / (CO / 4);
+  constexpr int DSTEP = DT / (CO / 4);
   static_assert(XSTEP % 32 == 0 || 32 % XSTEP == 0, "pass size must tile the 32-pixel rows");
   static_assert(DSTEP % 32 == 0 || 32 % DSTEP == 0, "pass size must tile the 32-pixel rows");
   const int dc = co0 + dc4 * 4;
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
     xoff[0] = (unsigned)(((xp0 / 32) * a.W + xp0 % 32) * a.x.cstride + a.x.coff + xc);
   }
   const unsigned doff0 = (unsigned)(((dp0 / 32) * a.W + dp0 % 32) * a.dz_cstride + dc);
-  const unsigned x_all = xc_ok ? ((X_UNITS % NPT == 0 || tid < X_UNITS % NPT) ? ((1u << X_PT) - 1u) : ((1u << (X_PT - 1)) - 1u)) : 0u;
+  const unsigned x_all = xc_ok ? ((X_UNITS % XT == 0 || tid < X_UNITS % XT) ? ((1u << X_PT) - 1u) : ((1u << (X_PT - 1)) - 1u)) : 0u;
   unsigned x_new = 0;        // RINGX: this thread's units that lie in the first TRW rows of the staged rectangle
 #pragma unroll
   for (int i = 0; i < X_PT; ++i)
@@ -416,7 +426,10 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
 #else
   constexpr bool abl_l2 = false, abl_nolds = false, abl_prod = false, abl_cons = false;
 #endif
-  auto load_tile = [&](Stage& sg) __attribute__((always_inline)) {
+  // role_tag: 0 = both tensors (every producer wave stages its share of both), 1 = the x units only, 2 = the dz units only (ROLES).
+  // A compile-time tag, not a branch: a uniform branch around the loads costs the counted waits (the trap described above).
+  auto load_tile = [&](Stage& sg, auto role_tag) __attribute__((always_inline)) {
+    constexpr bool DO_X = decltype(role_tag)::value != 2, DO_D = decltype(role_tag)::value != 1;
     if (abl_prod) return;
     const int x0 = ltx * 32, y0 = lty * TRW, b = lb;
     // RINGX: a tile right below its predecessor in the strip stages only its TRW new rows (image rows y0 + HALO ...)
@@ -531,13 +544,18 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
       load_x(std::true_type{});
       load_dz(std::true_type{});
     } else {
-      if (NP == 1 && a.x.bf16) load_x(std::true_type{});
-      else load_x(std::false_type{});
-      if (NP == 1 && a.dz_bf16) load_dz(std::true_type{});
-      else load_dz(std::false_type{});
+      if constexpr (DO_X) {
+        if (NP == 1 && a.x.bf16) load_x(std::true_type{});
+        else load_x(std::false_type{});
+      }
+      if constexpr (DO_D) {
+        if (NP == 1 && a.dz_bf16) load_dz(std::true_type{});
+        else load_dz(std::false_type{});
+      }
     }
   };
-  auto store_tile = [&](int buf, const Stage& sg) __attribute__((always_inline)) {
+  auto store_tile = [&](int buf, const Stage& sg, auto role_tag) __attribute__((always_inline)) {
+    constexpr bool DO_X = decltype(role_tag)::value != 2, DO_D = decltype(role_tag)::value != 1;
     if (abl_prod) return;
     unsigned short* s_x = RINGX ? s_base : s_base + buf * BUF;
     unsigned short* s_dz = RINGX ? s_base + NP * XPLANE + buf * (NP * DROWS * CO) : s_x + NP * XROWS * CI;
@@ -552,7 +570,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
         emask = 0;
 #pragma unroll
         for (int j = 0; j < X_PT; ++j) {
-          const int u = tid + (j0 + j) * NPT;
+          const int u = tid + (j0 + j) * XT;
           const int pp = u / (CI / 4);
           const int r = pp / TWh, col = pp - r * TWh;
           const int gx = sg.ex0 + col, gy = sg.ey0 + r;
@@ -568,7 +586,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
         x_affine(esc, esh);
 #pragma unroll
         for (int j = 0; j < X_PT; ++j) {
-          const int u = tid + (j0 + j) * NPT;
+          const int u = tid + (j0 + j) * XT;
           if ((j0 + j) < E_PT && u < EXTRA_UNITS) {
             f32x4 v = pe[j];
             if (aff) v = v * esc + esh;
@@ -592,11 +610,12 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
         }
       }
     };
+    if constexpr (DO_X) {
     f32x4 xsc, xsh;
     x_affine(xsc, xsh);
 #pragma unroll
     for (int i = 0; i < X_PT; ++i) {
-      const int u = tid + i * NPT;
+      const int u = tid + i * XT;
       if (u < xunits) {
         f32x4 v;
         if constexpr (RAW) {
@@ -630,6 +649,8 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
     if constexpr (LEANX) {
       if (sg.xfresh) extra_load(0);          // into the registers the x units above have left; converted behind the dz units
     }
+    }
+    if constexpr (DO_D) {
     f32x4 k1 = fk1, k2 = fk2, k3 = fk3;
     if constexpr (SPL && FA) {
       k1 = *reinterpret_cast<const f32x4*>(s_const + 2 * CI + dc4 * 4);
@@ -638,7 +659,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
     }
 #pragma unroll
     for (int i = 0; i < D_PT; ++i) {
-      const int u = tid + i * NPT;
+      const int u = tid + i * DT;
       if (u < D_UNITS) {
         u32x2 pl[NP];
         if constexpr (RAW) {
@@ -678,7 +699,8 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
         }
       }
     }
-    if constexpr (LEANX) {
+    }
+    if constexpr (LEANX && DO_X) {
       if (sg.xfresh) {
         extra_store(0);
 #pragma unroll
@@ -700,6 +722,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
   // ---- producer waves: stage tile mt+1 while the consumers work on tile mt; they take part in
   //      every barrier of the consumer path below (tile loop + K-split fold) and nothing else
   if (producer) {
+   auto produce = [&](auto role_tag) __attribute__((always_inline)) {
    if constexpr (DEPTH == 2) {
     Stage sa, sb;      // tile n of the strip travels through set / LDS buffer (n - t_begin) & 1
     int mt = t_begin;
@@ -707,41 +730,41 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
       // long strips: prologue and steady state carry no condition around a load, so the waits in
       // front of store_tile are s_waitcnt vmcnt(<loads of the younger tile>), not vmcnt(0)
       seek_tile(t_begin);
-      load_tile(sa);
-      load_tile(sb);
-      store_tile(0, sa);
-      load_tile(sa);
+      load_tile(sa, role_tag);
+      load_tile(sb, role_tag);
+      store_tile(0, sa, role_tag);
+      load_tile(sa, role_tag);
       __syncthreads();
       while (mt + 4 < t_end) {      // two tiles per trip
-        store_tile(1, sb);
-        load_tile(sb);
+        store_tile(1, sb, role_tag);
+        load_tile(sb, role_tag);
         __syncthreads();
-        store_tile(0, sa);
-        load_tile(sa);
+        store_tile(0, sa, role_tag);
+        load_tile(sa, role_tag);
         __syncthreads();
         mt += 2;
       }
     } else {
       if (t_begin < t_end) {
         seek_tile(t_begin);
-        load_tile(sa);
-        if (t_begin + 1 < t_end) load_tile(sb);
-        store_tile(0, sa);
-        if (t_begin + 2 < t_end) load_tile(sa);
+        load_tile(sa, role_tag);
+        if (t_begin + 1 < t_end) load_tile(sb, role_tag);
+        store_tile(0, sa, role_tag);
+        if (t_begin + 2 < t_end) load_tile(sa, role_tag);
       }
       __syncthreads();
     }
     for (; mt < t_end;) {
       // consumers on buffer 0: tile mt+1 -> buffer 1, then tile mt+3 takes its registers
       if (mt + 1 < t_end) {
-        store_tile(1, sb);
-        if (mt + 3 < t_end) load_tile(sb);
+        store_tile(1, sb, role_tag);
+        if (mt + 3 < t_end) load_tile(sb, role_tag);
       }
       __syncthreads();
       if (++mt >= t_end) break;
       if (mt + 1 < t_end) {
-        store_tile(0, sa);
-        if (mt + 3 < t_end) load_tile(sa);
+        store_tile(0, sa, role_tag);
+        if (mt + 3 < t_end) load_tile(sa, role_tag);
       }
       __syncthreads();
       ++mt;
@@ -756,15 +779,15 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
     if (t_end - t_begin > 2 * DEPTH) {
       // long strips: no condition around a load (counted waits, see above)
       seek_tile(t_begin);
-      c3d_wg_static_for<0, DEPTH>([&](auto k_tag) { load_tile(st[decltype(k_tag)::value]); });
-      store_tile(0, st[0]);
-      load_tile(st[0]);
+      c3d_wg_static_for<0, DEPTH>([&](auto k_tag) { load_tile(st[decltype(k_tag)::value], role_tag); });
+      store_tile(0, st[0], role_tag);
+      load_tile(st[0], role_tag);
       __syncthreads();
       while (mt + 2 * DEPTH < t_end) {      // DEPTH tiles per trip; the last load of a trip is tile mt + 2 * DEPTH
         c3d_wg_static_for<1, DEPTH + 1>([&](auto j_tag) {
           constexpr int J = decltype(j_tag)::value;
-          store_tile(J & 1, st[J % DEPTH]);
-          load_tile(st[J % DEPTH]);
+          store_tile(J & 1, st[J % DEPTH], role_tag);
+          load_tile(st[J % DEPTH], role_tag);
           __syncthreads();
         });
         mt += DEPTH;
@@ -772,13 +795,13 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
     } else {
       if (t_begin < t_end) {
         seek_tile(t_begin);
-        load_tile(st[0]);
+        load_tile(st[0], role_tag);
         c3d_wg_static_for<1, DEPTH>([&](auto k_tag) {
           constexpr int K = decltype(k_tag)::value;
-          if (t_begin + K < t_end) load_tile(st[K]);
+          if (t_begin + K < t_end) load_tile(st[K], role_tag);
         });
-        store_tile(0, st[0]);
-        if (t_begin + DEPTH < t_end) load_tile(st[0]);
+        store_tile(0, st[0], role_tag);
+        if (t_begin + DEPTH < t_end) load_tile(st[0], role_tag);
       }
       __syncthreads();
     }
@@ -788,8 +811,8 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
         constexpr int J = decltype(j_tag)::value;
         if (mt < t_end) {
           if (mt + 1 < t_end) {
-            store_tile(J & 1, st[J % DEPTH]);
-            if (mt + 1 + DEPTH < t_end) load_tile(st[J % DEPTH]);
+            store_tile(J & 1, st[J % DEPTH], role_tag);
+            if (mt + 1 + DEPTH < t_end) load_tile(st[J % DEPTH], role_tag);
           }
           __syncthreads();
           ++mt;
@@ -797,9 +820,16 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
       });
     }
    }
+   };
+   if constexpr (ROLES) {
+     if (xrole) produce(std::integral_constant<int, 1>{});
+     else produce(std::integral_constant<int, 2>{});
+   } else {
+     produce(std::integral_constant<int, 0>{});
+   }
     if constexpr (FA) {
       // per-thread sums of dz over the strip: [Cout][2][strips * DSTEP], row 0 (the launch's fold adds them in fp64)
-      if (fwrite) {
+      if (fwrite && (!ROLES || !xrole)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (dc + q < a.Cout) a.f_sum[((size_t)(dc + q) * 2) * a.f_sum_n + strip * DSTEP + dp0] = fsum[q];
@@ -1167,6 +1197,21 @@ int launch_tr(const WgradArgs& a, hipStream_t st) {
       return 0;
     }
   }
+  if constexpr (NP == 3 && NCW == 8) {
+    if (a.f_dy) {       // BatchNorm / LeakyReLU backward on load, producer waves split by tensor (ROLES at the kernel)
+      if (a.f_sum_n != a.strips * ((NPT / 2) / (CO / 4))) {
+        c3d_set_error("wgrad: fuse_sum was not sized with c3d_wgrad_fused_sum_n()");
+        return 1;
+      }
+      // (LEAN_FA: the 32-cout instance with a two-pixel halo -- nine whole-window x units per thread in flight twice spill
+      //  37 registers inside the x waves' tile loop; with the lean sets none)
+      constexpr bool LN = LEAN_FA && HALO > 0;
+      c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true, false, LN, NPW, NCW>>();
+      hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, true, false, LN, NPW, NCW>), grid, dim3(64 * (NCW + NPW)), lds, st, a);
+      C3D_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   if constexpr (NP == 1) {
     if (a.x.bf16 && a.dz_bf16 && !a.f_dy) {       // bf16 tensors on both sides: raw stages, four tiles in flight
       c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, true, false, NPW, NCW>>();
@@ -1216,10 +1261,12 @@ int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
       // sixteen-wave workgroup even with the per-channel constants in LDS (9-45 spilled registers, every reload a full drain of
       // the loads in flight: 64 -> 64 d2 0.467 -> 0.554 ms); those keep the four + four wave form.
       // (one plane: its four-row tiles of 64 couts with four raw tiles in flight spill at 128 registers -- the four + four wave form)
-      if constexpr (NP == 3) if (a.npw == 8 && a.T == 9 && !a.f_dy) return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 2, 2, 1, false, 8, 8>(a, st) : launch_tr<NP, 9, 1, 1, 1, 2, 2, 2, false, 8, 8>(a, st);
+      // (round 6: the fused launches too, with the producer waves split by tensor -- plan() hands them npw = 8 where the layer has
+      //  no pre-activation affine)
+      if constexpr (NP == 3) if (a.npw == 8 && a.T == 9) return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 2, 2, 1, false, 8, 8>(a, st) : launch_tr<NP, 9, 1, 1, 1, 2, 2, 2, false, 8, 8>(a, st);
       return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 2, (NP == 1 ? 4 : 2), 2>(a, st);
     default:
-      if constexpr (NP == 3 || NP == 1) if (a.npw == 8 && a.T == 9 && !a.f_dy) return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, 4, 1, false, 8, 8>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, 4, 2, false, 8, 8>(a, st);
+      if constexpr (NP == 3 || NP == 1) if (a.npw == 8 && a.T == 9 && (NP == 3 || !a.f_dy)) return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, 4, 1, false, 8, 8>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, 4, 2, NP == 3, 8, 8>(a, st);
       return halo <= 1 ? launch_tr<NP, 9, 1, 1, 1, 1, 4, 1>(a, st) : launch_tr<NP, 9, 1, 1, 1, 1, 4, 2, NP == 3>(a, st);
   }
 }

@@ -430,7 +430,7 @@ def _conv_kernel_name(b, h, w, src_c, src_bf16, cout, taps, grad, wpack_planes, 
     return name, halo
 
 
-def _wgrad_kernel_name(ci, co, nt, halo, fused=False, raw=False, h=0):
+def _wgrad_kernel_name(ci, co, nt, halo, fused=False, raw=False, h=0, pre=False):
     """Mirrors c3d_wgrad_cfg() (csrc/wgrad_common.h), plan() (wgrad_mfma.hip) and the launch tables of wgrad_mfma.hip /
     wgrad_tr.hip (names as rocprofv3 prints them; the eleventh template argument: lean register sets, the twelfth and thirteenth: producer
     and consumer waves, round 5)."""
@@ -458,9 +458,14 @@ def _wgrad_kernel_name(ci, co, nt, halo, fused=False, raw=False, h=0):
     if tr:       # (ninth template argument: BatchNorm backward applied on load, conv_wgrad(fuse=...); tenth: raw bf16 stages, four
         # tiles in flight -- the bf16 engine with bf16 tensors on both sides; eleventh: lean register sets)
         lean = bool(fused and x3 and lean_ok and (h + trw - 1) // trw >= 8)
-        # c3d_wgrad_producer_waves(): eight producer waves in the small 1x1 instances; unfused nine-tap launches: eight + eight
-        # consumer waves with the taps split (launch_tr_id in csrc/wgrad_tr.hip)
-        ncw = 8 if (nt == 9 and not fused and not (WGRAD_VARIANT & 128) and (x3 or co <= 32)) else 4
+        # c3d_wgrad_producer_waves(): eight producer waves in the small 1x1 instances; nine-tap launches: eight + eight
+        # consumer waves with the taps split (launch_tr_id in csrc/wgrad_tr.hip) -- round 6: the fused ones of the three-plane
+        # engine too, their producer waves split by tensor (not with a pre-activation affine, not with variant & 256); the
+        # 32-cout instance with a two-pixel halo always in its lean form there
+        roles = fused and x3 and nt == 9 and not pre and not (WGRAD_VARIANT & 256)
+        ncw = 8 if (nt == 9 and (not fused or roles) and not (WGRAD_VARIANT & 128) and (x3 or co <= 32)) else 4
+        if roles and ncw == 8:
+            lean = lean_ok
         npw = 8 if (ncw == 8 or (nt == 1 and not cfg.startswith("1, 2, 4") and not (WGRAD_VARIANT & 128))) else 4
         return (f"wgrad_tr_kernel<{3 if MFMA_MODE == 2 else 1}, {cfg}, {'true' if fused else 'false'}, "
                 f"{'true' if (raw and MFMA_MODE == 1 and not fused) else 'false'}, {'true' if lean else 'false'}, {npw}, {ncw}>")
@@ -532,7 +537,8 @@ def conv_wgrad(src, dz, dw, taps, cin_off=0, accumulate=False, slope=0.0, bias_p
     halo = max(max(abs(dy), abs(dx)) for dy, dx in taps)
     co, ci, nt = dw.shape[0], src.C, len(taps)
     name = _wgrad_kernel_name(ci, co, nt, halo, fused=fuse is not None,
-                              raw=src.t.dtype == torch.bfloat16 and dz.dtype == torch.bfloat16, h=h)
+                              raw=src.t.dtype == torch.bfloat16 and dz.dtype == torch.bfloat16, h=h,
+                              pre=fuse is not None and len(fuse) > 3 and fuse[3] is not None)
     with _Timed(name, 2.0 * b * h * w * dw.shape[0] * len(taps) * src.C, (h, w, ci, co, nt, halo, int(accumulate))):
         L.check(L.lib().c3d_conv_wgrad(C.byref(d), _stream()), "c3d_conv_wgrad")
     if d.fold_out:

@@ -61,9 +61,10 @@ def test_conv_and_weight_gradient_name_mirrors_name_kernels_of_the_library(mode,
         for fused in ((False, True) if mode == 2 else (False,)):
             for raw in ((False, True) if mode == 1 else (False,)):
                 for ci in srcs:
-                    name = ops._wgrad_kernel_name(ci, cout, len(taps), halo, fused=fused, raw=raw, h=H)
-                    if name not in have:
-                        missing.add(name)
+                    for pre in ((False, True) if fused else (False,)):        # (pre-activation affine: keeps the four + four wave form)
+                        name = ops._wgrad_kernel_name(ci, cout, len(taps), halo, fused=fused, raw=raw, h=H, pre=pre)
+                        if name not in have:
+                            missing.add(name)
     assert not missing, sorted(missing)[:20]
 
 

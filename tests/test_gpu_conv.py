@@ -354,6 +354,9 @@ def test_fused_pointwise_kernel_is_bit_identical_to_the_phased_one(B, H, W, srcC
     # round 5: the instances with lean register sets (columns of >= 8 tiles), ragged H / W, four taps at +-2
     (2, 32, 256, 32, 32, 2, 4, 2, True), (1, 70, 200, 32, 32, 3, 2, 2, True), (1, 70, 200, 64, 64, 2, 2, 1, True),
     (1, 66, 72, 128, 128, 2, 2, 1, False),
+    # round 6: nine taps on sixteen waves with the producer waves split by tensor -- several cin slices with a ragged last one, a
+    # column shorter than the register sets' pipeline, 16 input channels
+    (2, 32, 256, 160, 64, 3, 1, 1, True), (1, 5, 70, 64, 64, 3, 2, 2, True), (2, 32, 256, 16, 32, 3, 1, 1, False),
 ])
 def test_batchnorm_backward_applied_on_load_by_the_weight_gradient(B, H, W, Cin, Cout, k, dil, pad, bn):
     """Round 4: ops.conv_wgrad(fuse=(dy, act, k)) -- the layer's first weight-gradient launch
@@ -387,7 +390,8 @@ def test_batchnorm_backward_applied_on_load_by_the_weight_gradient(B, H, W, Cin,
         # choice is the 128 x 128 one, which does not spill: another strip layout, i.e. another fp32 summation order)
         wide = k == 1 and Cin >= 96 and Cout >= 192
         # +128 (round 5): four producer waves where the library runs eight (the three-plane 1x1 instances) -- the same bits
-        for variant in (0, 1 | 4, 2 | 4, 128, 128 | 4):
+        # +256 (round 6): the nine-tap launches on four + four waves instead of eight + eight with the producers split by tensor
+        for variant in (0, 1 | 4, 2 | 4, 128, 128 | 4, 256, 256 | 1, 256 | 2):
             dz = torch.full_like(act, float("nan"))
             dw = torch.zeros_like(dw_ref)
             db = torch.zeros_like(db_ref)

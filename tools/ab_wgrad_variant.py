@@ -12,6 +12,11 @@ fuse = len(sys.argv) > 3 and sys.argv[3] == "fuse"
 shapes = [(8, 64, 2048, 64, 64, 1, 1, 0), (8, 64, 2048, 32, 32, 1, 1, 0), (8, 64, 2048, 32, 64, 1, 1, 0), (8, 64, 2048, 64, 32, 1, 1, 0),
           (8, 32, 1024, 128, 128, 1, 1, 0), (8, 32, 1024, 64, 128, 1, 1, 0), (8, 16, 512, 256, 128, 1, 1, 0), (8, 16, 512, 128, 256, 1, 1, 0),
           (8, 32, 1024, 704, 256, 1, 1, 0), (8, 8, 256, 256, 256, 1, 1, 0), (8, 4, 128, 256, 256, 1, 1, 0), (8, 64, 2048, 64, 64, 3, 1, 1)]
+if len(sys.argv) > 4 and sys.argv[4] == "nine":      # the nine-tap layers of the step (256 against 0: four + four waves against the role split)
+    shapes = [(8, 64, 2048, 64, 64, 3, 2, 2), (8, 64, 2048, 64, 64, 3, 1, 1), (8, 64, 2048, 32, 64, 3, 1, 1), (8, 64, 2048, 32, 32, 3, 1, 1),
+              (8, 64, 2048, 32, 32, 3, 2, 2), (8, 64, 2048, 64, 32, 3, 1, 1), (8, 64, 2048, 16, 32, 3, 1, 1), (8, 32, 1024, 128, 128, 3, 2, 2),
+              (8, 32, 1024, 160, 64, 3, 1, 1), (8, 32, 1024, 64, 128, 3, 1, 1), (8, 16, 512, 256, 256, 3, 2, 2), (8, 16, 512, 288, 128, 3, 1, 1),
+              (8, 8, 256, 256, 256, 3, 2, 2), (8, 4, 128, 256, 256, 3, 1, 1), (2, 40, 1800, 32, 32, 3, 2, 2), (2, 5, 70, 64, 64, 3, 1, 1)]
 for (B, H, W, Ci, Co, k, dil, pad) in shapes:
     torch.manual_seed(Ci * 7 + Co + k)
     x = torch.randn(B, H, W, Ci, device=dev); dz = torch.randn(B, H, W, Co, device=dev)
