@@ -916,6 +916,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
       __builtin_amdgcn_sched_barrier(0);
       // The same accumulation order per tap as the four-wave form (K steps ascending, the six products in this order): the
       // same bits.  Operand planes of the next stage are read right after their last product of this one.
+      if (!abl_cons)       // (constant false outside a -DC3D_WGRAD_ABLATE build)
       c3d_wg_static_for<0, NSTAGE * NQ>([&](auto s_tag) {
         constexpr int sq = decltype(s_tag)::value, st = sq / NQ, q = sq % NQ, tl = st % TL;
         if (tl < 4 || th == 0) {             // (uniform; a real branch for the fifth tap only)
