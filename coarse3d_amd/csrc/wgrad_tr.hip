@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
   constexpr int NPT = 64 * NPW;        // producer threads
   constexpr int NCT = 64 * NCW;        // consumer threads
   constexpr bool SPL = NCW == 8;       // taps split across two consumer waves per SIMD
-  // ROLES (round 6, the nine-tap instances with the BatchNorm backward on load): the producer waves split by TENSOR -- waves
+  // ROLES (round 6, the nine-tap instances and the four-tap 64 x 64 one with the BatchNorm backward on load): the producer waves split by TENSOR -- waves
   // 0 .. NPW/2 - 1 stage the x units of a tile, the others its dz units (dy and the stored output in flight, the fmaf chain, the
   // dz store, the bias sums).  With both tensors in flight twice a producer wave did not fit the 128 registers of a sixteen-wave
   // workgroup (9-45 spilled registers: the fused launches stayed on the four + four wave form, one producer wave per SIMD with
@@ -210,8 +210,13 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
   constexpr bool ROLES = FA && SPL;
   constexpr int XT = ROLES ? NPT / 2 : NPT;
   constexpr int DT = ROLES ? NPT - XT : NPT;
-  static_assert(NCW == 4 || (NCW == 8 && NPW == 8 && TMAX == 9 && CI_T == 1 && CO_T == 1 && WCI == 1 && (NP == 3 || NP == 1)),
-                "split consumers: the nine-tap instances of the three-plane and one-plane engines, eight producer waves");
+  // SPL4 (round 6): the same split for the four-tap instance over 64 x 64 slices -- two taps per half, each wave its cin tile and
+  // BOTH cout tiles (4 accumulators = 64 registers instead of 128) -- so that its fused launches can take the ROLES form too
+  constexpr bool SPL4 = SPL && TMAX == 4;
+  static_assert(NCW == 4 || (NCW == 8 && NPW == 8 && TMAX == 9 && CI_T == 1 && CO_T == 1 && WCI == 1 && (NP == 3 || NP == 1)) ||
+                    (NCW == 8 && NPW == 8 && TMAX == 4 && CI_T == 1 && CO_T == 2 && WCI == 2 && WCO == 1 && NP == 3 && FA && !RAW),
+                "split consumers: the nine-tap instances of the three-plane and one-plane engines, the fused four-tap 64 x 64 one; eight producer waves");
+  constexpr int TLS = SPL ? (TMAX + 1) / 2 : 0;      // taps of a consumer half = barrier pairs of the final fold
   static_assert(!RAW || (NP == 1 && !FA), "raw bf16 stages belong to the one-plane engine without the fused apply");
   constexpr int DEPTH = RAW ? 4 : 2;   // tiles the producer waves keep in flight (register sets)
   using SU = std::conditional_t<RAW, u32x2, f32x4>;   // a staged unit in flight: four bf16 as loaded, or four floats
@@ -836,7 +841,7 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
       }
     }
     if constexpr (SPL) {
-      for (int t = 0; t < 5; ++t) {
+      for (int t = 0; t < TLS; ++t) {
         __syncthreads();
         __syncthreads();
       }
@@ -849,7 +854,126 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
     return;
   }
 
-  if constexpr (SPL) {
+  if constexpr (SPL4) {
+    // ---- consumer waves of the four-tap 64 x 64 slice, taps split: half th owns taps 2 th, 2 th + 1; wave (wci, wk) its 32 cin
+    //      and both 32-cout tiles.  Per accumulator the K steps ascend and the six products come in the order of the four-wave
+    //      form (stage = K step x local tap; the two cout tiles of a stage are independent MFMA chains): the same bits.
+    constexpr int TL = 2;
+    f32x16 acc[TL][CO_T];
+#pragma unroll
+    for (int t = 0; t < TL; ++t)
+#pragma unroll
+      for (int j = 0; j < CO_T; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+    int ldy[TL], ldx[TL];
+#pragma unroll
+    for (int t = 0; t < TL; ++t) {
+      ldy[t] = th ? a.dy[2 + t] : a.dy[t];
+      ldx[t] = th ? a.dx[2 + t] : a.dx[t];
+    }
+    constexpr int NQ = 6;
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};      // as the four-wave form: smallest products first
+    auto last_use = [](const int (&pl)[6], int plane) constexpr {
+      int l = -1;
+      for (int q = 0; q < NQ; ++q)
+        if (pl[q] == plane) l = q;
+      return l;
+    };
+    constexpr int NSTAGE = KPW * TL;
+    const unsigned lane_a = 2u * (unsigned)tr_swz<NSX>(lp, wci * 32 + lc);
+    unsigned lane_b[CO_T];
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j) lane_b[j] = 2u * (unsigned)tr_swz<NSD>(lp, j * 32 + lc);
+    // (64-channel rows are swizzled by the pixel row: the per-lane part of a fragment address is constant only where the
+    //  uniform row offset is a multiple of 4 -- always for dz; for x the tap shifts are not, so x fragments take tr_frag)
+    __syncthreads();
+    for (int mt = t_begin; mt < t_end; ++mt) {
+      const int cur = (mt - t_begin) & 1;
+      if constexpr (RINGX) {
+        if (mt != t_begin) cxbase = __builtin_amdgcn_readfirstlane((cxbase + ((mt % a.tiles_y == 0) ? THh : TRW)) % RING);
+      }
+      const unsigned short* s_x = RINGX ? s_base : s_base + cur * BUF;
+      const unsigned short* s_dz = RINGX ? s_base + NP * XPLANE + cur * (NP * DROWS * CO) : s_x + NP * XROWS * CI;
+      const unsigned lds_d = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned short*)s_dz;
+      bf16x8 ap[NP], bp[CO_T][NP];
+      auto read_a = [&](int st, int p) {
+        const int ks = wk * KPW + st / TL, tl = st % TL;
+        int Ux;
+        if constexpr (RINGX) {
+          int slot = cxbase + (ks >> 1) + HALO + ldy[tl];
+          slot = slot >= RING ? slot - RING : slot;
+          Ux = slot * TWh + HALO + (ks & 1) * 16 + ldx[tl];
+        } else {
+          Ux = ((ks >> 1) + HALO + ldy[tl]) * TWh + HALO + (ks & 1) * 16 + ldx[tl];
+        }
+        ap[p] = tr_frag<NSX>(s_x + p * XPLANE, Ux + lp, wci * 32 + lc);
+      };
+      auto read_b = [&](int st, int p) {
+        const int ks = wk * KPW + st / TL;
+        const int Ud = (ks >> 1) * 32 + (ks & 1) * 16;
+        const unsigned ub = lds_d + 2u * (unsigned)(p * DROWS * CO + Ud * (32 * NSD));
+#pragma unroll
+        for (int j = 0; j < CO_T; ++j) bp[j][p] = tr_frag_u<NSD>(ub, lane_b[j]);
+      };
+      (void)lane_a;
+      if (!abl_cons) {
+      c3d_wg_static_for<0, NQ>([&](auto q_tag) {
+        constexpr int q = decltype(q_tag)::value;
+        bool fa = true, fb = true;
+        for (int r = 0; r < q; ++r) {
+          if (PA[r] == PA[q]) fa = false;
+          if (PB[r] == PB[q]) fb = false;
+        }
+        if (fa) read_a(0, PA[q]);
+        if (fb) read_b(0, PB[q]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      c3d_wg_static_for<0, NSTAGE * NQ>([&](auto s_tag) {
+        constexpr int sq = decltype(s_tag)::value, st = sq / NQ, q = sq % NQ, tl = st % TL;
+#pragma unroll
+        for (int j = 0; j < CO_T; ++j) acc[tl][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[PA[q]], bp[j][PB[q]], acc[tl][j], 0, 0, 0);
+        if constexpr (st + 1 < NSTAGE) {
+          constexpr int n1 = st + 1;
+          if constexpr (last_use(PA, PA[q]) == q) read_a(n1, PA[q]);
+          if constexpr (n1 % TL == 0 && last_use(PB, PB[q]) == q) read_b(n1, PB[q]);      // the K step changes
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      }
+      __syncthreads();   // next buffer written, this one no longer read
+    }
+    // ---- fold the WK pixel groups of every tap through LDS (rank order, as the four-wave form); same partial layout
+    const size_t slice_floats = (size_t)a.T * CI * CO;
+    float* pout = a.partial + ((size_t)(sl * a.strips + strip)) * slice_floats;
+    float* red = smem;   // [consumer wave 0..7][cout tile][16][64]
+#pragma unroll
+    for (int tl = 0; tl < TL; ++tl) {
+      const int t = 2 * th + tl;
+      __syncthreads();
+      if (wk > 0) {
+#pragma unroll
+        for (int j = 0; j < CO_T; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((wave8 * CO_T + j) * 16 + r) * 64 + lane] = acc[tl][j][r];
+      }
+      __syncthreads();
+      if (wk == 0 && t < a.T) {
+#pragma unroll
+        for (int j = 0; j < CO_T; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[tl][j][r];
+#pragma unroll
+            for (int k = 1; k < WK; ++k) v += red[(((th * 4 + k * WCI + wci) * CO_T + j) * 16 + r) * 64 + lane];
+            const int ci = wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int co = j * 32 + l31;
+            pout[((size_t)t * CI + ci) * CO + co] = v;
+          }
+      }
+    }
+    return;
+  } else if constexpr (SPL) {
     // ---- consumer waves, taps split (see NCW at the head of the kernel): half 0 owns taps 0-4, half 1 taps 5-8
     constexpr int TL = 5;
     f32x16 acc[TL];
@@ -1162,12 +1286,13 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
 template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool LEAN_FA = false, int NPW = 4, int NCW = 4>
 int launch_tr(const WgradArgs& a, hipStream_t st) {
   constexpr int NPT = 64 * NPW;
-  static_assert(NPW == 4 || (((NP == 3 || NP == 1) && HALO == 0 && !LEAN_FA && NCW == 4) || ((NP == 3 || NP == 1) && TMAX == 9 && NCW == 8)),
-                "eight producer waves: the three-plane 1x1 instances, and the nine-tap ones with split consumers");
+  static_assert(NPW == 4 || (((NP == 3 || NP == 1) && HALO == 0 && !LEAN_FA && NCW == 4) || ((NP == 3 || NP == 1) && TMAX == 9 && NCW == 8) ||
+                             (NP == 3 && TMAX == 4 && NCW == 8)),
+                "eight producer waves: the three-plane 1x1 instances, the nine-tap ones with split consumers, the fused four-tap 64 x 64 one");
   constexpr int WK = 4 / (WCI * WCO);
   constexpr int CI = 32 * CI_T * WCI, CO = 32 * CO_T * WCO;
   size_t lds = 2 * (size_t)NP * ((size_t)(TRW + 2 * HALO) * (32 + 2 * HALO) * CI + (size_t)TRW * 32 * CO) * 2;   // two tile buffers
-  const size_t red = NCW == 8 ? (size_t)8 * 1024 * sizeof(float) : (size_t)(WK - 1) * WCI * WCO * CI_T * CO_T * 1024 * sizeof(float);
+  const size_t red = NCW == 8 ? (size_t)8 * CO_T * 1024 * sizeof(float) : (size_t)(WK - 1) * WCI * WCO * CI_T * CO_T * 1024 * sizeof(float);
   if (NCW == 8) lds += (size_t)(2 * CI + 3 * CO) * sizeof(float);      // the staging constants behind the tile buffers
   if (red > lds) lds = red;
   dim3 grid(a.strips * a.ci_slices * a.co_slices);
@@ -1221,10 +1346,15 @@ int launch_tr(const WgradArgs& a, hipStream_t st) {
       return 0;
     }
   }
-  c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, false, false, NPW, NCW>>();
-  hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, false, false, NPW, NCW>), grid, dim3(64 * (NCW + NPW)), lds, st, a);
-  C3D_CHECK_LAUNCH();
-  return 0;
+  if constexpr (TMAX == 4 && NCW == 8) {       // (the sixteen-wave four-tap form exists for fused launches only)
+    c3d_set_error("wgrad: the sixteen-wave four-tap instance takes fused launches only (plan())");
+    return 1;
+  } else {
+    c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, false, false, NPW, NCW>>();
+    hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, false, false, NPW, NCW>), grid, dim3(64 * (NCW + NPW)), lds, st, a);
+    C3D_CHECK_LAUNCH();
+    return 0;
+  }
 }
 
 // tile rows (TRW) must match c3d_wgrad_cfg(..., planes != 0)
@@ -1248,6 +1378,8 @@ int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
       // (halo <= 1 only: c3d_wgrad_cfg never hands this slice a two-pixel halo -- its two tile buffers would exceed the LDS; the
       //  instances that existed for it until round 5 were dead code, and the library's worst spillers)
       if constexpr (NP >= 2) {
+        // (round 6: the fused launch on sixteen waves, taps split 2 + 2, producer waves split by tensor; plan() hands it npw = 8)
+        if constexpr (NP == 3) if (halo <= 1 && a.npw == 8 && a.f_dy) return launch_tr<NP, 4, 1, 2, 2, 1, 2, 1, true, 8, 8>(a, st);
         if (halo <= 1) return launch_tr<NP, 4, 1, 2, 2, 1, 2, 1, NP == 3>(a, st);
         c3d_set_error("wgrad: the 64 x 64 four-tap slice has no two-pixel-halo form (c3d_wgrad_cfg)");
         return 1;

@@ -43,6 +43,7 @@ ALLOWED = {
     r"wgrad_tr_kernel<3, 9, 1, 1, 1, 2, 2, [12], true, false, false, 8, 8>": "sixteen-wave fused form: parked around the loops",
     r"wgrad_tr_kernel<3, 9, 1, 1, 1, 1, 4, 1, true, false, false, 8, 8>": "sixteen-wave fused form: parked around the loops",
     r"wgrad_tr_kernel<3, 9, 1, 1, 1, 1, 4, 2, true, false, true, 8, 8>": "sixteen-wave fused form: parked around the loops",
+    r"wgrad_tr_kernel<3, 4, 1, 2, 2, 1, 2, 1, true, false, true, 8, 8>": "sixteen-wave fused form (four taps): parked around the loops",
 }
 
 

@@ -17,6 +17,9 @@ if len(sys.argv) > 4 and sys.argv[4] == "nine":      # the nine-tap layers of th
               (8, 64, 2048, 32, 32, 3, 2, 2), (8, 64, 2048, 64, 32, 3, 1, 1), (8, 64, 2048, 16, 32, 3, 1, 1), (8, 32, 1024, 128, 128, 3, 2, 2),
               (8, 32, 1024, 160, 64, 3, 1, 1), (8, 32, 1024, 64, 128, 3, 1, 1), (8, 16, 512, 256, 256, 3, 2, 2), (8, 16, 512, 288, 128, 3, 1, 1),
               (8, 8, 256, 256, 256, 3, 2, 2), (8, 4, 128, 256, 256, 3, 1, 1), (2, 40, 1800, 32, 32, 3, 2, 2), (2, 5, 70, 64, 64, 3, 1, 1)]
+if len(sys.argv) > 4 and sys.argv[4] == "four":      # the 2x2 layers of the step (256 against 0, as "nine")
+    shapes = [(8, 64, 2048, 64, 64, 2, 2, 1), (8, 32, 1024, 128, 128, 2, 2, 1), (8, 16, 512, 256, 256, 2, 2, 1), (8, 8, 256, 256, 256, 2, 2, 1),
+              (8, 4, 128, 256, 256, 2, 2, 1), (2, 40, 1800, 64, 64, 2, 2, 1), (2, 5, 70, 64, 64, 2, 2, 1), (8, 64, 2048, 32, 32, 2, 2, 1)]
 for (B, H, W, Ci, Co, k, dil, pad) in shapes:
     torch.manual_seed(Ci * 7 + Co + k)
     x = torch.randn(B, H, W, Ci, device=dev); dz = torch.randn(B, H, W, Co, device=dev)
