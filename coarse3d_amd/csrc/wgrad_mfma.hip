@@ -419,13 +419,13 @@ void plan(const c3d_wgrad_desc* d, WgradArgs& a, WgCfg& c) {
   // nine taps with the BatchNorm backward on load: sixteen waves with the producer waves split by tensor (round 6, ROLES in
   // wgrad_tr.hip); layers with a pre-activation affine, three / six taps and variant & 256 keep the four + four wave form
   if (c.id >= 6 && d->fuse_dy && (a.npw != 8 || d->fuse_pre_scale || (d->variant & 256))) a.npw = 4;
-  // the fused four-tap launch over 64 x 64 slices alike (taps split 2 + 2; wgrad_tr.hip, SPL4)
-  if (c.id == 8 && d->fuse_dy && planes_for(d) == 3 && d->ntaps == 4 && halo <= 1 && !d->fuse_pre_scale && !(d->variant & (256 | 128))) a.npw = 8;
+  // the four-tap launch over 64 x 64 slices alike (taps split 2 + 2; wgrad_tr.hip, SPL4), fused or not
+  if (c.id == 8 && planes_for(d) == 3 && d->ntaps == 4 && halo <= 1 && !d->fuse_pre_scale && !(d->variant & (256 | 128))) a.npw = 8;
 }
 
 // threads the dz units of a fused launch are dealt to (= entries per strip and channel of fuse_sum, times CO / 4)
 int fused_dz_threads(const c3d_wgrad_desc* d, const WgradArgs& a, const WgCfg& c) {
-  return (c.id >= 6 && d->fuse_dy && a.npw == 8) ? 256 : 64 * a.npw;      // (id 8 included)
+  return (c.id >= 6 && d->fuse_dy && a.npw == 8) ? 256 : 64 * a.npw;      // (id 8 included; unfused launches have no sums)
 }
 
 template <int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int HALO, bool BF>

@@ -214,8 +214,8 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
   // BOTH cout tiles (4 accumulators = 64 registers instead of 128) -- so that its fused launches can take the ROLES form too
   constexpr bool SPL4 = SPL && TMAX == 4;
   static_assert(NCW == 4 || (NCW == 8 && NPW == 8 && TMAX == 9 && CI_T == 1 && CO_T == 1 && WCI == 1 && (NP == 3 || NP == 1)) ||
-                    (NCW == 8 && NPW == 8 && TMAX == 4 && CI_T == 1 && CO_T == 2 && WCI == 2 && WCO == 1 && NP == 3 && FA && !RAW),
-                "split consumers: the nine-tap instances of the three-plane and one-plane engines, the fused four-tap 64 x 64 one; eight producer waves");
+                    (NCW == 8 && NPW == 8 && TMAX == 4 && CI_T == 1 && CO_T == 2 && WCI == 2 && WCO == 1 && NP == 3 && !RAW),
+                "split consumers: the nine-tap instances of the three-plane and one-plane engines, the four-tap 64 x 64 one; eight producer waves");
   constexpr int TLS = SPL ? (TMAX + 1) / 2 : 0;      // taps of a consumer half = barrier pairs of the final fold
   static_assert(!RAW || (NP == 1 && !FA), "raw bf16 stages belong to the one-plane engine without the fused apply");
   constexpr int DEPTH = RAW ? 4 : 2;   // tiles the producer waves keep in flight (register sets)
@@ -1346,15 +1346,10 @@ int launch_tr(const WgradArgs& a, hipStream_t st) {
       return 0;
     }
   }
-  if constexpr (TMAX == 4 && NCW == 8) {       // (the sixteen-wave four-tap form exists for fused launches only)
-    c3d_set_error("wgrad: the sixteen-wave four-tap instance takes fused launches only (plan())");
-    return 1;
-  } else {
-    c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, false, false, NPW, NCW>>();
-    hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, false, false, NPW, NCW>), grid, dim3(64 * (NCW + NPW)), lds, st, a);
-    C3D_CHECK_LAUNCH();
-    return 0;
-  }
+  c3d_opt_in_lds<&wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, false, false, NPW, NCW>>();
+  hipLaunchKernelGGL((wgrad_tr_kernel<NP, TMAX, CI_T, CO_T, WCI, WCO, TRW, HALO, false, false, false, NPW, NCW>), grid, dim3(64 * (NCW + NPW)), lds, st, a);
+  C3D_CHECK_LAUNCH();
+  return 0;
 }
 
 // tile rows (TRW) must match c3d_wgrad_cfg(..., planes != 0)
@@ -1378,8 +1373,9 @@ int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
       // (halo <= 1 only: c3d_wgrad_cfg never hands this slice a two-pixel halo -- its two tile buffers would exceed the LDS; the
       //  instances that existed for it until round 5 were dead code, and the library's worst spillers)
       if constexpr (NP >= 2) {
-        // (round 6: the fused launch on sixteen waves, taps split 2 + 2, producer waves split by tensor; plan() hands it npw = 8)
-        if constexpr (NP == 3) if (halo <= 1 && a.npw == 8 && a.f_dy) return launch_tr<NP, 4, 1, 2, 2, 1, 2, 1, true, 8, 8>(a, st);
+        // (round 6: sixteen waves, taps split 2 + 2; a fused launch with its producer waves split by tensor, an unfused one -- every
+        //  weight gradient of a data-parallel step -- with eight producer waves of both tensors; plan() hands them npw = 8)
+        if constexpr (NP == 3) if (halo <= 1 && a.npw == 8 && a.T == 4) return launch_tr<NP, 4, 1, 2, 2, 1, 2, 1, true, 8, 8>(a, st);
         if (halo <= 1) return launch_tr<NP, 4, 1, 2, 2, 1, 2, 1, NP == 3>(a, st);
         c3d_set_error("wgrad: the 64 x 64 four-tap slice has no two-pixel-halo form (c3d_wgrad_cfg)");
         return 1;

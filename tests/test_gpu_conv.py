@@ -254,6 +254,9 @@ def _random_shape_cases(ops, rnd, dev):
     (2, 64, 2040, 32, 24, 1, 1, 0),
     (2, 64, 2048, 48, 64, 1, 1, 0),
     (4, 32, 1000, 128, 100, 1, 1, 0),
+    # round 6: the four-tap instance over 64 x 64 slices on sixteen waves (taps split 2 + 2), long strips / ragged W and couts
+    (2, 64, 2048, 64, 64, 2, 2, 1),
+    (1, 40, 1800, 128, 96, 2, 2, 1),
 ])
 def test_weight_gradient_long_strips(mode, B, H, W, Cin, Cout, k, dil, pad):
     """Weight gradients at sizes where every workgroup walks many pixel tiles (the unit cases above
@@ -274,9 +277,10 @@ def test_weight_gradient_long_strips(mode, B, H, W, Cin, Cout, k, dil, pad):
         dw = torch.zeros(Cout, Cin, k, k, device=dev)
         ops.conv_wgrad(ops.Source(x, sc, sh, lrelu=True), dz, dw, taps)
         torch.cuda.synchronize()
-        if k in (1, 3) and mode in ("bf16x3", "bf16"):
+        if (k in (1, 3) and mode in ("bf16x3", "bf16")) or (k == 2 and mode == "bf16x3" and Cin % 64 == 0):
             # the library's forms with eight producer waves (1x1) / eight + eight waves with the taps split across the consumers
-            # (nine taps, unfused) against the four + four wave form: the same LDS image, the same accumulation order, the same bits
+            # (nine taps; four taps over 64 x 64 slices; unfused) against the four + four wave form: the same LDS image, the same
+            # accumulation order, the same bits
             dw4 = torch.zeros_like(dw)
             ops.WGRAD_VARIANT = 128
             try:
