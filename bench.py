@@ -745,6 +745,15 @@ def main():
                 out["launch_by_launch"] = {"value": eager["value"], "ms_per_step": eager["ms_per_step"], "steps": eager["steps"],
                                            "note": "the first pass of this run: the same K steps launched one kernel at a time (python bench.py "
                                                    "--graph off); `roofline` holds the HIP-event kernel times of THIS pass' timed region"}
+                # Seen three times in ~40 runs of round 6 and not reproduced on demand (13 clean runs on two boxes): a
+                # process whose captured step replays ~5 % SLOWER than its own launch-by-launch pass.  `value` stays the captured
+                # step's, as documented; the line says so when it happens instead of leaving the reader to compare two numbers.
+                ratio = cap["ms_per_step"] / eager["ms_per_step"] if eager["ms_per_step"] > 0 else 1.0
+                out["captured_vs_launch_by_launch"] = {
+                    "ratio": round(ratio, 4), "captured_replay_slower_than_eager": bool(ratio > 1.02),
+                    "note": "captured ms_per_step / launch-by-launch ms_per_step of THIS process; normally 0.98-1.01.  > 1.02 is the "
+                            "unexplained slow-replay reading of DESIGN.md (d) 8: `value` is then ~5 % below what this GPU sustains "
+                            "launch by launch (`launch_by_launch.value`)"}
         elif launch_note:
             out["config"]["launch"] = launch_note
         return out
