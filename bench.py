@@ -477,6 +477,25 @@ class Bench:
             out["n_ranks"] = n_ranks
             out["value"] = round(self.wl["batch"] * n_ranks * steps / elapsed, 3)
             out["ms_per_step"] = round(elapsed / steps * 1e3, 3)
+            if graph and os.environ.get("C3D_BENCH_DIAG_REPLAY") and self.world == 1:
+                # DIAGNOSTIC ONLY (never set by the driver's command): behind the timed region, in the same process --
+                # the same graph again, then a second TrainStep with its own capture, then the first graph once more
+                def again(t, n=steps):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for s in range(n):
+                        t.step(*batches[warmup + s % steps], epoch=10)
+                    torch.cuda.synchronize()
+                    return round((time.perf_counter() - t1) / n * 1e3, 3)
+                diag = {"same_graph_next_K": again(ts)}
+                _m2, ts2 = self.build(True, wgrad_stream, graph_backbone)
+                for s in range(4):
+                    ts2.step(*batches[s], epoch=10)
+                diag["second_capture"] = again(ts2)
+                diag["first_graph_again"] = again(ts)
+                diag["mem_MiB"] = [torch.cuda.memory_allocated() >> 20, torch.cuda.memory_reserved() >> 20]
+                del ts2, _m2
+                out["diag_replay"] = diag
             completed = True
             return out
         finally:
@@ -749,6 +768,8 @@ def main():
                 # process whose captured step replays ~5 % SLOWER than its own launch-by-launch pass.  `value` stays the captured
                 # step's, as documented; the line says so when it happens instead of leaving the reader to compare two numbers.
                 ratio = cap["ms_per_step"] / eager["ms_per_step"] if eager["ms_per_step"] > 0 else 1.0
+                if cap.get("diag_replay"):
+                    out["diag_replay"] = cap["diag_replay"]
                 out["captured_vs_launch_by_launch"] = {
                     "ratio": round(ratio, 4), "captured_replay_slower_than_eager": bool(ratio > 1.02),
                     "note": "captured ms_per_step / launch-by-launch ms_per_step of THIS process; normally 0.98-1.01.  > 1.02 is the "

@@ -419,6 +419,8 @@ void plan(const c3d_wgrad_desc* d, WgradArgs& a, WgCfg& c) {
   // nine taps with the BatchNorm backward on load: sixteen waves with the producer waves split by tensor (round 6, ROLES in
   // wgrad_tr.hip); layers with a pre-activation affine, three / six taps and variant & 256 keep the four + four wave form
   if (c.id >= 6 && d->fuse_dy && (a.npw != 8 || d->fuse_pre_scale || (d->variant & 256))) a.npw = 4;
+  // unfused 1x1 launches over 128 x 256 slices (the projector's 704-wide layers): cout tiles split across the consumer halves (SPL1)
+  if (c.id == 0 && planes_for(d) == 3 && !d->fuse_dy && !(d->variant & (256 | 128))) a.npw = 8;
   // the four-tap launch over 64 x 64 slices alike (taps split 2 + 2; wgrad_tr.hip, SPL4), fused or not
   if (c.id == 8 && planes_for(d) == 3 && d->ntaps == 4 && halo <= 1 && !d->fuse_pre_scale && !(d->variant & (256 | 128))) a.npw = 8;
 }

@@ -213,10 +213,16 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
   // SPL4 (round 6): the same split for the four-tap instance over 64 x 64 slices -- two taps per half, each wave its cin tile and
   // BOTH cout tiles (4 accumulators = 64 registers instead of 128) -- so that its fused launches can take the ROLES form too
   constexpr bool SPL4 = SPL && TMAX == 4;
+  // SPL1 (round 6): the 1x1 instance over 128 x 256 slices (the projector's 704-wide layers) -- the COUT tiles of a wave split
+  // across the halves: half th owns cout tiles 2 th, 2 th + 1 of the wave's four, both cin tiles (4 accumulators = 64 registers
+  // instead of 128).  Its producers stage ~12 units per thread per 96 MFMAs of a consumer wave, twice the nine-tap instances'
+  // ratio: one wave per SIMD runs that chain at ~8 cycles per VALU instruction (ablation, profiles/round6_wgrad_roles.md).
+  constexpr bool SPL1 = SPL && TMAX == 1;
   static_assert(NCW == 4 || (NCW == 8 && NPW == 8 && TMAX == 9 && CI_T == 1 && CO_T == 1 && WCI == 1 && (NP == 3 || NP == 1)) ||
-                    (NCW == 8 && NPW == 8 && TMAX == 4 && CI_T == 1 && CO_T == 2 && WCI == 2 && WCO == 1 && NP == 3 && !RAW),
+                    (NCW == 8 && NPW == 8 && TMAX == 4 && CI_T == 1 && CO_T == 2 && WCI == 2 && WCO == 1 && NP == 3 && !RAW) ||
+                    (NCW == 8 && NPW == 8 && TMAX == 1 && CI_T == 2 && CO_T == 4 && WCI == 2 && WCO == 2 && NP == 3 && !RAW && !FA),
                 "split consumers: the nine-tap instances of the three-plane and one-plane engines, the four-tap 64 x 64 one; eight producer waves");
-  constexpr int TLS = SPL ? (TMAX + 1) / 2 : 0;      // taps of a consumer half = barrier pairs of the final fold
+  constexpr int TLS = (SPL && !SPL1) ? (TMAX + 1) / 2 : 0;      // taps of a consumer half = barrier pairs of the final fold (SPL1: WK = 1, no fold)
   static_assert(!RAW || (NP == 1 && !FA), "raw bf16 stages belong to the one-plane engine without the fused apply");
   constexpr int DEPTH = RAW ? 4 : 2;   // tiles the producer waves keep in flight (register sets)
   using SU = std::conditional_t<RAW, u32x2, f32x4>;   // a staged unit in flight: four bf16 as loaded, or four floats
@@ -854,7 +860,96 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void wgrad_tr_kernel(WgradArgs
     return;
   }
 
-  if constexpr (SPL4) {
+  if constexpr (SPL1) {
+    // ---- consumer waves of the 1x1 128 x 256 slice, cout tiles split: wave (wci, wco, half th) owns cin tiles 2 wci, 2 wci + 1 and
+    //      cout tiles 4 wco + 2 th, 4 wco + 2 th + 1.  Per accumulator: K steps ascending, the six products in the order of the
+    //      four-wave form -- the same bits.  WK = 1: no fold, the accumulators go straight to the partial.
+    static_assert(WK == 1 && HALO == 0, "one K group, no halo");
+    constexpr int JT = 2;                    // cout tiles of a half
+    f32x16 acc[CI_T][JT];
+#pragma unroll
+    for (int i = 0; i < CI_T; ++i)
+#pragma unroll
+      for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int NQ = 6;
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+    auto last_use = [](const int (&pl)[6], int plane) constexpr {
+      int l = -1;
+      for (int q = 0; q < NQ; ++q)
+        if (pl[q] == plane) l = q;
+      return l;
+    };
+    constexpr int NSTAGE = KPW;              // stage = K step
+    unsigned lane_a[CI_T], lane_b[JT];
+#pragma unroll
+    for (int i = 0; i < CI_T; ++i) lane_a[i] = 2u * (unsigned)tr_swz<NSX>(lp, (wci * CI_T + i) * 32 + lc);
+#pragma unroll
+    for (int j = 0; j < JT; ++j) lane_b[j] = 2u * (unsigned)tr_swz<NSD>(lp, (wco * CO_T + th * JT + j) * 32 + lc);
+    __syncthreads();
+    for (int mt = t_begin; mt < t_end; ++mt) {
+      const int cur = (mt - t_begin) & 1;
+      const unsigned short* s_x = s_base + cur * BUF;
+      const unsigned short* s_dz = s_x + NP * XROWS * CI;
+      const unsigned lds_x = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned short*)s_x;
+      const unsigned lds_d = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned short*)s_dz;
+      bf16x8 ap[CI_T][NP], bp[JT][NP];
+      auto read_a = [&](int st, int p) {
+        const int ks = st;                   // (wk = 0)
+        const int U = (ks >> 1) * 32 + (ks & 1) * 16;
+        const unsigned ub = lds_x + 2u * (unsigned)(p * XPLANE + U * (32 * NSX));
+#pragma unroll
+        for (int i = 0; i < CI_T; ++i) ap[i][p] = tr_frag_u<NSX>(ub, lane_a[i]);
+      };
+      auto read_b = [&](int st, int p) {
+        const int ks = st;
+        const int U = (ks >> 1) * 32 + (ks & 1) * 16;
+        const unsigned ub = lds_d + 2u * (unsigned)(p * DROWS * CO + U * (32 * NSD));
+#pragma unroll
+        for (int j = 0; j < JT; ++j) bp[j][p] = tr_frag_u<NSD>(ub, lane_b[j]);
+      };
+      if (!abl_cons) {
+      c3d_wg_static_for<0, NQ>([&](auto q_tag) {
+        constexpr int q = decltype(q_tag)::value;
+        bool fa = true, fb = true;
+        for (int r = 0; r < q; ++r) {
+          if (PA[r] == PA[q]) fa = false;
+          if (PB[r] == PB[q]) fb = false;
+        }
+        if (fa) read_a(0, PA[q]);
+        if (fb) read_b(0, PB[q]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      c3d_wg_static_for<0, NSTAGE * NQ>([&](auto s_tag) {
+        constexpr int sq = decltype(s_tag)::value, st = sq / NQ, q = sq % NQ;
+#pragma unroll
+        for (int i = 0; i < CI_T; ++i)
+#pragma unroll
+          for (int j = 0; j < JT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][PA[q]], bp[j][PB[q]], acc[i][j], 0, 0, 0);
+        if constexpr (st + 1 < NSTAGE) {
+          if constexpr (last_use(PA, PA[q]) == q) read_a(st + 1, PA[q]);
+          if constexpr (last_use(PB, PB[q]) == q) read_b(st + 1, PB[q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      }
+      __syncthreads();   // next buffer written, this one no longer read
+    }
+    const size_t slice_floats = (size_t)a.T * CI * CO;
+    float* pout = a.partial + ((size_t)(sl * a.strips + strip)) * slice_floats;
+#pragma unroll
+    for (int i = 0; i < CI_T; ++i)
+#pragma unroll
+      for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci = (wci * CI_T + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int co = (wco * CO_T + th * JT + j) * 32 + l31;
+          pout[(size_t)ci * CO + co] = acc[i][j][r];
+        }
+    return;
+  } else if constexpr (SPL4) {
     // ---- consumer waves of the four-tap 64 x 64 slice, taps split: half th owns taps 2 th, 2 th + 1; wave (wci, wk) its 32 cin
     //      and both 32-cout tiles.  Per accumulator the K steps ascend and the six products come in the order of the four-wave
     //      form (stage = K step x local tap; the two cout tiles of a stage are independent MFMA chains): the same bits.
@@ -1287,7 +1382,7 @@ template <int NP, int TMAX, int CI_T, int CO_T, int WCI, int WCO, int TRW, int H
 int launch_tr(const WgradArgs& a, hipStream_t st) {
   constexpr int NPT = 64 * NPW;
   static_assert(NPW == 4 || (((NP == 3 || NP == 1) && HALO == 0 && !LEAN_FA && NCW == 4) || ((NP == 3 || NP == 1) && TMAX == 9 && NCW == 8) ||
-                             (NP == 3 && TMAX == 4 && NCW == 8)),
+                             (NP == 3 && TMAX == 4 && NCW == 8) || (NP == 3 && TMAX == 1 && NCW == 8)),
                 "eight producer waves: the three-plane 1x1 instances, the nine-tap ones with split consumers, the fused four-tap 64 x 64 one");
   constexpr int WK = 4 / (WCI * WCO);
   constexpr int CI = 32 * CI_T * WCI, CO = 32 * CO_T * WCO;
@@ -1323,7 +1418,7 @@ int launch_tr(const WgradArgs& a, hipStream_t st) {
       return 0;
     }
   }
-  if constexpr (NP == 3 && NCW == 8) {
+  if constexpr (NP == 3 && NCW == 8 && TMAX != 1) {
     if (a.f_dy) {       // BatchNorm / LeakyReLU backward on load, producer waves split by tensor (ROLES at the kernel)
       if (a.f_sum_n != a.strips * ((NPT / 2) / (CO / 4))) {
         c3d_set_error("wgrad: fuse_sum was not sized with c3d_wgrad_fused_sum_n()");
@@ -1357,7 +1452,10 @@ template <int NP>
 int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
   switch (id) {
     //                         TMAX CI_T CO_T WCI WCO TRW HALO
-    case 0: return launch_tr<NP, 1, 2, 4, 2, 2, 1, 0>(a, st);
+    case 0:
+      // (round 6: unfused launches of the three-plane engine on sixteen waves, cout tiles split across the consumer halves; plan())
+      if constexpr (NP == 3) if (a.npw == 8 && !a.f_dy) return launch_tr<NP, 1, 2, 4, 2, 2, 1, 0, false, 8, 8>(a, st);
+      return launch_tr<NP, 1, 2, 4, 2, 2, 1, 0>(a, st);
     case 1:
       if constexpr (NP == 3 || NP == 1) if (a.npw == 8) return launch_tr<NP, 1, 2, 2, 2, 2, 1, 0, false, 8>(a, st);
       return launch_tr<NP, 1, 2, 2, 2, 2, 1, 0>(a, st);

@@ -467,6 +467,8 @@ def _wgrad_kernel_name(ci, co, nt, halo, fused=False, raw=False, h=0, pre=False)
         if roles and ncw == 8:
             lean = lean_ok
         # ... and the fused four-tap launch over 64 x 64 slices (taps split 2 + 2; exactly four taps, one-pixel halo)
+        if x3 and nt == 1 and cfg.startswith("1, 2, 4") and not fused and not (WGRAD_VARIANT & (256 | 128)):
+            ncw = 8                     # (the 128 x 256 slice: cout tiles split across the consumer halves)
         if (x3 and nt == 4 and cfg.startswith("4, 1, 2, 2, 1, 2, 1") and not pre and not (WGRAD_VARIANT & (256 | 128))):
             ncw, lean = 8, fused        # (unfused too: every weight gradient of a data-parallel step)
         npw = 8 if (ncw == 8 or (nt == 1 and not cfg.startswith("1, 2, 4") and not (WGRAD_VARIANT & 128))) else 4

@@ -222,7 +222,8 @@ typedef struct {
                              * in the 1x1 instances of the three-plane engine that run eight (round 5) -- the same bits.  Bit 8
                              * (256): fused nine-tap launches, and the fused four-tap one over 64 x 64 slices, on four + four
                              * waves instead of eight + eight with the producer waves split by tensor (round 6) -- the same
-                             * bits (dw, dz and the bias sums)                                                             */
+                             * bits (dw, dz and the bias sums).  Bits 7 and 8 alike keep the unfused four-tap 64 x 64 and the
+                             * unfused 1x1 128 x 256 launches on four + four waves (round 6: sixteen, consumers split)      */
   /* optional: fold the layer's bias-gradient partials in the same launch that folds the weight-gradient strips
    * (saves one tiny launch per conv layer): dbias[c] = sum_k bias_partial[c][0][k], k < bias_n, the
    * [Cout][2][bias_n] partials c3d_bn_bwd_apply wrote (what c3d_bias_from_partials computes).  NULL = off. */
