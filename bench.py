@@ -430,12 +430,28 @@ class Bench:
             counts0 = dict(D.COUNTS)
             if exposed and not graph:
                 D.EXPOSED = []                   # event-time what the main stream waits for each blocking exchange
+            # every run of Python's cyclic collector inside the timed region is written into the line (generation, ms, objects):
+            # the host thread is the one thing between the barrier and the first launch that the GPU queue cannot hide
+            import gc
+            gc_runs, gc_t = [], [0.0]
+
+            def gc_watch(phase, info):
+                if phase == "start":
+                    gc_t[0] = time.perf_counter()
+                else:
+                    gc_runs.append({"generation": info["generation"], "ms": round((time.perf_counter() - gc_t[0]) * 1e3, 3),
+                                    "collected": info["collected"]})
+            gc.callbacks.append(gc_watch)
             self.barrier()
             t0 = time.perf_counter()
+            step_host_ms = []
             for s in range(warmup, total):
+                h0 = time.perf_counter()
                 res = ts.step(*batches[s], epoch=10)
+                step_host_ms.append(round((time.perf_counter() - h0) * 1e3, 2))
             self.barrier()
             elapsed = time.perf_counter() - t0
+            gc.callbacks.remove(gc_watch)
             loss = float(res["loss"])
             if self.world > 1:
                 t = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
@@ -458,6 +474,7 @@ class Bench:
             ops.KERNEL_EVENTS = None
             ops.KERNEL_EVENT_FILTER = None
             out = {"elapsed": elapsed, "loss": loss, "steps": steps, "warmup": warmup, "survey": survey, "timed": timed,
+                   "gc_in_timed_region": gc_runs, "host_ms_per_step_call": step_host_ms,
                    "graph": bool(graph), "type": type(model).__name__}
             n_ranks = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
             if self.dp:
@@ -770,6 +787,9 @@ def main():
                 ratio = cap["ms_per_step"] / eager["ms_per_step"] if eager["ms_per_step"] > 0 else 1.0
                 if cap.get("diag_replay"):
                     out["diag_replay"] = cap["diag_replay"]
+                out["captured_pass_host"] = {"gc_in_timed_region": cap.get("gc_in_timed_region"), "host_ms_per_step_call": cap.get("host_ms_per_step_call"),
+                                             "note": "host time of each of the K ts.step() calls of the captured pass (enqueue only; the GPU "
+                                                     "runs behind) and every cyclic-GC run inside its timed region"}
                 out["captured_vs_launch_by_launch"] = {
                     "ratio": round(ratio, 4), "captured_replay_slower_than_eager": bool(ratio > 1.02),
                     "note": "captured ms_per_step / launch-by-launch ms_per_step of THIS process; normally 0.98-1.01.  > 1.02 is the "
