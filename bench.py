@@ -964,6 +964,9 @@ def short_config(c, dev, steps, events):
         hbm_frac = round(roof["step_hbm_traffic_GB"] * 1e9 / (cap["ms_per_step"] * 1e-3) / 8e12, 3)
     return {"workload": note, "value": cap["value"], "unit": "range-images/sec", "ms_per_step": cap["ms_per_step"], "steps": steps,
             "launch": "one hipGraph replay per step", "launch_by_launch": {"value": eager["value"], "ms_per_step": eager["ms_per_step"]},
+            # (this captured pass follows other trainers' lives in the process: DESIGN.md (d) 8 -- ~8 % of such passes lose ~one step's
+            #  time once; a ratio above 1.02 says this one did and `value` is low by that much)
+            "captured_vs_launch_by_launch": round(cap["ms_per_step"] / eager["ms_per_step"], 4) if eager["ms_per_step"] > 0 else None,
             "dtype": DTYPE_NOTE[wl["matrix_dtype"]].split(";")[0] if wl["matrix_dtype"] == "bf16x3" else DTYPE_NOTE[wl["matrix_dtype"]],
             "step_frac_of_hbm_peak": hbm_frac, "roofline": roof}
 
