@@ -1471,8 +1471,10 @@ int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
       // (halo <= 1 only: c3d_wgrad_cfg never hands this slice a two-pixel halo -- its two tile buffers would exceed the LDS; the
       //  instances that existed for it until round 5 were dead code, and the library's worst spillers)
       if constexpr (NP >= 2) {
-        // (round 6: sixteen waves, taps split 2 + 2; a fused launch with its producer waves split by tensor, an unfused one -- every
-        //  weight gradient of a data-parallel step -- with eight producer waves of both tensors; plan() hands them npw = 8)
+        // (round 6: sixteen waves, taps split 2 + 2; a fused launch with its producer waves split by tensor, an unfused one -- a
+        //  layer's second and later sources, the second-stream mode, direct API use; NOT the data-parallel step, which has run the
+        //  same fused launches as the plain step since round 5 put it on one stream -- with eight producer waves of both tensors;
+        //  plan() hands them npw = 8)
         if constexpr (NP == 3) if (halo <= 1 && a.npw == 8 && a.T == 4) return launch_tr<NP, 4, 1, 2, 2, 1, 2, 1, true, 8, 8>(a, st);
         if (halo <= 1) return launch_tr<NP, 4, 1, 2, 2, 1, 2, 1, NP == 3>(a, st);
         c3d_set_error("wgrad: the 64 x 64 four-tap slice has no two-pixel-halo form (c3d_wgrad_cfg)");
@@ -1481,7 +1483,8 @@ int launch_tr_id(int id, int halo, const WgradArgs& a, hipStream_t st) {
         return -1;
       }
     case 6:
-      // Nine taps, unfused (every weight gradient of a data-parallel step, whose BatchNorm backward is a pass of its own): taps split
+      // Nine taps, unfused (through round 4 every weight gradient of a data-parallel step; since round 5's one-stream form that step runs
+      // the fused launches of the plain one -- unfused are a layer's second and later sources and the second-stream mode): taps split
       // across eight consumer waves + eight producer waves (NCW at the kernel).  Measured at 8 x 64 x 2048 / 32 x 1024 / 16 x 512:
       // 64 -> 64 0.438 -> 0.403 ms, 32 -> 32 0.125 -> 0.117, 128 -> 128 0.439 -> 0.417, 256 -> 256 0.405 -> 0.365.  NOT the launches
       // with the BatchNorm backward on load: dy, the stored output and x in flight twice do not fit the 128 registers of a

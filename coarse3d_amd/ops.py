@@ -470,7 +470,7 @@ def _wgrad_kernel_name(ci, co, nt, halo, fused=False, raw=False, h=0, pre=False)
         if x3 and nt == 1 and cfg.startswith("1, 2, 4") and not fused and not (WGRAD_VARIANT & (256 | 128)):
             ncw = 8                     # (the 128 x 256 slice: cout tiles split across the consumer halves)
         if (x3 and nt == 4 and cfg.startswith("4, 1, 2, 2, 1, 2, 1") and not pre and not (WGRAD_VARIANT & (256 | 128))):
-            ncw, lean = 8, fused        # (unfused too: every weight gradient of a data-parallel step)
+            ncw, lean = 8, fused        # (unfused launches too)
         npw = 8 if (ncw == 8 or (nt == 1 and not cfg.startswith("1, 2, 4") and not (WGRAD_VARIANT & 128))) else 4
         return (f"wgrad_tr_kernel<{3 if MFMA_MODE == 2 else 1}, {cfg}, {'true' if fused else 'false'}, "
                 f"{'true' if (raw and MFMA_MODE == 1 and not fused) else 'false'}, {'true' if lean else 'false'}, {npw}, {ncw}>")
