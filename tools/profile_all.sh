@@ -1,6 +1,6 @@
 #!/bin/bash
 # The judged rocprofv3 evidence of a round, one capture per (workload, engine) that bench.py reports a roofline for:
-#   tools/profile_all.sh   (on the GPU box; ~15 min)   -> gpurun_out/prof/round6_<workload>_<engine>_{kernel_stats.csv,hbm.md,hbm.json}
+#   tools/profile_all.sh   (on the GPU box; ~3 min of box time on a warm image, more on a fresh one)   -> gpurun_out/prof/round6_<workload>_<engine>_{kernel_stats.csv,hbm.md,hbm.json}
 # copy the files into profiles/ afterwards.
 set -e
 cd "$(dirname "$0")/.."
